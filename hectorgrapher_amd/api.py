@@ -1,0 +1,359 @@
+"""Host-side mirror of the reference interface for the TSDF hot path.
+
+Class and method names follow cartographer::mapping (ref paths relative to
+/root/reference/cartographer/):
+  HybridGridTSDF            mapping/3d/hybrid_grid_tsdf.h:59-134
+  RangeData                 sensor/range_data.h:44-57
+  TSDFRangeDataInserter3D   mapping/3d/tsdf_range_data_inserter_3d.{h,cc} (Insert :395)
+  Problem                   the ceres::Problem of optimizing_local_trajectory_builder.cc:1238-1291
+  CeresScanMatcher3D        mapping/internal/3d/scan_matching/ceres_scan_matcher_3d.cc:72-118
+Everything computes on the GPU through the C ABI (include/hg_mi355x.h); numpy
+arrays are host buffers, torch CUDA tensors are passed as device pointers.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import InsertOpts, InsertStats, SolverOpts, SolverSummary, HgError, check  # noqa: F401
+
+
+def _is_device(a):
+    return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
+
+
+def _host(a, dtype, shape_last=None):
+    a = np.ascontiguousarray(a, dtype)
+    if shape_last is not None:
+        a = a.reshape(-1, shape_last)
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP stream on one device (hg_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.hg_ctx_create(int(device), stream, C.byref(h)), "hg_ctx_create")
+        self._h = h
+        self.device = int(device)
+        self._children = weakref.WeakSet()  # grids / problems: destroyed before the context
+
+    def synchronize(self):
+        check(self._L.hg_ctx_synchronize(self._h), "hg_ctx_synchronize")
+
+    @property
+    def stream(self):
+        return self._L.hg_ctx_stream(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for child in list(self._children):
+                child.close()
+            self._L.hg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RangeData:
+    """sensor::RangeData: origin + returns (+ width of the structured cloud)."""
+
+    def __init__(self, origin, returns, width=0):
+        self.origin = np.ascontiguousarray(origin, np.float32).reshape(3)
+        self.returns = returns
+        self.width = int(width)
+
+
+class HybridGridTSDF:
+    def __init__(self, ctx, resolution, relative_truncation_distance=2.5, max_weight=1000.0,
+                 max_blocks=1 << 16):
+        self._L = _lib.load()
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(self._L.hg_grid_create(ctx._h, resolution, relative_truncation_distance, max_weight,
+                                     int(max_blocks), C.byref(h)), "hg_grid_create")
+        self._h = h
+        ctx._children.add(self)
+        self._resolution = np.float32(resolution)
+        # codec constants in float32, as the device computes them (tsd_value_converter.cc:22-32)
+        f = np.float32
+        self.max_tsd = f(relative_truncation_distance) * f(resolution)
+        self.min_tsd = -self.max_tsd
+        self.max_weight = f(max_weight)
+        self.max_blocks = int(max_blocks)
+
+    def resolution(self):
+        return self._resolution
+
+    def clear(self):
+        check(self._L.hg_grid_clear(self._h), "hg_grid_clear")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hg_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- HybridGridBase::GetCellIndex / GetCenterOfCell (hybrid_grid_base.h:428-446) --
+    def GetCellIndex(self, point):
+        p = np.asarray(point, np.float32) / self._resolution
+        # std::lround: half away from zero
+        return (np.sign(p) * np.floor(np.abs(p) + np.float32(0.5))).astype(np.int32)
+
+    def GetCenterOfCell(self, index):
+        return np.asarray(index, np.int32).astype(np.float32) * self._resolution
+
+    # -- SetCell / value access --
+    def SetCell(self, index, tsd, weight):
+        self.set_cells(np.asarray(index, np.int32).reshape(1, 3), [tsd], [weight])
+
+    def set_cells(self, ijk, tsd, weight):
+        ijk = _host(ijk, np.int32, 3)
+        tsd = _host(tsd, np.float32)
+        weight = _host(weight, np.float32)
+        check(self._L.hg_grid_set_cells(self._h, _p(ijk), len(ijk), _p(tsd), _p(weight)),
+              "hg_grid_set_cells")
+
+    def read_cells(self, ijk):
+        """Raw (discrete_tsd, discrete_weight) codes of TSDFVoxel."""
+        ijk = _host(ijk, np.int32, 3)
+        t = np.empty(len(ijk), np.uint16)
+        w = np.empty(len(ijk), np.uint16)
+        check(self._L.hg_grid_read_cells(self._h, _p(ijk), len(ijk), _p(t), _p(w)),
+              "hg_grid_read_cells")
+        return t, w
+
+    def _decode(self, code, lower, upper, unknown):
+        f = np.float32
+        scale = (f(upper) - f(lower)) / f(32766.0)
+        v = (code & 0x7FFF).astype(np.float32)
+        out = v * scale + (f(lower) - scale)
+        return np.where((code & 0x7FFF) == 0, f(unknown), out).astype(np.float32)
+
+    def GetTSD(self, ijk):
+        t, _ = self.read_cells(ijk)
+        return self._decode(t, self.min_tsd, self.max_tsd, self.min_tsd)
+
+    def GetWeight(self, ijk):
+        _, w = self.read_cells(ijk)
+        return self._decode(w, 0.0, self.max_weight, 0.0)
+
+    def IsKnown(self, ijk):
+        _, w = self.read_cells(ijk)
+        return w != 0
+
+    def count(self):
+        n = C.c_size_t()
+        check(self._L.hg_grid_count(self._h, C.byref(n)), "hg_grid_count")
+        return n.value
+
+    def num_blocks(self):
+        n = C.c_uint32()
+        check(self._L.hg_grid_num_blocks(self._h, C.byref(n)), "hg_grid_num_blocks")
+        return n.value
+
+    def export(self):
+        """(ijk, tsd codes, weight codes) in the reference iterator order (ToProto order)."""
+        n = self.count()
+        ijk = np.empty((n, 3), np.int32)
+        t = np.empty(n, np.uint16)
+        w = np.empty(n, np.uint16)
+        got = C.c_size_t()
+        check(self._L.hg_grid_export(self._h, _p(ijk), _p(t), _p(w), n, C.byref(got)),
+              "hg_grid_export")
+        return ijk, t, w
+
+    def block_arrays(self):
+        """Device pointers (keys u64[nb], voxels u32[nb*512]) and nb, for the multi-GPU gather."""
+        k, v, n = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        check(self._L.hg_grid_block_arrays(self._h, C.byref(k), C.byref(v), C.byref(n)),
+              "hg_grid_block_arrays")
+        return k.value, v.value, n.value
+
+    def import_blocks(self, keys, voxels, num_blocks=None):
+        if _is_device(keys):
+            nb = int(num_blocks if num_blocks is not None else keys.numel())
+            check(self._L.hg_grid_import_blocks(self._h, keys.data_ptr(), voxels.data_ptr(), nb,
+                                                _lib.HG_DEVICE), "hg_grid_import_blocks")
+        else:
+            keys = _host(keys, np.uint64)
+            voxels = _host(voxels, np.uint32)
+            check(self._L.hg_grid_import_blocks(self._h, _p(keys), _p(voxels), len(keys),
+                                                _lib.HG_HOST), "hg_grid_import_blocks")
+
+
+class TSDFRangeDataInserter3D:
+    """RangeDataInserterInterface implementation for TSDF grids."""
+
+    def __init__(self, options=None, mode=_lib.HG_INSERT_EXACT):
+        self._L = _lib.load()
+        self.options = options or InsertOpts()
+        self.mode = mode
+        self.last_stats = InsertStats()
+
+    def RequiresStructuredData(self):
+        return bool(self.options.project_sdf_distance_to_scan_normal)
+
+    def Insert(self, range_data, grid, pose_tq=None):
+        """Insert(range_data, grid). `pose_tq` optionally applies Submap3D::InsertData's
+        local_pose().inverse().cast<float>() (submap_3d.cc:436-437) on the device."""
+        origin = range_data.origin
+        pose = None if pose_tq is None else np.ascontiguousarray(pose_tq, np.float32)
+        r = range_data.returns
+        if _is_device(r):
+            n = r.shape[0]
+            ptr, space = r.data_ptr(), _lib.HG_DEVICE
+        else:
+            r = _host(r, np.float32, 3)
+            n = len(r)
+            ptr, space = _p(r), _lib.HG_HOST
+        st = InsertStats()
+        check(self._L.hg_grid_insert(grid._h, C.byref(self.options), _p(origin), ptr, n,
+                                     range_data.width, _p(pose), self.mode, space, C.byref(st)),
+              "hg_grid_insert")
+        self.last_stats = st
+        return st
+
+    def InsertBatch(self, origins, returns, scan_offsets, grid, width=0, poses_tq=None):
+        """Stream form: scans applied in order in one call (hg_grid_insert_batch)."""
+        origins = _host(origins, np.float32, 3)
+        offs = _host(scan_offsets, np.uint64)
+        poses = None if poses_tq is None else _host(poses_tq, np.float32, 7)
+        if _is_device(returns):
+            ptr, space = returns.data_ptr(), _lib.HG_DEVICE
+        else:
+            returns = _host(returns, np.float32, 3)
+            ptr, space = _p(returns), _lib.HG_HOST
+        st = InsertStats()
+        check(self._L.hg_grid_insert_batch(grid._h, C.byref(self.options), _p(origins), ptr,
+                                           _p(offs), len(offs) - 1, int(width), _p(poses),
+                                           self.mode, space, C.byref(st)), "hg_grid_insert_batch")
+        self.last_stats = st
+        return st
+
+
+class Problem:
+    """ceres::Problem restricted to TSDF space cost functions over pose blocks."""
+
+    def __init__(self, ctx):
+        self._L = _lib.load()
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(self._L.hg_problem_create(ctx._h, C.byref(h)), "hg_problem_create")
+        self._h = h
+        ctx._children.add(self)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hg_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_pose(self, tq, constant=False):
+        tq = _host(tq, np.float64)
+        return check(self._L.hg_problem_add_pose(self._h, _p(tq), int(constant)), "add_pose")
+
+    def set_pose(self, idx, tq):
+        tq = _host(tq, np.float64)
+        check(self._L.hg_problem_set_pose(self._h, idx, _p(tq)), "set_pose")
+
+    def get_pose(self, idx):
+        out = np.empty(7, np.float64)
+        check(self._L.hg_problem_get_pose(self._h, idx, _p(out)), "get_pose")
+        return out
+
+    def add_block(self, xyz, grids, scaling_factor, pose_a, pose_b=-1, interpolation_ratio=0.0,
+                  multi_res=False):
+        arr = (C.c_void_p * len(grids))(*[g._h for g in grids])
+        if _is_device(xyz):
+            n, ptr, space = xyz.shape[0], xyz.data_ptr(), _lib.HG_DEVICE
+            self._keep.append(xyz)
+        else:
+            xyz = _host(xyz, np.float32, 3)
+            n, ptr, space = len(xyz), _p(xyz), _lib.HG_HOST
+        self._keep.append(grids)
+        return check(self._L.hg_problem_add_block(self._h, ptr, n, space, arr, len(grids),
+                                                  int(multi_res), float(scaling_factor), pose_a,
+                                                  pose_b, float(interpolation_ratio)), "add_block")
+
+    def num_residuals(self):
+        return check(self._L.hg_problem_num_residuals(self._h))
+
+    def num_columns(self):
+        return check(self._L.hg_problem_num_columns(self._h))
+
+    def evaluate(self, want_residuals=True):
+        """Returns (cost, residuals, gradient, JtJ) in the local parameterisation."""
+        n, c = self.num_residuals(), self.num_columns()
+        cost = C.c_double()
+        r = np.empty(n, np.float64) if want_residuals else None
+        g = np.empty(c, np.float64)
+        H = np.empty((c, c), np.float64)
+        check(self._L.hg_problem_evaluate(self._h, C.byref(cost), _p(r), _p(g), _p(H)), "evaluate")
+        return cost.value, r, g, H
+
+    def solve(self, **kw):
+        o = SolverOpts()
+        self._L.hg_solver_default_opts(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        s = SolverSummary()
+        check(self._L.hg_problem_solve(self._h, C.byref(o), C.byref(s)), "solve")
+        return s
+
+
+class CeresScanMatcher3D:
+    """Single-pose matcher shape (Match / Evaluate) for TSDF grids.
+
+    `occupied_space_weights[i]` pairs with the i-th (point cloud, grid) entry
+    (ceres_scan_matcher_3d.cc:129-156). The translation/rotation prior blocks of
+    the reference (:162-172) are not part of the TSDF hot path and are omitted.
+    """
+
+    def __init__(self, ctx, occupied_space_weights, **solver_kw):
+        self.ctx = ctx
+        self.weights = list(occupied_space_weights)
+        self.solver_kw = solver_kw
+
+    def _problem(self, initial_pose, clouds_and_grids):
+        p = Problem(self.ctx)
+        i = p.add_pose(initial_pose)
+        for w, (cloud, grid) in zip(self.weights, clouds_and_grids):
+            n = cloud.shape[0]
+            p.add_block(cloud, [grid], w / np.sqrt(float(n)), i)
+        return p, i
+
+    def Match(self, initial_pose_estimate, point_clouds_and_hybrid_grids):
+        p, i = self._problem(initial_pose_estimate, point_clouds_and_hybrid_grids)
+        summary = p.solve(**self.solver_kw)
+        pose = p.get_pose(i)
+        p.close()
+        return pose, summary
+
+    def Evaluate(self, initial_pose_estimate, point_clouds_and_hybrid_grids):
+        p, _ = self._problem(initial_pose_estimate, point_clouds_and_hybrid_grids)
+        out = p.evaluate()
+        p.close()
+        return out

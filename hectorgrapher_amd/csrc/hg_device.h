@@ -1,0 +1,153 @@
+// hg_device.h — shared host/device definitions for the gfx950 TSDF path.
+// Written for CDNA4 (wave64) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hg_mi355x.h"
+
+namespace hg {
+
+constexpr int kWave = 64;
+constexpr uint32_t kVoxelsPerBlock = 512;  // 8^3, one FlatGrid<TSDFVoxel,3> leaf (2 KiB)
+constexpr int kIndexOffset = 8192;         // cell index range [-8192, 8191] (hybrid_grid_tsdf.h:58)
+constexpr uint32_t kSlotPending = 0xFFFFFFu;
+constexpr uint16_t kUpdateMarker = 1u << 15;
+
+// Device view of one HybridGridTSDF. Passed to kernels by value.
+struct GridView {
+  unsigned long long* table;  // open-addressing hash: 0 = empty, else ((key + 1) << 24) | slot
+  uint32_t table_mask;        // capacity - 1 (power of two)
+  uint32_t max_blocks;
+  uint32_t* voxels;           // max_blocks * 512, voxel = tsd_code | weight_code << 16
+  unsigned long long* block_keys;  // key of slot s
+  uint32_t* counters;         // [0] num_blocks, [1] error flags, [2] hits, [3] updates(lo) ...
+  float resolution;
+  float max_tsd, min_tsd, max_weight;
+  float tsd_resolution, weight_resolution;  // encode scales (tsd_value_converter.cc:27-28)
+  float tsd_scale, tsd_offset;              // decode: code * scale + offset (value_conversion_tables.cc:35-36)
+  float weight_scale, weight_offset;
+};
+
+enum : uint32_t { kFlagCapacity = 1u, kFlagRange = 2u };
+
+// ---- codec (ref mapping/2d/tsd_value_converter.h:39-67, value_conversion_tables.cc:29-37) ----
+__host__ __device__ inline float clampf(float v, float lo, float hi) {
+  if (v > hi) return hi;
+  if (v < lo) return lo;
+  return v;
+}
+__device__ inline int round_to_int(float x) { return static_cast<int>(roundf(x)); }  // lround
+
+__device__ inline uint32_t tsd_to_value(const GridView& g, float tsd) {
+  return static_cast<uint32_t>(round_to_int((clampf(tsd, g.min_tsd, g.max_tsd) - g.min_tsd) *
+                                            g.tsd_resolution) + 1);
+}
+__device__ inline uint32_t weight_to_value(const GridView& g, float w) {
+  return static_cast<uint32_t>(round_to_int((clampf(w, 0.f, g.max_weight) - 0.f) *
+                                            g.weight_resolution) + 1);
+}
+__device__ inline float value_to_tsd(const GridView& g, uint32_t code) {
+  const uint32_t v = code & 0x7FFFu;
+  if (v == 0) return g.min_tsd;
+  return static_cast<float>(v) * g.tsd_scale + g.tsd_offset;
+}
+__device__ inline float value_to_weight(const GridView& g, uint32_t code) {
+  const uint32_t v = code & 0x7FFFu;
+  if (v == 0) return 0.f;
+  return static_cast<float>(v) * g.weight_scale + g.weight_offset;
+}
+
+// ---- indexing (ref mapping/3d/hybrid_grid_base.h:40-43,428-446) ----
+__device__ inline int cell_index_1d(float p, float resolution) { return round_to_int(p / resolution); }
+
+// Block key of a cell index: 11 bits per axis of (index + 8192) >> 3.
+__device__ inline bool cell_in_range(int x, int y, int z) {
+  return (static_cast<unsigned>(x + kIndexOffset) < 16384u) &&
+         (static_cast<unsigned>(y + kIndexOffset) < 16384u) &&
+         (static_cast<unsigned>(z + kIndexOffset) < 16384u);
+}
+__device__ inline unsigned long long block_key(int x, int y, int z) {
+  const unsigned long long bx = static_cast<unsigned>(x + kIndexOffset) >> 3;
+  const unsigned long long by = static_cast<unsigned>(y + kIndexOffset) >> 3;
+  const unsigned long long bz = static_cast<unsigned>(z + kIndexOffset) >> 3;
+  return (bz << 22) | (by << 11) | bx;
+}
+__device__ inline uint32_t voxel_in_block(int x, int y, int z) {
+  return ((static_cast<unsigned>(z + kIndexOffset) & 7u) << 6) |
+         ((static_cast<unsigned>(y + kIndexOffset) & 7u) << 3) |
+         (static_cast<unsigned>(x + kIndexOffset) & 7u);
+}
+__host__ __device__ inline void key_to_block_origin(unsigned long long key, int* x, int* y, int* z) {
+  *x = (static_cast<int>(key & 2047u) << 3) - kIndexOffset;
+  *y = (static_cast<int>((key >> 11) & 2047u) << 3) - kIndexOffset;
+  *z = (static_cast<int>((key >> 22) & 2047u) << 3) - kIndexOffset;
+}
+
+// ---- hash table ----
+__host__ __device__ inline uint32_t hash_key(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return static_cast<uint32_t>(k);
+}
+
+// Read-only lookup. Returns the slot or 0xFFFFFFFF if the block does not exist.
+__device__ inline uint32_t find_block(const GridView& g, unsigned long long key) {
+  uint32_t h = hash_key(key) & g.table_mask;
+  const unsigned long long tag = key + 1ull;
+  for (uint32_t probe = 0; probe <= g.table_mask; ++probe) {
+    const unsigned long long e = g.table[h];
+    if (e == 0ull) return 0xFFFFFFFFu;
+    if ((e >> 24) == tag) return static_cast<uint32_t>(e & 0xFFFFFFu);
+    h = (h + 1) & g.table_mask;
+  }
+  return 0xFFFFFFFFu;
+}
+
+// Insert-or-get for kernels in which each distinct key is inserted by at most one thread.
+// Returns the slot, or 0xFFFFFFFF when the pool/table is full (flag set).
+__device__ inline uint32_t insert_block_unique(const GridView& g, unsigned long long key) {
+  uint32_t h = hash_key(key) & g.table_mask;
+  const unsigned long long tag = key + 1ull;
+  for (uint32_t probe = 0; probe <= g.table_mask; ++probe) {
+    unsigned long long e = g.table[h];
+    if (e == 0ull) {
+      const unsigned long long pending = (tag << 24) | kSlotPending;
+      const unsigned long long prev = atomicCAS(&g.table[h], 0ull, pending);
+      if (prev == 0ull) {
+        const uint32_t slot = atomicAdd(&g.counters[0], 1u);
+        if (slot >= g.max_blocks || slot >= kSlotPending) {
+          atomicSub(&g.counters[0], 1u);
+          atomicOr(&g.counters[1], kFlagCapacity);
+          // leave the entry pending: lookups treat a pending slot as missing
+          return 0xFFFFFFFFu;
+        }
+        g.block_keys[slot] = key;
+        atomicExch(&g.table[h], (tag << 24) | slot);
+        return slot;
+      }
+      e = prev;
+    }
+    if ((e >> 24) == tag) {
+      const uint32_t s = static_cast<uint32_t>(e & 0xFFFFFFu);
+      return s == kSlotPending ? 0xFFFFFFFFu : s;
+    }
+    h = (h + 1) & g.table_mask;
+  }
+  atomicOr(&g.counters[1], kFlagCapacity);
+  return 0xFFFFFFFFu;
+}
+
+// Voxel fetch for lookups: unknown block -> 0 (default TSDFVoxel).
+__device__ inline uint32_t load_voxel(const GridView& g, int x, int y, int z) {
+  if (!cell_in_range(x, y, z)) return 0u;
+  const uint32_t slot = find_block(g, block_key(x, y, z));
+  if (slot >= g.max_blocks) return 0u;
+  return g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + voxel_in_block(x, y, z)];
+}
+
+}  // namespace hg

@@ -1,0 +1,417 @@
+// hg_grid.hip — context and HybridGridTSDF storage on the device.
+//
+// Storage layout (HBM): a pool of 8x8x8-voxel blocks, 2 KiB each, voxel = u32
+// {u16 tsd code | u16 weight code << 16} in the reference leaf's z-major order
+// (ref mapping/3d/hybrid_grid_base.h:40-43,69-141, hybrid_grid_tsdf.h:41-51),
+// addressed through an open-addressing hash keyed by the block coordinate.
+// The reference's DynamicGrid/NestedGrid pointer tree (:144-407) is replaced
+// by this flat pool; export restores the tree's iteration order.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "hg_internal.h"
+
+namespace hg {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+__global__ void k_set_cells_serial(GridView g, const int* ijk, size_t m, const float* tsd,
+                                   const float* weight) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (size_t i = 0; i < m; ++i) {
+    const int x = ijk[3 * i], y = ijk[3 * i + 1], z = ijk[3 * i + 2];
+    if (!cell_in_range(x, y, z)) {
+      atomicOr(&g.counters[1], kFlagRange);
+      continue;
+    }
+    const uint32_t slot = insert_block_unique(g, block_key(x, y, z));
+    if (slot >= g.max_blocks) continue;
+    // SetCell: hybrid_grid_tsdf.h:87-92
+    const uint32_t code = (tsd_to_value(g, tsd[i]) + kUpdateMarker) | (weight_to_value(g, weight[i]) << 16);
+    g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + voxel_in_block(x, y, z)] = code;
+  }
+}
+
+__global__ void k_read_cells(GridView g, const int* ijk, size_t m, uint16_t* tsd, uint16_t* weight) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t v = load_voxel(g, ijk[3 * i], ijk[3 * i + 1], ijk[3 * i + 2]);
+  tsd[i] = static_cast<uint16_t>(v & 0xFFFFu);
+  weight[i] = static_cast<uint16_t>(v >> 16);
+}
+
+// One wave per block (in export order): number of non-default voxels.
+__global__ void k_export_count(GridView g, const uint32_t* order, uint32_t nblocks, uint32_t* counts) {
+  const uint32_t b = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const uint32_t lane = threadIdx.x % kWave;
+  if (b >= nblocks) return;
+  const uint32_t* vox = g.voxels + static_cast<size_t>(order[b]) * kVoxelsPerBlock;
+  uint32_t c = 0;
+  for (int it = 0; it < 8; ++it) c += (vox[it * kWave + lane] != 0u) ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if (lane == 0) counts[b] = c;
+}
+
+// One wave per block: ordered compaction of non-default voxels to (ijk, tsd, weight).
+__global__ void k_export_write(GridView g, const uint32_t* order, const uint64_t* offsets,
+                               uint32_t nblocks, int* ijk, uint16_t* tsd, uint16_t* weight,
+                               uint64_t cap) {
+  const uint32_t b = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const uint32_t lane = threadIdx.x % kWave;
+  if (b >= nblocks) return;
+  const uint32_t slot = order[b];
+  const uint32_t* vox = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock;
+  int ox, oy, oz;
+  key_to_block_origin(g.block_keys[slot], &ox, &oy, &oz);
+  uint64_t base = offsets[b];
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t idx = it * kWave + lane;
+    const uint32_t v = vox[idx];
+    const unsigned long long mask = __ballot(v != 0u);
+    if (v != 0u) {
+      const uint64_t pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < cap) {
+        ijk[3 * pos] = ox + static_cast<int>(idx & 7u);
+        ijk[3 * pos + 1] = oy + static_cast<int>((idx >> 3) & 7u);
+        ijk[3 * pos + 2] = oz + static_cast<int>(idx >> 6);
+        tsd[pos] = static_cast<uint16_t>(v & 0xFFFFu);
+        weight[pos] = static_cast<uint16_t>(v >> 16);
+      }
+    }
+    base += __popcll(mask);
+  }
+}
+
+// Thread per imported block: insert key, copy 2 KiB (one wave per block).
+__global__ void k_import_blocks(GridView g, const unsigned long long* keys, const uint32_t* voxels,
+                                uint32_t nblocks) {
+  const uint32_t b = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const uint32_t lane = threadIdx.x % kWave;
+  if (b >= nblocks) return;
+  uint32_t slot = 0;
+  if (lane == 0) slot = insert_block_unique(g, keys[b]);
+  slot = __shfl(slot, 0);
+  if (slot >= g.max_blocks) return;
+  const uint4* src = reinterpret_cast<const uint4*>(voxels + static_cast<size_t>(b) * kVoxelsPerBlock);
+  uint4* dst = reinterpret_cast<uint4*>(g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock);
+  dst[lane] = src[lane];
+  dst[lane + kWave] = src[lane + kWave];
+}
+
+static uint32_t next_pow2(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace hg
+
+using namespace hg;
+
+extern "C" {
+
+const char* hg_last_error(void) { return g_last_error.c_str(); }
+const char* hg_version(void) { return "hectorgrapher_amd 0.1 (gfx950)"; }
+
+int hg_ctx_create(int device, void* stream, hg_ctx** out) {
+  if (!out) return HG_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    set_last_error("no HIP device visible");
+    return HG_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    set_last_error("device index out of range");
+    return HG_ERR_INVALID;
+  }
+  HG_HIP_CHECK(hipSetDevice(device));
+  hg_ctx* c = new hg_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      set_last_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+      delete c;
+      return HG_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  if (hipHostMalloc(&c->pinned, 4096) != hipSuccess) c->pinned = nullptr;
+  *out = c;
+  return HG_OK;
+}
+
+int hg_ctx_destroy(hg_ctx* c) {
+  if (!c) return HG_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DeviceBuffer* b : {&c->ws_points, &c->ws_scan_table, &c->ws_gate, &c->ws_counts,
+                          &c->ws_offsets, &c->ws_keys_a, &c->ws_keys_b, &c->ws_vals_a,
+                          &c->ws_vals_b, &c->ws_temp, &c->ws_misc})
+    b->release();
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return HG_OK;
+}
+
+int hg_ctx_synchronize(hg_ctx* c) {
+  if (!c) return HG_ERR_INVALID;
+  HG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return HG_OK;
+}
+
+void* hg_ctx_stream(hg_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_distance,
+                   float max_weight, uint32_t max_blocks, hg_grid** out) {
+  if (!ctx || !out || !(resolution > 0.f) || !(max_weight > 0.f) ||
+      !(relative_truncation_distance > 0.f) || max_blocks == 0 || max_blocks >= kSlotPending)
+    return HG_ERR_INVALID;
+  *out = nullptr;
+  HG_HIP_CHECK(hipSetDevice(ctx->device));
+  hg_grid* g = new hg_grid();
+  g->ctx = ctx;
+  g->relative_truncation_distance = relative_truncation_distance;
+  GridView& v = g->view;
+  v.max_blocks = max_blocks;
+  g->table_capacity = next_pow2(std::max<uint32_t>(1024u, max_blocks * 2u));
+  v.table_mask = g->table_capacity - 1;
+  v.resolution = resolution;
+  // HybridGridTSDF ctor (hybrid_grid_tsdf.h:61-67) + TSDValueConverter ctor
+  // (tsd_value_converter.cc:22-32) + SlowValueToBoundedFloat scale.
+  v.max_tsd = relative_truncation_distance * resolution;
+  v.min_tsd = -v.max_tsd;
+  v.max_weight = max_weight;
+  v.tsd_resolution = 32766.f / (v.max_tsd - v.min_tsd);
+  v.weight_resolution = 32766.f / (v.max_weight - 0.f);
+  v.tsd_scale = (v.max_tsd - v.min_tsd) / 32766.f;
+  v.tsd_offset = v.min_tsd - v.tsd_scale;
+  v.weight_scale = (v.max_weight - 0.f) / 32766.f;
+  v.weight_offset = 0.f - v.weight_scale;
+  hipError_t e;
+  e = hipMalloc(reinterpret_cast<void**>(&v.table), sizeof(unsigned long long) * g->table_capacity);
+  if (e == hipSuccess)
+    e = hipMalloc(reinterpret_cast<void**>(&v.voxels), sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(max_blocks));
+  if (e == hipSuccess)
+    e = hipMalloc(reinterpret_cast<void**>(&v.block_keys), sizeof(unsigned long long) * max_blocks);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v.counters), 256);
+  if (e != hipSuccess) {
+    set_last_error(std::string("hipMalloc grid: ") + hipGetErrorString(e));
+    hg_grid_destroy(g);
+    return HG_ERR_HIP;
+  }
+  *out = g;
+  return hg_grid_clear(g);
+}
+
+int hg_grid_destroy(hg_grid* g) {
+  if (!g) return HG_ERR_INVALID;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->view.table) (void)hipFree(g->view.table);
+  if (g->view.voxels) (void)hipFree(g->view.voxels);
+  if (g->view.block_keys) (void)hipFree(g->view.block_keys);
+  if (g->view.counters) (void)hipFree(g->view.counters);
+  delete g;
+  return HG_OK;
+}
+
+int hg_grid_clear(hg_grid* g) {
+  if (!g) return HG_ERR_INVALID;
+  hipStream_t s = g->ctx->stream;
+  HG_HIP_CHECK(hipMemsetAsync(g->view.table, 0, sizeof(unsigned long long) * g->table_capacity, s));
+  HG_HIP_CHECK(hipMemsetAsync(g->view.voxels, 0,
+                              sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(g->view.max_blocks), s));
+  HG_HIP_CHECK(hipMemsetAsync(g->view.counters, 0, 256, s));
+  return HG_OK;
+}
+
+float hg_grid_resolution(const hg_grid* g) { return g ? g->view.resolution : 0.f; }
+
+static int read_counters(hg_grid* g, uint32_t* out8) {
+  HG_HIP_CHECK(hipMemcpyAsync(out8, g->view.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              g->ctx->stream));
+  HG_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+  return HG_OK;
+}
+
+int hg_grid_num_blocks(hg_grid* g, uint32_t* num_blocks) {
+  if (!g || !num_blocks) return HG_ERR_INVALID;
+  uint32_t c[8];
+  int rc = read_counters(g, c);
+  if (rc != HG_OK) return rc;
+  *num_blocks = std::min(c[0], g->view.max_blocks);
+  return HG_OK;
+}
+
+int hg_grid_set_cells(hg_grid* g, const int32_t* ijk, size_t m, const float* tsd,
+                      const float* weight) {
+  if (!g || (m && (!ijk || !tsd || !weight))) return HG_ERR_INVALID;
+  if (m == 0) return HG_OK;
+  hipStream_t s = g->ctx->stream;
+  DeviceBuffer& b = g->ctx->ws_misc;
+  const size_t bytes_ijk = m * 3 * sizeof(int), bytes_f = m * sizeof(float);
+  int rc = b.reserve(bytes_ijk + 2 * bytes_f + 64);
+  if (rc != HG_OK) return rc;
+  char* base = b.as<char>();
+  HG_HIP_CHECK(hipMemcpyAsync(base, ijk, bytes_ijk, hipMemcpyHostToDevice, s));
+  HG_HIP_CHECK(hipMemcpyAsync(base + bytes_ijk, tsd, bytes_f, hipMemcpyHostToDevice, s));
+  HG_HIP_CHECK(hipMemcpyAsync(base + bytes_ijk + bytes_f, weight, bytes_f, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_set_cells_serial, dim3(1), dim3(64), 0, s, g->view,
+                     reinterpret_cast<const int*>(base), m,
+                     reinterpret_cast<const float*>(base + bytes_ijk),
+                     reinterpret_cast<const float*>(base + bytes_ijk + bytes_f));
+  HG_HIP_CHECK(hipGetLastError());
+  uint32_t c[8];
+  rc = read_counters(g, c);
+  if (rc != HG_OK) return rc;
+  if (c[1] & kFlagCapacity) return HG_ERR_CAPACITY;
+  if (c[1] & kFlagRange) return HG_ERR_RANGE;
+  return HG_OK;
+}
+
+int hg_grid_read_cells(hg_grid* g, const int32_t* ijk, size_t m, uint16_t* tsd, uint16_t* weight) {
+  if (!g || (m && (!ijk || !tsd || !weight))) return HG_ERR_INVALID;
+  if (m == 0) return HG_OK;
+  hipStream_t s = g->ctx->stream;
+  DeviceBuffer& b = g->ctx->ws_misc;
+  const size_t bytes_ijk = m * 3 * sizeof(int), bytes_h = ((m * sizeof(uint16_t) + 15) / 16) * 16;
+  int rc = b.reserve(bytes_ijk + 2 * bytes_h + 64);
+  if (rc != HG_OK) return rc;
+  char* base = b.as<char>();
+  HG_HIP_CHECK(hipMemcpyAsync(base, ijk, bytes_ijk, hipMemcpyHostToDevice, s));
+  uint16_t* d_t = reinterpret_cast<uint16_t*>(base + bytes_ijk);
+  uint16_t* d_w = reinterpret_cast<uint16_t*>(base + bytes_ijk + bytes_h);
+  hipLaunchKernelGGL(k_read_cells, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, s,
+                     g->view, reinterpret_cast<const int*>(base), m, d_t, d_w);
+  HG_HIP_CHECK(hipGetLastError());
+  HG_HIP_CHECK(hipMemcpyAsync(tsd, d_t, m * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipMemcpyAsync(weight, d_w, m * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipStreamSynchronize(s));
+  return HG_OK;
+}
+
+// Export order key of a block (ref hybrid_grid_base.h:304-372: meta cells of 64^3 voxels z-major,
+// then 8^3 leaves z-major). The DynamicGrid's centring shift is a multiple of 64 cells, so the
+// order is independent of how far the reference tree has grown.
+static uint64_t export_order_key(unsigned long long key) {
+  const uint64_t bx = key & 2047u, by = (key >> 11) & 2047u, bz = (key >> 22) & 2047u;
+  const uint64_t mx = bx >> 3, my = by >> 3, mz = bz >> 3;
+  const uint64_t lx = bx & 7u, ly = by & 7u, lz = bz & 7u;
+  return (((((mz << 8 | my) << 8 | mx) << 3 | lz) << 3 | ly) << 3) | lx;
+}
+
+static int export_impl(hg_grid* g, int32_t* ijk, uint16_t* tsd, uint16_t* weight, size_t cap,
+                       size_t* count) {
+  hipStream_t s = g->ctx->stream;
+  uint32_t nb = 0;
+  int rc = hg_grid_num_blocks(g, &nb);
+  if (rc != HG_OK) return rc;
+  *count = 0;
+  if (nb == 0) return HG_OK;
+  std::vector<unsigned long long> keys(nb);
+  HG_HIP_CHECK(hipMemcpyAsync(keys.data(), g->view.block_keys, nb * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<uint32_t> order(nb);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    return export_order_key(keys[a]) < export_order_key(keys[b]);
+  });
+  DeviceBuffer& b = g->ctx->ws_misc;
+  const size_t bytes_order = nb * sizeof(uint32_t);
+  const size_t bytes_off = nb * sizeof(uint64_t);
+  rc = b.reserve(2 * bytes_order + bytes_off + 256);
+  if (rc != HG_OK) return rc;
+  char* base = b.as<char>();
+  uint64_t* d_off = reinterpret_cast<uint64_t*>(base);
+  uint32_t* d_order = reinterpret_cast<uint32_t*>(base + bytes_off);
+  uint32_t* d_counts = reinterpret_cast<uint32_t*>(base + bytes_off + bytes_order);
+  HG_HIP_CHECK(hipMemcpyAsync(d_order, order.data(), bytes_order, hipMemcpyHostToDevice, s));
+  const unsigned wg = 256, per = wg / kWave;
+  hipLaunchKernelGGL(k_export_count, dim3((nb + per - 1) / per), dim3(wg), 0, s, g->view, d_order,
+                     nb, d_counts);
+  HG_HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> counts(nb);
+  HG_HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts, bytes_order, hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<uint64_t> offsets(nb);
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < nb; ++i) {
+    offsets[i] = total;
+    total += counts[i];
+  }
+  *count = static_cast<size_t>(total);
+  if (!ijk || cap == 0 || total == 0) return HG_OK;
+  const size_t n_out = std::min<size_t>(cap, total);
+  DeviceBuffer& o = g->ctx->ws_temp;
+  const size_t b_ijk = n_out * 3 * sizeof(int), b_h = ((n_out * sizeof(uint16_t) + 15) / 16) * 16;
+  rc = o.reserve(b_ijk + 2 * b_h + 64);
+  if (rc != HG_OK) return rc;
+  char* ob = o.as<char>();
+  HG_HIP_CHECK(hipMemcpyAsync(d_off, offsets.data(), bytes_off, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_export_write, dim3((nb + per - 1) / per), dim3(wg), 0, s, g->view, d_order,
+                     d_off, nb, reinterpret_cast<int*>(ob),
+                     reinterpret_cast<uint16_t*>(ob + b_ijk),
+                     reinterpret_cast<uint16_t*>(ob + b_ijk + b_h), static_cast<uint64_t>(n_out));
+  HG_HIP_CHECK(hipGetLastError());
+  HG_HIP_CHECK(hipMemcpyAsync(ijk, ob, b_ijk, hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipMemcpyAsync(tsd, ob + b_ijk, n_out * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipMemcpyAsync(weight, ob + b_ijk + b_h, n_out * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipStreamSynchronize(s));
+  return HG_OK;
+}
+
+int hg_grid_count(hg_grid* g, size_t* count) {
+  if (!g || !count) return HG_ERR_INVALID;
+  return export_impl(g, nullptr, nullptr, nullptr, 0, count);
+}
+
+int hg_grid_export(hg_grid* g, int32_t* ijk, uint16_t* tsd, uint16_t* weight, size_t cap,
+                   size_t* count) {
+  if (!g || !count || (cap && (!ijk || !tsd || !weight))) return HG_ERR_INVALID;
+  return export_impl(g, ijk, tsd, weight, cap, count);
+}
+
+int hg_grid_block_arrays(hg_grid* g, void** keys_dev, void** voxels_dev, uint32_t* num_blocks) {
+  if (!g || !keys_dev || !voxels_dev || !num_blocks) return HG_ERR_INVALID;
+  *keys_dev = g->view.block_keys;
+  *voxels_dev = g->view.voxels;
+  return hg_grid_num_blocks(g, num_blocks);
+}
+
+int hg_grid_import_blocks(hg_grid* g, const void* keys, const void* voxels, uint32_t nb,
+                          int memspace) {
+  if (!g || (nb && (!keys || !voxels))) return HG_ERR_INVALID;
+  if (nb == 0) return HG_OK;
+  hipStream_t s = g->ctx->stream;
+  const unsigned long long* d_keys = static_cast<const unsigned long long*>(keys);
+  const uint32_t* d_vox = static_cast<const uint32_t*>(voxels);
+  if (memspace == HG_HOST) {
+    DeviceBuffer& b = g->ctx->ws_temp;
+    const size_t bk = nb * sizeof(unsigned long long), bv = static_cast<size_t>(nb) * 2048;
+    int rc = b.reserve(bk + bv);
+    if (rc != HG_OK) return rc;
+    HG_HIP_CHECK(hipMemcpyAsync(b.as<char>() + bv, keys, bk, hipMemcpyHostToDevice, s));
+    HG_HIP_CHECK(hipMemcpyAsync(b.as<char>(), voxels, bv, hipMemcpyHostToDevice, s));
+    d_keys = reinterpret_cast<const unsigned long long*>(b.as<char>() + bv);
+    d_vox = reinterpret_cast<const uint32_t*>(b.as<char>());
+  }
+  const unsigned wg = 256, per = wg / kWave;
+  hipLaunchKernelGGL(k_import_blocks, dim3((nb + per - 1) / per), dim3(wg), 0, s, g->view, d_keys,
+                     d_vox, nb);
+  HG_HIP_CHECK(hipGetLastError());
+  uint32_t c[8];
+  int rc = read_counters(g, c);
+  if (rc != HG_OK) return rc;
+  if (c[1] & kFlagCapacity) return HG_ERR_CAPACITY;
+  return HG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+/* hg_mi355x.h — C ABI of the MI355X (gfx950) TSDF insertion + TSDF scan-matching path.
+ *
+ * Drop-in boundary behind HectorGrapher's C++ seams (all paths relative to
+ * /root/reference/cartographer/):
+ *   - hg_grid_*          replaces  mapping/3d/hybrid_grid_tsdf.h:59-134 (HybridGridTSDF storage,
+ *                                  codec mapping/2d/tsd_value_converter.h:39-67, indexing
+ *                                  mapping/3d/hybrid_grid_base.h:428-446, iteration :304-372)
+ *   - hg_grid_insert*    replaces  RangeDataInserterInterface::Insert
+ *                                  (mapping/range_data_inserter_interface.h:37-45) as implemented by
+ *                                  TSDFRangeDataInserter3D::Insert
+ *                                  (mapping/3d/tsdf_range_data_inserter_3d.cc:395-737), with the
+ *                                  optional frame change of Submap3D::InsertData
+ *                                  (mapping/3d/submap_3d.cc:436-437)
+ *   - hg_problem_*       replaces  the ceres::Problem that OptimizingLocalTrajectoryBuilder builds
+ *                                  from the TSDF cost functions and hands to ceres::Solve
+ *                                  (mapping/internal/3d/optimizing_local_trajectory_builder.cc:
+ *                                  323-511,1238-1291; cost functors
+ *                                  mapping/internal/3d/scan_matching/{,interpolated_}{,multi_resolution_}tsdf_space_cost_function_3d.h)
+ *   - hg_match_*         replaces  CeresScanMatcher3D::{Match,Evaluate} for one TSDF block
+ *                                  (mapping/internal/3d/scan_matching/ceres_scan_matcher_3d.cc:72-118)
+ *
+ * Conventions: every function returns an int status (HG_OK = 0, negative = error); nothing
+ * aborts or throws. Handles are not thread-safe; all work of a context runs on one HIP stream.
+ * Pointers are plain host pointers unless the parameter says `memspace`, where HG_DEVICE means
+ * a device pointer valid on the context's device. Poses are (t.x t.y t.z q.w q.x q.y q.z).
+ */
+#ifndef HG_MI355X_H_
+#define HG_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hg_ctx hg_ctx;
+typedef struct hg_grid hg_grid;
+typedef struct hg_problem hg_problem;
+
+enum {
+  HG_OK = 0,
+  HG_ERR_INVALID = -1,     /* bad argument */
+  HG_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture */
+  HG_ERR_HIP = -3,         /* HIP runtime error, see hg_last_error */
+  HG_ERR_CAPACITY = -4,    /* block pool or hash table full */
+  HG_ERR_UNSUPPORTED = -5, /* option not implemented on the device path */
+  HG_ERR_RANGE = -6        /* cell index outside +-8192 (reference: CHECK_LE(new_bits, 8)) */
+};
+
+enum { HG_HOST = 0, HG_DEVICE = 1 };
+
+/* Insert modes. HG_INSERT_EXACT reproduces the reference's sequential per-voxel update order
+ * bit for bit. */
+enum { HG_INSERT_EXACT = 0 };
+
+/* Fields of proto::TSDFRangeDataInserterOptions3D that the path reads
+ * (mapping/proto/3d/tsdf_range_data_inserter_options_3d.proto:5-49). */
+typedef struct hg_insert_opts {
+  double relative_truncation_distance;
+  double maximum_weight;
+  int32_t num_free_space_voxels;
+  int32_t project_sdf_distance_to_scan_normal;
+  double weight_function_epsilon;
+  double weight_function_sigma;
+  double min_range;
+  double max_range;
+  double insertion_ratio;
+  int32_t normal_computation_method; /* 1 = CLOUD_STRUCTURE */
+  int32_t normal_computation_horizontal_stride;
+  int32_t normal_computation_vertical_stride;
+  int32_t reserved;
+} hg_insert_opts;
+
+typedef struct hg_insert_stats {
+  uint64_t num_hits;    /* returns that reached the ray walk (N_in) */
+  uint64_t num_updates; /* UpdateCell calls applied (U) */
+  uint64_t num_blocks;  /* allocated 8^3 blocks after the call */
+  uint64_t flags;       /* bit0: capacity exceeded, bit1: index out of range */
+} hg_insert_stats;
+
+/* Ceres 1.13 Solver::Options fields the path sets or relies on
+ * (common/ceres_solver_options.cc:35-43 + Ceres defaults). */
+typedef struct hg_solver_opts {
+  int32_t max_num_iterations;
+  int32_t jacobi_scaling;
+  double initial_trust_region_radius;
+  double max_trust_region_radius;
+  double min_trust_region_radius;
+  double min_relative_decrease;
+  double min_lm_diagonal;
+  double max_lm_diagonal;
+  double function_tolerance;
+  double gradient_tolerance;
+  double parameter_tolerance;
+} hg_solver_opts;
+
+/* Subset of ceres::Solver::Summary. */
+typedef struct hg_solver_summary {
+  double initial_cost, final_cost, final_radius;
+  int32_t num_iterations, num_successful_steps, num_unsuccessful_steps;
+  int32_t num_cost_evaluations, num_jacobian_evaluations;
+  int32_t termination_type;   /* 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE */
+  int32_t termination_reason; /* 1 gradient, 2 parameter, 3 function tol, 4 max iter, 5 min radius, 6 invalid steps */
+  int32_t reserved;
+} hg_solver_summary;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t to run on, or NULL to create a private stream. */
+int hg_ctx_create(int device, void* stream, hg_ctx** out);
+int hg_ctx_destroy(hg_ctx* ctx);
+int hg_ctx_synchronize(hg_ctx* ctx);
+void* hg_ctx_stream(hg_ctx* ctx);
+const char* hg_last_error(void);
+const char* hg_version(void);
+
+/* ---- grid: HybridGridTSDF --------------------------------------------------------------- */
+/* max_blocks = capacity of the 8x8x8-voxel block pool (2 KiB per block). */
+int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_distance,
+                   float max_weight, uint32_t max_blocks, hg_grid** out);
+int hg_grid_destroy(hg_grid* grid);
+int hg_grid_clear(hg_grid* grid);
+float hg_grid_resolution(const hg_grid* grid);
+/* SetCell for m cells (host arrays): ijk[m*3], tsd[m], weight[m] floats are encoded by the codec. */
+int hg_grid_set_cells(hg_grid* grid, const int32_t* ijk, size_t m, const float* tsd,
+                      const float* weight);
+/* Raw codes (update marker included, as the reference stores them). Unknown cells read 0/0. */
+int hg_grid_read_cells(hg_grid* grid, const int32_t* ijk, size_t m, uint16_t* tsd,
+                       uint16_t* weight);
+int hg_grid_count(hg_grid* grid, size_t* count);
+/* Non-default voxels in the reference's iterator order (what ToProto emits). */
+int hg_grid_export(hg_grid* grid, int32_t* ijk, uint16_t* tsd, uint16_t* weight, size_t cap,
+                   size_t* count);
+int hg_grid_num_blocks(hg_grid* grid, uint32_t* num_blocks);
+/* Device views for the multi-GPU gather: keys[num_blocks] (u64) and voxels[num_blocks*512] (u32). */
+int hg_grid_block_arrays(hg_grid* grid, void** keys_dev, void** voxels_dev, uint32_t* num_blocks);
+/* Merge blocks (e.g. received from another rank) into this grid; existing blocks are overwritten. */
+int hg_grid_import_blocks(hg_grid* grid, const void* keys, const void* voxels, uint32_t num_blocks,
+                          int memspace);
+
+/* ---- insertion: TSDFRangeDataInserter3D::Insert ----------------------------------------- */
+/* xyz: n x 3 floats in the grid (submap) frame, or — when pose_tq != NULL — in the frame that
+ * pose_tq (float[7], = local_pose().inverse().cast<float>()) maps into the grid frame; the origin
+ * is transformed the same way. */
+int hg_grid_insert(hg_grid* grid, const hg_insert_opts* opts, const float origin[3],
+                   const float* xyz, size_t n, size_t width, const float* pose_tq, int mode,
+                   int memspace, hg_insert_stats* stats);
+/* Stream form: n_scans scans applied in order; scan s owns points [scan_offsets[s], scan_offsets[s+1]).
+ * origins: n_scans x 3, poses_tq: n_scans x 7 or NULL (host arrays); xyz per memspace. */
+int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float* origins,
+                         const float* xyz, const uint64_t* scan_offsets, size_t n_scans,
+                         size_t width, const float* poses_tq, int mode, int memspace,
+                         hg_insert_stats* stats);
+
+/* ---- scan matching: ceres::Problem over TSDF cost functions ----------------------------- */
+int hg_problem_create(hg_ctx* ctx, hg_problem** out);
+int hg_problem_destroy(hg_problem* p);
+/* Returns the pose index (>= 0) or an error. constant != 0: SetParameterBlockConstant. */
+int hg_problem_add_pose(hg_problem* p, const double tq[7], int constant);
+int hg_problem_set_pose(hg_problem* p, int index, const double tq[7]);
+int hg_problem_get_pose(hg_problem* p, int index, double tq[7]);
+/* One residual block. pose_b < 0: [MultiResolution]TSDFSpaceCostFunction3D on pose_a;
+ * pose_b >= 0: Interpolated[MultiResolution]TSDFSpaceCostFunction3D between pose_a and pose_b at
+ * interpolation_ratio. multi_res != 0 selects the InterpolatedMultiResolutionTSDF lookup over
+ * `pyramid` (ascending voxel size), else pyramid[0] with the single-resolution lookup.
+ * The points are copied (HG_HOST) or referenced (HG_DEVICE: must stay valid). */
+int hg_problem_add_block(hg_problem* p, const float* xyz, size_t n, int memspace,
+                         hg_grid* const* pyramid, int levels, int multi_res,
+                         double scaling_factor, int pose_a, int pose_b,
+                         double interpolation_ratio);
+int hg_problem_num_residuals(hg_problem* p);
+int hg_problem_num_columns(hg_problem* p);
+/* ceres::Problem::Evaluate shape: cost = 0.5 |r|^2; residuals[num_residuals]; gradient and JtJ in
+ * the local (tangent) parameterisation, 6 columns per non-constant pose; any output may be NULL. */
+int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* gradient,
+                        double* JtJ);
+int hg_solver_default_opts(hg_solver_opts* opts);
+/* ceres::Solve: Levenberg-Marquardt trust region on the device; poses are updated in place. */
+int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summary* summary);
+
+/* ---- one-block convenience (CeresScanMatcher3D::{Evaluate,Match} shape) ----------------- */
+int hg_match_evaluate(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_res,
+                      const float* xyz, size_t n, int memspace, double scaling_factor,
+                      const double pose0[7], const double* pose1 /* NULL: single pose */,
+                      double interpolation_ratio, double* cost, double* JtJ, double* Jtr,
+                      double* residuals);
+int hg_match_solve(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_res,
+                   const float* xyz, size_t n, int memspace, double scaling_factor,
+                   double pose0[7], double* pose1, int pose0_constant,
+                   double interpolation_ratio, const hg_solver_opts* opts,
+                   hg_solver_summary* summary);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HG_MI355X_H_ */

@@ -1,0 +1,172 @@
+"""GPU parity: HIP TSDF inserter vs the CPU oracle, bit-exact on the uint16 voxel codes."""
+import numpy as np
+import pytest
+
+from hectorgrapher_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_grids_equal(og, gg):
+    o_ijk, o_t, o_w = og.export()
+    g_ijk, g_t, g_w = gg.export()
+    assert len(o_ijk) == len(g_ijk)
+    # same cells in the same (reference iterator) order, identical codes
+    assert np.array_equal(o_ijk, g_ijk)
+    assert np.array_equal(o_t, g_t)
+    assert np.array_equal(o_w, g_w)
+
+
+def test_ka1_axis_aligned_hit(po, hg, ctx):
+    """SURVEY Appendix B KA-1 (x.5 rounding ties at 7.5 and 12.5)."""
+    g = hg.HybridGridTSDF(ctx, 0.1, max_blocks=64)
+    ins = hg.TSDFRangeDataInserter3D()
+    st = ins.Insert(hg.RangeData([0, 0, 0], np.array([[1, 0, 0]], np.float32)), g)
+    assert (st.num_hits, st.num_updates) == (1, 6)
+    ijk = np.array([[x, 0, 0] for x in range(7, 15)], np.int32)
+    t, w = g.read_cells(ijk)
+    assert t.tolist() == [0, 62258, 55705, 49152, 42599, 36046, 32769, 0]
+    assert w.tolist() == [0, 34, 34, 34, 34, 34, 34, 0]
+    ins.Insert(hg.RangeData([0, 0, 0], np.array([[1, 0, 0]], np.float32)), g)
+    t, w = g.read_cells(ijk)
+    assert t.tolist() == [0, 62258, 55705, 49152, 42599, 36046, 32769, 0]
+    assert w.tolist() == [0, 67, 67, 67, 67, 67, 67, 0]
+    np.testing.assert_allclose(g.GetWeight(ijk[1:2]), [2.0142829], rtol=1e-6)
+
+
+def test_unknown_cells(hg, ctx):
+    """KA-2 / hybrid_grid_tsdf_test.cc:31-53."""
+    g = hg.HybridGridTSDF(ctx, 1.0, 0.5, 1.0, max_blocks=64)
+    ijk = np.array([[0, 0, 0], [0, 1, 0], [1, 0, 0], [1, 1, 0], [0, 0, 1], [0, 1, 1], [1, 0, 1],
+                    [1, 1, 1]], np.int32)
+    assert not g.IsKnown(ijk).any()
+    g.SetCell([1, 0, 1], 0.1, 0.5)
+    assert g.IsKnown([[1, 0, 1]])[0]
+    assert abs(g.GetTSD([[1, 0, 1]])[0] - 0.1) < 1e-4
+    assert abs(g.GetWeight([[1, 0, 1]])[0] - 0.5) < 1e-4
+    assert abs(g.GetTSD([[0, 0, 1]])[0] + 0.5) < 1e-4
+    assert abs(g.GetWeight([[0, 0, 1]])[0]) < 1e-4
+
+
+@pytest.mark.parametrize("res", [0.05, 0.10, 0.20, 0.45])
+def test_single_scan_bit_exact(po, hg, ctx, res):
+    pose = synth.pose_k(3)
+    pts = synth.generate_scan(pose, 16, 256, stream=3)
+    loc = synth.transform_points(pose, pts)
+    og = po.Grid(res)
+    gg = hg.HybridGridTSDF(ctx, res, max_blocks=1 << 15)
+    n_in, u = og.insert(pose[:3], loc)
+    st = hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(pose[:3], loc), gg)
+    assert (st.num_hits, st.num_updates) == (n_in, u)
+    assert_grids_equal(og, gg)
+
+
+def test_accumulated_scans_bit_exact(po, hg, ctx):
+    """10 scans into one grid: order-dependent re-quantisation must match after every scan."""
+    from conftest import build_map
+    og, gg = build_map(po, (ctx, hg), [0.10], 16, 625, 10)
+    assert_grids_equal(og[0], gg[0])
+
+
+def test_weight_saturation(po, hg, ctx):
+    """Same hit 1100 times: weights saturate at maximum_weight (2-D precedent:
+    tsdf_range_data_inserter_2d_test.cc:118-143)."""
+    og = po.Grid(0.1)
+    gg = hg.HybridGridTSDF(ctx, 0.1, max_blocks=64)
+    pts = np.tile(np.array([[1.03, 0.02, -0.01]], np.float32), (1100, 1))
+    og.insert([0, 0, 0], pts)
+    hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], pts), gg)
+    assert_grids_equal(og, gg)
+    _, w = gg.export()[1:]
+    assert w.max() == 32767
+
+
+def test_gates_nan_range_ratio(po, hg, ctx):
+    rng = np.random.default_rng(7)
+    pts = (rng.standard_normal((4000, 3)) * 6).astype(np.float32)
+    pts[::37] = np.nan
+    pts[5] = [0.01, 0.0, 0.0]     # below min_range
+    pts[6] = [100.0, 0.0, 0.0]    # beyond max_range
+    kw = dict(insertion_ratio=0.1, min_range=1.0, max_range=12.0)
+    og = po.Grid(0.2)
+    gg = hg.HybridGridTSDF(ctx, 0.2, max_blocks=1 << 14)
+    a = og.insert([0.1, -0.2, 0.3], pts, po.InsertOpts(**kw))
+    st = hg.TSDFRangeDataInserter3D(hg.InsertOpts(**kw)).Insert(hg.RangeData([0.1, -0.2, 0.3], pts), gg)
+    assert (st.num_hits, st.num_updates) == a
+    assert_grids_equal(og, gg)
+
+
+def test_submap_pose_transform(po, hg, ctx):
+    """Submap3D::InsertData frame change (submap_3d.cc:436-437) fused on the device."""
+    pose = synth.pose_k(5)
+    pts = synth.generate_scan(pose, 8, 128, stream=5)
+    loc = synth.transform_points(pose, pts)
+    inv = synth.pose_inverse(synth.pose_k(2)).astype(np.float32)
+    og = po.Grid(0.1)
+    gg = hg.HybridGridTSDF(ctx, 0.1, max_blocks=1 << 14)
+    og.insert(pose[:3], loc, pose_tq=inv)
+    hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(pose[:3], loc), gg, pose_tq=inv)
+    assert_grids_equal(og, gg)
+
+
+def test_free_space_and_weight_dropoff(po, hg, ctx):
+    """num_free_space_voxels > 0 walks from the origin (:303-307); epsilon < 1 enables the
+    exponential weight (:333-340, double exp => codes compared with 1 LSB slack on weight)."""
+    pose = synth.pose_k(1)
+    pts = synth.generate_scan(pose, 4, 64, stream=9)
+    kw = dict(num_free_space_voxels=1)
+    og = po.Grid(0.2)
+    gg = hg.HybridGridTSDF(ctx, 0.2, max_blocks=1 << 15)
+    og.insert([0, 0, 0], pts, po.InsertOpts(**kw))
+    hg.TSDFRangeDataInserter3D(hg.InsertOpts(**kw)).Insert(hg.RangeData([0, 0, 0], pts), gg)
+    assert_grids_equal(og, gg)
+    kw = dict(weight_function_epsilon=0.5)
+    og = po.Grid(0.2)
+    gg = hg.HybridGridTSDF(ctx, 0.2, max_blocks=1 << 15)
+    og.insert([0, 0, 0], pts, po.InsertOpts(**kw))
+    hg.TSDFRangeDataInserter3D(hg.InsertOpts(**kw)).Insert(hg.RangeData([0, 0, 0], pts), gg)
+    o_ijk, o_t, o_w = og.export()
+    g_ijk, g_t, g_w = gg.export()
+    assert np.array_equal(o_ijk, g_ijk)
+    assert np.abs(o_t.astype(int) - g_t.astype(int)).max() <= 1
+    assert np.abs(o_w.astype(int) - g_w.astype(int)).max() <= 1
+
+
+def test_batch_equals_sequential(po, hg, ctx):
+    """Stream form (hg_grid_insert_batch) == scans inserted one at a time == oracle."""
+    res = 0.1
+    scans, origins, offs = [], [], [0]
+    for k in range(6):
+        pose = synth.pose_k(k)
+        pts = synth.transform_points(pose, synth.generate_scan(pose, 8, 200, stream=k))
+        scans.append(pts)
+        origins.append(pose[:3])
+        offs.append(offs[-1] + len(pts))
+    og = po.Grid(res)
+    for o, p in zip(origins, scans):
+        og.insert(o, p)
+    gg = hg.HybridGridTSDF(ctx, res, max_blocks=1 << 14)
+    hg.TSDFRangeDataInserter3D().InsertBatch(np.array(origins), np.concatenate(scans), offs, gg)
+    assert_grids_equal(og, gg)
+
+
+def test_empty_and_capacity(hg, ctx):
+    g = hg.HybridGridTSDF(ctx, 0.1, max_blocks=4)
+    st = hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], np.zeros((0, 3), np.float32)), g)
+    assert st.num_updates == 0 and g.count() == 0
+    pts = synth.generate_scan(synth.pose_k(0), 8, 128)
+    with pytest.raises(hg.HgError):
+        hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], pts), g)
+
+
+def test_device_resident_input(po, hg, ctx):
+    torch = pytest.importorskip("torch")
+    pose = synth.pose_k(0)
+    pts = synth.generate_scan(pose, 16, 625)
+    og = po.Grid(0.05)
+    og.insert([0, 0, 0], pts)
+    gg = hg.HybridGridTSDF(ctx, 0.05, max_blocks=1 << 16)
+    d = torch.from_numpy(pts).to("cuda:0")
+    torch.cuda.synchronize()
+    hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], d), gg)
+    assert_grids_equal(og, gg)

@@ -1,0 +1,126 @@
+"""GPU parity: HIP residual/normal-equation kernel and on-device LM vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from hectorgrapher_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4     # BASELINE.json: pose vs CPU within 1e-4 m / 1e-4 rad
+POSE_TOL_RAD = 1e-4
+
+
+def rot_angle(qa, qb):
+    d = abs(float(np.dot(qa, qb)))
+    return 2.0 * np.arccos(min(1.0, d))
+
+
+@pytest.fixture(scope="module")
+def maps(po, hg, ctx):
+    from conftest import build_map
+    return build_map(po, (ctx, hg), [0.05, 0.10, 0.20], 16, 625, 10, max_blocks=1 << 16)
+
+
+def query(K=10, rings=16, cols=625):
+    pose = synth.pose_k(K)
+    pts = synth.generate_scan(pose, rings, cols, stream=K)
+    guess = synth.pose_mul(pose, synth.perturbation())
+    return pose, pts, guess
+
+
+def both_problems(po, hg, ctx, maps, levels, multi, pts, poses, constants, pose_b=-1, factor=0.0):
+    og, gg = maps
+    op, gp = po.Problem(), hg.Problem(ctx)
+    for tq, c in zip(poses, constants):
+        op.add_pose(tq, c)
+        gp.add_pose(tq, c)
+    s = 1.0 / np.sqrt(len(pts))
+    op.add_block(pts, [og[l] for l in levels], s, 0, pose_b, factor, multi)
+    gp.add_block(pts, [gg[l] for l in levels], s, 0, pose_b, factor, multi)
+    return op, gp
+
+
+def compare_evaluate(op, gp):
+    c0, r0, J0, g0 = op.evaluate()
+    c1, r1, g1, H1 = gp.evaluate()
+    assert abs(c0 - c1) <= 1e-12 * max(1.0, abs(c0))
+    np.testing.assert_allclose(r1, r0, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(H1, J0.T @ J0, rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("levels,multi", [([1], False), ([0], False), ([0, 1, 2], True)])
+def test_evaluate_single_pose(po, hg, ctx, maps, levels, multi):
+    _, pts, guess = query()
+    op, gp = both_problems(po, hg, ctx, maps, levels, multi, pts, [guess], [False])
+    compare_evaluate(op, gp)
+
+
+def test_evaluate_interpolated_two_poses(po, hg, ctx, maps):
+    _, pts, guess = query()
+    p0 = synth.pose_k(9)
+    op, gp = both_problems(po, hg, ctx, maps, [1], False, pts, [p0, guess], [False, False], 1, 0.7)
+    compare_evaluate(op, gp)
+    op, gp = both_problems(po, hg, ctx, maps, [0, 1, 2], True, pts, [p0, guess], [True, False], 1, 0.35)
+    compare_evaluate(op, gp)
+
+
+@pytest.mark.parametrize("levels,multi", [([1], False), ([0, 1, 2], True)])
+def test_solve_single_pose(po, hg, ctx, maps, levels, multi):
+    truth, pts, guess = query()
+    op, gp = both_problems(po, hg, ctx, maps, levels, multi, pts, [guess], [False])
+    so, sg = op.solve(), gp.solve()
+    a, b = op.get_pose(0), gp.get_pose(0)
+    assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+    assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+    assert so.num_iterations == sg.num_iterations
+    assert so.termination_reason == sg.termination_reason
+    assert so.num_successful_steps == sg.num_successful_steps
+    assert abs(so.final_cost - sg.final_cost) <= 1e-9 * so.final_cost
+    # and the solve actually registers the scan
+    assert np.linalg.norm(b[:3] - truth[:3]) < 0.02 < np.linalg.norm(guess[:3] - truth[:3])
+
+
+def test_solve_two_pose_window(po, hg, ctx, maps):
+    """First control point constant (oltb.cc:1268-1275), scan between the two control points."""
+    truth, pts, guess = query()
+    p0 = synth.pose_k(9)
+    op, gp = both_problems(po, hg, ctx, maps, [1], False, pts, [p0, guess], [True, False], 1, 0.8)
+    so, sg = op.solve(), gp.solve()
+    for i in range(2):
+        a, b = op.get_pose(i), gp.get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+        assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+    assert so.num_iterations == sg.num_iterations
+    np.testing.assert_array_equal(gp.get_pose(0), p0)
+
+
+def test_empty_cloud_and_empty_grid(po, hg, ctx, maps):
+    """KA-3: an empty-cloud block leaves the state untouched; an empty grid gives -tau, zero grad."""
+    _, pts, guess = query()
+    gp = hg.Problem(ctx)
+    gp.add_pose(guess)
+    gp.add_block(np.zeros((0, 3), np.float32), [maps[1][1]], 1.0, 0)
+    s = gp.solve()
+    np.testing.assert_array_equal(gp.get_pose(0), guess)
+    empty = hg.HybridGridTSDF(ctx, 0.1, max_blocks=16)
+    gp = hg.Problem(ctx)
+    gp.add_pose(guess)
+    gp.add_block(pts[:100], [empty], 1.0, 0)
+    c, r, g, H = gp.evaluate()
+    np.testing.assert_allclose(r, -0.25, atol=1e-7)
+    assert np.all(g == 0) and np.all(H == 0)
+
+
+def test_ceres_scan_matcher_shape(po, hg, ctx, maps):
+    truth, pts, guess = query()
+    m = hg.CeresScanMatcher3D(ctx, [1.0, 6.0])
+    pose, summary = m.Match(guess, [(pts, maps[1][1]), (pts[::4], maps[1][2])])
+    op = po.Problem()
+    op.add_pose(guess)
+    op.add_block(pts, [maps[0][1]], 1.0 / np.sqrt(len(pts)), 0)
+    op.add_block(pts[::4], [maps[0][2]], 6.0 / np.sqrt(len(pts[::4])), 0)
+    op.solve()
+    a = op.get_pose(0)
+    assert np.linalg.norm(a[:3] - pose[:3]) < POSE_TOL_M
+    assert rot_angle(a[3:], pose[3:]) < POSE_TOL_RAD
