@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libhg_mi355x.so")
 HG_OK = 0
 HG_HOST, HG_DEVICE = 0, 1
 HG_INSERT_EXACT = 0
+KERNELS = {"ray_count": 0, "ray_expand": 1, "sort": 2, "alloc": 3, "apply": 4, "residuals": 5,
+           "lm": 6, "scan": 7}
 
 ERRORS = {-1: "HG_ERR_INVALID", -2: "HG_ERR_NO_DEVICE", -3: "HG_ERR_HIP", -4: "HG_ERR_CAPACITY",
           -5: "HG_ERR_UNSUPPORTED", -6: "HG_ERR_RANGE"}
@@ -19,10 +21,10 @@ ERRORS = {-1: "HG_ERR_INVALID", -2: "HG_ERR_NO_DEVICE", -3: "HG_ERR_HIP", -4: "H
 # Every symbol include/hg_mi355x.h declares.
 SYMBOLS = [
     "hg_ctx_create", "hg_ctx_destroy", "hg_ctx_synchronize", "hg_ctx_stream", "hg_last_error",
-    "hg_version", "hg_grid_create", "hg_grid_destroy", "hg_grid_clear", "hg_grid_resolution",
+    "hg_version", "hg_prof_enable", "hg_prof_reset", "hg_prof_read", "hg_grid_create", "hg_grid_destroy", "hg_grid_clear", "hg_grid_resolution",
     "hg_grid_set_cells", "hg_grid_read_cells", "hg_grid_count", "hg_grid_export",
     "hg_grid_num_blocks", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
-    "hg_grid_insert_batch", "hg_problem_create", "hg_problem_destroy", "hg_problem_add_pose",
+    "hg_grid_insert_batch", "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
     "hg_problem_set_pose", "hg_problem_get_pose", "hg_problem_add_block",
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
     "hg_solver_default_opts", "hg_problem_solve", "hg_match_evaluate", "hg_match_solve",
@@ -121,6 +123,9 @@ def load():
     L.hg_ctx_stream.argtypes = [vp]
     L.hg_last_error.restype = C.c_char_p
     L.hg_version.restype = C.c_char_p
+    L.hg_prof_enable.argtypes = [vp, i32]
+    L.hg_prof_reset.argtypes = [vp]
+    L.hg_prof_read.argtypes = [vp, i32, P(C.c_uint64), P(f64), P(C.c_uint64)]
     L.hg_grid_create.argtypes = [vp, f32, f32, f32, u32, P(vp)]
     L.hg_grid_destroy.argtypes = [vp]
     L.hg_grid_clear.argtypes = [vp]
@@ -138,6 +143,7 @@ def load():
                                        P(InsertStats)]
     L.hg_problem_create.argtypes = [vp, P(vp)]
     L.hg_problem_destroy.argtypes = [vp]
+    L.hg_problem_reset.argtypes = [vp]
     L.hg_problem_add_pose.argtypes = [vp, vp, i32]
     L.hg_problem_set_pose.argtypes = [vp, i32, vp]
     L.hg_problem_get_pose.argtypes = [vp, i32, vp]

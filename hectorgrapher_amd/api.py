@@ -48,6 +48,22 @@ class Context:
     def synchronize(self):
         check(self._L.hg_ctx_synchronize(self._h), "hg_ctx_synchronize")
 
+    def prof_enable(self, on=True):
+        check(self._L.hg_prof_enable(self._h, int(on)), "hg_prof_enable")
+
+    def prof_reset(self):
+        check(self._L.hg_prof_reset(self._h), "hg_prof_reset")
+
+    def prof_read(self):
+        """{kernel: (launches, total_ms, units)} measured with HIP events on this stream."""
+        out = {}
+        for name, k in _lib.KERNELS.items():
+            n, ms, u = C.c_uint64(), C.c_double(), C.c_uint64()
+            check(self._L.hg_prof_read(self._h, k, C.byref(n), C.byref(ms), C.byref(u)),
+                  "hg_prof_read")
+            out[name] = (n.value, ms.value, u.value)
+        return out
+
     @property
     def stream(self):
         return self._L.hg_ctx_stream(self._h)
@@ -270,6 +286,10 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+    def reset(self):
+        check(self._L.hg_problem_reset(self._h), "hg_problem_reset")
+        self._keep = []
 
     def add_pose(self, tq, constant=False):
         tq = _host(tq, np.float64)

@@ -115,6 +115,21 @@ extern "C" {
 const char* hg_last_error(void) { return g_last_error.c_str(); }
 const char* hg_version(void) { return "hectorgrapher_amd 0.1 (gfx950)"; }
 
+static void prof_resolve(hg_ctx* c) {
+  (void)hipStreamSynchronize(c->stream);
+  for (ProfRecord& r : c->prof_records) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      c->prof_ms[r.kernel] += ms;
+      c->prof_launches[r.kernel] += 1;
+      c->prof_units[r.kernel] += r.units;
+    }
+    c->prof_free_events.push_back(r.start);
+    c->prof_free_events.push_back(r.stop);
+  }
+  c->prof_records.clear();
+}
+
 int hg_ctx_create(int device, void* stream, hg_ctx** out) {
   if (!out) return HG_ERR_INVALID;
   *out = nullptr;
@@ -154,6 +169,8 @@ int hg_ctx_destroy(hg_ctx* c) {
                           &c->ws_offsets, &c->ws_keys_a, &c->ws_keys_b, &c->ws_vals_a,
                           &c->ws_vals_b, &c->ws_temp, &c->ws_misc})
     b->release();
+  prof_resolve(c);
+  for (hipEvent_t e : c->prof_free_events) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -167,6 +184,33 @@ int hg_ctx_synchronize(hg_ctx* c) {
 }
 
 void* hg_ctx_stream(hg_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int hg_prof_enable(hg_ctx* c, int on) {
+  if (!c) return HG_ERR_INVALID;
+  prof_resolve(c);
+  c->prof_on = on != 0;
+  return HG_OK;
+}
+
+int hg_prof_reset(hg_ctx* c) {
+  if (!c) return HG_ERR_INVALID;
+  prof_resolve(c);
+  for (int i = 0; i < 16; ++i) {
+    c->prof_ms[i] = 0;
+    c->prof_launches[i] = 0;
+    c->prof_units[i] = 0;
+  }
+  return HG_OK;
+}
+
+int hg_prof_read(hg_ctx* c, int kernel, uint64_t* launches, double* total_ms, uint64_t* units) {
+  if (!c || kernel < 0 || kernel >= HG_K_COUNT) return HG_ERR_INVALID;
+  prof_resolve(c);
+  if (launches) *launches = c->prof_launches[kernel];
+  if (total_ms) *total_ms = c->prof_ms[kernel];
+  if (units) *units = c->prof_units[kernel];
+  return HG_OK;
+}
 
 int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_distance,
                    float max_weight, uint32_t max_blocks, hg_grid** out) {

@@ -255,16 +255,22 @@ int insert_chunk(hg_grid* grid, const InsertParams& p, const ScanTable* h_scans,
   const unsigned wg = 256;
   const unsigned nwg = static_cast<unsigned>((n + wg - 1) / wg);
   HG_HIP_CHECK(hipMemsetAsync(d_counts + n, 0, sizeof(uint32_t), s));
-  hipLaunchKernelGGL(k_ray_count, dim3(nwg), dim3(wg), 0, s, grid->view, p, d_scans, n_scans, d_xyz,
-                     n, d_gate, d_counts);
+  {
+    ProfScope ps(c, HG_K_RAY_COUNT, n);
+    hipLaunchKernelGGL(k_ray_count, dim3(nwg), dim3(wg), 0, s, grid->view, p, d_scans, n_scans,
+                       d_xyz, n, d_gate, d_counts);
+  }
   HG_HIP_CHECK(hipGetLastError());
   // exclusive scan over n+1 counts -> offsets[n] = total number of records
   size_t temp_bytes = 0;
   HG_HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, d_counts, d_offsets, 0ull, n + 1,
                                        rocprim::plus<unsigned long long>(), s));
   if ((rc = c->ws_temp.reserve(temp_bytes)) != HG_OK) return rc;
-  HG_HIP_CHECK(rocprim::exclusive_scan(c->ws_temp.ptr, temp_bytes, d_counts, d_offsets, 0ull, n + 1,
-                                       rocprim::plus<unsigned long long>(), s));
+  {
+    ProfScope ps(c, HG_K_SCAN, n);
+    HG_HIP_CHECK(rocprim::exclusive_scan(c->ws_temp.ptr, temp_bytes, d_counts, d_offsets, 0ull, n + 1,
+                                         rocprim::plus<unsigned long long>(), s));
+  }
   unsigned long long total = 0;
   HG_HIP_CHECK(hipMemcpyAsync(&total, d_offsets + n, sizeof(total), hipMemcpyDeviceToHost, s));
   HG_HIP_CHECK(hipStreamSynchronize(s));
@@ -277,20 +283,32 @@ int insert_chunk(hg_grid* grid, const InsertParams& p, const ScanTable* h_scans,
   unsigned long long* kb = c->ws_keys_b.as<unsigned long long>();
   unsigned long long* va = c->ws_vals_a.as<unsigned long long>();
   unsigned long long* vb = c->ws_vals_b.as<unsigned long long>();
-  hipLaunchKernelGGL(k_ray_expand, dim3(nwg), dim3(wg), 0, s, grid->view, p, d_scans, n_scans, d_xyz,
-                     n, d_gate, d_offsets, ka, va);
+  {
+    ProfScope ps(c, HG_K_RAY_EXPAND, n);
+    hipLaunchKernelGGL(k_ray_expand, dim3(nwg), dim3(wg), 0, s, grid->view, p, d_scans, n_scans,
+                       d_xyz, n, d_gate, d_offsets, ka, va);
+  }
   HG_HIP_CHECK(hipGetLastError());
   // stable LSD radix sort on the 42 key bits (33 block + 9 voxel); dropped records (~0) need bit 42+
   const unsigned end_bit = 43;
   temp_bytes = 0;
   HG_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, ka, kb, va, vb, total, 0u, end_bit, s));
   if ((rc = c->ws_temp.reserve(temp_bytes)) != HG_OK) return rc;
-  HG_HIP_CHECK(rocprim::radix_sort_pairs(c->ws_temp.ptr, temp_bytes, ka, kb, va, vb, total, 0u,
-                                         end_bit, s));
+  {
+    ProfScope ps(c, HG_K_SORT, total);
+    HG_HIP_CHECK(rocprim::radix_sort_pairs(c->ws_temp.ptr, temp_bytes, ka, kb, va, vb, total, 0u,
+                                           end_bit, s));
+  }
   const unsigned nwg_r = static_cast<unsigned>((total + wg - 1) / wg);
-  hipLaunchKernelGGL(k_alloc_blocks, dim3(nwg_r), dim3(wg), 0, s, grid->view, kb, total);
+  {
+    ProfScope ps(c, HG_K_ALLOC, total);
+    hipLaunchKernelGGL(k_alloc_blocks, dim3(nwg_r), dim3(wg), 0, s, grid->view, kb, total);
+  }
   HG_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_apply_runs, dim3(nwg_r), dim3(wg), 0, s, grid->view, p, kb, vb, total);
+  {
+    ProfScope ps(c, HG_K_APPLY, total);
+    hipLaunchKernelGGL(k_apply_runs, dim3(nwg_r), dim3(wg), 0, s, grid->view, p, kb, vb, total);
+  }
   HG_HIP_CHECK(hipGetLastError());
   return HG_OK;
 }

@@ -51,8 +51,22 @@ struct DeviceBuffer {
 
 }  // namespace hg
 
+namespace hg {
+struct ProfRecord {
+  int kernel;
+  unsigned long long units;
+  hipEvent_t start, stop;
+};
+}  // namespace hg
+
 struct hg_ctx {
   int device = 0;
+  bool prof_on = false;
+  std::vector<hg::ProfRecord> prof_records;   // pending (not yet resolved)
+  std::vector<hipEvent_t> prof_free_events;   // recycled events
+  unsigned long long prof_launches[16] = {0};
+  unsigned long long prof_units[16] = {0};
+  double prof_ms[16] = {0};
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // insertion workspace
@@ -60,6 +74,38 @@ struct hg_ctx {
       ws_vals_a, ws_vals_b, ws_temp, ws_misc;
   void* pinned = nullptr;  // small pinned host staging (4 KiB)
 };
+
+namespace hg {
+// Brackets a launch (or library call) with events when profiling is on.
+struct ProfScope {
+  hg_ctx* c;
+  hipEvent_t stop = nullptr;
+  ProfScope(hg_ctx* ctx, int kernel, unsigned long long units) : c(ctx) {
+    if (!c->prof_on) return;
+    ProfRecord r;
+    r.kernel = kernel;
+    r.units = units;
+    auto get = [&]() {
+      hipEvent_t e = nullptr;
+      if (!c->prof_free_events.empty()) {
+        e = c->prof_free_events.back();
+        c->prof_free_events.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    r.start = get();
+    r.stop = get();
+    (void)hipEventRecord(r.start, c->stream);
+    stop = r.stop;
+    c->prof_records.push_back(r);
+  }
+  ~ProfScope() {
+    if (stop) (void)hipEventRecord(stop, c->stream);
+  }
+};
+}  // namespace hg
 
 struct hg_grid {
   hg_ctx* ctx = nullptr;

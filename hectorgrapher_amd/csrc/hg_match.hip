@@ -781,6 +781,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool check_done) {
     pv.levels = static_cast<int>(hb.pyramid.size());
     pv.multi_res = hb.multi_res;
     for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
+    ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n);
     hipLaunchKernelGGL(k_tsdf_residuals, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv, hb.d_xyz,
                        bi.n, bi.scaling, p->d_xf + b,
                        p->partials.as<double>() + static_cast<size_t>(bi.partial_offset) * kAcc,
@@ -839,6 +840,17 @@ int hg_problem_destroy(hg_problem* p) {
   p->partials.release();
   p->residuals.release();
   delete p;
+  return HG_OK;
+}
+
+int hg_problem_reset(hg_problem* p) {
+  if (!p) return HG_ERR_INVALID;
+  (void)hipStreamSynchronize(p->ctx->stream);
+  for (auto& b : p->blocks)
+    if (b.owned) (void)hipFree(b.owned);
+  p->blocks.clear();
+  p->poses.clear();
+  p->constant.clear();
   return HG_OK;
 }
 
@@ -977,7 +989,10 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
   for (int it = 0; it <= max_it; ++it) {
     rc = launch_eval(p, nullptr, true);
     if (rc != HG_OK) return rc;
-    hipLaunchKernelGGL(k_lm, dim3(1), dim3(256), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_STEP);
+    {
+      ProfScope ps(p->ctx, HG_K_LM, 1);
+      hipLaunchKernelGGL(k_lm, dim3(1), dim3(256), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_STEP);
+    }
     HG_HIP_CHECK(hipGetLastError());
   }
   HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmState), hipMemcpyDeviceToHost, s));

@@ -1,0 +1,78 @@
+"""Multi-GPU batch mapping: independent submaps per rank + one gather of finished TSDF blocks.
+
+The path shards only across independent units: inside one submap scans are
+sequentially dependent, so submap s runs on rank s mod world with no communication during
+mapping. The single exchange step is a gather of the occupied 8^3 blocks (8-byte key + 2 KiB
+voxels each) to rank 0: counts first (all_gather), then point-to-point send/recv per peer —
+variable sizes, no reduction (submaps are disjoint). Works on any torch.distributed backend
+(nccl = RCCL over xGMI on the GPU box, gloo in the CPU tests).
+"""
+import torch
+
+
+def shard(num_items, rank, world):
+    """Indices of the independent units (submaps) owned by `rank`."""
+    return list(range(rank, num_items, world))
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch.as_tensor."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def grid_block_tensors(grid, dev):
+    """(keys int64[nb], voxels int32[nb, 512]) tensors aliasing the grid's block pool."""
+    kptr, vptr, nb = grid.block_arrays()
+    if nb == 0:
+        return (torch.empty(0, dtype=torch.int64, device=dev),
+                torch.empty((0, 512), dtype=torch.int32, device=dev))
+    keys = torch.as_tensor(_DevArray(kptr, (nb,), "<i8"), device=dev)
+    vox = torch.as_tensor(_DevArray(vptr, (nb, 512), "<i4"), device=dev)
+    return keys, vox
+
+
+def gather_block_arrays(keys, vox, dist, rank, world, dst=0):
+    """Gathers variable-length (keys[nb], vox[nb,512]) from every rank to `dst`.
+
+    Returns on dst a list over source ranks of (keys, vox); elsewhere None.
+    """
+    dev = keys.device
+    n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    if rank == dst:
+        out = []
+        reqs = []
+        for src in range(world):
+            if src == dst:
+                out.append((keys.clone(), vox.clone()))
+                continue
+            k = torch.empty(counts[src], dtype=torch.int64, device=dev)
+            v = torch.empty((counts[src], 512), dtype=torch.int32, device=dev)
+            out.append((k, v))
+            if counts[src] > 0:
+                reqs.append(dist.irecv(k, src=src))
+                reqs.append(dist.irecv(v, src=src))
+        for r in reqs:
+            r.wait()
+        return out
+    if keys.shape[0] > 0:
+        r1 = dist.isend(keys.contiguous(), dst=dst)
+        r2 = dist.isend(vox.contiguous(), dst=dst)
+        r1.wait()
+        r2.wait()
+    return None
+
+
+def gather_grids(grids, dist, rank, world, dev, dst=0):
+    """Gathers every pyramid level's blocks to `dst`. Returns [level][src_rank] -> (keys, vox)."""
+    out = []
+    for g in grids:
+        g.ctx.synchronize()
+        keys, vox = grid_block_tensors(g, dev)
+        out.append(gather_block_arrays(keys, vox, dist, rank, world, dst))
+    return out

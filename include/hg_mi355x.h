@@ -114,6 +114,18 @@ void* hg_ctx_stream(hg_ctx* ctx);
 const char* hg_last_error(void);
 const char* hg_version(void);
 
+/* ---- per-kernel timing (HIP events on the context's stream) ------------------------------ */
+enum {
+  HG_K_RAY_COUNT = 0, HG_K_RAY_EXPAND = 1, HG_K_SORT = 2, HG_K_ALLOC = 3, HG_K_APPLY = 4,
+  HG_K_RESIDUALS = 5, HG_K_LM = 6, HG_K_SCAN = 7, HG_K_COUNT = 8
+};
+/* on != 0: bracket every launch of the kernels above with hipEvents (costs ~2 event records per
+ * launch). hg_prof_read synchronises the stream and returns launches / summed milliseconds since
+ * the last hg_prof_reset; `units` sums the per-launch work items (points, records). */
+int hg_prof_enable(hg_ctx* ctx, int on);
+int hg_prof_reset(hg_ctx* ctx);
+int hg_prof_read(hg_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);
+
 /* ---- grid: HybridGridTSDF --------------------------------------------------------------- */
 /* max_blocks = capacity of the 8x8x8-voxel block pool (2 KiB per block). */
 int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_distance,
@@ -155,6 +167,9 @@ int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float*
 /* ---- scan matching: ceres::Problem over TSDF cost functions ----------------------------- */
 int hg_problem_create(hg_ctx* ctx, hg_problem** out);
 int hg_problem_destroy(hg_problem* p);
+/* Drops all poses and blocks but keeps the device buffers (one ceres::Problem per solve in the
+ * reference; reuse avoids hipMalloc in the loop). */
+int hg_problem_reset(hg_problem* p);
 /* Returns the pose index (>= 0) or an error. constant != 0: SetParameterBlockConstant. */
 int hg_problem_add_pose(hg_problem* p, const double tq[7], int constant);
 int hg_problem_set_pose(hg_problem* p, int index, const double tq[7]);
