@@ -24,7 +24,8 @@ SYMBOLS = [
     "hg_version", "hg_prof_enable", "hg_prof_reset", "hg_prof_read", "hg_grid_create", "hg_grid_destroy", "hg_grid_clear", "hg_grid_resolution",
     "hg_grid_set_cells", "hg_grid_read_cells", "hg_grid_count", "hg_grid_export",
     "hg_grid_num_blocks", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
-    "hg_grid_insert_batch", "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
+    "hg_grid_insert_batch", "hg_pyramid_insert", "hg_pyramid_insert_batch", "hg_grid_status",
+    "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
     "hg_problem_set_pose", "hg_problem_get_pose", "hg_problem_add_block",
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
     "hg_solver_default_opts", "hg_problem_solve", "hg_match_evaluate", "hg_match_solve",
@@ -141,6 +142,9 @@ def load():
     L.hg_grid_insert.argtypes = [vp, P(InsertOpts), vp, vp, sz, sz, vp, i32, i32, P(InsertStats)]
     L.hg_grid_insert_batch.argtypes = [vp, P(InsertOpts), vp, vp, vp, sz, sz, vp, i32, i32,
                                        P(InsertStats)]
+    L.hg_pyramid_insert.argtypes = [vp, vp, i32, vp, vp, sz, sz, vp, i32, i32, vp]
+    L.hg_pyramid_insert_batch.argtypes = [vp, vp, i32, vp, vp, vp, sz, sz, vp, i32, i32, vp]
+    L.hg_grid_status.argtypes = [vp, P(InsertStats)]
     L.hg_problem_create.argtypes = [vp, P(vp)]
     L.hg_problem_destroy.argtypes = [vp]
     L.hg_problem_reset.argtypes = [vp]

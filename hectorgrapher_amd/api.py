@@ -174,6 +174,12 @@ class HybridGridTSDF:
         _, w = self.read_cells(ijk)
         return w != 0
 
+    def status(self):
+        """Synchronises; returns the last insert's counters and raises on sticky error flags."""
+        st = InsertStats()
+        check(self._L.hg_grid_status(self._h, C.byref(st)), "hg_grid_status")
+        return st
+
     def count(self):
         n = C.c_size_t()
         check(self._L.hg_grid_count(self._h, C.byref(n)), "hg_grid_count")
@@ -262,6 +268,28 @@ class TSDFRangeDataInserter3D:
                                            self.mode, space, C.byref(st)), "hg_grid_insert_batch")
         self.last_stats = st
         return st
+
+
+def insert_pyramid(inserters, range_data, grids, pose_tq=None, want_stats=True):
+    """Submap3D::InsertData shape (submap_3d.cc:427-452): the same range data goes through
+    inserters[l] into grids[l] (high resolution, low resolution, ...) in one fused device pass.
+    Returns a list of InsertStats (or None when want_stats is False: fully asynchronous)."""
+    L = _lib.load()
+    n_l = len(grids)
+    opts = (InsertOpts * n_l)(*[i.options for i in inserters])
+    garr = (C.c_void_p * n_l)(*[g._h for g in grids])
+    origin = range_data.origin
+    pose = None if pose_tq is None else np.ascontiguousarray(pose_tq, np.float32)
+    r = range_data.returns
+    if _is_device(r):
+        n, ptr, space = r.shape[0], r.data_ptr(), _lib.HG_DEVICE
+    else:
+        r = _host(r, np.float32, 3)
+        n, ptr, space = len(r), _p(r), _lib.HG_HOST
+    st = (InsertStats * n_l)() if want_stats else None
+    check(L.hg_pyramid_insert(garr, opts, n_l, _p(origin), ptr, n, range_data.width, _p(pose),
+                              inserters[0].mode, space, st), "hg_pyramid_insert")
+    return list(st) if want_stats else None
 
 
 class Problem:

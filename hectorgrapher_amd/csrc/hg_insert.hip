@@ -146,8 +146,13 @@ __global__ void k_ray_count(GridView g, InsertParams p, const ScanTable* scans, 
     counts[i] = r.valid ? static_cast<uint32_t>(r.n + 1) : 0u;
     hit = r.valid;
   }
+  __shared__ unsigned wg_hits;
+  if (threadIdx.x == 0) wg_hits = 0;
+  __syncthreads();
   const unsigned long long m = __ballot(hit);
-  if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicAdd(&g.counters[2], static_cast<uint32_t>(__popcll(m)));
+  if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicAdd(&wg_hits, static_cast<unsigned>(__popcll(m)));
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_hits) atomicAdd(&g.counters[2], wg_hits);
 }
 
 // key = block_key << 9 | voxel ; value = tsd bits | weight bits << 32
@@ -219,6 +224,265 @@ __global__ void k_apply_runs(GridView g, InsertParams p, const unsigned long lon
   atomicAdd(reinterpret_cast<unsigned long long*>(&g.counters[4]), static_cast<unsigned long long>(applied));
 }
 
+
+// ==========================================================================================
+// Fused pyramid path: all levels of a pyramid in one expand / sort / alloc / apply sequence,
+// fixed 8 record slots per (return, level) so no prefix scan and no host read-back is needed.
+// ==========================================================================================
+constexpr int kMaxInsLevels = 4;
+constexpr int kSlots = 8;  // >= num_samples + 1 for relative_truncation_distance <= 3
+
+struct LevelIns {
+  GridView g;
+  InsertParams p;
+  int base[3];          // block coordinate the 32-bit keys are relative to
+  const uint8_t* gate;  // insertion_ratio decimation mask or nullptr
+};
+struct PyramidIns {
+  LevelIns lv[kMaxInsLevels];
+  int levels;
+  ScanTable scan0;  // the scan when a call carries exactly one (no table upload needed)
+};
+
+enum : uint32_t { kFlagStride = 4u };
+
+// Record key: sorts by (level, block, voxel); equal keys keep generation order (stable sort).
+template <typename K> struct KeyCodec;
+template <> struct KeyCodec<uint32_t> {  // [level:2][rz:7][ry:7][rx:7][voxel:9], level 3 = invalid
+  static constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+  static constexpr unsigned kBits = 32;
+  __device__ static uint32_t make(const LevelIns& L, int level, int cx, int cy, int cz, bool* range_err) {
+    const int rx = ((cx + kIndexOffset) >> 3) - L.base[0] + 64;
+    const int ry = ((cy + kIndexOffset) >> 3) - L.base[1] + 64;
+    const int rz = ((cz + kIndexOffset) >> 3) - L.base[2] + 64;
+    if ((static_cast<unsigned>(rx) | static_cast<unsigned>(ry) | static_cast<unsigned>(rz)) > 127u) {
+      *range_err = true;
+      return kInvalid;
+    }
+    return (static_cast<uint32_t>(level) << 30) | (static_cast<uint32_t>(rz) << 23) |
+           (static_cast<uint32_t>(ry) << 16) | (static_cast<uint32_t>(rx) << 9) | voxel_in_block(cx, cy, cz);
+  }
+  __device__ static bool valid(uint32_t k) { return (k >> 30) != 3u; }
+  __device__ static int level(uint32_t k) { return static_cast<int>(k >> 30); }
+  __device__ static unsigned long long block(const LevelIns& L, uint32_t k) {
+    const unsigned long long bx = static_cast<unsigned long long>(static_cast<int>((k >> 9) & 127u) - 64 + L.base[0]);
+    const unsigned long long by = static_cast<unsigned long long>(static_cast<int>((k >> 16) & 127u) - 64 + L.base[1]);
+    const unsigned long long bz = static_cast<unsigned long long>(static_cast<int>((k >> 23) & 127u) - 64 + L.base[2]);
+    return (bz << 22) | (by << 11) | bx;
+  }
+};
+template <> struct KeyCodec<unsigned long long> {  // [level:2][block key:33][voxel:9]
+  static constexpr unsigned long long kInvalid = ~0ull;
+  static constexpr unsigned kBits = 45;
+  __device__ static unsigned long long make(const LevelIns&, int level, int cx, int cy, int cz, bool*) {
+    return (static_cast<unsigned long long>(level) << 42) | (block_key(cx, cy, cz) << 9) | voxel_in_block(cx, cy, cz);
+  }
+  __device__ static bool valid(unsigned long long k) { return k != kInvalid; }
+  __device__ static int level(unsigned long long k) { return static_cast<int>((k >> 42) & 3ull); }
+  __device__ static unsigned long long block(const LevelIns&, unsigned long long k) {
+    return (k >> 9) & ((1ull << 33) - 1ull);
+  }
+};
+
+// Record value: tsd only (update weight is provably 1: weight_function_epsilon >= 1) or tsd + weight.
+template <typename V> struct ValCodec;
+template <> struct ValCodec<uint32_t> {
+  __device__ static uint32_t make(float tsd, float) { return __float_as_uint(tsd); }
+  __device__ static float tsd(uint32_t v) { return __uint_as_float(v); }
+  __device__ static float weight(uint32_t) { return 1.0f; }
+};
+template <> struct ValCodec<unsigned long long> {
+  __device__ static unsigned long long make(float tsd, float w) {
+    return static_cast<unsigned long long>(__float_as_uint(tsd)) |
+           (static_cast<unsigned long long>(__float_as_uint(w)) << 32);
+  }
+  __device__ static float tsd(unsigned long long v) { return __uint_as_float(static_cast<uint32_t>(v)); }
+  __device__ static float weight(unsigned long long v) { return __uint_as_float(static_cast<uint32_t>(v >> 32)); }
+};
+
+// grid (ceil(n/256), levels): one thread per (return, level) writes its 8 record slots.
+template <typename K, typename V>
+__global__ __launch_bounds__(256) void k_expand_fixed(PyramidIns P, const ScanTable* scans,
+                                                      uint32_t n_scans, const float* xyz,
+                                                      unsigned long long n, K* keys, V* vals,
+                                                      unsigned* wg_hits) {
+  const int level = blockIdx.y;
+  const LevelIns& L = P.lv[level];
+  const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+  __shared__ unsigned s_hits;
+  if (threadIdx.x == 0) s_hits = 0;
+  __syncthreads();
+  bool hit = false;
+  if (i < n) {
+    const ScanTable& sc = (n_scans == 1) ? P.scan0 : scans[find_scan(scans, n_scans, i)];
+    const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
+    K kk[kSlots];
+    V vv[kSlots];
+    bool range_err = false, stride_err = false;
+    if (r.valid && r.n + 1 > kSlots) stride_err = true;
+    hit = r.valid && !stride_err;
+#pragma unroll
+    for (int pos = 0; pos < kSlots; ++pos) {
+      kk[pos] = KeyCodec<K>::kInvalid;
+      vv[pos] = 0;
+      if (hit && pos <= r.n) {
+        int cx, cy, cz;
+        float tsd, w;
+        ray_sample(L.g, L.p, r, pos, cx, cy, cz, tsd, w);
+        if (!cell_in_range(cx, cy, cz)) range_err = true;
+        else if (w != 0.f) kk[pos] = KeyCodec<K>::make(L, level, cx, cy, cz, &range_err);
+        vv[pos] = ValCodec<V>::make(tsd, w);
+      }
+    }
+    if (range_err) atomicOr(&L.g.counters[1], kFlagRange);
+    if (stride_err) atomicOr(&L.g.counters[1], kFlagStride);
+    const unsigned long long o = (static_cast<unsigned long long>(level) * n + i) * kSlots;
+    typedef K __attribute__((ext_vector_type(16 / sizeof(K)))) KVec;
+    typedef V __attribute__((ext_vector_type(16 / sizeof(V)))) VVec;
+    constexpr int kPerK = 16 / sizeof(K), kPerV = 16 / sizeof(V);
+    KVec* ko = reinterpret_cast<KVec*>(keys + o);
+    VVec* vo = reinterpret_cast<VVec*>(vals + o);
+#pragma unroll
+    for (int c = 0; c < kSlots / kPerK; ++c) {
+      KVec t;
+#pragma unroll
+      for (int e = 0; e < kPerK; ++e) t[e] = kk[c * kPerK + e];
+      ko[c] = t;
+    }
+#pragma unroll
+    for (int c = 0; c < kSlots / kPerV; ++c) {
+      VVec t;
+#pragma unroll
+      for (int e = 0; e < kPerV; ++e) t[e] = vv[c * kPerV + e];
+      vo[c] = t;
+    }
+  }
+  const unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
+  __syncthreads();
+  if (threadIdx.x == 0) wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
+}
+
+// After the sort each distinct (level, block) starts exactly one run: that record's thread
+// inserts the block (no two threads insert the same key).
+template <typename K>
+__global__ void k_alloc_sorted(PyramidIns P, const K* keys, unsigned long long n) {
+  const unsigned long long i = blockIdx.x * static_cast<unsigned long long>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const K k = keys[i];
+  if (!KeyCodec<K>::valid(k)) return;
+  if (i > 0 && (keys[i - 1] >> 9) == (k >> 9)) return;
+  const LevelIns& L = P.lv[KeyCodec<K>::level(k)];
+  insert_block_unique(L.g, KeyCodec<K>::block(L, k));
+}
+
+// One wavefront per 64 sorted records. Every run head applies its run sequentially; record
+// values reach the head lane by cross-lane shuffles (coalesced loads, no per-update memory
+// latency). A run that continues past the chunk is finished by its head lane from further
+// 64-record chunks.
+template <typename K, typename V>
+__global__ __launch_bounds__(256) void k_apply_wave(PyramidIns P, const K* __restrict__ keys,
+                                                    const V* __restrict__ vals, unsigned long long n,
+                                                    unsigned* wg_updates /* [gridDim.x][4] */) {
+  __shared__ unsigned s_upd[kMaxInsLevels];
+  if (threadIdx.x < kMaxInsLevels) s_upd[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned long long base = (blockIdx.x * 4ull + (threadIdx.x >> 6)) * kWave;
+  if (base < n) {
+    const unsigned long long i = base + lane;
+    const K k = (i < n) ? keys[i] : KeyCodec<K>::kInvalid;
+    const V v = (i < n) ? vals[i] : V(0);
+    const bool valid = KeyCodec<K>::valid(k);
+    K kprev = __shfl_up(k, 1);
+    bool first = false;
+    if (lane == 0) {
+      if (base == 0) first = true; else kprev = keys[base - 1];
+    }
+    const bool head = valid && (first || k != kprev);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long valids = __ballot(valid);
+    const int nv = __popcll(valids);  // invalid records sort last: valid lanes are a prefix
+    const int lvl = valid ? KeyCodec<K>::level(k) : 0;
+    for (int l = 0; l < P.levels; ++l) {
+      const unsigned long long ml = __ballot(valid && lvl == l);
+      if (lane == 0 && ml) atomicAdd(&s_upd[l], static_cast<unsigned>(__popcll(ml)));
+    }
+    int len = 0;
+    uint32_t* cell = nullptr;
+    uint32_t code = 0;
+    const LevelIns& L = P.lv[lvl];
+    if (head) {
+      const unsigned long long rest = (lane == 63) ? 0ull : (heads >> (lane + 1));
+      const int next = rest ? lane + 1 + __builtin_ctzll(rest) : kWave;
+      len = min(next, nv) - lane;
+      const uint32_t slot = find_block(L.g, KeyCodec<K>::block(L, k));
+      if (slot < L.g.max_blocks) {
+        cell = L.g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + (static_cast<uint32_t>(k) & 511u);
+        code = *cell;
+      }
+    }
+    for (int s = 0; __ballot(head && s < len); ++s) {
+      const V vs = __shfl(v, lane + s);
+      if (head && s < len)
+        code = update_cell(L.g, L.p.maximum_weight, code, ValCodec<V>::tsd(vs), ValCodec<V>::weight(vs));
+    }
+    // continuation of the chunk's last run into the following chunks
+    if (heads != 0ull && nv == kWave) {
+      const int hl = 63 - __builtin_clzll(heads);
+      const K krun = __shfl(k, 63);
+      unsigned long long nb = base + kWave;
+      while (nb < n) {
+        const unsigned long long i2 = nb + lane;
+        const K k2 = (i2 < n) ? keys[i2] : KeyCodec<K>::kInvalid;
+        const V v2 = (i2 < n) ? vals[i2] : V(0);
+        const unsigned long long mm = __ballot(k2 == krun);
+        const int cnt = (mm == ~0ull) ? kWave : __builtin_ctzll(~mm);
+        for (int j = 0; j < cnt; ++j) {
+          const V vj = __shfl(v2, j);
+          if (lane == hl)
+            code = update_cell(L.g, L.p.maximum_weight, code, ValCodec<V>::tsd(vj), ValCodec<V>::weight(vj));
+        }
+        if (cnt < kWave) break;
+        nb += kWave;
+      }
+    }
+    if (head && cell) *cell = code;
+  }
+  __syncthreads();
+  if (threadIdx.x < kMaxInsLevels) wg_updates[blockIdx.x * kMaxInsLevels + threadIdx.x] = s_upd[threadIdx.x];
+}
+
+// Adds the per-workgroup hit / update counts of one call into each level's grid counters.
+__global__ void k_sum_stats(PyramidIns P, const unsigned* wg_hits, unsigned n_expand_wg,
+                            const unsigned* wg_updates, unsigned n_apply_wg) {
+  __shared__ unsigned long long red[256];
+  for (int l = 0; l < P.levels; ++l) {
+    unsigned long long h = 0, u = 0;
+    for (unsigned i = threadIdx.x; i < n_expand_wg; i += blockDim.x) h += wg_hits[l * n_expand_wg + i];
+    for (unsigned i = threadIdx.x; i < n_apply_wg; i += blockDim.x) u += wg_updates[i * kMaxInsLevels + l];
+    red[threadIdx.x] = h;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    const unsigned long long hs = red[0];
+    __syncthreads();
+    red[threadIdx.x] = u;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      P.lv[l].g.counters[2] += static_cast<uint32_t>(hs);
+      *reinterpret_cast<unsigned long long*>(&P.lv[l].g.counters[4]) += red[0];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace hg
 
 using namespace hg;
@@ -239,17 +503,29 @@ void build_gate(double ratio, size_t n, uint8_t* out) {
   }
 }
 
-int insert_chunk(hg_grid* grid, const InsertParams& p, const ScanTable* h_scans, uint32_t n_scans,
-                 const float* d_xyz, unsigned long long n, const uint8_t* d_gate) {
+InsertParams make_params(const hg_insert_opts& o, const hg_grid* grid, bool has_pose) {
+  InsertParams p;
+  p.min_range = o.min_range;
+  p.max_range = o.max_range;
+  p.truncation_distance =
+      static_cast<float>(o.relative_truncation_distance * static_cast<double>(grid->view.resolution));
+  p.maximum_weight = static_cast<float>(o.maximum_weight);
+  p.epsilon = static_cast<float>(o.weight_function_epsilon);
+  p.sigma = static_cast<float>(o.weight_function_sigma);
+  p.free_space = o.num_free_space_voxels > 0 ? 1 : 0;
+  p.has_pose = has_pose ? 1 : 0;
+  return p;
+}
+
+// ---- compaction path (exact record count; any options), one level ---------------------------
+int insert_chunk_compact(hg_grid* grid, const InsertParams& p, const ScanTable* d_scans,
+                         uint32_t n_scans, const float* d_xyz, unsigned long long n,
+                         const uint8_t* d_gate) {
   hg_ctx* c = grid->ctx;
   hipStream_t s = c->stream;
   int rc;
-  if ((rc = c->ws_scan_table.reserve(sizeof(ScanTable) * n_scans)) != HG_OK) return rc;
-  HG_HIP_CHECK(hipMemcpyAsync(c->ws_scan_table.ptr, h_scans, sizeof(ScanTable) * n_scans,
-                              hipMemcpyHostToDevice, s));
   if ((rc = c->ws_counts.reserve(sizeof(uint32_t) * (n + 1))) != HG_OK) return rc;
   if ((rc = c->ws_offsets.reserve(sizeof(unsigned long long) * (n + 1))) != HG_OK) return rc;
-  const ScanTable* d_scans = c->ws_scan_table.as<ScanTable>();
   uint32_t* d_counts = c->ws_counts.as<uint32_t>();
   unsigned long long* d_offsets = c->ws_offsets.as<unsigned long long>();
   const unsigned wg = 256;
@@ -261,7 +537,6 @@ int insert_chunk(hg_grid* grid, const InsertParams& p, const ScanTable* h_scans,
                        d_xyz, n, d_gate, d_counts);
   }
   HG_HIP_CHECK(hipGetLastError());
-  // exclusive scan over n+1 counts -> offsets[n] = total number of records
   size_t temp_bytes = 0;
   HG_HIP_CHECK(rocprim::exclusive_scan(nullptr, temp_bytes, d_counts, d_offsets, 0ull, n + 1,
                                        rocprim::plus<unsigned long long>(), s));
@@ -289,8 +564,7 @@ int insert_chunk(hg_grid* grid, const InsertParams& p, const ScanTable* h_scans,
                        d_xyz, n, d_gate, d_offsets, ka, va);
   }
   HG_HIP_CHECK(hipGetLastError());
-  // stable LSD radix sort on the 42 key bits (33 block + 9 voxel); dropped records (~0) need bit 42+
-  const unsigned end_bit = 43;
+  const unsigned end_bit = 43;  // 33 block + 9 voxel bits; dropped records (~0) differ in bit 42
   temp_bytes = 0;
   HG_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, ka, kb, va, vb, total, 0u, end_bit, s));
   if ((rc = c->ws_temp.reserve(temp_bytes)) != HG_OK) return rc;
@@ -313,22 +587,118 @@ int insert_chunk(hg_grid* grid, const InsertParams& p, const ScanTable* h_scans,
   return HG_OK;
 }
 
+// ---- fused fixed-stride path ----------------------------------------------------------------
+template <typename K, typename V>
+int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans, uint32_t n_scans,
+                       const float* d_xyz, unsigned long long n, bool want_stats) {
+  hipStream_t s = c->stream;
+  const unsigned long long slots = n * static_cast<unsigned long long>(P.levels) * kSlots;
+  int rc;
+  if ((rc = c->ws_keys_a.reserve(sizeof(K) * slots)) != HG_OK) return rc;
+  if ((rc = c->ws_keys_b.reserve(sizeof(K) * slots)) != HG_OK) return rc;
+  if ((rc = c->ws_vals_a.reserve(sizeof(V) * slots)) != HG_OK) return rc;
+  if ((rc = c->ws_vals_b.reserve(sizeof(V) * slots)) != HG_OK) return rc;
+  const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
+  const unsigned nwg_a = static_cast<unsigned>((slots + 255) / 256);
+  if ((rc = c->ws_counts.reserve(sizeof(unsigned) * (static_cast<size_t>(nwg_e) * kMaxInsLevels +
+                                                     static_cast<size_t>(nwg_a) * kMaxInsLevels))) != HG_OK)
+    return rc;
+  unsigned* wg_hits = c->ws_counts.as<unsigned>();
+  unsigned* wg_upd = wg_hits + static_cast<size_t>(nwg_e) * kMaxInsLevels;
+  K* ka = c->ws_keys_a.as<K>();
+  K* kb = c->ws_keys_b.as<K>();
+  V* va = c->ws_vals_a.as<V>();
+  V* vb = c->ws_vals_b.as<V>();
+  {
+    ProfScope ps(c, HG_K_RAY_EXPAND, n * P.levels);
+    hipLaunchKernelGGL((k_expand_fixed<K, V>), dim3(nwg_e, P.levels), dim3(256), 0, s, P, d_scans,
+                       n_scans, d_xyz, n, ka, va, wg_hits);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  unsigned end_bit = KeyCodec<K>::kBits;
+  size_t temp_bytes = 0;
+  HG_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, ka, kb, va, vb, slots, 0u, end_bit, s));
+  if ((rc = c->ws_temp.reserve(temp_bytes)) != HG_OK) return rc;
+  {
+    ProfScope ps(c, HG_K_SORT, slots);
+    HG_HIP_CHECK(rocprim::radix_sort_pairs(c->ws_temp.ptr, temp_bytes, ka, kb, va, vb, slots, 0u,
+                                           end_bit, s));
+  }
+  {
+    ProfScope ps(c, HG_K_ALLOC, slots);
+    hipLaunchKernelGGL((k_alloc_sorted<K>), dim3(nwg_a), dim3(256), 0, s, P, kb, slots);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  {
+    ProfScope ps(c, HG_K_APPLY, slots);
+    hipLaunchKernelGGL((k_apply_wave<K, V>), dim3(nwg_a), dim3(256), 0, s, P, kb, vb, slots, wg_upd);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  if (want_stats) {
+    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, wg_upd, nwg_a);
+    HG_HIP_CHECK(hipGetLastError());
+  }
+  return HG_OK;
+}
+
+int read_stats(hg_grid* grid, hg_insert_stats* out) {
+  uint32_t cnt[8];
+  hipStream_t s = grid->ctx->stream;
+  HG_HIP_CHECK(hipMemcpyAsync(cnt, grid->view.counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipStreamSynchronize(s));
+  hg_insert_stats st;
+  st.num_hits = cnt[2];
+  st.num_updates = static_cast<uint64_t>(cnt[4]) | (static_cast<uint64_t>(cnt[5]) << 32);
+  st.num_blocks = std::min(cnt[0], grid->view.max_blocks);
+  st.flags = cnt[1];
+  grid->last_stats = st;
+  if (out) *out = st;
+  if (cnt[1] & kFlagCapacity) {
+    set_last_error("block pool exhausted: raise max_blocks");
+    return HG_ERR_CAPACITY;
+  }
+  if (cnt[1] & kFlagRange) {
+    set_last_error("cell index outside +-8192 (or outside the 32-bit key window)");
+    return HG_ERR_RANGE;
+  }
+  if (cnt[1] & kFlagStride) {
+    set_last_error("ray produced more than 8 samples on the fixed-stride path");
+    return HG_ERR_UNSUPPORTED;
+  }
+  return HG_OK;
+}
+
+void host_transform(const float* pose, const float* in, float* out) {
+  const float qw = pose[3], qx = pose[4], qy = pose[5], qz = pose[6];
+  const float x = in[0], y = in[1], z = in[2];
+  float ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
+  ux += ux; uy += uy; uz += uz;
+  out[0] = x + qw * ux + (qy * uz - qz * uy) + pose[0];
+  out[1] = y + qw * uy + (qz * ux - qx * uz) + pose[1];
+  out[2] = z + qw * uz + (qx * uy - qy * ux) + pose[2];
+}
+
 }  // namespace
 
 extern "C" {
 
-int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float* origins,
-                         const float* xyz, const uint64_t* scan_offsets, size_t n_scans,
-                         size_t width, const float* poses_tq, int mode, int memspace,
-                         hg_insert_stats* stats) {
+int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                            const float* origins, const float* xyz, const uint64_t* scan_offsets,
+                            size_t n_scans, size_t width, const float* poses_tq, int mode,
+                            int memspace, hg_insert_stats* stats) {
   (void)width;
-  if (!grid || !opts || !origins || !scan_offsets || n_scans == 0) return HG_ERR_INVALID;
+  if (!grids || !opts || levels < 1 || levels > kMaxInsLevels || !origins || !scan_offsets || n_scans == 0)
+    return HG_ERR_INVALID;
   if (mode != HG_INSERT_EXACT) return HG_ERR_UNSUPPORTED;
-  if (opts->project_sdf_distance_to_scan_normal) {
-    set_last_error("project_sdf_distance_to_scan_normal is not implemented on the device path");
-    return HG_ERR_UNSUPPORTED;
+  hg_ctx* c = grids[0] ? grids[0]->ctx : nullptr;
+  if (!c) return HG_ERR_INVALID;
+  for (int l = 0; l < levels; ++l) {
+    if (!grids[l] || grids[l]->ctx != c) return HG_ERR_INVALID;
+    if (opts[l].project_sdf_distance_to_scan_normal) {
+      set_last_error("project_sdf_distance_to_scan_normal is not implemented on the device path");
+      return HG_ERR_UNSUPPORTED;
+    }
   }
-  hg_ctx* c = grid->ctx;
   hipStream_t s = c->stream;
   HG_HIP_CHECK(hipSetDevice(c->device));
   const unsigned long long n_total = scan_offsets[n_scans] - scan_offsets[0];
@@ -336,49 +706,98 @@ int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float*
   for (size_t i = 0; i < n_scans; ++i)
     if (scan_offsets[i + 1] < scan_offsets[i]) return HG_ERR_INVALID;
 
-  InsertParams p;
-  p.min_range = opts->min_range;
-  p.max_range = opts->max_range;
-  p.truncation_distance =
-      static_cast<float>(opts->relative_truncation_distance * static_cast<double>(grid->view.resolution));
-  p.maximum_weight = static_cast<float>(opts->maximum_weight);
-  p.epsilon = static_cast<float>(opts->weight_function_epsilon);
-  p.sigma = static_cast<float>(opts->weight_function_sigma);
-  p.free_space = opts->num_free_space_voxels > 0 ? 1 : 0;
-  p.has_pose = poses_tq ? 1 : 0;
+  // per-call counters (hits, updates) restart; num_blocks and sticky flags stay
+  for (int l = 0; l < levels; ++l)
+    HG_HIP_CHECK(hipMemsetAsync(grids[l]->view.counters + 2, 0, 6 * sizeof(uint32_t), s));
 
-  // reset per-call counters (hits, updates); keep num_blocks and sticky flags
-  HG_HIP_CHECK(hipMemsetAsync(grid->view.counters + 2, 0, 6 * sizeof(uint32_t), s));
-
-  const float* d_xyz = xyz;
-  if (memspace == HG_HOST && n_total) {
-    int rc = c->ws_points.reserve(n_total * 3 * sizeof(float));
-    if (rc != HG_OK) return rc;
-    HG_HIP_CHECK(hipMemcpyAsync(c->ws_points.ptr, xyz + 3 * scan_offsets[0],
-                                n_total * 3 * sizeof(float), hipMemcpyHostToDevice, s));
-    d_xyz = c->ws_points.as<float>();
-  } else if (n_total) {
-    d_xyz = xyz + 3 * scan_offsets[0];
+  const float* d_xyz = nullptr;
+  if (n_total) {
+    if (memspace == HG_HOST) {
+      int rc = c->ws_points.reserve(n_total * 3 * sizeof(float));
+      if (rc != HG_OK) return rc;
+      HG_HIP_CHECK(hipMemcpyAsync(c->ws_points.ptr, xyz + 3 * scan_offsets[0],
+                                  n_total * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+      d_xyz = c->ws_points.as<float>();
+    } else {
+      d_xyz = xyz + 3 * scan_offsets[0];
+    }
   }
 
-  const uint8_t* d_gate = nullptr;
-  if (opts->insertion_ratio < 1.0 && n_total) {
-    std::vector<uint8_t> gate(n_total);
+  // insertion_ratio decimation masks (host, sequential recurrence on the index only)
+  const uint8_t* d_gate[kMaxInsLevels] = {nullptr, nullptr, nullptr, nullptr};
+  {
+    size_t need = 0;
+    for (int l = 0; l < levels; ++l)
+      if (opts[l].insertion_ratio < 1.0) need += n_total;
+    if (need) {
+      int rc = c->ws_gate.reserve(need);
+      if (rc != HG_OK) return rc;
+      std::vector<uint8_t> gate(n_total);
+      size_t off = 0;
+      for (int l = 0; l < levels; ++l) {
+        if (!(opts[l].insertion_ratio < 1.0)) continue;
+        for (size_t i = 0; i < n_scans; ++i)
+          build_gate(opts[l].insertion_ratio, scan_offsets[i + 1] - scan_offsets[i],
+                     gate.data() + (scan_offsets[i] - scan_offsets[0]));
+        HG_HIP_CHECK(hipMemcpyAsync(c->ws_gate.as<uint8_t>() + off, gate.data(), n_total,
+                                    hipMemcpyHostToDevice, s));
+        HG_HIP_CHECK(hipStreamSynchronize(s));
+        d_gate[l] = c->ws_gate.as<uint8_t>() + off;
+        off += n_total;
+      }
+    }
+  }
+
+  // choose the path
+  bool fixed_ok = true, unit_weight = true;
+  for (int l = 0; l < levels; ++l) {
+    if (opts[l].num_free_space_voxels > 0 || !(opts[l].relative_truncation_distance <= 3.0)) fixed_ok = false;
+    if (!(static_cast<float>(opts[l].weight_function_epsilon) >= 1.0f)) unit_weight = false;
+  }
+  if (!fixed_ok && levels > 1) {
+    // general options: fall back to one compaction pass per level
+    int rc = HG_OK;
+    for (int l = 0; l < levels && rc == HG_OK; ++l)
+      rc = hg_pyramid_insert_batch(grids + l, opts + l, 1, origins, xyz, scan_offsets, n_scans, width,
+                                   poses_tq, mode, memspace, stats ? stats + l : nullptr);
+    return rc;
+  }
+
+  // grid-frame origins (for the 32-bit key window)
+  std::vector<float> go(3 * n_scans);
+  for (size_t i = 0; i < n_scans; ++i) {
+    if (poses_tq) host_transform(poses_tq + 7 * i, origins + 3 * i, go.data() + 3 * i);
+    else std::memcpy(go.data() + 3 * i, origins + 3 * i, 3 * sizeof(float));
+  }
+  bool key32 = fixed_ok && levels <= 3;
+  PyramidIns P;
+  std::memset(&P, 0, sizeof(P));
+  P.levels = levels;
+  for (int l = 0; l < levels; ++l) {
+    LevelIns& L = P.lv[l];
+    L.g = grids[l]->view;
+    L.p = make_params(opts[l], grids[l], poses_tq != nullptr);
+    L.gate = d_gate[l];
+    const float res = L.g.resolution;
+    for (int a = 0; a < 3; ++a) {
+      const long ci = std::lround(go[a] / res);
+      L.base[a] = static_cast<int>((ci + kIndexOffset) >> 3);
+    }
+    // every sample lies within max_range + tau (+1 cell) of its scan origin
+    double reach = 0.0;
     for (size_t i = 0; i < n_scans; ++i)
-      build_gate(opts->insertion_ratio, scan_offsets[i + 1] - scan_offsets[i],
-                 gate.data() + (scan_offsets[i] - scan_offsets[0]));
-    int rc = c->ws_gate.reserve(n_total);
-    if (rc != HG_OK) return rc;
-    HG_HIP_CHECK(hipMemcpyAsync(c->ws_gate.ptr, gate.data(), n_total, hipMemcpyHostToDevice, s));
-    HG_HIP_CHECK(hipStreamSynchronize(s));  // `gate` goes out of scope
-    d_gate = c->ws_gate.as<uint8_t>();
+      for (int a = 0; a < 3; ++a)
+        reach = std::max(reach, static_cast<double>(std::fabs(go[3 * i + a] - go[a])));
+    reach += opts[l].max_range + L.p.truncation_distance + 2.0 * res;
+    if (!(reach / (8.0 * res) < 62.0)) key32 = false;
   }
 
-  // Chunk by scans so a chunk's record workspace stays bounded.
-  const unsigned long long kMaxChunkPoints = 8ull << 20;
+  // chunk by scans so the record workspace stays bounded
+  const unsigned long long kMaxChunkPoints = 4ull << 20;
   std::vector<ScanTable> table;
   size_t s0 = 0;
-  while (s0 < n_scans) {
+  int rc = HG_OK;
+  while (s0 < n_scans && rc == HG_OK) {
     size_t s1 = s0;
     unsigned long long pts = 0;
     table.clear();
@@ -393,33 +812,54 @@ int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float*
       ++s1;
     }
     if (pts > 0) {
+      const ScanTable* d_scans = nullptr;
+      if (table.size() > 1 || !fixed_ok) {
+        if ((rc = c->ws_scan_table.reserve(sizeof(ScanTable) * table.size())) != HG_OK) return rc;
+        HG_HIP_CHECK(hipMemcpyAsync(c->ws_scan_table.ptr, table.data(), sizeof(ScanTable) * table.size(),
+                                    hipMemcpyHostToDevice, s));
+        HG_HIP_CHECK(hipStreamSynchronize(s));  // `table` is reused by the next chunk
+        d_scans = c->ws_scan_table.as<ScanTable>();
+      }
       const unsigned long long first = scan_offsets[s0] - scan_offsets[0];
-      int rc = insert_chunk(grid, p, table.data(), static_cast<uint32_t>(table.size()),
-                            d_xyz + 3 * first, pts, d_gate ? d_gate + first : nullptr);
-      if (rc != HG_OK) return rc;
+      PyramidIns Pc = P;
+      Pc.scan0 = table[0];
+      for (int l = 0; l < levels; ++l)
+        if (Pc.lv[l].gate) Pc.lv[l].gate += first;
+      if (fixed_ok) {
+        const bool ws = stats != nullptr;
+        if (key32 && unit_weight)
+          rc = insert_chunk_fixed<uint32_t, uint32_t>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
+        else if (key32)
+          rc = insert_chunk_fixed<uint32_t, unsigned long long>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
+        else if (unit_weight)
+          rc = insert_chunk_fixed<unsigned long long, uint32_t>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
+        else
+          rc = insert_chunk_fixed<unsigned long long, unsigned long long>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
+      } else {
+        rc = insert_chunk_compact(grids[0], Pc.lv[0].p, d_scans, static_cast<uint32_t>(table.size()),
+                                  d_xyz + 3 * first, pts, Pc.lv[0].gate);
+      }
     }
     s0 = s1;
   }
+  if (rc != HG_OK) return rc;
+  if (stats) {
+    for (int l = 0; l < levels; ++l) {
+      const int r2 = read_stats(grids[l], stats + l);
+      if (r2 != HG_OK) rc = r2;
+    }
+  }
+  return rc;
+}
 
-  uint32_t cnt[8];
-  HG_HIP_CHECK(hipMemcpyAsync(cnt, grid->view.counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
-  HG_HIP_CHECK(hipStreamSynchronize(s));
-  hg_insert_stats st;
-  st.num_hits = cnt[2];
-  st.num_updates = static_cast<uint64_t>(cnt[4]) | (static_cast<uint64_t>(cnt[5]) << 32);
-  st.num_blocks = std::min(cnt[0], grid->view.max_blocks);
-  st.flags = cnt[1];
-  grid->last_stats = st;
-  if (stats) *stats = st;
-  if (cnt[1] & kFlagCapacity) {
-    set_last_error("block pool exhausted: raise max_blocks");
-    return HG_ERR_CAPACITY;
-  }
-  if (cnt[1] & kFlagRange) {
-    set_last_error("cell index outside +-8192");
-    return HG_ERR_RANGE;
-  }
-  return HG_OK;
+int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float* origins,
+                         const float* xyz, const uint64_t* scan_offsets, size_t n_scans,
+                         size_t width, const float* poses_tq, int mode, int memspace,
+                         hg_insert_stats* stats) {
+  if (!grid || !opts) return HG_ERR_INVALID;
+  hg_grid* g[1] = {grid};
+  return hg_pyramid_insert_batch(g, opts, 1, origins, xyz, scan_offsets, n_scans, width, poses_tq,
+                                 mode, memspace, stats);
 }
 
 int hg_grid_insert(hg_grid* grid, const hg_insert_opts* opts, const float origin[3],
@@ -429,6 +869,20 @@ int hg_grid_insert(hg_grid* grid, const hg_insert_opts* opts, const float origin
   const uint64_t offsets[2] = {0, n};
   return hg_grid_insert_batch(grid, opts, origin, xyz, offsets, 1, width, pose_tq, mode, memspace,
                               stats);
+}
+
+int hg_pyramid_insert(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                      const float origin[3], const float* xyz, size_t n, size_t width,
+                      const float* pose_tq, int mode, int memspace, hg_insert_stats* stats) {
+  if (!origin) return HG_ERR_INVALID;
+  const uint64_t offsets[2] = {0, n};
+  return hg_pyramid_insert_batch(grids, opts, levels, origin, xyz, offsets, 1, width, pose_tq, mode,
+                                 memspace, stats);
+}
+
+int hg_grid_status(hg_grid* grid, hg_insert_stats* stats) {
+  if (!grid) return HG_ERR_INVALID;
+  return read_stats(grid, stats);
 }
 
 }  // extern "C"

@@ -28,11 +28,14 @@
 namespace hg {
 
 constexpr int kMaxLevels = 4;
-constexpr int kMaxPoses = 8;
+constexpr int kMaxPoses = 6;
 constexpr int kMaxCols = 6 * kMaxPoses;
-constexpr int kMaxBlocks = 32;
+constexpr int kMaxBlocks = 16;
 constexpr int kAcc = 36;  // 28 (upper triangle of 7x7) + 7 + 1
 constexpr int kEvalThreads = 256;
+constexpr int kLmThreads = 64;   // the LM state machine runs in one wavefront
+constexpr int kLmBlock = 256;    // waves 1-3 only help summing the workgroup partials
+constexpr int kStripes = kLmBlock / kAcc;  // 7 stripes x 36 sums
 
 struct PyramidView {
   GridView level[kMaxLevels];
@@ -60,7 +63,9 @@ struct BlockInfo {
 enum { PHASE_INIT = 0, PHASE_CANDIDATE = 1 };
 enum { MODE_PREPARE = 0, MODE_STEP = 1, MODE_ASSEMBLE = 2 };
 
-struct LmState {
+// Scalars and small vectors of the solver; lives in global memory between launches and in LDS
+// while k_lm runs.
+struct LmHead {
   int num_poses, num_blocks, ncols, done;
   int iteration, phase, step_is_successful, reuse_diagonal;
   int invalid_steps, termination_type, termination_reason, num_iterations;
@@ -74,10 +79,13 @@ struct LmState {
   int col[kMaxPoses];
   double scale[kMaxCols], diagonal[kMaxCols], g[kMaxCols], step[kMaxCols], delta[kMaxCols];
   double gc[kMaxCols];
-  double H[kMaxCols * kMaxCols];
-  double Hc[kMaxCols * kMaxCols];
-  double work[kMaxCols * kMaxCols];
   BlockInfo blocks[kMaxBlocks];
+};
+
+struct LmState {
+  LmHead h;
+  double H[kMaxCols * kMaxCols];   // J^T J at x (unscaled), n x n used
+  double Hc[kMaxCols * kMaxCols];  // J^T J at the candidate
 };
 
 // ------------------------------------------------------------------------------------------
@@ -109,9 +117,19 @@ __device__ inline void interpolate_linear(double both_invalid, const D3& q1, con
   }
 }
 
-// One pyramid level. Returns false when the multi-resolution lookup must fall through to the
-// next coarser level (any of the 8 weights is zero).
-__device__ inline bool level_tsd(const GridView& g, bool multi, double x, double y, double z, D3& out) {
+// Geometry + memory addresses of one level's 2x2x2 lookup, split into phases so that the hash
+// probes and the voxel loads of ALL corners (and all pyramid levels) are in flight together:
+// the per-return cost is two memory round trips instead of up to 16 dependent ones.
+struct LevelFetch {
+  double x1, y1, z1, x2, y2, z2;
+  unsigned long long key[8];
+  unsigned long long entry[8];
+  uint32_t vox[8];
+  uint32_t code[8];
+  bool in_range[8];
+};
+
+__device__ inline void fetch_setup(const GridView& g, double x, double y, double z, LevelFetch& f) {
   const float res = g.resolution;
   // CenterOfLowerVoxel (interpolated_tsdf.h:176-192): float centre, compared against the double
   float cx = static_cast<float>(cell_index_1d(static_cast<float>(x), res)) * res;
@@ -120,58 +138,67 @@ __device__ inline bool level_tsd(const GridView& g, bool multi, double x, double
   if (static_cast<double>(cx) > x) cx -= res;
   if (static_cast<double>(cy) > y) cy -= res;
   if (static_cast<double>(cz) > z) cz -= res;
-  const double x1 = cx, y1 = cy, z1 = cz;
-  const double x2 = cx + res, y2 = cy + res, z2 = cz + res;
+  f.x1 = cx; f.y1 = cy; f.z1 = cz;
+  f.x2 = cx + res; f.y2 = cy + res; f.z2 = cz + res;
   const int ix = cell_index_1d(cx, res), iy = cell_index_1d(cy, res), iz = cell_index_1d(cz, res);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    // corner order: c = dx*4 + dy*2 + dz  (111,112,121,122,211,212,221,222)
+    const int px = ix + (c >> 2), py = iy + ((c >> 1) & 1), pz = iz + (c & 1);
+    f.in_range[c] = cell_in_range(px, py, pz);
+    f.key[c] = f.in_range[c] ? block_key(px, py, pz) : 0ull;
+    f.vox[c] = voxel_in_block(px, py, pz);
+  }
+}
+__device__ inline void fetch_probe(const GridView& g, LevelFetch& f) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) f.entry[c] = g.table[hash_key(f.key[c]) & g.table_mask];
+}
+__device__ inline void fetch_voxels(const GridView& g, LevelFetch& f) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t slot = 0xFFFFFFFFu;
+    const unsigned long long e = f.entry[c];
+    if (f.in_range[c] && e != 0ull) {
+      if ((e >> 24) == f.key[c] + 1ull) slot = static_cast<uint32_t>(e & 0xFFFFFFu);
+      else slot = find_block(g, f.key[c]);  // first slot taken by another key: linear probing
+    }
+    f.code[c] = (slot < g.max_blocks)
+                    ? g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + f.vox[c]] : 0u;
+  }
+}
 
-  // 8 voxel codes; corners that share the first corner's block reuse its slot
+// Codec constants + geometry + codes of the level a lane interpolates on.
+struct LevelSel {
+  double x1, y1, z1, x2, y2, z2;
   uint32_t code[8];
-  {
-    const bool in0 = cell_in_range(ix, iy, iz);
-    const unsigned long long key0 = in0 ? block_key(ix, iy, iz) : ~0ull;
-    const uint32_t slot0 = in0 ? find_block(g, key0) : 0xFFFFFFFFu;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      // corner order: c = dx*4 + dy*2 + dz  (111,112,121,122,211,212,221,222)
-      const int px = ix + (c >> 2), py = iy + ((c >> 1) & 1), pz = iz + (c & 1);
-      uint32_t v = 0u;
-      if (cell_in_range(px, py, pz)) {
-        const unsigned long long key = block_key(px, py, pz);
-        const uint32_t slot = (key == key0) ? slot0 : find_block(g, key);
-        if (slot < g.max_blocks)
-          v = g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + voxel_in_block(px, py, pz)];
-      }
-      code[c] = v;
-    }
-  }
+  float tsd_scale, tsd_offset, min_tsd, weight_scale, weight_offset;
+};
+
+__device__ inline float sel_weight(const LevelSel& s, uint32_t code) {
+  const uint32_t v = (code >> 16) & 0x7FFFu;
+  return v == 0 ? 0.f : static_cast<float>(v) * s.weight_scale + s.weight_offset;
+}
+__device__ inline float sel_tsd(const LevelSel& s, uint32_t code) {
+  const uint32_t v = code & 0x7FFFu;
+  return v == 0 ? s.min_tsd : static_cast<float>(v) * s.tsd_scale + s.tsd_offset;
+}
+
+// InterpolatedTSDF::GetTSD (interpolated_tsdf.h:72-116) on the selected level; `both_invalid`
+// is -0.3 (single resolution) or the level's getMinTSD() (multi resolution).
+__device__ inline D3 interp_selected(const LevelSel& s, double both_invalid, double x, double y, double z) {
   double w[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) w[c] = static_cast<double>(value_to_weight(g, code[c] >> 16));
-  double both_invalid;
-  if (multi) {
-    int invalid = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) invalid += (w[c] == 0.0) ? 1 : 0;
-    if (invalid > 0) return false;
-    both_invalid = static_cast<double>(g.min_tsd);
-  } else {
-    bool all_zero = true;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) all_zero = all_zero && (w[c] == 0.0);
-    if (all_zero) {
-      out = {static_cast<double>(g.min_tsd), 0.0, 0.0, 0.0};
-      return true;
-    }
-    both_invalid = -0.3;
-  }
   D3 q[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
-    q[c] = {static_cast<double>(value_to_tsd(g, code[c] & 0xFFFFu)), 0.0, 0.0, 0.0};
-  const double ix_inv = 1.0 / (x2 - x1), iy_inv = 1.0 / (y2 - y1), iz_inv = 1.0 / (z2 - z1);
-  const D3 nx = {(x - x1) / (x2 - x1), ix_inv, 0.0, 0.0};
-  const D3 ny = {(y - y1) / (y2 - y1), 0.0, iy_inv, 0.0};
-  const D3 nz = {(z - z1) / (z2 - z1), 0.0, 0.0, iz_inv};
+  for (int c = 0; c < 8; ++c) {
+    w[c] = static_cast<double>(sel_weight(s, s.code[c]));
+    q[c] = {static_cast<double>(sel_tsd(s, s.code[c])), 0.0, 0.0, 0.0};
+  }
+  // Jet / double: Ceres multiplies by the inverse (jet.h operator/(Jet, T))
+  const double ix_inv = 1.0 / (s.x2 - s.x1), iy_inv = 1.0 / (s.y2 - s.y1), iz_inv = 1.0 / (s.z2 - s.z1);
+  const D3 nx = {(x - s.x1) * ix_inv, ix_inv, 0.0, 0.0};
+  const D3 ny = {(y - s.y1) * iy_inv, 0.0, iy_inv, 0.0};
+  const D3 nz = {(z - s.z1) * iz_inv, 0.0, 0.0, iz_inv};
   D3 q11, q12, q21, q22, q1, q2, qq;
   double w11, w12, w21, w22, w1, w2, ww;
   interpolate_linear(both_invalid, q[0], q[1], w[0], w[1], nz, q11, w11);
@@ -181,19 +208,64 @@ __device__ inline bool level_tsd(const GridView& g, bool multi, double x, double
   interpolate_linear(both_invalid, q11, q12, w11, w12, ny, q1, w1);
   interpolate_linear(both_invalid, q21, q22, w21, w22, ny, q2, w2);
   interpolate_linear(both_invalid, q1, q2, w1, w2, nx, qq, ww);
-  out = qq;
-  return true;
+  return qq;
+}
+
+__device__ inline void select_level(const GridView& g, const LevelFetch& f, LevelSel& s) {
+  s.x1 = f.x1; s.y1 = f.y1; s.z1 = f.z1; s.x2 = f.x2; s.y2 = f.y2; s.z2 = f.z2;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) s.code[c] = f.code[c];
+  s.tsd_scale = g.tsd_scale; s.tsd_offset = g.tsd_offset; s.min_tsd = g.min_tsd;
+  s.weight_scale = g.weight_scale; s.weight_offset = g.weight_offset;
+}
+
+// All levels are fetched together; every lane then interpolates exactly once, on the level the
+// reference would have chosen (first level whose 8 weights are all non-zero, :99-106), so a
+// wavefront does not run the interpolation once per level.
+template <int LEVELS>
+__device__ inline D3 pyramid_tsd_n(const PyramidView& pv, double x, double y, double z) {
+  LevelFetch f[LEVELS];
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) fetch_setup(pv.level[l], x, y, z, f[l]);
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) fetch_probe(pv.level[l], f[l]);
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) fetch_voxels(pv.level[l], f[l]);
+  LevelSel s;
+  select_level(pv.level[0], f[0], s);
+  if (!pv.multi_res) {
+    bool all_zero = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) all_zero = all_zero && ((s.code[c] >> 16) & 0x7FFFu) <= 1u;
+    // weight code 0 (unknown) and code 1 (exactly 0.0) both decode to 0.0
+    const D3 r = interp_selected(s, -0.3, x, y, z);
+    if (all_zero) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :86-89
+    return r;
+  }
+  bool found = false;
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) {
+    bool valid = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) valid = valid && ((f[l].code[c] >> 16) & 0x7FFFu) > 1u;
+    if (!found && valid) {
+      select_level(pv.level[l], f[l], s);
+      found = true;
+    }
+  }
+  const D3 r = interp_selected(s, static_cast<double>(s.min_tsd), x, y, z);
+  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
+  return r;
 }
 
 __device__ inline D3 pyramid_tsd(const PyramidView& pv, double x, double y, double z) {
-  D3 out;
-  if (!pv.multi_res) {
-    level_tsd(pv.level[0], false, x, y, z, out);
-    return out;
+  const int levels = pv.multi_res ? pv.levels : 1;
+  switch (levels) {  // wave-uniform
+    case 1: return pyramid_tsd_n<1>(pv, x, y, z);
+    case 2: return pyramid_tsd_n<2>(pv, x, y, z);
+    case 3: return pyramid_tsd_n<3>(pv, x, y, z);
+    default: return pyramid_tsd_n<4>(pv, x, y, z);
   }
-  for (int l = 0; l < pv.levels; ++l)
-    if (level_tsd(pv.level[l], true, x, y, z, out)) return out;
-  return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};
 }
 
 __device__ inline void cross3(const double* a, const double* b, double* c) {
@@ -414,285 +486,399 @@ __device__ void prepare_block(const BlockInfo& b, const double (*poses)[7], Bloc
   }
 }
 
-__device__ inline void pose_plus(const LmState* S, const double (*x)[7], const double* delta,
-                                 double (*out)[7]) {
-  for (int p = 0; p < S->num_poses; ++p) {
-    if (S->constant[p]) {
-      for (int k = 0; k < 7; ++k) out[p][k] = x[p][k];
-      continue;
-    }
-    const double* d = delta + S->col[p];
-    for (int k = 0; k < 3; ++k) out[p][k] = x[p][k] + d[k];
-    quaternion_plus(x[p] + 3, d + 3, out[p] + 3);
-  }
+// Everything below runs in ONE wavefront: scalars are computed redundantly by every lane,
+// vectors/matrices live in LDS and their loops are spread over the lanes.
+struct LmShared {
+  double stripe[kStripes * kMaxBlocks * kAcc];
+  LmHead h;
+  double H[kMaxCols * kMaxCols];
+  double Hc[kMaxCols * kMaxCols];
+  double A[kMaxCols * kMaxCols];
+  double rhs[kMaxCols], y[kMaxCols];
+  double sums[kMaxBlocks * kAcc];
+  double AM[7 * 12];
+  double red[kLmThreads];
+};
+
+__device__ inline void wave_sync() { __syncthreads(); }  // 64-thread workgroup
+
+__device__ inline double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
 }
 
-__device__ bool cholesky_solve(int n, double* A /*n x n, destroyed*/, const double* b, double* x,
-                               double* y) {
-  for (int j = 0; j < n; ++j) {
-    double d = A[j * n + j];
-    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
-    if (!(d > 0.0) || !isfinite(d)) return false;
-    const double l = sqrt(d);
-    A[j * n + j] = l;
-    for (int i = j + 1; i < n; ++i) {
-      double s = A[i * n + j];
-      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
-      A[i * n + j] = s / l;
+__device__ inline void pose_plus(const LmHead& h, const double (*x)[7], const double* delta,
+                                 double (*out)[7], int lane) {
+  if (lane < h.num_poses) {
+    const int p = lane;
+    if (h.constant[p]) {
+      for (int k = 0; k < 7; ++k) out[p][k] = x[p][k];
+    } else {
+      const double* d = delta + h.col[p];
+      for (int k = 0; k < 3; ++k) out[p][k] = x[p][k] + d[k];
+      double q[4];
+      quaternion_plus(x[p] + 3, d + 3, q);
+      for (int k = 0; k < 4; ++k) out[p][3 + k] = q[k];
     }
   }
+  wave_sync();
+}
+
+// Right-looking Cholesky + column-oriented substitutions on an n x n LDS matrix (n <= 36).
+// Term order per entry equals the sequential left-looking form (k ascending).
+__device__ bool cholesky_solve_wave(int n, double* A, const double* b, double* x, double* y, int lane) {
+  for (int j = 0; j < n; ++j) {
+    const double d = A[j * n + j];
+    if (!(d > 0.0) || !isfinite(d)) return false;  // uniform
+    const double l = sqrt(d);
+    wave_sync();
+    if (lane == 0) A[j * n + j] = l;
+    for (int i = j + 1 + lane; i < n; i += kLmThreads) A[i * n + j] = A[i * n + j] / l;
+    wave_sync();
+    const int m = n - j - 1;
+    for (int idx = lane; idx < m * m; idx += kLmThreads) {
+      const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+      if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
+    }
+    wave_sync();
+  }
+  for (int i = lane; i < n; i += kLmThreads) y[i] = b[i];
+  wave_sync();
   for (int i = 0; i < n; ++i) {
-    double s = b[i];
-    for (int k = 0; k < i; ++k) s -= A[i * n + k] * y[k];
-    y[i] = s / A[i * n + i];
+    if (lane == 0) y[i] = y[i] / A[i * n + i];
+    wave_sync();
+    const double yi = y[i];
+    for (int r = i + 1 + lane; r < n; r += kLmThreads) y[r] -= A[r * n + i] * yi;
+    wave_sync();
   }
   for (int i = n - 1; i >= 0; --i) {
-    double s = y[i];
-    for (int k = i + 1; k < n; ++k) s -= A[k * n + i] * x[k];
-    x[i] = s / A[i * n + i];
+    if (lane == 0) x[i] = y[i] / A[i * n + i];
+    wave_sync();
+    const double xi = x[i];
+    for (int r = lane; r < i; r += kLmThreads) y[r] -= A[i * n + r] * xi;
+    wave_sync();
   }
-  for (int i = 0; i < n; ++i)
-    if (!isfinite(x[i])) return false;
-  return true;
+  bool ok = true;
+  for (int i = 0; i < n; ++i) ok = ok && isfinite(x[i]);
+  return ok;
 }
 
-__device__ inline void finish(LmState* S, int type, int reason) {
-  S->done = 1;
-  S->termination_type = type;
-  S->termination_reason = reason;
+__device__ inline void finish(LmHead& h, int type, int reason) {
+  h.done = 1;
+  h.termination_type = type;
+  h.termination_reason = reason;
 }
 
 // |x - Plus(x, -g)|_inf in the ambient space (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-__device__ double gradient_max_norm(const LmState* S) {
+__device__ double gradient_max_norm(const LmHead& h) {
   double m = 0.0;
-  for (int p = 0; p < S->num_poses; ++p) {
-    if (S->constant[p]) continue;
-    const double* g = S->g + S->col[p];
+  for (int p = 0; p < h.num_poses; ++p) {
+    if (h.constant[p]) continue;
+    const double* g = h.g + h.col[p];
     const double neg[6] = {-g[0], -g[1], -g[2], -g[3], -g[4], -g[5]};
-    for (int k = 0; k < 3; ++k) m = fmax(m, fabs(S->x[p][k] - (S->x[p][k] + neg[k])));
+    for (int k = 0; k < 3; ++k) m = fmax(m, fabs(h.x[p][k] - (h.x[p][k] + neg[k])));
     double q[4];
-    quaternion_plus(S->x[p] + 3, neg + 3, q);
-    for (int k = 0; k < 4; ++k) m = fmax(m, fabs(S->x[p][3 + k] - q[k]));
+    quaternion_plus(h.x[p] + 3, neg + 3, q);
+    for (int k = 0; k < 4; ++k) m = fmax(m, fabs(h.x[p][3 + k] - q[k]));
   }
   return m;
 }
 
 // LevenbergMarquardtStrategy::ComputeStep + TrustRegionMinimizer::ComputeTrustRegionStep,
-// looping over invalid steps (each one is an iteration). Leaves the next candidate in S->cand
-// or terminates.
-__device__ void compute_next_candidate(LmState* S) {
-  const int n = S->ncols;
-  const hg_solver_opts& o = S->opt;
+// looping over invalid steps (each one is an iteration). Leaves the next candidate in h.cand
+// or terminates. Scalar updates of `h` are done by lane 0 between syncs; every lane reads them.
+__device__ void compute_next_candidate(LmShared& S, int lane) {
+  LmHead& h = S.h;
+  const int n = h.ncols;
   while (true) {
-    // FinalizeIterationAndCheckIfMinimizerCanContinue
-    if (S->step_is_successful) ++S->num_successful; else ++S->num_unsuccessful;
-    if (S->iteration >= o.max_num_iterations) return finish(S, 1, 4);
-    if (S->step_is_successful && S->gradient_max_norm <= o.gradient_tolerance) return finish(S, 0, 1);
-    if (S->radius <= o.min_trust_region_radius) return finish(S, 0, 5);
-    ++S->iteration;
-    ++S->num_iterations;
-    S->step_is_successful = 0;
-    if (!S->reuse_diagonal) {
-      for (int k = 0; k < n; ++k) {
-        const double s = S->H[k * n + k] * S->scale[k] * S->scale[k];
-        S->diagonal[k] = fmin(fmax(s, o.min_lm_diagonal), o.max_lm_diagonal);
+    wave_sync();
+    // FinalizeIterationAndCheckIfMinimizerCanContinue (all lanes evaluate the same predicates)
+    const bool stop_iter = h.iteration >= h.opt.max_num_iterations;
+    const bool stop_grad = h.step_is_successful && h.gradient_max_norm <= h.opt.gradient_tolerance;
+    const bool stop_rad = h.radius <= h.opt.min_trust_region_radius;
+    wave_sync();
+    if (lane == 0) {
+      if (h.step_is_successful) ++h.num_successful; else ++h.num_unsuccessful;
+      if (stop_iter) finish(h, 1, 4);
+      else if (stop_grad) finish(h, 0, 1);
+      else if (stop_rad) finish(h, 0, 5);
+      else {
+        ++h.iteration;
+        ++h.num_iterations;
+        h.step_is_successful = 0;
       }
     }
-    double* A = S->work;
-    double* rhs = S->delta;  // reused below
-    for (int a = 0; a < n; ++a) {
-      for (int b = 0; b < n; ++b) A[a * n + b] = S->H[a * n + b] * S->scale[a] * S->scale[b];
-      const double lm = sqrt(S->diagonal[a] / S->radius);
-      A[a * n + a] += lm * lm;
-      rhs[a] = S->g[a] * S->scale[a];
+    wave_sync();
+    if (stop_iter || stop_grad || stop_rad) return;
+    if (!h.reuse_diagonal) {
+      for (int k = lane; k < n; k += kLmThreads) {
+        const double s = S.H[k * n + k] * h.scale[k] * h.scale[k];
+        h.diagonal[k] = fmin(fmax(s, h.opt.min_lm_diagonal), h.opt.max_lm_diagonal);
+      }
     }
-    double y[kMaxCols];
-    bool valid = cholesky_solve(n, A, rhs, S->step, y);
-    S->reuse_diagonal = 1;
+    wave_sync();
+    for (int idx = lane; idx < n * n; idx += kLmThreads) {
+      const int a = idx / n, b = idx % n;
+      double v = S.H[idx] * h.scale[a] * h.scale[b];
+      if (a == b) {
+        const double lm = sqrt(h.diagonal[a] / h.radius);
+        v += lm * lm;
+      }
+      S.A[idx] = v;
+    }
+    for (int a = lane; a < n; a += kLmThreads) S.rhs[a] = h.g[a] * h.scale[a];
+    wave_sync();
+    bool valid = cholesky_solve_wave(n, S.A, S.rhs, h.step, S.y, lane);
+    wave_sync();
     double mcc = 0.0;
     if (valid) {
-      for (int k = 0; k < n; ++k) S->step[k] = -S->step[k];
+      for (int k = lane; k < n; k += kLmThreads) h.step[k] = -h.step[k];
+      wave_sync();
       // model_cost_change = -(step.J^T r + step^T J^T J step / 2) on the scaled system
-      double lin = 0.0, quad = 0.0;
-      for (int a = 0; a < n; ++a) {
-        lin += S->step[a] * S->g[a] * S->scale[a];
+      double part = 0.0;
+      for (int a = lane; a < n; a += kLmThreads) {
         double row = 0.0;
-        for (int b = 0; b < n; ++b) row += S->H[a * n + b] * S->scale[a] * S->scale[b] * S->step[b];
-        quad += S->step[a] * row;
+        for (int b = 0; b < n; ++b) row += S.H[a * n + b] * h.scale[a] * h.scale[b] * h.step[b];
+        part += h.step[a] * (h.g[a] * h.scale[a]) + 0.5 * (h.step[a] * row);
       }
-      mcc = -(lin + 0.5 * quad);
+      mcc = -wave_sum(part);
       valid = mcc > 0.0;
     }
+    wave_sync();
     if (!valid) {
-      if (++S->invalid_steps >= 5) return finish(S, 2, 6);  // max_num_consecutive_invalid_steps
-      S->radius = S->radius / S->decrease_factor;
-      S->decrease_factor *= 2.0;
-      S->reuse_diagonal = 1;
+      const bool fail = (h.invalid_steps + 1) >= 5;  // max_num_consecutive_invalid_steps
+      wave_sync();
+      if (lane == 0) {
+        ++h.invalid_steps;
+        h.reuse_diagonal = 1;
+        if (fail) finish(h, 2, 6);
+        else {
+          h.radius = h.radius / h.decrease_factor;
+          h.decrease_factor *= 2.0;
+        }
+      }
+      wave_sync();
+      if (fail) return;
       continue;
     }
-    S->invalid_steps = 0;
-    S->model_cost_change = mcc;
-    for (int k = 0; k < n; ++k) S->delta[k] = S->step[k] * S->scale[k];
-    pose_plus(S, S->x, S->delta, S->cand);
+    if (lane == 0) {
+      h.reuse_diagonal = 1;
+      h.invalid_steps = 0;
+      h.model_cost_change = mcc;
+    }
+    for (int k = lane; k < n; k += kLmThreads) h.delta[k] = h.step[k] * h.scale[k];
+    wave_sync();
+    pose_plus(h, h.x, h.delta, h.cand, lane);
     return;
   }
 }
 
-// Sums the workgroup partials of every block (all threads), then thread 0 maps them through
-// M into Hc / gc / cand_cost.
-__device__ void assemble(LmState* S, const BlockXform* xf, const double* partials,
-                         double* sums /*LDS [kMaxBlocks*kAcc]*/, double* stripe /*LDS [4][kMaxBlocks*kAcc]*/) {
-  const int n = S->ncols;
-  // thread (k, j): column k of the 36 sums, stripe j of the workgroup partials; fixed order
-  const int stripes = blockDim.x / 64;
-  const int k = threadIdx.x % 64, j = threadIdx.x / 64;
-  for (int b = 0; b < S->num_blocks; ++b) {
-    const BlockInfo& bi = S->blocks[b];
-    if (k < kAcc) {
-      double s = 0.0;
-      if (bi.active)
-        for (unsigned wgi = j; wgi < bi.num_wg; wgi += stripes)
-          s += partials[(static_cast<size_t>(bi.partial_offset) + wgi) * kAcc + k];
-      stripe[(j * kMaxBlocks + b) * kAcc + k] = s;
-    }
-  }
-  __syncthreads();
-  for (int b = 0; b < S->num_blocks; ++b) {
-    if (threadIdx.x < kAcc) {
-      double s = 0.0;
-      for (int jj = 0; jj < stripes; ++jj) s += stripe[(jj * kMaxBlocks + b) * kAcc + threadIdx.x];
-      sums[b * kAcc + threadIdx.x] = s;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  for (int i = 0; i < n * n; ++i) S->Hc[i] = 0.0;
-  for (int i = 0; i < n; ++i) S->gc[i] = 0.0;
-  double cost = 0.0;
-  for (int b = 0; b < S->num_blocks; ++b) {
-    const BlockInfo& bi = S->blocks[b];
-    if (!bi.active) continue;
-    const double* sm = sums + b * kAcc;
-    double A7[7][7];
-    int o = 0;
-    for (int a = 0; a < 7; ++a)
-      for (int c = a; c < 7; ++c) {
-        A7[a][c] = sm[o];
-        A7[c][a] = sm[o];
-        ++o;
+// All 256 threads: thread (stripe j, column k) sums every kStripes-th workgroup partial of
+// column k with 8 loads in flight; the stripes are then added in a fixed order.
+__device__ void reduce_partials(LmShared& S, const double* partials) {
+  const LmHead& h = S.h;
+  const int t = threadIdx.x;
+  const int j = t / kAcc, k = t % kAcc;
+  for (int b = 0; b < h.num_blocks; ++b) {
+    const BlockInfo& bi = h.blocks[b];
+    if (j < kStripes) {
+      double acc = 0.0;
+      if (bi.active) {
+        const double* p = partials + static_cast<size_t>(bi.partial_offset) * kAcc + k;
+        unsigned w = j;
+        for (; w + 7 * kStripes < bi.num_wg; w += 8 * kStripes) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = p[static_cast<size_t>(w + u * kStripes) * kAcc];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; w < bi.num_wg; w += kStripes) acc += p[static_cast<size_t>(w) * kAcc];
       }
+      S.stripe[(j * kMaxBlocks + b) * kAcc + k] = acc;
+    }
+  }
+  __syncthreads();
+  for (int b = 0; b < h.num_blocks; ++b) {
+    if (t < kAcc) {
+      double s = 0.0;
+      for (int jj = 0; jj < kStripes; ++jj) s += S.stripe[(jj * kMaxBlocks + b) * kAcc + t];
+      S.sums[b * kAcc + t] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// Maps the per-block 7x7 sums through M into Hc / gc / cand_cost.
+__device__ void assemble(LmShared& S, const BlockXform* xf, const double* partials, int lane) {
+  LmHead& h = S.h;
+  const int n = h.ncols;
+  // S.sums was filled by reduce_partials (all 256 threads) before the other waves retired
+  for (int i = lane; i < n * n; i += kLmThreads) S.Hc[i] = 0.0;
+  for (int i = lane; i < n; i += kLmThreads) h.gc[i] = 0.0;
+  wave_sync();
+  double cost = 0.0;
+  for (int b = 0; b < h.num_blocks; ++b) {
+    const BlockInfo& bi = h.blocks[b];
+    if (!bi.active) continue;
+    const double* sm = S.sums + b * kAcc;
     cost += sm[35];
     const double* M = xf[b].M;
-    // columns of this block: pose_a -> M[:,0:6], pose_b -> M[:,6:12]
-    int cols[12];
-    for (int c = 0; c < 12; ++c) cols[c] = -1;
-    if (!S->constant[bi.pose_a])
-      for (int c = 0; c < 6; ++c) cols[c] = S->col[bi.pose_a] + c;
-    if (bi.pose_b >= 0 && !S->constant[bi.pose_b])
-      for (int c = 0; c < 6; ++c) cols[6 + c] = S->col[bi.pose_b] + c;
-    double AM[7][12];
-    for (int a = 0; a < 7; ++a)
-      for (int c = 0; c < 12; ++c) {
-        double s = 0.0;
-        for (int k = 0; k < 7; ++k) s += A7[a][k] * M[k * 12 + c];
-        AM[a][c] = s;
+    // AM = A7 * M (7 x 12)
+    for (int idx = lane; idx < 7 * 12; idx += kLmThreads) {
+      const int a = idx / 12, c = idx % 12;
+      double s = 0.0;
+      for (int k = 0; k < 7; ++k) {
+        const int lo = a < k ? a : k, hi = a < k ? k : a;
+        // upper-triangle index of (lo, hi): rows 0..lo-1 hold 7,6,.. entries
+        const int tri = lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo);
+        s += sm[tri] * M[k * 12 + c];
       }
-    for (int c1 = 0; c1 < 12; ++c1) {
-      if (cols[c1] < 0) continue;
-      double gsum = 0.0;
-      for (int k = 0; k < 7; ++k) gsum += M[k * 12 + c1] * sm[28 + k];
-      S->gc[cols[c1]] += gsum;
-      for (int c2 = 0; c2 < 12; ++c2) {
-        if (cols[c2] < 0) continue;
-        double s = 0.0;
-        for (int k = 0; k < 7; ++k) s += M[k * 12 + c1] * AM[k][c2];
-        S->Hc[cols[c1] * n + cols[c2]] += s;
+      S.AM[idx] = s;
+    }
+    wave_sync();
+    const int ca = h.constant[bi.pose_a] ? -1 : h.col[bi.pose_a];
+    const int cb = (bi.pose_b >= 0 && !h.constant[bi.pose_b]) ? h.col[bi.pose_b] : -1;
+    for (int idx = lane; idx < 12 * 12; idx += kLmThreads) {
+      const int c1 = idx / 12, c2 = idx % 12;
+      const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
+      const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
+      if (g1 < 0 || g2 < 0) continue;
+      double s = 0.0;
+      for (int k = 0; k < 7; ++k) s += M[k * 12 + c1] * S.AM[k * 12 + c2];
+      S.Hc[g1 * n + g2] += s;  // (g1, g2) is unique per lane within this block
+    }
+    if (lane < 12) {
+      const int c1 = lane;
+      const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
+      if (g1 >= 0) {
+        double gs = 0.0;
+        for (int k = 0; k < 7; ++k) gs += M[k * 12 + c1] * sm[28 + k];
+        h.gc[g1] += gs;
       }
     }
+    wave_sync();
   }
-  S->cand_cost = 0.5 * cost;
+  if (lane == 0) h.cand_cost = 0.5 * cost;
+  wave_sync();
 }
 
-__global__ __launch_bounds__(256) void k_lm(LmState* S, BlockXform* xf, const double* partials, int mode) {
-  __shared__ double sums[kMaxBlocks * kAcc];
-  __shared__ double stripe[4 * kMaxBlocks * kAcc];
-  if (S->done && mode == MODE_STEP) return;
+__global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials, int mode) {
+  __shared__ LmShared S;
+  const int lane = threadIdx.x;
+  if (mode == MODE_STEP && G->h.done) return;
+  // load the head (8-byte words) and H
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&S.h);
+    for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += kLmBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+  LmHead& h = S.h;
+  const int n = h.ncols;
   if (mode == MODE_PREPARE) {
-    // transforms of every block at S->cand
-    if (threadIdx.x < S->num_blocks) prepare_block(S->blocks[threadIdx.x], S->cand, &xf[threadIdx.x]);
+    if (lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &xf[lane]);
     return;
   }
-  assemble(S, xf, partials, sums, stripe);
-  __syncthreads();
-  if (mode == MODE_ASSEMBLE) return;
-  if (threadIdx.x == 0) {
-    const int n = S->ncols;
-    const hg_solver_opts& o = S->opt;
-    if (S->phase == PHASE_INIT) {
-      // IterationZero: EvaluateGradientAndJacobian at x (= cand)
-      ++S->num_cost_evals;
-      ++S->num_jac_evals;
-      S->x_cost = S->cand_cost;
-      S->initial_cost = S->cand_cost;
-      for (int i = 0; i < n * n; ++i) S->H[i] = S->Hc[i];
-      for (int i = 0; i < n; ++i) S->g[i] = S->gc[i];
-      for (int k = 0; k < n; ++k)
-        S->scale[k] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(S->H[k * n + k])) : 1.0;
-      S->gradient_max_norm = gradient_max_norm(S);
-      S->step_is_successful = 1;
-      S->num_iterations = 1;
-      S->phase = PHASE_CANDIDATE;
-      compute_next_candidate(S);
-    } else {
-      // candidate evaluated
-      ++S->num_cost_evals;
-      // ParameterToleranceReached
-      double sn = 0.0, xn = 0.0;
-      for (int p = 0; p < S->num_poses; ++p) {
-        if (S->constant[p]) continue;
-        for (int k = 0; k < 7; ++k) {
-          const double d = S->x[p][k] - S->cand[p][k];
-          sn += d * d;
-          xn += S->x[p][k] * S->x[p][k];
-        }
-      }
-      sn = sqrt(sn);
-      xn = sqrt(xn);
-      if (sn <= o.parameter_tolerance * (xn + o.parameter_tolerance)) {
-        finish(S, 0, 2);
-      } else {
-        const double cost_change = S->x_cost - S->cand_cost;
-        if (fabs(cost_change) <= o.function_tolerance * S->x_cost) {
-          finish(S, 0, 3);
-        } else {
-          const double relative_decrease = cost_change / S->model_cost_change;
-          if (relative_decrease > o.min_relative_decrease) {
-            // HandleSuccessfulStep: the candidate's normal equations become x's
-            for (int p = 0; p < S->num_poses; ++p)
-              for (int k = 0; k < 7; ++k) S->x[p][k] = S->cand[p][k];
-            S->x_cost = S->cand_cost;
-            for (int i = 0; i < n * n; ++i) S->H[i] = S->Hc[i];
-            for (int i = 0; i < n; ++i) S->g[i] = S->gc[i];
-            ++S->num_jac_evals;
-            S->gradient_max_norm = gradient_max_norm(S);
-            S->step_is_successful = 1;
-            S->radius = S->radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3.0));
-            S->radius = fmin(o.max_trust_region_radius, S->radius);
-            S->decrease_factor = 2.0;
-            S->reuse_diagonal = 0;
-          } else {
-            S->radius = S->radius / S->decrease_factor;
-            S->decrease_factor *= 2.0;
-            S->reuse_diagonal = 1;
-          }
-          compute_next_candidate(S);
-        }
+  reduce_partials(S, partials);
+  if (threadIdx.x >= kLmThreads) return;  // retired waves no longer take part in barriers
+  if (h.phase != PHASE_INIT)
+    for (int i = lane; i < n * n; i += kLmThreads) S.H[i] = G->H[i];
+  assemble(S, xf, partials, lane);
+  if (mode == MODE_ASSEMBLE) {
+    for (int i = lane; i < n * n; i += kLmThreads) G->Hc[i] = S.Hc[i];
+    for (int i = lane; i < n; i += kLmThreads) G->h.gc[i] = h.gc[i];
+    if (lane == 0) G->h.cand_cost = h.cand_cost;
+    return;
+  }
+  bool h_changed = false;
+  if (h.phase == PHASE_INIT) {
+    // IterationZero: EvaluateGradientAndJacobian at x (= cand)
+    for (int i = lane; i < n * n; i += kLmThreads) S.H[i] = S.Hc[i];
+    for (int i = lane; i < n; i += kLmThreads) h.g[i] = h.gc[i];
+    wave_sync();
+    for (int k = lane; k < n; k += kLmThreads)
+      h.scale[k] = h.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(S.H[k * n + k])) : 1.0;
+    wave_sync();
+    const double gmn = gradient_max_norm(h);
+    wave_sync();
+    if (lane == 0) {
+      ++h.num_cost_evals;
+      ++h.num_jac_evals;
+      h.x_cost = h.cand_cost;
+      h.initial_cost = h.cand_cost;
+      h.gradient_max_norm = gmn;
+      h.step_is_successful = 1;
+      h.num_iterations = 1;
+      h.phase = PHASE_CANDIDATE;
+    }
+    h_changed = true;
+    compute_next_candidate(S, lane);
+  } else {
+    // candidate evaluated: ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful
+    double sn = 0.0, xn = 0.0;
+    for (int p = 0; p < h.num_poses; ++p) {
+      if (h.constant[p]) continue;
+      for (int k = 0; k < 7; ++k) {
+        const double d = h.x[p][k] - h.cand[p][k];
+        sn += d * d;
+        xn += h.x[p][k] * h.x[p][k];
       }
     }
+    sn = sqrt(sn);
+    xn = sqrt(xn);
+    const double cost_change = h.x_cost - h.cand_cost;
+    const bool ptol = sn <= h.opt.parameter_tolerance * (xn + h.opt.parameter_tolerance);
+    const bool ftol = fabs(cost_change) <= h.opt.function_tolerance * h.x_cost;
+    const double relative_decrease = cost_change / h.model_cost_change;
+    const bool accept = relative_decrease > h.opt.min_relative_decrease;
+    wave_sync();
+    if (lane == 0) ++h.num_cost_evals;
+    if (ptol) {
+      if (lane == 0) finish(h, 0, 2);
+    } else if (ftol) {
+      if (lane == 0) finish(h, 0, 3);
+    } else {
+      if (accept) {
+        // HandleSuccessfulStep: the candidate's normal equations become x's
+        for (int i = lane; i < n * n; i += kLmThreads) S.H[i] = S.Hc[i];
+        for (int i = lane; i < n; i += kLmThreads) h.g[i] = h.gc[i];
+        if (lane < h.num_poses)
+          for (int k = 0; k < 7; ++k) h.x[lane][k] = h.cand[lane][k];
+        h_changed = true;
+        wave_sync();
+        const double gmn = gradient_max_norm(h);
+        wave_sync();
+        if (lane == 0) {
+          h.x_cost = h.cand_cost;
+          ++h.num_jac_evals;
+          h.gradient_max_norm = gmn;
+          h.step_is_successful = 1;
+          h.radius = h.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3.0));
+          h.radius = fmin(h.opt.max_trust_region_radius, h.radius);
+          h.decrease_factor = 2.0;
+          h.reuse_diagonal = 0;
+        }
+      } else {
+        if (lane == 0) {
+          h.radius = h.radius / h.decrease_factor;
+          h.decrease_factor *= 2.0;
+          h.reuse_diagonal = 1;
+        }
+      }
+      compute_next_candidate(S, lane);
+    }
   }
-  __syncthreads();
-  if (!S->done && threadIdx.x < S->num_blocks)
-    prepare_block(S->blocks[threadIdx.x], S->cand, &xf[threadIdx.x]);
+  wave_sync();
+  if (!h.done && lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &xf[lane]);
+  // store the head and (if it changed) H
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&G->h);
+    for (unsigned i = lane; i < sizeof(LmHead) / 8; i += kLmThreads) dst[i] = src[i];
+  }
+  if (h_changed)
+    for (int i = lane; i < n * n; i += kLmThreads) G->H[i] = S.H[i];
 }
 
 }  // namespace hg
@@ -731,8 +917,9 @@ bool block_active(const hg_problem* p, const hg_problem::Block& b) {
 
 // Fills h_state's static part and uploads it. cand = x = current poses.
 int upload_state(hg_problem* p, const hg_solver_opts* opts) {
-  LmState& S = p->h_state;
-  std::memset(&S, 0, sizeof(S));
+  LmState& ST = p->h_state;
+  std::memset(&ST, 0, sizeof(ST));
+  LmHead& S = ST.h;
   S.num_poses = static_cast<int>(p->poses.size());
   S.num_blocks = static_cast<int>(p->blocks.size());
   int col = 0;
@@ -765,13 +952,13 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   }
   int rc = p->partials.reserve(static_cast<size_t>(std::max(1u, wg_off)) * kAcc * sizeof(double));
   if (rc != HG_OK) return rc;
-  HG_HIP_CHECK(hipMemcpyAsync(p->d_state, &S, sizeof(S), hipMemcpyHostToDevice, p->ctx->stream));
+  HG_HIP_CHECK(hipMemcpyAsync(p->d_state, &ST, sizeof(LmHead), hipMemcpyHostToDevice, p->ctx->stream));
   return HG_OK;
 }
 
 int launch_eval(hg_problem* p, double* d_residuals, bool check_done) {
   hipStream_t s = p->ctx->stream;
-  const LmState& S = p->h_state;
+  const LmHead& S = p->h_state.h;
   for (int b = 0; b < S.num_blocks; ++b) {
     const BlockInfo& bi = S.blocks[b];
     if (!bi.active) continue;
@@ -786,7 +973,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool check_done) {
                        bi.n, bi.scaling, p->d_xf + b,
                        p->partials.as<double>() + static_cast<size_t>(bi.partial_offset) * kAcc,
                        d_residuals ? d_residuals + bi.row_offset : nullptr,
-                       check_done ? &p->d_state->done : nullptr);
+                       check_done ? &p->d_state->h.done : nullptr);
     HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
@@ -953,19 +1140,19 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
     if (rc != HG_OK) return rc;
     d_res = p->residuals.as<double>();
   }
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(256), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_PREPARE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_PREPARE);
   HG_HIP_CHECK(hipGetLastError());
   rc = launch_eval(p, d_res, false);
   if (rc != HG_OK) return rc;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(256), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_ASSEMBLE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_ASSEMBLE);
   HG_HIP_CHECK(hipGetLastError());
   HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmState), hipMemcpyDeviceToHost, s));
   if (d_res) HG_HIP_CHECK(hipMemcpyAsync(residuals, d_res, sizeof(double) * nres, hipMemcpyDeviceToHost, s));
   HG_HIP_CHECK(hipStreamSynchronize(s));
-  const LmState& S = p->h_state;
+  const LmHead& S = p->h_state.h;
   if (cost) *cost = S.cand_cost;
   if (gradient) std::memcpy(gradient, S.gc, sizeof(double) * S.ncols);
-  if (JtJ) std::memcpy(JtJ, S.Hc, sizeof(double) * S.ncols * S.ncols);
+  if (JtJ) std::memcpy(JtJ, p->h_state.Hc, sizeof(double) * S.ncols * S.ncols);
   return HG_OK;
 }
 
@@ -975,7 +1162,7 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
   HG_HIP_CHECK(hipSetDevice(p->ctx->device));
   int rc = upload_state(p, opts);
   if (rc != HG_OK) return rc;
-  const LmState& S0 = p->h_state;
+  const LmHead& S0 = p->h_state.h;
   if (S0.ncols == 0) {
     if (summary) {
       std::memset(summary, 0, sizeof(*summary));
@@ -984,20 +1171,20 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
     return HG_OK;
   }
   const int max_it = S0.opt.max_num_iterations;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(256), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_PREPARE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_PREPARE);
   HG_HIP_CHECK(hipGetLastError());
   for (int it = 0; it <= max_it; ++it) {
     rc = launch_eval(p, nullptr, true);
     if (rc != HG_OK) return rc;
     {
       ProfScope ps(p->ctx, HG_K_LM, 1);
-      hipLaunchKernelGGL(k_lm, dim3(1), dim3(256), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_STEP);
+      hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_STEP);
     }
     HG_HIP_CHECK(hipGetLastError());
   }
-  HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmState), hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmHead), hipMemcpyDeviceToHost, s));
   HG_HIP_CHECK(hipStreamSynchronize(s));
-  const LmState& S = p->h_state;
+  const LmHead& S = p->h_state.h;
   for (int i = 0; i < S.num_poses; ++i) std::memcpy(p->poses[i].data(), S.x[i], sizeof(double) * 7);
   if (summary) {
     summary->initial_cost = S.initial_cost;

@@ -164,6 +164,20 @@ int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float*
                          size_t width, const float* poses_tq, int mode, int memspace,
                          hg_insert_stats* stats);
 
+/* Pyramid form: the same range data inserted into `levels` grids (e.g. the high- and low-resolution
+ * grids of Submap3D::InsertData, submap_3d.cc:441-444) with per-level options opts[levels], in one
+ * fused device pass. stats: array[levels] or NULL. With stats == NULL the call does not synchronise;
+ * errors (capacity, range) then surface at the next hg_grid_status / stats-returning call. */
+int hg_pyramid_insert(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                      const float origin[3], const float* xyz, size_t n, size_t width,
+                      const float* pose_tq, int mode, int memspace, hg_insert_stats* stats);
+int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                            const float* origins, const float* xyz, const uint64_t* scan_offsets,
+                            size_t n_scans, size_t width, const float* poses_tq, int mode,
+                            int memspace, hg_insert_stats* stats);
+/* Synchronises and returns the counters of the last insert call + sticky error flags. */
+int hg_grid_status(hg_grid* grid, hg_insert_stats* stats);
+
 /* ---- scan matching: ceres::Problem over TSDF cost functions ----------------------------- */
 int hg_problem_create(hg_ctx* ctx, hg_problem** out);
 int hg_problem_destroy(hg_problem* p);

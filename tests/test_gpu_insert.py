@@ -170,3 +170,58 @@ def test_device_resident_input(po, hg, ctx):
     torch.cuda.synchronize()
     hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], d), gg)
     assert_grids_equal(og, gg)
+
+
+def test_pyramid_insert_high_low_res_options(po, hg, ctx):
+    """Submap3D::InsertData: same range data through the high- and low-resolution inserters
+    (trajectory_builder_3d.lua:78-93 vs :100-115: different min/max range and insertion_ratio),
+    fused into one device pass."""
+    hi = dict(min_range=0.4, max_range=15.0, insertion_ratio=1.0)
+    lo = dict(min_range=1.0, max_range=60.0, insertion_ratio=0.1)
+    res = [0.10, 0.45]
+    og = [po.Grid(r) for r in res]
+    gg = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 15) for r in res]
+    ins = [hg.TSDFRangeDataInserter3D(hg.InsertOpts(**hi)), hg.TSDFRangeDataInserter3D(hg.InsertOpts(**lo))]
+    for k in range(4):
+        pose = synth.pose_k(k)
+        loc = synth.transform_points(pose, synth.generate_scan(pose, 16, 300, stream=k))
+        a0 = og[0].insert(pose[:3], loc, po.InsertOpts(**hi))
+        a1 = og[1].insert(pose[:3], loc, po.InsertOpts(**lo))
+        st = hg.insert_pyramid(ins, hg.RangeData(pose[:3], loc), gg)
+        assert (st[0].num_hits, st[0].num_updates) == a0
+        assert (st[1].num_hits, st[1].num_updates) == a1
+    for o, g in zip(og, gg):
+        assert_grids_equal(o, g)
+
+
+def test_pyramid_three_levels_async_and_status(po, hg, ctx):
+    res = [0.05, 0.10, 0.20]
+    og = [po.Grid(r) for r in res]
+    gg = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in res]
+    ins = [hg.TSDFRangeDataInserter3D() for _ in res]
+    for k in range(3):
+        pose = synth.pose_k(k)
+        pts = synth.generate_scan(pose, 16, 625, stream=k)
+        for o in og:
+            o.insert(pose[:3], synth.transform_points(pose, pts))
+        # sensor-frame points + pose applied on the device, no stats => no synchronisation
+        assert hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), gg,
+                                 pose_tq=pose.astype(np.float32), want_stats=False) is None
+    for o, g in zip(og, gg):
+        g.status()
+        assert_grids_equal(o, g)
+
+
+def test_far_points_use_wide_keys(po, hg, ctx):
+    """max_range large enough that the 32-bit key window does not fit: 64-bit key path."""
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((3000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts = (d * rng.uniform(1.0, 55.0, (3000, 1))).astype(np.float32)
+    kw = dict(max_range=60.0)
+    og = po.Grid(0.05)
+    gg = hg.HybridGridTSDF(ctx, 0.05, max_blocks=1 << 16)
+    a = og.insert([0, 0, 0], pts, po.InsertOpts(**kw))
+    st = hg.TSDFRangeDataInserter3D(hg.InsertOpts(**kw)).Insert(hg.RangeData([0, 0, 0], pts), gg)
+    assert (st.num_hits, st.num_updates) == a
+    assert_grids_equal(og, gg)
