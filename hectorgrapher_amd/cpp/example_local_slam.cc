@@ -1,0 +1,39 @@
+// example_local_slam.cc — drives the C++ adapter the way GlobalTrajectoryBuilder drives a local
+// trajectory builder (global_trajectory_builder.cc:52-85): AddRangeData per scan, read back poses.
+// Build: g++ -std=c++11 -O2 example_local_slam.cc -L.. -lhg_mi355x -Wl,-rpath,'$ORIGIN/..' -o example_local_slam
+#include <cstdio>
+
+#include "hg_adapter.h"
+
+int main() {
+  using namespace hg_amd;
+  try {
+    Context ctx(0);
+    mapping::LocalTrajectoryBuilder3D::Options options;
+    mapping::LocalTrajectoryBuilder3D builder(&ctx, options);
+    // a box room seen from a sensor moving along x: 16 rings x 360 columns
+    for (int k = 0; k < 5; ++k) {
+      sensor::TimedPointCloudData scan;
+      scan.time = 0.1 * k;
+      const float sx = 0.05f * k;
+      for (int c = 0; c < 360; ++c)
+        for (int r = 0; r < 16; ++r) {
+          const float az = 6.2831853f * c / 360.f, el = (-15.f + 2.f * r) * 0.01745329f;
+          const float d[3] = {std::cos(el) * std::cos(az), std::cos(el) * std::sin(az), std::sin(el)};
+          float t = 1e9f;  // room [-5,5] x [-4,4] x [-1,3] seen from (sx, 0, 0)
+          const float lo[3] = {-5.f - sx, -4.f, -1.f}, hi[3] = {5.f - sx, 4.f, 3.f};
+          for (int a = 0; a < 3; ++a) {
+            if (d[a] > 1e-6f) t = std::fmin(t, hi[a] / d[a]);
+            if (d[a] < -1e-6f) t = std::fmin(t, lo[a] / d[a]);
+          }
+          scan.ranges.push_back({{d[0] * t, d[1] * t, d[2] * t, 0.f}});
+        }
+      auto result = builder.AddRangeData("lidar", scan);
+      if (result) std::printf("scan %d pose %.4f %.4f %.4f\n", k, result->local_pose[0], result->local_pose[1], result->local_pose[2]);
+    }
+  } catch (const Error& e) {
+    std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
+    return 1;
+  }
+  return 0;
+}

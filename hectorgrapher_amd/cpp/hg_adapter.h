@@ -1,0 +1,349 @@
+// hg_adapter.h — C++ host-side adapter over the C ABI (include/hg_mi355x.h).
+//
+// Mirrors the reference's C++ seams for the TSDF hot path so a maintainer can swap the CPU
+// classes for these behind the same call sites (paths relative to /root/reference/cartographer/):
+//   hg_amd::mapping::HybridGridTSDF            mapping/3d/hybrid_grid_tsdf.h:59-134
+//   hg_amd::mapping::TSDFRangeDataInserter3D   mapping/3d/tsdf_range_data_inserter_3d.h (Insert)
+//                                              via mapping/range_data_inserter_interface.h:37-45
+//   hg_amd::mapping::scan_matching::TsdfScanMatcher3D
+//                                              mapping/internal/3d/scan_matching/ceres_scan_matcher_3d.h
+//                                              (Match / Evaluate shape, TSDF blocks only)
+//   hg_amd::mapping::LocalTrajectoryBuilder3D  mapping/internal/3d/local_trajectory_builder_3d.h:46-79
+//                                              (AddImuData / AddRangeData / AddOdometryData /
+//                                              MatchingResult / InsertionResult)
+// Header-only, C++11, no Eigen: poses are std::array<double, 7> (t xyz, q wxyz), points are
+// std::array<float, 3>. Errors throw hg_amd::Error (the reference CHECK-aborts instead).
+#ifndef HG_ADAPTER_H_
+#define HG_ADAPTER_H_
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hg_mi355x.h"
+
+namespace hg_amd {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(const std::string& what, int c) : std::runtime_error(what + ": " + hg_last_error()), code(c) {}
+};
+inline void Check(int rc, const char* what) {
+  if (rc < 0) throw Error(what, rc);
+}
+
+using Pose = std::array<double, 7>;  // t.x t.y t.z q.w q.x q.y q.z
+using Point = std::array<float, 3>;
+
+namespace transform {
+inline Pose Multiply(const Pose& a, const Pose& b) {  // Rigid3d operator* (rigid_transform.h:184-190)
+  const double w = a[3], x = a[4], y = a[5], z = a[6];
+  auto rot = [&](const double* v, double* o) {
+    const double ux = y * v[2] - z * v[1], uy = z * v[0] - x * v[2], uz = x * v[1] - y * v[0];
+    const double tx = ux + ux, ty = uy + uy, tz = uz + uz;
+    o[0] = v[0] + w * tx + (y * tz - z * ty);
+    o[1] = v[1] + w * ty + (z * tx - x * tz);
+    o[2] = v[2] + w * tz + (x * ty - y * tx);
+  };
+  Pose r;
+  rot(&b[0], &r[0]);
+  for (int i = 0; i < 3; ++i) r[i] += a[i];
+  r[3] = w * b[3] - x * b[4] - y * b[5] - z * b[6];
+  r[4] = w * b[4] + x * b[3] + y * b[6] - z * b[5];
+  r[5] = w * b[5] + y * b[3] + z * b[4] - x * b[6];
+  r[6] = w * b[6] + z * b[3] + x * b[5] - y * b[4];
+  const double n = std::sqrt(r[3] * r[3] + r[4] * r[4] + r[5] * r[5] + r[6] * r[6]);
+  for (int i = 3; i < 7; ++i) r[i] /= n;
+  return r;
+}
+inline Pose Inverse(const Pose& a) {  // Rigid3::inverse (rigid_transform.h:159-163)
+  Pose c{{0, 0, 0, a[3], -a[4], -a[5], -a[6]}};
+  Pose t{{-a[0], -a[1], -a[2], 1, 0, 0, 0}};
+  Pose r = Multiply(c, t);
+  r[3] = c[3]; r[4] = c[4]; r[5] = c[5]; r[6] = c[6];
+  return r;
+}
+inline std::array<float, 7> ToFloat(const Pose& p) {
+  std::array<float, 7> f;
+  for (int i = 0; i < 7; ++i) f[i] = static_cast<float>(p[i]);
+  return f;
+}
+}  // namespace transform
+
+namespace sensor {
+struct RangeData {  // sensor/range_data.h:44-57 (misses are unused by the TSDF inserter)
+  Point origin{{0.f, 0.f, 0.f}};
+  std::vector<Point> returns;
+  size_t width = 0;
+};
+struct TimedPointCloudData {  // sensor/timed_point_cloud_data.h:27-32
+  double time = 0.0;
+  Point origin{{0.f, 0.f, 0.f}};
+  std::vector<std::array<float, 4>> ranges;  // xyz + relative time
+};
+struct OdometryData { double time; Pose pose; };
+struct ImuData { double time; std::array<double, 3> linear_acceleration, angular_velocity; };
+}  // namespace sensor
+
+class Context {
+ public:
+  explicit Context(int device = 0, void* stream = nullptr) { Check(hg_ctx_create(device, stream, &ctx_), "hg_ctx_create"); }
+  ~Context() { if (ctx_) hg_ctx_destroy(ctx_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  hg_ctx* get() const { return ctx_; }
+ private:
+  hg_ctx* ctx_ = nullptr;
+};
+
+namespace mapping {
+
+class HybridGridTSDF {
+ public:
+  HybridGridTSDF(Context* ctx, float resolution, float relative_truncation_distance, float max_weight,
+                 uint32_t max_blocks = 1u << 18)
+      : resolution_(resolution) {
+    Check(hg_grid_create(ctx->get(), resolution, relative_truncation_distance, max_weight, max_blocks, &grid_),
+          "hg_grid_create");
+  }
+  ~HybridGridTSDF() { if (grid_) hg_grid_destroy(grid_); }
+  HybridGridTSDF(const HybridGridTSDF&) = delete;
+  HybridGridTSDF& operator=(const HybridGridTSDF&) = delete;
+  float resolution() const { return resolution_; }
+  std::array<int, 3> GetCellIndex(const Point& p) const {
+    return {{static_cast<int>(std::lround(p[0] / resolution_)), static_cast<int>(std::lround(p[1] / resolution_)),
+             static_cast<int>(std::lround(p[2] / resolution_))}};
+  }
+  void SetCell(const std::array<int, 3>& index, float tsd, float weight) {
+    Check(hg_grid_set_cells(grid_, index.data(), 1, &tsd, &weight), "hg_grid_set_cells");
+  }
+  // Raw TSDFVoxel codes; unknown cells read {0, 0}.
+  void ReadCells(const std::vector<std::array<int, 3>>& cells, std::vector<uint16_t>* tsd,
+                 std::vector<uint16_t>* weight) const {
+    tsd->resize(cells.size());
+    weight->resize(cells.size());
+    Check(hg_grid_read_cells(grid_, cells.empty() ? nullptr : cells[0].data(), cells.size(), tsd->data(),
+                             weight->data()), "hg_grid_read_cells");
+  }
+  // What `for (auto it : grid)` / ToProto visits, in the reference iteration order.
+  size_t Export(std::vector<std::array<int, 3>>* cells, std::vector<uint16_t>* tsd, std::vector<uint16_t>* weight) const {
+    size_t n = 0;
+    Check(hg_grid_count(grid_, &n), "hg_grid_count");
+    cells->resize(n); tsd->resize(n); weight->resize(n);
+    if (n) Check(hg_grid_export(grid_, (*cells)[0].data(), tsd->data(), weight->data(), n, &n), "hg_grid_export");
+    return n;
+  }
+  hg_grid* get() const { return grid_; }
+ private:
+  float resolution_;
+  hg_grid* grid_ = nullptr;
+};
+
+// proto::TSDFRangeDataInserterOptions3D defaults of configuration_files/trajectory_builder_3d.lua:78-93
+inline hg_insert_opts DefaultTSDFInserterOptions() {
+  hg_insert_opts o{};
+  o.relative_truncation_distance = 2.5; o.maximum_weight = 1000.; o.num_free_space_voxels = 0;
+  o.project_sdf_distance_to_scan_normal = 0; o.weight_function_epsilon = 1.0; o.weight_function_sigma = 4.;
+  o.min_range = 0.4; o.max_range = 15.0; o.insertion_ratio = 1.0; o.normal_computation_method = 1;
+  o.normal_computation_horizontal_stride = 5; o.normal_computation_vertical_stride = 1;
+  return o;
+}
+
+class TSDFRangeDataInserter3D {
+ public:
+  explicit TSDFRangeDataInserter3D(const hg_insert_opts& options) : options_(options) {}
+  // RangeDataInserterInterface::Insert
+  void Insert(const sensor::RangeData& range_data, HybridGridTSDF* grid) const {
+    Check(hg_grid_insert(grid->get(), &options_, range_data.origin.data(),
+                         range_data.returns.empty() ? nullptr : range_data.returns[0].data(),
+                         range_data.returns.size(), range_data.width, nullptr, HG_INSERT_EXACT, HG_HOST, nullptr),
+          "hg_grid_insert");
+  }
+  bool RequiresStructuredData() const { return options_.project_sdf_distance_to_scan_normal != 0; }
+  const hg_insert_opts& options() const { return options_; }
+ private:
+  hg_insert_opts options_;
+};
+
+// Submap3D::InsertData for the TSDF grids of one submap (submap_3d.cc:427-452): frame change by
+// local_pose().inverse().cast<float>() and both inserters, fused into one device pass.
+inline void InsertIntoSubmap(const sensor::RangeData& range_data_in_local, const Pose& submap_local_pose,
+                             const TSDFRangeDataInserter3D& high, const TSDFRangeDataInserter3D& low,
+                             HybridGridTSDF* high_grid, HybridGridTSDF* low_grid) {
+  hg_grid* grids[2] = {high_grid->get(), low_grid->get()};
+  const hg_insert_opts opts[2] = {high.options(), low.options()};
+  const std::array<float, 7> inv = transform::ToFloat(transform::Inverse(submap_local_pose));
+  Check(hg_pyramid_insert(grids, opts, 2, range_data_in_local.origin.data(),
+                          range_data_in_local.returns.empty() ? nullptr : range_data_in_local.returns[0].data(),
+                          range_data_in_local.returns.size(), range_data_in_local.width, inv.data(), HG_INSERT_EXACT,
+                          HG_HOST, nullptr), "hg_pyramid_insert");
+}
+
+namespace scan_matching {
+
+struct PointCloudAndGrid {
+  const std::vector<Point>* point_cloud;
+  const HybridGridTSDF* grid;
+};
+
+class TsdfScanMatcher3D {
+ public:
+  TsdfScanMatcher3D(Context* ctx, std::vector<double> occupied_space_weights, int max_num_iterations = 12)
+      : ctx_(ctx), weights_(std::move(occupied_space_weights)) {
+    hg_solver_default_opts(&solver_);
+    solver_.max_num_iterations = max_num_iterations;
+    Check(hg_problem_create(ctx->get(), &problem_), "hg_problem_create");
+  }
+  ~TsdfScanMatcher3D() { if (problem_) hg_problem_destroy(problem_); }
+  // CeresScanMatcher3D::Match (ceres_scan_matcher_3d.cc:72-95), TSDF blocks.
+  void Match(const Pose& initial_pose_estimate, const std::vector<PointCloudAndGrid>& clouds_and_grids,
+             Pose* pose_estimate, hg_solver_summary* summary) {
+    Setup(initial_pose_estimate, clouds_and_grids);
+    Check(hg_problem_solve(problem_, &solver_, summary), "hg_problem_solve");
+    Check(hg_problem_get_pose(problem_, 0, pose_estimate->data()), "hg_problem_get_pose");
+  }
+  // CeresScanMatcher3D::Evaluate (:97-118): cost, residuals, and J^T J / J^T r instead of the dense J.
+  void Evaluate(const Pose& pose, const std::vector<PointCloudAndGrid>& clouds_and_grids, double* cost,
+                std::vector<double>* residuals, std::array<double, 36>* JtJ, std::array<double, 6>* Jtr) {
+    Setup(pose, clouds_and_grids);
+    if (residuals) residuals->resize(hg_problem_num_residuals(problem_));
+    Check(hg_problem_evaluate(problem_, cost, residuals ? residuals->data() : nullptr, Jtr ? Jtr->data() : nullptr,
+                              JtJ ? JtJ->data() : nullptr), "hg_problem_evaluate");
+  }
+ private:
+  void Setup(const Pose& pose, const std::vector<PointCloudAndGrid>& cg) {
+    Check(hg_problem_reset(problem_), "hg_problem_reset");
+    const int p = hg_problem_add_pose(problem_, pose.data(), 0);
+    Check(p, "hg_problem_add_pose");
+    for (size_t i = 0; i < cg.size(); ++i) {
+      hg_grid* g = cg[i].grid->get();
+      const std::vector<Point>& pc = *cg[i].point_cloud;
+      // occupied_space_weight_i / sqrt(N)  (ceres_scan_matcher_3d.cc:149-151)
+      Check(hg_problem_add_block(problem_, pc.empty() ? nullptr : pc[0].data(), pc.size(), HG_HOST, &g, 1, 0,
+                                 weights_.at(i) / std::sqrt(static_cast<double>(pc.size())), p, -1, 0.0),
+            "hg_problem_add_block");
+    }
+  }
+  Context* ctx_;
+  std::vector<double> weights_;
+  hg_solver_opts solver_;
+  hg_problem* problem_ = nullptr;
+};
+
+}  // namespace scan_matching
+
+// LocalTrajectoryBuilder3D-shaped driver for the scan-matching + insertion subset: constant-velocity
+// prediction from the last two poses (or odometry deltas when provided), multi-resolution TSDF match on
+// the device, then insertion of the scan at the matched pose into every pyramid level.
+class LocalTrajectoryBuilder3D {
+ public:
+  struct InsertionResult {
+    std::vector<const HybridGridTSDF*> insertion_grids;
+  };
+  struct MatchingResult {
+    double time;
+    Pose local_pose;
+    sensor::RangeData range_data_in_local;
+    std::unique_ptr<const InsertionResult> insertion_result;  // nullptr if map update is disabled
+  };
+  struct Options {
+    std::vector<float> resolutions{0.05f, 0.10f, 0.20f};
+    float relative_truncation_distance = 2.5f, maximum_weight = 1000.f;
+    uint32_t max_blocks = 1u << 18;
+    hg_insert_opts inserter = DefaultTSDFInserterOptions();
+    double high_resolution_grid_weight = 1.0;
+    int max_num_iterations = 12;
+    float min_range = 1.f, max_range = 60.f;  // trajectory_builder_3d.lua:18-19
+  };
+
+  LocalTrajectoryBuilder3D(Context* ctx, const Options& options) : ctx_(ctx), options_(options) {
+    for (float r : options.resolutions)
+      grids_.emplace_back(new HybridGridTSDF(ctx, r, options.relative_truncation_distance, options.maximum_weight,
+                                             options.max_blocks));
+    Check(hg_problem_create(ctx->get(), &problem_), "hg_problem_create");
+    hg_solver_default_opts(&solver_);
+    solver_.max_num_iterations = options.max_num_iterations;
+    pose_ = Pose{{0, 0, 0, 1, 0, 0, 0}};
+    prev_pose_ = pose_;
+  }
+  ~LocalTrajectoryBuilder3D() { if (problem_) hg_problem_destroy(problem_); }
+
+  void AddImuData(const sensor::ImuData&) {}  // IMU residuals are outside the TSDF hot path
+  void AddOdometryData(const sensor::OdometryData& odom) {
+    if (have_odom_) odom_delta_ = transform::Multiply(transform::Inverse(last_odom_.pose), odom.pose);
+    last_odom_ = odom;
+    have_odom_ = true;
+  }
+  void SetMapUpdateEnabled(bool enabled) { map_update_enabled_ = enabled; }
+  void UseScanMatching(bool use) { use_scan_matching_ = use; }
+
+  std::unique_ptr<MatchingResult> AddRangeData(const std::string& /*sensor_id*/,
+                                               const sensor::TimedPointCloudData& data) {
+    // range crop + NaN drop (optimizing_local_trajectory_builder.cc:214-227)
+    std::vector<Point> cloud;
+    cloud.reserve(data.ranges.size());
+    for (const auto& p : data.ranges) {
+      const float dx = p[0] - data.origin[0], dy = p[1] - data.origin[1], dz = p[2] - data.origin[2];
+      const float r = std::sqrt(dx * dx + dy * dy + dz * dz);
+      if (r >= options_.min_range && r <= options_.max_range) cloud.push_back(Point{{p[0], p[1], p[2]}});
+    }
+    if (cloud.empty()) return nullptr;
+    // prediction
+    Pose predicted = num_scans_ < 2 ? pose_
+                     : have_odom_  ? transform::Multiply(pose_, odom_delta_)
+                                   : transform::Multiply(pose_, transform::Multiply(transform::Inverse(prev_pose_), pose_));
+    Pose estimate = predicted;
+    if (use_scan_matching_ && num_scans_ > 0) {
+      Check(hg_problem_reset(problem_), "hg_problem_reset");
+      const int p = hg_problem_add_pose(problem_, predicted.data(), 0);
+      Check(p, "hg_problem_add_pose");
+      std::vector<hg_grid*> pyr;
+      for (auto& g : grids_) pyr.push_back(g->get());
+      Check(hg_problem_add_block(problem_, cloud[0].data(), cloud.size(), HG_HOST, pyr.data(), static_cast<int>(pyr.size()),
+                                 pyr.size() > 1, options_.high_resolution_grid_weight / std::sqrt(double(cloud.size())),
+                                 p, -1, 0.0), "hg_problem_add_block");
+      hg_solver_summary summary;
+      Check(hg_problem_solve(problem_, &solver_, &summary), "hg_problem_solve");
+      Check(hg_problem_get_pose(problem_, p, estimate.data()), "hg_problem_get_pose");
+    }
+    prev_pose_ = pose_;
+    pose_ = estimate;
+    ++num_scans_;
+    std::unique_ptr<MatchingResult> result(new MatchingResult);
+    result->time = data.time;
+    result->local_pose = estimate;
+    result->range_data_in_local.origin = data.origin;
+    if (map_update_enabled_) {
+      std::vector<hg_grid*> pyr;
+      std::vector<hg_insert_opts> opts(grids_.size(), options_.inserter);
+      for (auto& g : grids_) pyr.push_back(g->get());
+      const std::array<float, 7> pf = transform::ToFloat(estimate);
+      Check(hg_pyramid_insert(pyr.data(), opts.data(), static_cast<int>(pyr.size()), data.origin.data(), cloud[0].data(),
+                              cloud.size(), 0, pf.data(), HG_INSERT_EXACT, HG_HOST, nullptr), "hg_pyramid_insert");
+      std::unique_ptr<InsertionResult> ins(new InsertionResult);
+      for (auto& g : grids_) ins->insertion_grids.push_back(g.get());
+      result->insertion_result = std::move(ins);
+    }
+    return result;
+  }
+  const std::vector<std::unique_ptr<HybridGridTSDF>>& grids() const { return grids_; }
+
+ private:
+  Context* ctx_;
+  Options options_;
+  std::vector<std::unique_ptr<HybridGridTSDF>> grids_;
+  hg_problem* problem_ = nullptr;
+  hg_solver_opts solver_;
+  Pose pose_, prev_pose_, odom_delta_{{0, 0, 0, 1, 0, 0, 0}};
+  sensor::OdometryData last_odom_{};
+  bool have_odom_ = false, map_update_enabled_ = true, use_scan_matching_ = true;
+  int num_scans_ = 0;
+};
+
+}  // namespace mapping
+}  // namespace hg_amd
+#endif  // HG_ADAPTER_H_

@@ -1,0 +1,54 @@
+"""The C-ABI library builds, loads and exports every symbol include/hg_mi355x.h declares.
+No compute calls here (no GPU needed)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "hg_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from hectorgrapher_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product path fails loudly (HG_ERR_NO_DEVICE), it never computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hectorgrapher_amd import api
+    with pytest.raises(api.HgError):
+        api.Context(0)
+
+
+def test_product_package_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "hectorgrapher_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cc")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in src and "hg_oracle" not in src, f
+
+
+def test_structs_match_header_layout():
+    import ctypes
+    from hectorgrapher_amd import _lib
+    assert ctypes.sizeof(_lib.InsertOpts) == 80
+    assert ctypes.sizeof(_lib.InsertStats) == 32
+    assert ctypes.sizeof(_lib.SolverOpts) == 80
+    assert ctypes.sizeof(_lib.SolverSummary) == 56
