@@ -140,10 +140,7 @@ def main():
         problem.reset()
         pi = problem.add_pose(guesses[i])
         problem.add_block(d_scans[i], grids, scale, pi, multi_res=True)
-        problem.solve()
-        est = problem.get_pose(pi)
-        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d_scans[i]), grids,
-                           pose_tq=est.astype(np.float32), want_stats=False)
+        est, _ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i]), grids)
         errs.append(float(np.linalg.norm(est[:3] - query[i][0][:3])))
 
     def barrier():

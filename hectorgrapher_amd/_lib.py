@@ -28,7 +28,8 @@ SYMBOLS = [
     "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
     "hg_problem_set_pose", "hg_problem_get_pose", "hg_problem_add_block",
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
-    "hg_solver_default_opts", "hg_problem_solve", "hg_match_evaluate", "hg_match_solve",
+    "hg_solver_default_opts", "hg_problem_solve", "hg_problem_solve_async", "hg_problem_fetch",
+    "hg_register_scan", "hg_match_evaluate", "hg_match_solve",
 ]
 
 
@@ -157,6 +158,10 @@ def load():
     L.hg_problem_evaluate.argtypes = [vp, vp, vp, vp, vp]
     L.hg_solver_default_opts.argtypes = [P(SolverOpts)]
     L.hg_problem_solve.argtypes = [vp, P(SolverOpts), P(SolverSummary)]
+    L.hg_problem_solve_async.argtypes = [vp, P(SolverOpts)]
+    L.hg_problem_fetch.argtypes = [vp, P(SolverSummary)]
+    L.hg_register_scan.argtypes = [vp, P(SolverOpts), i32, vp, vp, i32, vp, vp, sz, sz, i32, vp,
+                                   P(SolverSummary)]
     L.hg_match_evaluate.argtypes = [vp, vp, i32, i32, vp, sz, i32, f64, vp, vp, f64, vp, vp, vp, vp]
     L.hg_match_solve.argtypes = [vp, vp, i32, i32, vp, sz, i32, f64, vp, vp, i32, f64,
                                  P(SolverOpts), P(SolverSummary)]

@@ -372,6 +372,31 @@ class Problem:
         return s
 
 
+def register_scan(problem, pose_index, inserters, range_data, grids, **solver_kw):
+    """One registration step on the device (hg_register_scan): solve `problem`, then insert
+    `range_data` (tracking frame) into `grids` at the solved pose. Returns (pose, summary)."""
+    L = _lib.load()
+    o = SolverOpts()
+    L.hg_solver_default_opts(C.byref(o))
+    for k, v in solver_kw.items():
+        setattr(o, k, v)
+    n_l = len(grids)
+    opts = (InsertOpts * n_l)(*[i.options for i in inserters])
+    garr = (C.c_void_p * n_l)(*[g._h for g in grids])
+    r = range_data.returns
+    if _is_device(r):
+        n, ptr, space = r.shape[0], r.data_ptr(), _lib.HG_DEVICE
+    else:
+        r = _host(r, np.float32, 3)
+        n, ptr, space = len(r), _p(r), _lib.HG_HOST
+    pose = np.empty(7, np.float64)
+    s = SolverSummary()
+    check(L.hg_register_scan(problem._h, C.byref(o), pose_index, garr, opts, n_l,
+                             _p(range_data.origin), ptr, n, range_data.width, space, _p(pose),
+                             C.byref(s)), "hg_register_scan")
+    return pose, s
+
+
 class CeresScanMatcher3D:
     """Single-pose matcher shape (Match / Evaluate) for TSDF grids.
 

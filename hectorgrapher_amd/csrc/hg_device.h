@@ -86,13 +86,19 @@ __host__ __device__ inline void key_to_block_origin(unsigned long long key, int*
 }
 
 // ---- hash table ----
+// Spatial hash, separable per axis so the 8 corners of a 2x2x2 lookup share the per-axis products.
+__host__ __device__ inline uint32_t hash_mix(uint32_t h) {
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  return h;
+}
+__host__ __device__ inline uint32_t hash_x(uint32_t bx) { return bx * 73856093u; }
+__host__ __device__ inline uint32_t hash_y(uint32_t by) { return by * 19349663u; }
+__host__ __device__ inline uint32_t hash_z(uint32_t bz) { return bz * 83492791u; }
 __host__ __device__ inline uint32_t hash_key(unsigned long long k) {
-  k ^= k >> 33;
-  k *= 0xff51afd7ed558ccdULL;
-  k ^= k >> 33;
-  k *= 0xc4ceb9fe1a85ec53ULL;
-  k ^= k >> 33;
-  return static_cast<uint32_t>(k);
+  return hash_mix(hash_x(static_cast<uint32_t>(k) & 2047u) ^ hash_y(static_cast<uint32_t>(k >> 11) & 2047u) ^
+                  hash_z(static_cast<uint32_t>(k >> 22) & 2047u));
 }
 
 // Read-only lookup. Returns the slot or 0xFFFFFFFF if the block does not exist.

@@ -242,6 +242,8 @@ struct PyramidIns {
   LevelIns lv[kMaxInsLevels];
   int levels;
   ScanTable scan0;  // the scan when a call carries exactly one (no table upload needed)
+  const double* d_pose;  // optional: pose (t xyz, q wxyz, fp64) in device memory, e.g. the pose a
+                         // solve left there; cast to float as Rigid3d::cast<float>() does
 };
 
 enum : uint32_t { kFlagStride = 4u };
@@ -314,7 +316,11 @@ __global__ __launch_bounds__(256) void k_expand_fixed(PyramidIns P, const ScanTa
   __syncthreads();
   bool hit = false;
   if (i < n) {
-    const ScanTable& sc = (n_scans == 1) ? P.scan0 : scans[find_scan(scans, n_scans, i)];
+    ScanTable sc = (n_scans == 1) ? P.scan0 : scans[find_scan(scans, n_scans, i)];
+    if (P.d_pose) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) sc.pose[k] = static_cast<float>(P.d_pose[k]);
+    }
     const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
     K kk[kSlots];
     V vv[kSlots];
@@ -476,8 +482,8 @@ __global__ void k_sum_stats(PyramidIns P, const unsigned* wg_hits, unsigned n_ex
       __syncthreads();
     }
     if (threadIdx.x == 0) {
-      P.lv[l].g.counters[2] += static_cast<uint32_t>(hs);
-      *reinterpret_cast<unsigned long long*>(&P.lv[l].g.counters[4]) += red[0];
+      P.lv[l].g.counters[2] = static_cast<uint32_t>(hs);
+      *reinterpret_cast<unsigned long long*>(&P.lv[l].g.counters[4]) = red[0];
     }
     __syncthreads();
   }
@@ -520,7 +526,7 @@ InsertParams make_params(const hg_insert_opts& o, const hg_grid* grid, bool has_
 // ---- compaction path (exact record count; any options), one level ---------------------------
 int insert_chunk_compact(hg_grid* grid, const InsertParams& p, const ScanTable* d_scans,
                          uint32_t n_scans, const float* d_xyz, unsigned long long n,
-                         const uint8_t* d_gate) {
+                         const uint8_t* d_gate, bool first_chunk) {
   hg_ctx* c = grid->ctx;
   hipStream_t s = c->stream;
   int rc;
@@ -531,6 +537,8 @@ int insert_chunk_compact(hg_grid* grid, const InsertParams& p, const ScanTable* 
   const unsigned wg = 256;
   const unsigned nwg = static_cast<unsigned>((n + wg - 1) / wg);
   HG_HIP_CHECK(hipMemsetAsync(d_counts + n, 0, sizeof(uint32_t), s));
+  if (first_chunk)  // per-call counters (hits, updates) restart; num_blocks and sticky flags stay
+    HG_HIP_CHECK(hipMemsetAsync(grid->view.counters + 2, 0, 6 * sizeof(uint32_t), s));
   {
     ProfScope ps(c, HG_K_RAY_COUNT, n);
     hipLaunchKernelGGL(k_ray_count, dim3(nwg), dim3(wg), 0, s, grid->view, p, d_scans, n_scans,
@@ -682,11 +690,29 @@ void host_transform(const float* pose, const float* in, float* out) {
 
 extern "C" {
 
+}  // extern "C"
+
+extern "C" {
+
 int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                             const float* origins, const float* xyz, const uint64_t* scan_offsets,
                             size_t n_scans, size_t width, const float* poses_tq, int mode,
                             int memspace, hg_insert_stats* stats) {
+  return pyramid_insert_impl(grids, opts, levels, origins, xyz, scan_offsets, n_scans, width,
+                             poses_tq, nullptr, mode, memspace, stats);
+}
+
+}  // extern "C"
+
+// poses_tq: host float poses per scan (also used for the key window when d_pose_tq is given, where
+// it must hold an approximation of the device pose); d_pose_tq: fp64 pose in device memory that
+// the kernels read instead (single-scan calls only).
+int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                            const float* origins, const float* xyz, const uint64_t* scan_offsets,
+                            size_t n_scans, size_t width, const float* poses_tq,
+                            const double* d_pose_tq, int mode, int memspace, hg_insert_stats* stats) {
   (void)width;
+  if (d_pose_tq && (n_scans != 1 || !poses_tq)) return HG_ERR_INVALID;
   if (!grids || !opts || levels < 1 || levels > kMaxInsLevels || !origins || !scan_offsets || n_scans == 0)
     return HG_ERR_INVALID;
   if (mode != HG_INSERT_EXACT) return HG_ERR_UNSUPPORTED;
@@ -706,9 +732,6 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
   for (size_t i = 0; i < n_scans; ++i)
     if (scan_offsets[i + 1] < scan_offsets[i]) return HG_ERR_INVALID;
 
-  // per-call counters (hits, updates) restart; num_blocks and sticky flags stay
-  for (int l = 0; l < levels; ++l)
-    HG_HIP_CHECK(hipMemsetAsync(grids[l]->view.counters + 2, 0, 6 * sizeof(uint32_t), s));
 
   const float* d_xyz = nullptr;
   if (n_total) {
@@ -757,9 +780,10 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
   if (!fixed_ok && levels > 1) {
     // general options: fall back to one compaction pass per level
     int rc = HG_OK;
+    if (d_pose_tq) return HG_ERR_UNSUPPORTED;
     for (int l = 0; l < levels && rc == HG_OK; ++l)
-      rc = hg_pyramid_insert_batch(grids + l, opts + l, 1, origins, xyz, scan_offsets, n_scans, width,
-                                   poses_tq, mode, memspace, stats ? stats + l : nullptr);
+      rc = pyramid_insert_impl(grids + l, opts + l, 1, origins, xyz, scan_offsets, n_scans, width,
+                               poses_tq, nullptr, mode, memspace, stats ? stats + l : nullptr);
     return rc;
   }
 
@@ -773,6 +797,8 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
   PyramidIns P;
   std::memset(&P, 0, sizeof(P));
   P.levels = levels;
+  P.d_pose = d_pose_tq;
+  if (d_pose_tq && !fixed_ok) return HG_ERR_UNSUPPORTED;
   for (int l = 0; l < levels; ++l) {
     LevelIns& L = P.lv[l];
     L.g = grids[l]->view;
@@ -788,7 +814,7 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
     for (size_t i = 0; i < n_scans; ++i)
       for (int a = 0; a < 3; ++a)
         reach = std::max(reach, static_cast<double>(std::fabs(go[3 * i + a] - go[a])));
-    reach += opts[l].max_range + L.p.truncation_distance + 2.0 * res;
+    reach += opts[l].max_range + L.p.truncation_distance + 2.0 * res + (d_pose_tq ? 2.0 : 0.0);
     if (!(reach / (8.0 * res) < 62.0)) key32 = false;
   }
 
@@ -837,7 +863,7 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
           rc = insert_chunk_fixed<unsigned long long, unsigned long long>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
       } else {
         rc = insert_chunk_compact(grids[0], Pc.lv[0].p, d_scans, static_cast<uint32_t>(table.size()),
-                                  d_xyz + 3 * first, pts, Pc.lv[0].gate);
+                                  d_xyz + 3 * first, pts, Pc.lv[0].gate, s0 == 0);
       }
     }
     s0 = s1;
@@ -851,6 +877,8 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
   }
   return rc;
 }
+
+extern "C" {
 
 int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float* origins,
                          const float* xyz, const uint64_t* scan_offsets, size_t n_scans,

@@ -107,6 +107,13 @@ struct ProfScope {
 };
 }  // namespace hg
 
+namespace hg {
+int pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                        const float* origins, const float* xyz, const uint64_t* scan_offsets,
+                        size_t n_scans, size_t width, const float* poses_tq,
+                        const double* d_pose_tq, int mode, int memspace, hg_insert_stats* stats);
+}
+
 struct hg_grid {
   hg_ctx* ctx = nullptr;
   hg::GridView view{};

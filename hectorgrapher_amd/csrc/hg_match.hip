@@ -19,6 +19,7 @@
 //                     tolerances) entirely on the device.
 #include <algorithm>
 #include <array>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -32,10 +33,10 @@ constexpr int kMaxPoses = 6;
 constexpr int kMaxCols = 6 * kMaxPoses;
 constexpr int kMaxBlocks = 16;
 constexpr int kAcc = 36;  // 28 (upper triangle of 7x7) + 7 + 1
-constexpr int kEvalThreads = 256;
+constexpr int kEvalThreads = 512;
 constexpr int kLmThreads = 64;   // the LM state machine runs in one wavefront
 constexpr int kLmBlock = 256;    // waves 1-3 only help summing the workgroup partials
-constexpr int kStripes = kLmBlock / kAcc;  // 7 stripes x 36 sums
+constexpr int kMaxStripes = 512 / kAcc;  // stripes of the partial reduction (block size / 36)
 
 struct PyramidView {
   GridView level[kMaxLevels];
@@ -80,6 +81,9 @@ struct LmHead {
   double scale[kMaxCols], diagonal[kMaxCols], g[kMaxCols], step[kMaxCols], delta[kMaxCols];
   double gc[kMaxCols];
   BlockInfo blocks[kMaxBlocks];
+#ifdef HG_LM_STAMPS
+  long long stamps[16];  // diagnostic build only: s_memtime at phase boundaries of the last LM step
+#endif
 };
 
 struct LmState {
@@ -124,6 +128,7 @@ struct LevelFetch {
   double x1, y1, z1, x2, y2, z2;
   unsigned long long key[8];
   unsigned long long entry[8];
+  uint32_t hash[8];
   uint32_t vox[8];
   uint32_t code[8];
   bool in_range[8];
@@ -140,19 +145,38 @@ __device__ inline void fetch_setup(const GridView& g, double x, double y, double
   if (static_cast<double>(cz) > z) cz -= res;
   f.x1 = cx; f.y1 = cy; f.z1 = cz;
   f.x2 = cx + res; f.y2 = cy + res; f.z2 = cz + res;
-  const int ix = cell_index_1d(cx, res), iy = cell_index_1d(cy, res), iz = cell_index_1d(cz, res);
+  const int i0[3] = {cell_index_1d(cx, res), cell_index_1d(cy, res), cell_index_1d(cz, res)};
+  // per-axis pieces of key / hash / voxel index for index i and i + 1
+  uint32_t kb[3][2], hs[3][2], vx[3][2];
+  bool ok[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const unsigned s = static_cast<unsigned>(i0[a] + d + kIndexOffset);
+      ok[a][d] = s < 16384u;
+      kb[a][d] = (s >> 3) & 2047u;
+      vx[a][d] = s & 7u;
+    }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    hs[0][d] = hash_x(kb[0][d]);
+    hs[1][d] = hash_y(kb[1][d]);
+    hs[2][d] = hash_z(kb[2][d]);
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     // corner order: c = dx*4 + dy*2 + dz  (111,112,121,122,211,212,221,222)
-    const int px = ix + (c >> 2), py = iy + ((c >> 1) & 1), pz = iz + (c & 1);
-    f.in_range[c] = cell_in_range(px, py, pz);
-    f.key[c] = f.in_range[c] ? block_key(px, py, pz) : 0ull;
-    f.vox[c] = voxel_in_block(px, py, pz);
+    const int dx = c >> 2, dy = (c >> 1) & 1, dz = c & 1;
+    f.in_range[c] = ok[0][dx] && ok[1][dy] && ok[2][dz];
+    f.key[c] = (static_cast<unsigned long long>(kb[2][dz]) << 22) | ((kb[1][dy] << 11) | kb[0][dx]);
+    f.hash[c] = hash_mix(hs[0][dx] ^ hs[1][dy] ^ hs[2][dz]);
+    f.vox[c] = (vx[2][dz] << 6) | (vx[1][dy] << 3) | vx[0][dx];
   }
 }
 __device__ inline void fetch_probe(const GridView& g, LevelFetch& f) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) f.entry[c] = g.table[hash_key(f.key[c]) & g.table_mask];
+  for (int c = 0; c < 8; ++c) f.entry[c] = g.table[f.hash[c] & g.table_mask];
 }
 __device__ inline void fetch_voxels(const GridView& g, LevelFetch& f) {
 #pragma unroll
@@ -275,15 +299,12 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
 }
 
 // residuals of one block at its current transform + 36 partial sums per workgroup
-__global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
-    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
+__device__ __forceinline__ void tsdf_residuals_body(
+    const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
-    double* __restrict__ residuals, const int* __restrict__ done_flag) {
-  if (done_flag && *done_flag) return;
+    double* __restrict__ residuals) {
   const unsigned i = blockIdx.x * kEvalThreads + threadIdx.x;
-  double acc[kAcc];
-#pragma unroll
-  for (int k = 0; k < kAcc; ++k) acc[k] = 0.0;
+  double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (i < n) {
     const double qw = xf->q[0];
     const double u[3] = {xf->q[1], xf->q[2], xf->q[3]};
@@ -317,33 +338,56 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
       const double c2k = qw * duv[2] + eku[k][2] + ud[2];
       row[4 + k] = g[0] * c0 + g[1] * c1 + g[2] * c2k;
     }
-    int o = 0;
 #pragma unroll
-    for (int a = 0; a < 7; ++a)
-#pragma unroll
-      for (int b = a; b < 7; ++b) acc[o++] = row[a] * row[b];
-#pragma unroll
-    for (int a = 0; a < 7; ++a) acc[28 + a] = row[a] * r;
-    acc[35] = r * r;
+    for (int a = 0; a < 7; ++a) row8[a] = row[a];
+    row8[7] = r;
   }
-  // wavefront butterfly, then 4 waves through LDS
-  __shared__ double lds[kEvalThreads / kWave][kAcc];
-#pragma unroll
-  for (int k = 0; k < kAcc; ++k) {
-    double s = acc[k];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    acc[k] = s;
-  }
+  // J^T J accumulation on the matrix cores: per wavefront X = [row | r] is 64 x 8 (padded to 16
+  // columns); 16 x v_mfma_f64_16x16x4_f64 accumulate X^T X, whose upper-left 8 x 8 block holds
+  // J^T J (7x7), J^T r (column 7) and r^T r. Operand layout: lane l feeds A[i = l%16][k = l/16] and
+  // B[k = l/16][j = l%16] — here the same element X[4s + l/16][l%16]; D[l/16 + 4v][l%16] comes back
+  // in accumulator register v (verified against the CPU oracle by the parity tests).
+  __shared__ double xs[kEvalThreads / kWave][kWave][8];
+  __shared__ double cs[kEvalThreads / kWave][64];
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  if (lane == 0) {
+  {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* dst = reinterpret_cast<d2*>(&xs[wave][lane][0]);
 #pragma unroll
-    for (int k = 0; k < kAcc; ++k) lds[wave][k] = acc[k];
+    for (int c = 0; c < 4; ++c) dst[c] = d2{row8[2 * c], row8[2 * c + 1]};
+  }
+  __syncthreads();
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 cacc = {0.0, 0.0, 0.0, 0.0};
+  const int mj = lane & 15, mk = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const double a = (mj < 8) ? xs[wave][4 * s + mk][mj] : 0.0;
+    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+  }
+  if (mj < 8) {  // rows 0..7 of D sit in accumulator registers 0 and 1 (row = l/16 + 4v)
+    cs[wave][mk * 8 + mj] = cacc[0];
+    cs[wave][(mk + 4) * 8 + mj] = cacc[1];
   }
   __syncthreads();
   if (threadIdx.x < kAcc) {
+    // partial layout: 28 upper-triangle entries of the 7x7 block (row-major), 7 x J^T r, r^T r
+    int a, b;
+    if (threadIdx.x < 28) {
+      int t = threadIdx.x;
+      a = 0;
+      while (t >= 7 - a) { t -= 7 - a; ++a; }
+      b = a + t;
+    } else if (threadIdx.x < 35) {
+      a = threadIdx.x - 28;
+      b = 7;
+    } else {
+      a = 7;
+      b = 7;
+    }
     double s = 0.0;
 #pragma unroll
-    for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += lds[wv][threadIdx.x];
+    for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += cs[wv][a * 8 + b];
     partials[static_cast<size_t>(blockIdx.x) * kAcc + threadIdx.x] = s;
   }
 }
@@ -488,8 +532,14 @@ __device__ void prepare_block(const BlockInfo& b, const double (*poses)[7], Bloc
 
 // Everything below runs in ONE wavefront: scalars are computed redundantly by every lane,
 // vectors/matrices live in LDS and their loops are spread over the lanes.
+#ifdef HG_LM_STAMPS
+#define HG_STAMP(S, i) do { if (threadIdx.x == 0) (S).h.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HG_STAMP(S, i) do {} while (0)
+#endif
+
 struct LmShared {
-  double stripe[kStripes * kMaxBlocks * kAcc];
+  double stripe[kMaxStripes * kAcc];
   LmHead h;
   double H[kMaxCols * kMaxCols];
   double Hc[kMaxCols * kMaxCols];
@@ -497,6 +547,7 @@ struct LmShared {
   double rhs[kMaxCols], y[kMaxCols];
   double sums[kMaxBlocks * kAcc];
   double AM[7 * 12];
+  double M[kMaxBlocks * 7 * 12];  // d(t,q)/d(local) of every block, staged from xf
   double red[kLmThreads];
 };
 
@@ -560,6 +611,57 @@ __device__ bool cholesky_solve_wave(int n, double* A, const double* b, double* x
   }
   bool ok = true;
   for (int i = 0; i < n; ++i) ok = ok && isfinite(x[i]);
+  return ok;
+}
+
+// Small systems: every lane factorises its own register copy (no LDS round trips, no barriers);
+// same left-looking term order as the sequential reference form.
+template <int N>
+__device__ bool cholesky_solve_regs(const double* A_lds, const double* b_lds, double* x_lds, int lane) {
+  double L[N][N], y[N], x[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[i][j] = A_lds[i * N + j];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double d = L[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    ok = ok && (d > 0.0) && isfinite(d);
+    const double l = sqrt(d);
+    L[j][j] = l;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double s = L[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+      L[i][j] = s / l;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = b_lds[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+    y[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) ok = ok && isfinite(x[i]);
+  wave_sync();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x_lds[i] = x[i];
+  }
+  wave_sync();
   return ok;
 }
 
@@ -628,7 +730,11 @@ __device__ void compute_next_candidate(LmShared& S, int lane) {
     }
     for (int a = lane; a < n; a += kLmThreads) S.rhs[a] = h.g[a] * h.scale[a];
     wave_sync();
-    bool valid = cholesky_solve_wave(n, S.A, S.rhs, h.step, S.y, lane);
+    HG_STAMP(S, 4);
+    bool valid = (n == 6)    ? cholesky_solve_regs<6>(S.A, S.rhs, h.step, lane)
+                 : (n == 12) ? cholesky_solve_regs<12>(S.A, S.rhs, h.step, lane)
+                             : cholesky_solve_wave(n, S.A, S.rhs, h.step, S.y, lane);
+    HG_STAMP(S, 5);
     wave_sync();
     double mcc = 0.0;
     if (valid) {
@@ -673,40 +779,40 @@ __device__ void compute_next_candidate(LmShared& S, int lane) {
   }
 }
 
-// All 256 threads: thread (stripe j, column k) sums every kStripes-th workgroup partial of
-// column k with 8 loads in flight; the stripes are then added in a fixed order.
+// All threads of the workgroup: thread (stripe j, column k) sums every stripes-th workgroup
+// partial of column k with up to 8 loads in flight; the stripes are then added in a fixed order.
 __device__ void reduce_partials(LmShared& S, const double* partials) {
   const LmHead& h = S.h;
   const int t = threadIdx.x;
+  const int stripes = min(static_cast<int>(blockDim.x) / kAcc, kMaxStripes);
   const int j = t / kAcc, k = t % kAcc;
   for (int b = 0; b < h.num_blocks; ++b) {
     const BlockInfo& bi = h.blocks[b];
-    if (j < kStripes) {
+    if (j < stripes) {
       double acc = 0.0;
       if (bi.active) {
         const double* p = partials + static_cast<size_t>(bi.partial_offset) * kAcc + k;
-        unsigned w = j;
-        for (; w + 7 * kStripes < bi.num_wg; w += 8 * kStripes) {
+        for (unsigned w = j; w < bi.num_wg; w += 8 * stripes) {
           double v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = p[static_cast<size_t>(w + u * kStripes) * kAcc];
+          for (int u = 0; u < 8; ++u) {  // 8 independent loads in flight, masked at the end
+            const unsigned idx = w + u * stripes;
+            v[u] = idx < bi.num_wg ? p[static_cast<size_t>(idx) * kAcc] : 0.0;
+          }
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        for (; w < bi.num_wg; w += kStripes) acc += p[static_cast<size_t>(w) * kAcc];
       }
-      S.stripe[(j * kMaxBlocks + b) * kAcc + k] = acc;
+      S.stripe[j * kAcc + k] = acc;
     }
-  }
-  __syncthreads();
-  for (int b = 0; b < h.num_blocks; ++b) {
+    __syncthreads();
     if (t < kAcc) {
       double s = 0.0;
-      for (int jj = 0; jj < kStripes; ++jj) s += S.stripe[(jj * kMaxBlocks + b) * kAcc + t];
+      for (int jj = 0; jj < stripes; ++jj) s += S.stripe[jj * kAcc + t];
       S.sums[b * kAcc + t] = s;
     }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
 // Maps the per-block 7x7 sums through M into Hc / gc / cand_cost.
@@ -723,7 +829,7 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
     if (!bi.active) continue;
     const double* sm = S.sums + b * kAcc;
     cost += sm[35];
-    const double* M = xf[b].M;
+    const double* M = S.M + b * 84;
     // AM = A7 * M (7 x 12)
     for (int idx = lane; idx < 7 * 12; idx += kLmThreads) {
       const int a = idx / 12, c = idx % 12;
@@ -763,15 +869,15 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
   wave_sync();
 }
 
-__global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials, int mode) {
-  __shared__ LmShared S;
+// One LM iteration by the calling workgroup (any size >= 64): loads the solver head, sums the
+// partials, and lets wavefront 0 advance the state machine. Called from k_lm and from the tail of
+// the last k_tsdf_residuals workgroup of an iteration.
+__device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* partials, int mode) {
   const int lane = threadIdx.x;
-  if (mode == MODE_STEP && G->h.done) return;
-  // load the head (8-byte words) and H
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&S.h);
-    for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += kLmBlock) dst[i] = src[i];
+    for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
   LmHead& h = S.h;
@@ -780,11 +886,16 @@ __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, con
     if (lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &xf[lane]);
     return;
   }
+  HG_STAMP(S, 0);
+  // stage M (all blocks) and H into LDS; these loads and the first partial loads overlap
+  for (int i = threadIdx.x; i < h.num_blocks * 84; i += blockDim.x) S.M[i] = xf[i / 84].M[i % 84];
+  if (h.phase != PHASE_INIT)
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) S.H[i] = G->H[i];
   reduce_partials(S, partials);
   if (threadIdx.x >= kLmThreads) return;  // retired waves no longer take part in barriers
-  if (h.phase != PHASE_INIT)
-    for (int i = lane; i < n * n; i += kLmThreads) S.H[i] = G->H[i];
+  HG_STAMP(S, 1);
   assemble(S, xf, partials, lane);
+  HG_STAMP(S, 2);
   if (mode == MODE_ASSEMBLE) {
     for (int i = lane; i < n * n; i += kLmThreads) G->Hc[i] = S.Hc[i];
     for (int i = lane; i < n; i += kLmThreads) G->h.gc[i] = h.gc[i];
@@ -833,6 +944,7 @@ __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, con
     const double relative_decrease = cost_change / h.model_cost_change;
     const bool accept = relative_decrease > h.opt.min_relative_decrease;
     wave_sync();
+    HG_STAMP(S, 3);
     if (lane == 0) ++h.num_cost_evals;
     if (ptol) {
       if (lane == 0) finish(h, 0, 2);
@@ -854,7 +966,10 @@ __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, con
           ++h.num_jac_evals;
           h.gradient_max_norm = gmn;
           h.step_is_successful = 1;
-          h.radius = h.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3.0));
+          {
+            const double t = 2.0 * relative_decrease - 1.0;
+            h.radius = h.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+          }
           h.radius = fmin(h.opt.max_trust_region_radius, h.radius);
           h.decrease_factor = 2.0;
           h.reuse_diagonal = 0;
@@ -870,7 +985,10 @@ __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, con
     }
   }
   wave_sync();
+  HG_STAMP(S, 6);
   if (!h.done && lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &xf[lane]);
+  HG_STAMP(S, 7);
+  wave_sync();
   // store the head and (if it changed) H
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
@@ -879,6 +997,45 @@ __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, con
   }
   if (h_changed)
     for (int i = lane; i < n * n; i += kLmThreads) G->H[i] = S.H[i];
+}
+
+// Residual kernel of one block. With `G` set, the last workgroup of the iteration (a ticket counts
+// the workgroups of all blocks' launches) runs the LM step in its tail, so an iteration is ONE
+// launch: release/acquire at agent scope around the ticket makes the other workgroups' partials
+// visible to it (cdna_hip_programming.md Guideline 16).
+__global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
+    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
+    const BlockXform* __restrict__ xf, double* __restrict__ partials,
+    double* __restrict__ residuals, LmState* G, BlockXform* xf_all, const double* partials_all,
+    unsigned* ticket, unsigned total_wg) {
+  if (G && G->h.done) return;
+  tsdf_residuals_body(pv, xyz, n, scaling, xf, partials, residuals);
+  if (!G) return;
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last = (t == total_wg - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *ticket = 0u;  // ready for the next iteration's launches
+  }
+  __syncthreads();
+  __shared__ LmShared S;
+  lm_step(S, G, xf_all, partials_all, MODE_STEP);
+}
+
+__global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials, int mode) {
+  __shared__ LmShared S;
+  if (mode == MODE_STEP && G->h.done) return;
+  lm_step(S, G, xf, partials, mode);
 }
 
 }  // namespace hg
@@ -902,9 +1059,12 @@ struct hg_problem {
   std::vector<int> constant;
   // device state
   LmState* d_state = nullptr;
+  unsigned* d_ticket = nullptr;
   BlockXform* d_xf = nullptr;
   DeviceBuffer partials, residuals;
-  LmState h_state;  // staging
+  bool solve_pending = false;
+  LmState* h_pin = nullptr;  // pinned staging for uploads / read-backs
+  LmState h_state;            // host copy
 };
 
 namespace {
@@ -952,13 +1112,18 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   }
   int rc = p->partials.reserve(static_cast<size_t>(std::max(1u, wg_off)) * kAcc * sizeof(double));
   if (rc != HG_OK) return rc;
-  HG_HIP_CHECK(hipMemcpyAsync(p->d_state, &ST, sizeof(LmHead), hipMemcpyHostToDevice, p->ctx->stream));
+  // the pinned buffer may still be the source of the previous (finished) upload: solves are
+  // synchronised by their fetch before the next upload
+  std::memcpy(&p->h_pin->h, &ST.h, sizeof(LmHead));
+  HG_HIP_CHECK(hipMemcpyAsync(p->d_state, p->h_pin, sizeof(LmHead), hipMemcpyHostToDevice, p->ctx->stream));
   return HG_OK;
 }
 
-int launch_eval(hg_problem* p, double* d_residuals, bool check_done) {
+int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
   hipStream_t s = p->ctx->stream;
   const LmHead& S = p->h_state.h;
+  unsigned total_wg = 0;
+  for (int b = 0; b < S.num_blocks; ++b) total_wg += S.blocks[b].num_wg;
   for (int b = 0; b < S.num_blocks; ++b) {
     const BlockInfo& bi = S.blocks[b];
     if (!bi.active) continue;
@@ -973,7 +1138,8 @@ int launch_eval(hg_problem* p, double* d_residuals, bool check_done) {
                        bi.n, bi.scaling, p->d_xf + b,
                        p->partials.as<double>() + static_cast<size_t>(bi.partial_offset) * kAcc,
                        d_residuals ? d_residuals + bi.row_offset : nullptr,
-                       check_done ? &p->d_state->h.done : nullptr);
+                       fused_lm ? p->d_state : nullptr, p->d_xf, p->partials.as<double>(),
+                       p->d_ticket, total_wg);
     HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
@@ -1007,6 +1173,9 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
   p->ctx = ctx;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(LmState));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_xf), sizeof(BlockXform) * kMaxBlocks);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 256);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_pin), sizeof(LmState));
+  if (e == hipSuccess) e = hipMemset(p->d_ticket, 0, 256);
   if (e != hipSuccess) {
     set_last_error(std::string("hipMalloc problem: ") + hipGetErrorString(e));
     hg_problem_destroy(p);
@@ -1024,6 +1193,8 @@ int hg_problem_destroy(hg_problem* p) {
     if (b.owned) (void)hipFree(b.owned);
   if (p->d_state) (void)hipFree(p->d_state);
   if (p->d_xf) (void)hipFree(p->d_xf);
+  if (p->d_ticket) (void)hipFree(p->d_ticket);
+  if (p->h_pin) (void)hipHostFree(p->h_pin);
   p->partials.release();
   p->residuals.release();
   delete p;
@@ -1032,7 +1203,9 @@ int hg_problem_destroy(hg_problem* p) {
 
 int hg_problem_reset(hg_problem* p) {
   if (!p) return HG_ERR_INVALID;
-  (void)hipStreamSynchronize(p->ctx->stream);
+  bool owned = false;
+  for (auto& b : p->blocks) owned = owned || b.owned;
+  if (owned) (void)hipStreamSynchronize(p->ctx->stream);
   for (auto& b : p->blocks)
     if (b.owned) (void)hipFree(b.owned);
   p->blocks.clear();
@@ -1156,35 +1329,51 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
   return HG_OK;
 }
 
-int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summary* summary) {
+int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
   if (!p) return HG_ERR_INVALID;
   hipStream_t s = p->ctx->stream;
   HG_HIP_CHECK(hipSetDevice(p->ctx->device));
   int rc = upload_state(p, opts);
   if (rc != HG_OK) return rc;
   const LmHead& S0 = p->h_state.h;
-  if (S0.ncols == 0) {
-    if (summary) {
-      std::memset(summary, 0, sizeof(*summary));
-      summary->termination_type = 0;
-    }
-    return HG_OK;
-  }
+  p->solve_pending = true;
+  if (S0.ncols == 0) return HG_OK;
   const int max_it = S0.opt.max_num_iterations;
   hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_PREPARE);
   HG_HIP_CHECK(hipGetLastError());
+  bool any_active = false;
+  for (int b = 0; b < S0.num_blocks; ++b) any_active = any_active || S0.blocks[b].active;
   for (int it = 0; it <= max_it; ++it) {
-    rc = launch_eval(p, nullptr, true);
-    if (rc != HG_OK) return rc;
-    {
+    if (any_active) {
+      // residuals of every block at the candidate + (tail of the last workgroup) one LM step
+      rc = launch_eval(p, nullptr, true);
+      if (rc != HG_OK) return rc;
+    } else {
       ProfScope ps(p->ctx, HG_K_LM, 1);
       hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_STEP);
+      HG_HIP_CHECK(hipGetLastError());
     }
-    HG_HIP_CHECK(hipGetLastError());
   }
-  HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmHead), hipMemcpyDeviceToHost, s));
+  return HG_OK;
+}
+
+int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
+  if (!p || !p->solve_pending) return HG_ERR_INVALID;
+  hipStream_t s = p->ctx->stream;
+  p->solve_pending = false;
+  if (p->h_state.h.ncols == 0) {
+    if (summary) std::memset(summary, 0, sizeof(*summary));
+    return HG_OK;
+  }
+  HG_HIP_CHECK(hipMemcpyAsync(p->h_pin, p->d_state, sizeof(LmHead), hipMemcpyDeviceToHost, s));
   HG_HIP_CHECK(hipStreamSynchronize(s));
+  std::memcpy(&p->h_state.h, &p->h_pin->h, sizeof(LmHead));
   const LmHead& S = p->h_state.h;
+#ifdef HG_LM_STAMPS
+  fprintf(stderr, "lm stamps (cycles of the last step):");
+  for (int i = 1; i < 8; ++i) fprintf(stderr, " [%d]%lld", i, S.stamps[i] - S.stamps[i - 1]);
+  fprintf(stderr, "\n");
+#endif
   for (int i = 0; i < S.num_poses; ++i) std::memcpy(p->poses[i].data(), S.x[i], sizeof(double) * 7);
   if (summary) {
     summary->initial_cost = S.initial_cost;
@@ -1200,6 +1389,35 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
     summary->reserved = 0;
   }
   return HG_OK;
+}
+
+int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summary* summary) {
+  int rc = hg_problem_solve_async(p, opts);
+  if (rc != HG_OK) return rc;
+  return hg_problem_fetch(p, summary);
+}
+
+int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
+                     hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
+                     const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
+                     double pose_out[7], hg_solver_summary* summary) {
+  if (!p || !grids || !iopts || !origin || pose_index < 0 ||
+      pose_index >= static_cast<int>(p->poses.size()))
+    return HG_ERR_INVALID;
+  int rc = hg_problem_solve_async(p, sopts);
+  if (rc != HG_OK) return rc;
+  // insertion at the pose the solve leaves in device memory; the host only knows the initial
+  // guess, which sizes the key window
+  float approx[7];
+  for (int k = 0; k < 7; ++k) approx[k] = static_cast<float>(p->poses[pose_index][k]);
+  const double* d_pose = (p->h_state.h.ncols == 0) ? nullptr : &p->d_state->h.x[pose_index][0];
+  const uint64_t offsets[2] = {0, n};
+  rc = pyramid_insert_impl(grids, iopts, levels, origin, xyz, offsets, 1, width, approx, d_pose,
+                           HG_INSERT_EXACT, memspace, nullptr);
+  const int rc2 = hg_problem_fetch(p, summary);
+  if (rc == HG_OK) rc = rc2;
+  if (rc == HG_OK && pose_out) std::memcpy(pose_out, p->poses[pose_index].data(), sizeof(double) * 7);
+  return rc;
 }
 
 int hg_match_evaluate(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_res,

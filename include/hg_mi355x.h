@@ -207,6 +207,20 @@ int hg_solver_default_opts(hg_solver_opts* opts);
 /* ceres::Solve: Levenberg-Marquardt trust region on the device; poses are updated in place. */
 int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summary* summary);
 
+/* Enqueue-only solve and the matching read-back (hg_problem_solve = both). Between the two the
+ * solved poses live in device memory only. */
+int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts);
+int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary);
+/* One registration step (what OptimizingLocalTrajectoryBuilder::AddRangeData does with a scan,
+ * optimizing_local_trajectory_builder.cc:1283 then :1437-1499): solve the prepared problem, then
+ * insert `xyz` — given in the frame of pose `pose_index` (tracking frame), `origin` likewise —
+ * into the pyramid at the SOLVED pose (cast to float as optimized_pose.cast<float>()), without a
+ * host round trip in between; one synchronisation at the end returns pose and summary. */
+int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
+                     hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
+                     const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
+                     double pose_out[7], hg_solver_summary* summary);
+
 /* ---- one-block convenience (CeresScanMatcher3D::{Evaluate,Match} shape) ----------------- */
 int hg_match_evaluate(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_res,
                       const float* xyz, size_t n, int memspace, double scaling_factor,

@@ -124,3 +124,37 @@ def test_ceres_scan_matcher_shape(po, hg, ctx, maps):
     a = op.get_pose(0)
     assert np.linalg.norm(a[:3] - pose[:3]) < POSE_TOL_M
     assert rot_angle(a[3:], pose[3:]) < POSE_TOL_RAD
+
+
+def test_register_scan_equals_solve_then_insert(po, hg, ctx):
+    """hg_register_scan (pose handed to the inserter in device memory) == solve, read the pose
+    back, insert at float(pose) == the oracle doing the same on the CPU."""
+    from conftest import build_map
+    res = [0.05, 0.10, 0.20]
+    og, gg = build_map(po, (ctx, hg), res, 16, 400, 4, max_blocks=1 << 16)
+    truth = synth.pose_k(4)
+    pts = synth.generate_scan(truth, 16, 400, stream=4)
+    guess = synth.pose_mul(truth, synth.perturbation())
+    s = 1.0 / np.sqrt(len(pts))
+    op = po.Problem()
+    op.add_pose(guess)
+    op.add_block(pts, og, s, 0, multi_res=True)
+    op.solve()
+    est = op.get_pose(0)
+    for g in og:
+        g.insert([0, 0, 0], pts, pose_tq=est.astype(np.float32))
+    gp = hg.Problem(ctx)
+    gp.add_pose(guess)
+    gp.add_block(pts, gg, s, 0, multi_res=True)
+    ins = [hg.TSDFRangeDataInserter3D() for _ in gg]
+    pose, summary = hg.register_scan(gp, 0, ins, hg.RangeData([0, 0, 0], pts), gg)
+    assert np.linalg.norm(pose[:3] - est[:3]) < POSE_TOL_M
+    assert rot_angle(pose[3:], est[3:]) < POSE_TOL_RAD
+    if np.array_equal(pose.astype(np.float32), est.astype(np.float32)):
+        # identical float pose => identical voxels
+        for o, g in zip(og, gg):
+            g.status()
+            assert all(np.array_equal(a, b) for a, b in zip(o.export(), g.export()))
+    else:
+        for o, g in zip(og, gg):
+            assert abs(o.count() - g.count()) < 0.01 * o.count()
