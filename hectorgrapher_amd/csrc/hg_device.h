@@ -22,7 +22,13 @@ struct GridView {
   uint32_t max_blocks;
   uint32_t* voxels;           // max_blocks * 512, voxel = tsd_code | weight_code << 16
   unsigned long long* block_keys;  // key of slot s
-  uint32_t* counters;         // [0] num_blocks, [1] error flags, [2] hits, [3] updates(lo) ...
+  uint32_t* counters;         // [0] num_blocks, [1] error flags, [2] hits, [4..5] updates (u64),
+                              // [6] touched blocks being collected, [7] touched blocks to apply
+  uint32_t* bin_count;        // per block slot: records of the current insert call
+  uint32_t* bin_offset;       // per block slot: first record of its bin
+  uint32_t* touched;          // slots touched by the current insert call
+  unsigned long long* work;   // apply work items: slot | lo << 24 | hi << 34 | n << 44
+  uint32_t work_capacity;
   float resolution;
   float max_tsd, min_tsd, max_weight;
   float tsd_resolution, weight_resolution;  // encode scales (tsd_value_converter.cc:27-28)
@@ -146,6 +152,59 @@ __device__ inline uint32_t insert_block_unique(const GridView& g, unsigned long 
   }
   atomicOr(&g.counters[1], kFlagCapacity);
   return 0xFFFFFFFFu;
+}
+
+// Insert-or-get when several threads may insert the same key concurrently. A thread that loses
+// the CAS on its own key waits for the winner to publish the slot; the winner publishes inside the
+// same loop iteration it won in, so lanes of one wavefront cannot wait on each other forever.
+__device__ inline uint32_t insert_block_shared(const GridView& g, unsigned long long key) {
+  uint32_t h = hash_key(key) & g.table_mask;
+  const unsigned long long tag = key + 1ull;
+  uint32_t result = 0xFFFFFFFFu;
+  bool done = false;
+  uint32_t probes = 0;
+  while (!done) {
+    unsigned long long e = __hip_atomic_load(&g.table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e == 0ull) {
+      const unsigned long long pending = (tag << 24) | kSlotPending;
+      const unsigned long long prev = atomicCAS(&g.table[h], 0ull, pending);
+      if (prev == 0ull) {
+        const uint32_t slot = atomicAdd(&g.counters[0], 1u);
+        if (slot >= g.max_blocks || slot >= kSlotPending) {
+          atomicSub(&g.counters[0], 1u);
+          atomicOr(&g.counters[1], kFlagCapacity);
+          // publish a poisoned entry so waiters stop: slot field stays pending but tag is cleared
+          atomicExch(&g.table[h], (0x1FFFFFFFFFull << 24) | kSlotPending);
+          done = true;
+        } else {
+          g.block_keys[slot] = key;
+          atomicExch(&g.table[h], (tag << 24) | slot);
+          result = slot;
+          done = true;
+        }
+      } else {
+        e = prev;
+      }
+    }
+    if (!done) {
+      if ((e >> 24) == tag) {
+        const uint32_t s = static_cast<uint32_t>(e & 0xFFFFFFu);
+        if (s != kSlotPending) {
+          result = s;
+          done = true;
+        } else {
+          __builtin_amdgcn_s_sleep(1);  // winner is publishing
+        }
+      } else {
+        h = (h + 1) & g.table_mask;
+        if (++probes > g.table_mask) {
+          atomicOr(&g.counters[1], kFlagCapacity);
+          done = true;
+        }
+      }
+    }
+  }
+  return result;
 }
 
 // Voxel fetch for lookups: unknown block -> 0 (default TSDFVoxel).

@@ -245,6 +245,14 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
   if (e == hipSuccess)
     e = hipMalloc(reinterpret_cast<void**>(&v.block_keys), sizeof(unsigned long long) * max_blocks);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v.counters), 256);
+  // bin_count | bin_offset | touched (u32 each) | work (u64, 2 entries per block)
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v.bin_count), sizeof(uint32_t) * 8 * static_cast<size_t>(max_blocks));
+  if (e == hipSuccess) {
+    v.bin_offset = v.bin_count + max_blocks;
+    v.touched = v.bin_offset + max_blocks;
+    v.work = reinterpret_cast<unsigned long long*>(v.bin_count + 4 * static_cast<size_t>(max_blocks));
+    v.work_capacity = 2 * max_blocks;
+  }
   if (e != hipSuccess) {
     set_last_error(std::string("hipMalloc grid: ") + hipGetErrorString(e));
     hg_grid_destroy(g);
@@ -262,6 +270,7 @@ int hg_grid_destroy(hg_grid* g) {
   if (g->view.voxels) (void)hipFree(g->view.voxels);
   if (g->view.block_keys) (void)hipFree(g->view.block_keys);
   if (g->view.counters) (void)hipFree(g->view.counters);
+  if (g->view.bin_count) (void)hipFree(g->view.bin_count);
   delete g;
   return HG_OK;
 }
@@ -273,6 +282,7 @@ int hg_grid_clear(hg_grid* g) {
   HG_HIP_CHECK(hipMemsetAsync(g->view.voxels, 0,
                               sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(g->view.max_blocks), s));
   HG_HIP_CHECK(hipMemsetAsync(g->view.counters, 0, 256, s));
+  HG_HIP_CHECK(hipMemsetAsync(g->view.bin_count, 0, sizeof(uint32_t) * 8 * static_cast<size_t>(g->view.max_blocks), s));
   return HG_OK;
 }
 

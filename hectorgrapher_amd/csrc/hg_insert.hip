@@ -12,6 +12,7 @@
 // which reproduces the reference bit for bit while different voxels proceed in parallel.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 
@@ -200,6 +201,40 @@ __device__ inline uint32_t update_cell(const GridView& g, float maximum_weight, 
   const float updated_sdf = (old_sdf * old_weight + update_sdf * update_weight) / updated_weight;
   updated_weight = (maximum_weight < updated_weight) ? maximum_weight : updated_weight;  // std::min
   return (tsd_to_value(g, updated_sdf) + kUpdateMarker) | (weight_to_value(g, updated_weight) << 16);
+}
+
+// lround(t) for 0 <= t < 2^23 without the generic half-away-from-zero sequence: trunc is exact,
+// the fraction t - trunc(t) is exact, ties (>= 0.5) go up. Returns the rounded value as float.
+__device__ inline float round_nonneg(float t) {
+  const float r = truncf(t);
+  return (t - r >= 0.5f) ? r + 1.0f : r;
+}
+
+// `count` consecutive UpdateCell calls with update weight 1 on one voxel (values vals[0..count)),
+// bit-identical to calling update_cell in a loop: codes stay in float form (code - 1 as a float)
+// between updates, so the dependent chain per update is ~35 instructions instead of ~75.
+__device__ inline uint32_t update_chain_unit(const GridView& g, float maximum_weight, uint32_t code,
+                                             const uint32_t* vals, unsigned count) {
+  if (count == 0) return code;
+  const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
+  float d = tc == 0 ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
+  float w = wc == 0 ? 0.f : static_cast<float>(wc) * g.weight_scale + g.weight_offset;
+  float rt = 0.f, rw = 0.f;
+  for (unsigned j = 0; j < count; ++j) {
+    const float u = __uint_as_float(vals[j]);
+    float uw = w + 1.0f;
+    const float ud = (d * w + u) / uw;            // u * 1.0f == u
+    uw = (maximum_weight < uw) ? maximum_weight : uw;
+    // TSDToValue / WeightToValue (values are finite: med3 == the reference's two-sided clamp)
+    rt = round_nonneg((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * g.tsd_resolution);
+    rw = round_nonneg((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * g.weight_resolution);
+    // ValueToTSD / ValueToWeight of the codes rt + 1, rw + 1 (never 0)
+    d = (rt + 1.0f) * g.tsd_scale + g.tsd_offset;
+    w = (rw + 1.0f) * g.weight_scale + g.weight_offset;
+  }
+  const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt)) + 1u;
+  const uint32_t nw = static_cast<uint32_t>(static_cast<int>(rw)) + 1u;
+  return (nt + kUpdateMarker) | (nw << 16);
 }
 
 __global__ void k_apply_runs(GridView g, InsertParams p, const unsigned long long* keys,
@@ -483,7 +518,438 @@ __global__ void k_sum_stats(PyramidIns P, const unsigned* wg_hits, unsigned n_ex
     }
     if (threadIdx.x == 0) {
       P.lv[l].g.counters[2] = static_cast<uint32_t>(hs);
-      *reinterpret_cast<unsigned long long*>(&P.lv[l].g.counters[4]) = red[0];
+      if (wg_updates) *reinterpret_cast<unsigned long long*>(&P.lv[l].g.counters[4]) = red[0];
+    }
+    __syncthreads();
+  }
+}
+
+
+// ==========================================================================================
+// Binned path (single scan, unit update weight): no global sort.
+//   k_bin_count    per (return, level): walks the ray, inserts the blocks it touches into the
+//                  hash, counts its records per block bin (one atomic per run of samples inside
+//                  one block) and collects the touched blocks.
+//   k_bin_offsets  per level: exclusive scan of the touched bins' counts -> bin offsets.
+//   k_bin_scatter  per (return, level): walks the ray again and writes {voxel | seq, tsd} records
+//                  into its blocks' bins (arrival order inside a bin is arbitrary).
+//   k_bin_apply    one workgroup per touched block: groups the bin by voxel in LDS (counting
+//                  sort), orders every voxel's records by seq (rank counting), then one thread
+//                  per voxel applies its updates in reference order on the block's voxels.
+// seq = return index * 8 + sample position restores the reference's update order exactly.
+// ==========================================================================================
+constexpr int kBinCap = 4096;       // records per LDS pass of k_bin_apply
+constexpr int kBinThreads = 512;    // one thread per voxel of a block
+constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
+
+enum : uint32_t { kFlagBinOverflow = 8u };
+
+__device__ inline void ray_cell(const Ray& r, int pos, int& cx, int& cy, int& cz) {
+  const float fp = static_cast<float>(pos), fn = static_cast<float>(r.n);
+  cx = r.bx + static_cast<int>(roundf(static_cast<float>(r.dx) * fp / fn));
+  cy = r.by + static_cast<int>(roundf(static_cast<float>(r.dy) * fp / fn));
+  cz = r.bz + static_cast<int>(roundf(static_cast<float>(r.dz) * fp / fn));
+}
+
+__device__ inline ScanTable scan_of(const PyramidIns& P) {
+  ScanTable sc = P.scan0;
+  if (P.d_pose) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sc.pose[k] = static_cast<float>(P.d_pose[k]);
+  }
+  return sc;
+}
+
+constexpr int kMaxRuns = 4;  // a straight 8-sample walk visits at most 4 blocks (monotone per axis)
+
+// Splits the samples of a ray into runs that stay inside one block. Returns the number of runs.
+__device__ inline int ray_block_runs(const Ray& r, unsigned long long* run_key, int* run_begin,
+                                     int* run_len, bool* range_err) {
+  int nr = 0;
+  unsigned long long cur = ~0ull;
+  for (int pos = 0; pos <= r.n; ++pos) {
+    int cx, cy, cz;
+    ray_cell(r, pos, cx, cy, cz);
+    if (!cell_in_range(cx, cy, cz)) {
+      *range_err = true;
+      cur = ~0ull;
+      continue;
+    }
+    const unsigned long long key = block_key(cx, cy, cz);
+    if (key != cur) {
+      if (nr == kMaxRuns) break;  // cannot happen for a straight walk; guards the arrays
+      run_key[nr] = key;
+      run_begin[nr] = pos;
+      run_len[nr] = 0;
+      ++nr;
+      cur = key;
+    }
+    ++run_len[nr - 1];
+  }
+  return nr;
+}
+
+// Per-thread result of k_bin_count, consumed by k_bin_scatter: for each of <= 4 runs the block
+// slot and the run's first record position inside the block's bin. begin/len: 4 bits each.
+struct RunInfo {
+  uint32_t slot[kMaxRuns];
+  uint32_t off[kMaxRuns];
+  uint32_t packed;  // run k: begin = (packed >> 8k) & 15, len = (packed >> (8k + 4)) & 15
+  uint32_t pad[3];
+};
+
+// Groups the lanes of a wavefront by `slot` (lanes with want == false stay out): returns the
+// group's lowest lane, the exclusive prefix of `cnt` inside the group in lane order and the
+// group total. Pure cross-lane work (ballot / shuffles), no memory traffic.
+__device__ inline void wave_group(uint32_t slot, unsigned cnt, bool want, int* leader_out,
+                                  unsigned* prefix_out, unsigned* total_out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  int my_leader = lane;
+  unsigned my_prefix = 0, my_total = cnt;
+  unsigned long long pending = __ballot(want);
+  while (pending) {
+    const int leader = __builtin_ctzll(pending);
+    const uint32_t ls = __shfl(slot, leader);
+    const bool mine = want && slot == ls;
+    const unsigned long long grp = __ballot(mine);
+    unsigned incl = mine ? cnt : 0u;
+    const unsigned v = incl;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    const unsigned total = __shfl(incl, 63);
+    if (mine) {
+      my_leader = leader;
+      my_prefix = incl - v;
+      my_total = total;
+    }
+    pending &= ~grp;
+  }
+  *leader_out = my_leader;
+  *prefix_out = my_prefix;
+  *total_out = my_total;
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xyz, unsigned n,
+                                                   RunInfo* runs, unsigned* wg_hits) {
+  const int level = blockIdx.y;
+  const LevelIns& L = P.lv[level];
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  __shared__ unsigned s_hits;
+  if (threadIdx.x == 0) s_hits = 0;
+  __syncthreads();
+  bool hit = false;
+  unsigned long long run_key[kMaxRuns];
+  int run_begin[kMaxRuns], run_len[kMaxRuns];
+  int nr = 0;
+  if (i < n) {
+    const ScanTable sc = scan_of(P);
+    const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
+    hit = r.valid && r.n + 1 <= kSlots;
+    if (r.valid && !hit) atomicOr(&L.g.counters[1], kFlagStride);
+    if (hit) {
+      bool range_err = false;
+      nr = ray_block_runs(r, run_key, run_begin, run_len, &range_err);
+      if (range_err) atomicOr(&L.g.counters[1], kFlagRange);
+    }
+  }
+  // block slots: all probes of the wave in flight together, inserts only where the block is new
+  unsigned long long entry[kMaxRuns];
+  uint32_t slot[kMaxRuns];
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k)
+    entry[k] = (k < nr) ? L.g.table[hash_key(run_key[k]) & L.g.table_mask] : 0ull;
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) {
+    slot[k] = 0xFFFFFFFFu;
+    if (k < nr) {
+      if ((entry[k] >> 24) == run_key[k] + 1ull && (entry[k] & 0xFFFFFFu) != kSlotPending)
+        slot[k] = static_cast<uint32_t>(entry[k] & 0xFFFFFFu);
+      else
+        slot[k] = insert_block_shared(L.g, run_key[k]);
+    }
+  }
+  // one atomic per (wavefront, block, round); all rounds' atomics in flight together
+  int leader[kMaxRuns];
+  unsigned prefix[kMaxRuns], total[kMaxRuns], base[kMaxRuns];
+  bool want[kMaxRuns];
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) {
+    want[k] = k < nr && slot[k] < L.g.max_blocks;
+    wave_group(slot[k], want[k] ? static_cast<unsigned>(run_len[k]) : 0u, want[k], &leader[k],
+               &prefix[k], &total[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) {
+    base[k] = 0;
+    if (want[k] && lane == leader[k]) base[k] = atomicAdd(&L.g.bin_count[slot[k]], total[k]);
+  }
+  RunInfo info;
+  info.packed = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) {
+    const unsigned b = __shfl(base[k], leader[k]);
+    if (want[k] && lane == leader[k] && b == 0u)  // first records of this bin in this call
+      L.g.touched[atomicAdd(&L.g.counters[6], 1u)] = slot[k];
+    info.slot[k] = want[k] ? slot[k] : 0xFFFFFFFFu;
+    info.off[k] = b + prefix[k];
+    if (k < nr) info.packed |= (static_cast<uint32_t>(run_begin[k]) | (static_cast<uint32_t>(run_len[k]) << 4)) << (8 * k);
+  }
+  info.pad[0] = info.pad[1] = info.pad[2] = 0;
+  if (i < n) runs[static_cast<size_t>(level) * n + i] = info;
+  const unsigned long long m = __ballot(hit);
+  if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
+  __syncthreads();
+  if (threadIdx.x == 0) wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
+}
+
+// Lanes of the wavefront (among `valid` ones) that hold the same 9-bit value as this lane.
+__device__ inline unsigned long long match_voxel(unsigned v, bool valid) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 9; ++b) {
+    const bool bit = (v >> b) & 1u;
+    const unsigned long long bb = __ballot(bit);
+    m &= bit ? bb : ~bb;
+  }
+  return valid ? m : 0ull;
+}
+
+// Exclusive prefix sum over the workgroup (blockDim.x a multiple of 64, <= 1024): wave scan by
+// shuffles, wave totals through LDS. Returns the exclusive prefix; *total = sum over the block.
+__device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* s_wave /*[16]*/, unsigned* total) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int nwaves = blockDim.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();  // s_wave may still be read from a previous call
+  if (lane == kWave - 1) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+  for (int w = 0; w < nwaves; ++w) {
+    const unsigned t = s_wave[w];
+    if (w < wave) before += t;
+    all += t;
+  }
+  *total = all;
+  return before + incl - v;
+}
+
+// grid (levels), 1024 threads: bin offsets by an exclusive scan over the touched list, and the
+// apply work list: a bin larger than one LDS pass is split into voxel slices handled by
+// different workgroups (voxels are independent of each other).
+__global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned records_per_level) {
+  const LevelIns& L = P.lv[blockIdx.x];
+  __shared__ unsigned s_scan[16];
+  __shared__ unsigned s_base, s_work;
+  const unsigned nt = L.g.counters[6];
+  if (threadIdx.x == 0) { s_base = 0; s_work = 0; }
+  __syncthreads();
+  // two rounds over the touched list: round 0 assigns offsets and emits the work items of large
+  // bins (their long per-voxel chains are the critical path, so they are scheduled first),
+  // round 1 emits the rest
+  for (int round = 0; round < 2; ++round) {
+    for (unsigned c0 = 0; c0 < nt; c0 += 1024) {
+      const unsigned i = c0 + threadIdx.x;
+      const unsigned slot = i < nt ? L.g.touched[i] : 0u;
+      unsigned cnt = 0;
+      cnt = i < nt ? L.g.bin_count[slot] : 0u;
+      unsigned chunk_total = 0;
+      if (round == 0) {
+        const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
+        if (i < nt) L.g.bin_offset[slot] = blockIdx.x * records_per_level + s_base + excl;
+      }
+      const bool large = cnt > 1024u;
+      if (i < nt && ((round == 0) == large)) {
+        unsigned slices = 1;
+        while (slices < 64 && cnt > slices * 2048u) slices <<= 1;
+        const unsigned w0 = atomicAdd(&s_work, slices);
+        const unsigned step = 512u / slices;
+        for (unsigned k = 0; k < slices; ++k) {
+          if (w0 + k < L.g.work_capacity)
+            L.g.work[w0 + k] = static_cast<unsigned long long>(slot) |
+                               (static_cast<unsigned long long>(k * step) << 24) |
+                               (static_cast<unsigned long long>((k + 1) * step) << 34) |
+                               (static_cast<unsigned long long>(cnt) << 44);
+          else
+            atomicOr(&L.g.counters[1], kFlagCapacity);
+        }
+      }
+      if (round == 1 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
+      __syncthreads();
+      if (round == 0 && threadIdx.x == 0) s_base += chunk_total;
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    L.g.counters[7] = min(s_work, L.g.work_capacity);  // consumed by k_bin_apply
+    L.g.counters[6] = 0;                                // next call collects from scratch
+    *reinterpret_cast<unsigned long long*>(&L.g.counters[4]) = s_base;  // U of this call
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const float* xyz, unsigned n,
+                                                     const RunInfo* runs, uint32_t* rec_keys,
+                                                     uint32_t* rec_vals) {
+  const int level = blockIdx.y;
+  const LevelIns& L = P.lv[level];
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const RunInfo info = runs[static_cast<size_t>(level) * n + i];
+  if (info.packed == 0u) return;
+  const ScanTable sc = scan_of(P);
+  const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) {
+    const int len = (info.packed >> (8 * k + 4)) & 15;
+    if (len == 0 || info.slot[k] == 0xFFFFFFFFu) continue;
+    const int begin = (info.packed >> (8 * k)) & 15;
+    const unsigned dst = L.g.bin_offset[info.slot[k]] + info.off[k];
+    int q = 0;
+    for (int pos = begin; q < len; ++pos) {
+      int cx, cy, cz;
+      float tsd, w;
+      ray_sample(L.g, L.p, r, pos, cx, cy, cz, tsd, w);
+      if (!cell_in_range(cx, cy, cz)) continue;  // skipped inside the run by ray_block_runs
+      rec_keys[dst + q] = (voxel_in_block(cx, cy, cz) << kSeqBits) | (i * kSlots + pos);
+      rec_vals[dst + q] = __float_as_uint(tsd);
+      ++q;
+    }
+  }
+}
+
+// grid (G, levels), 512 threads, loops over the level's work items (block, voxel range).
+__global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
+                                                          const uint32_t* __restrict__ rec_vals) {
+  // workgroups are dispatched in blockIdx order: the last (coarsest) level has the longest per-voxel
+  // chains, so it goes first
+  const LevelIns& L = P.lv[P.levels - 1 - blockIdx.y];
+  const GridView& g = L.g;
+  __shared__ unsigned hist[512];      // records per voxel (inside the item's voxel range)
+  __shared__ unsigned base[512];      // exclusive prefix of hist
+  __shared__ unsigned cursor[512];
+  __shared__ uint32_t gk[kBinCap];    // grouped by voxel, arbitrary order inside a group
+  __shared__ uint32_t gv[kBinCap];
+  __shared__ uint32_t sv[kBinCap];    // values in (voxel, seq) order
+  __shared__ unsigned s_hi;
+  const unsigned nwork = g.counters[7];
+  const unsigned tid = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const unsigned long long item = g.work[wi];
+    const uint32_t slot = static_cast<uint32_t>(item & 0xFFFFFFu);
+    const unsigned v_lo = static_cast<unsigned>(item >> 24) & 1023u;
+    const unsigned v_hi = static_cast<unsigned>(item >> 34) & 1023u;
+    const unsigned n = static_cast<unsigned>(item >> 44);
+    const uint32_t* bk = rec_keys + g.bin_offset[slot];
+    const uint32_t* bv = rec_vals + g.bin_offset[slot];
+    hist[tid] = 0;
+    __syncthreads();
+    for (unsigned i0 = 0; i0 < n; i0 += 4 * kBinThreads) {  // 4 loads in flight per thread
+      uint32_t k4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned i = i0 + u * kBinThreads + tid;
+        k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned v = k4[u] >> kSeqBits;
+        if (k4[u] != 0xFFFFFFFFu && v >= v_lo && v < v_hi) atomicAdd(&hist[v], 1u);
+      }
+    }
+    __syncthreads();
+    // exclusive prefix of hist over the 512 voxels -> base
+    {
+      unsigned tot;
+      base[tid] = block_exclusive_scan(hist[tid], cursor, &tot);
+    }
+    __syncthreads();
+    unsigned lo = v_lo;
+    while (lo < v_hi) {
+      // voxel range [lo, hi): the longest prefix of voxels whose records fit one LDS pass
+      const unsigned b_lo = base[lo];
+      if (tid == 0) s_hi = 1024;
+      __syncthreads();
+      {
+        const unsigned end_v = base[tid] + hist[tid] - b_lo;  // records in [lo, tid]
+        const bool fits = tid >= lo && tid < v_hi && end_v <= static_cast<unsigned>(kBinCap);
+        const bool next_fits = tid + 1 < v_hi && (base[tid + 1] + hist[tid + 1] - b_lo) <= static_cast<unsigned>(kBinCap);
+        if (fits && !next_fits) s_hi = tid + 1;
+        if (tid == lo && !fits) s_hi = lo;  // the first voxel alone does not fit
+      }
+      __syncthreads();
+      unsigned hi = s_hi;
+      unsigned cnt = 0;
+      if (hi == lo) {  // a single voxel exceeds the pass capacity: not supported on this path
+        if (tid == 0) atomicOr(&g.counters[1], kFlagBinOverflow);
+        hi = lo + 1;
+      } else {
+        cnt = base[hi - 1] + hist[hi - 1] - b_lo;
+      }
+      cursor[tid] = 0;
+      __syncthreads();
+      if (cnt) {
+        // group by voxel (arbitrary order inside a group)
+        for (unsigned i0 = 0; i0 < n; i0 += 4 * kBinThreads) {
+          uint32_t k4[4], v4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * kBinThreads + tid;
+            k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+            v4[u] = i < n ? bv[i] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned v = k4[u] >> kSeqBits;
+            if (k4[u] != 0xFFFFFFFFu && v >= lo && v < hi) {
+              const unsigned p = base[v] - b_lo + atomicAdd(&cursor[v], 1u);
+              gk[p] = k4[u];
+              gv[p] = v4[u];
+            }
+          }
+        }
+        __syncthreads();
+        // order each group by seq: rank = number of group members with a smaller key
+        for (unsigned i = tid; i < cnt; i += kBinThreads) {
+          const uint32_t k = gk[i];
+          const unsigned v = k >> kSeqBits;
+          const unsigned b0 = base[v] - b_lo, b1 = b0 + hist[v];
+          unsigned rank = 0;
+          unsigned j = b0;
+          for (; j + 4 <= b1; j += 4) {
+            const uint32_t a0 = gk[j], a1 = gk[j + 1], a2 = gk[j + 2], a3 = gk[j + 3];
+            rank += (a0 < k ? 1u : 0u) + (a1 < k ? 1u : 0u) + (a2 < k ? 1u : 0u) + (a3 < k ? 1u : 0u);
+          }
+          for (; j < b1; ++j) rank += (gk[j] < k) ? 1u : 0u;
+          sv[b0 + rank] = gv[i];
+        }
+        __syncthreads();
+        // one thread per voxel applies its updates in reference order; a wavefront that holds a
+        // long chain is the critical path of the whole insert: give it issue priority
+        {
+          const unsigned mine = (tid >= lo && tid < hi) ? hist[tid] : 0u;
+          if (__ballot(mine > 48u)) __builtin_amdgcn_s_setprio(3);
+        }
+        if (tid >= lo && tid < hi && hist[tid]) {
+          uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + tid;
+          uint32_t code = *cell;
+          const unsigned b0 = base[tid] - b_lo, b1 = b0 + hist[tid];
+          code = update_chain_unit(g, L.p.maximum_weight, code, sv + b0, b1 - b0);
+          *cell = code;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+      }
+      lo = hi;
     }
     __syncthreads();
   }
@@ -649,6 +1115,52 @@ int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans,
   return HG_OK;
 }
 
+// ---- binned path (single scan, unit weight) ------------------------------------------------
+int insert_chunk_binned(hg_ctx* c, const PyramidIns& P, const float* d_xyz, unsigned long long n,
+                        bool want_stats) {
+  hipStream_t s = c->stream;
+  const unsigned records_per_level = static_cast<unsigned>(n) * kSlots;
+  const size_t slots = static_cast<size_t>(records_per_level) * P.levels;
+  int rc;
+  if ((rc = c->ws_keys_a.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
+  if ((rc = c->ws_vals_a.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
+  const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
+  if ((rc = c->ws_counts.reserve(sizeof(unsigned) * static_cast<size_t>(nwg_e) * kMaxInsLevels)) != HG_OK) return rc;
+  if ((rc = c->ws_keys_b.reserve(sizeof(RunInfo) * n * P.levels)) != HG_OK) return rc;
+  unsigned* wg_hits = c->ws_counts.as<unsigned>();
+  uint32_t* rk = c->ws_keys_a.as<uint32_t>();
+  uint32_t* rv = c->ws_vals_a.as<uint32_t>();
+  RunInfo* runs = c->ws_keys_b.as<RunInfo>();
+  {
+    ProfScope ps(c, HG_K_RAY_COUNT, n * P.levels);
+    hipLaunchKernelGGL(k_bin_count, dim3(nwg_e, P.levels), dim3(256), 0, s, P, d_xyz,
+                       static_cast<unsigned>(n), runs, wg_hits);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  {
+    ProfScope ps(c, HG_K_SCAN, P.levels);
+    hipLaunchKernelGGL(k_bin_offsets, dim3(P.levels), dim3(1024), 0, s, P, records_per_level);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  {
+    ProfScope ps(c, HG_K_RAY_EXPAND, n * P.levels);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nwg_e, P.levels), dim3(256), 0, s, P, d_xyz,
+                       static_cast<unsigned>(n), runs, rk, rv);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  {
+    ProfScope ps(c, HG_K_APPLY, slots);
+    hipLaunchKernelGGL(k_bin_apply, dim3(1024, P.levels), dim3(kBinThreads), 0, s, P, rk, rv);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  if (want_stats) {
+    // hits from the per-workgroup counts; updates were written by k_bin_offsets
+    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, nullptr, 0u);
+    HG_HIP_CHECK(hipGetLastError());
+  }
+  return HG_OK;
+}
+
 int read_stats(hg_grid* grid, hg_insert_stats* out) {
   uint32_t cnt[8];
   hipStream_t s = grid->ctx->stream;
@@ -671,6 +1183,10 @@ int read_stats(hg_grid* grid, hg_insert_stats* out) {
   }
   if (cnt[1] & kFlagStride) {
     set_last_error("ray produced more than 8 samples on the fixed-stride path");
+    return HG_ERR_UNSUPPORTED;
+  }
+  if (cnt[1] & kFlagBinOverflow) {
+    set_last_error("a voxel received more updates in one scan than the binned path supports");
     return HG_ERR_UNSUPPORTED;
   }
   return HG_OK;
@@ -851,7 +1367,11 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
       Pc.scan0 = table[0];
       for (int l = 0; l < levels; ++l)
         if (Pc.lv[l].gate) Pc.lv[l].gate += first;
-      if (fixed_ok) {
+      const char* force_sort = getenv("HG_INSERT_SORT");
+      if (fixed_ok && unit_weight && table.size() == 1 && pts < (1ull << 20) &&
+          !(force_sort && force_sort[0] == '1')) {
+        rc = insert_chunk_binned(c, Pc, d_xyz + 3 * first, pts, stats != nullptr);
+      } else if (fixed_ok) {
         const bool ws = stats != nullptr;
         if (key32 && unit_weight)
           rc = insert_chunk_fixed<uint32_t, uint32_t>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
