@@ -12,7 +12,9 @@
 // which reproduces the reference bit for bit while different voxels proceed in parallel.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <cstring>
 #include <string.h>
 
@@ -538,7 +540,7 @@ __global__ void k_sum_stats(PyramidIns P, const unsigned* wg_hits, unsigned n_ex
 //                  per voxel applies its updates in reference order on the block's voxels.
 // seq = return index * 8 + sample position restores the reference's update order exactly.
 // ==========================================================================================
-constexpr int kBinCap = 4096;       // records per LDS pass of k_bin_apply
+constexpr int kBinCap = 2048;       // records per LDS pass of k_bin_apply (4 per thread)
 constexpr int kBinThreads = 512;    // one thread per voxel of a block
 constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
 
@@ -766,10 +768,10 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
         if (i < nt) L.g.bin_offset[slot] = blockIdx.x * records_per_level + s_base + excl;
       }
-      const bool large = cnt > 1024u;
+      const bool large = cnt > 512u;
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
-        while (slices < 64 && cnt > slices * 2048u) slices <<= 1;
+        while (slices < 64 && cnt > slices * 1024u) slices <<= 1;
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -827,8 +829,17 @@ __global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const float* 
 }
 
 // grid (G, levels), 512 threads, loops over the level's work items (block, voxel range).
+#ifdef HG_BIN_STAMPS
+#define BIN_STAMP(i) do { if (threadIdx.x == 0) stamps[(static_cast<size_t>(blockIdx.y) * 4096 + wi) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BIN_STAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
-                                                          const uint32_t* __restrict__ rec_vals) {
+                                                          const uint32_t* __restrict__ rec_vals
+#ifdef HG_BIN_STAMPS
+                                                          , long long* stamps
+#endif
+                                                          ) {
   // workgroups are dispatched in blockIdx order: the last (coarsest) level has the longest per-voxel
   // chains, so it goes first
   const LevelIns& L = P.lv[P.levels - 1 - blockIdx.y];
@@ -842,7 +853,6 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
   __shared__ unsigned s_hi;
   const unsigned nwork = g.counters[7];
   const unsigned tid = threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
   for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     const unsigned long long item = g.work[wi];
     const uint32_t slot = static_cast<uint32_t>(item & 0xFFFFFFu);
@@ -851,22 +861,31 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
     const unsigned n = static_cast<unsigned>(item >> 44);
     const uint32_t* bk = rec_keys + g.bin_offset[slot];
     const uint32_t* bv = rec_vals + g.bin_offset[slot];
+    BIN_STAMP(0);
+#ifdef HG_BIN_STAMPS
+    if (threadIdx.x == 0) stamps[(static_cast<size_t>(blockIdx.y) * 4096 + wi) * 8 + 6] = n;
+#endif
     hist[tid] = 0;
     __syncthreads();
+    const bool single = n <= static_cast<unsigned>(kBinCap);  // whole bin in registers: one read
+    uint32_t rk4[4], rv4[4];
     for (unsigned i0 = 0; i0 < n; i0 += 4 * kBinThreads) {  // 4 loads in flight per thread
       uint32_t k4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const unsigned i = i0 + u * kBinThreads + tid;
         k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+        if (single) rv4[u] = i < n ? bv[i] : 0u;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
+        if (single) rk4[u] = k4[u];
         const unsigned v = k4[u] >> kSeqBits;
         if (k4[u] != 0xFFFFFFFFu && v >= v_lo && v < v_hi) atomicAdd(&hist[v], 1u);
       }
     }
     __syncthreads();
+    BIN_STAMP(1);
     // exclusive prefix of hist over the 512 voxels -> base
     {
       unsigned tot;
@@ -904,8 +923,13 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const unsigned i = i0 + u * kBinThreads + tid;
-            k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
-            v4[u] = i < n ? bv[i] : 0u;
+            if (single) {
+              k4[u] = rk4[u];
+              v4[u] = rv4[u];
+            } else {
+              k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+              v4[u] = i < n ? bv[i] : 0u;
+            }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -918,6 +942,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
           }
         }
         __syncthreads();
+        BIN_STAMP(2);
         // order each group by seq: rank = number of group members with a smaller key
         for (unsigned i = tid; i < cnt; i += kBinThreads) {
           const uint32_t k = gk[i];
@@ -933,6 +958,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
           sv[b0 + rank] = gv[i];
         }
         __syncthreads();
+        BIN_STAMP(3);
         // one thread per voxel applies its updates in reference order; a wavefront that holds a
         // long chain is the critical path of the whole insert: give it issue priority
         {
@@ -948,6 +974,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
+        BIN_STAMP(4);
       }
       lo = hi;
     }
@@ -1150,7 +1177,41 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P, const float* d_xyz, unsi
   HG_HIP_CHECK(hipGetLastError());
   {
     ProfScope ps(c, HG_K_APPLY, slots);
+#ifdef HG_BIN_STAMPS
+    static long long* d_st = nullptr;
+    if (!d_st) hipMalloc(reinterpret_cast<void**>(&d_st), 3 * 4096 * 8 * sizeof(long long));
+    hipMemsetAsync(d_st, 0, 3 * 4096 * 8 * sizeof(long long), s);
+    hipLaunchKernelGGL(k_bin_apply, dim3(1024, P.levels), dim3(kBinThreads), 0, s, P, rk, rv, d_st);
+    {
+      std::vector<long long> h(3 * 4096 * 8);
+      hipMemcpy(h.data(), d_st, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      long long t0 = -1;
+      for (size_t i = 0; i < h.size(); i += 8) if (h[i] && (t0 < 0 || h[i] < t0)) t0 = h[i];
+      for (int y = 0; y < 3; ++y) {
+        // summary: count, mean phase durations, and the latest finishing items
+        double sum[5] = {0, 0, 0, 0, 0};
+        int cnt = 0;
+        long long last_end = 0; int last_i = -1;
+        for (int w = 0; w < 4096; ++w) {
+          const long long* e = &h[(static_cast<size_t>(y) * 4096 + w) * 8];
+          if (!e[0]) continue;
+          ++cnt;
+          for (int k = 1; k <= 4; ++k) if (e[k]) sum[k] += double(e[k] - e[k - 1]);
+          long long end = e[4] ? e[4] : e[1];
+          if (end > last_end) { last_end = end; last_i = w; }
+        }
+        fprintf(stderr, "bin y=%d items=%d mean cycles hist=%.0f group=%.0f rank=%.0f chain=%.0f; last item %d ends at %lld",
+                y, cnt, cnt ? sum[1] / cnt : 0, cnt ? sum[2] / cnt : 0, cnt ? sum[3] / cnt : 0, cnt ? sum[4] / cnt : 0, last_i, last_end - t0);
+        if (last_i >= 0) {
+          const long long* e = &h[(static_cast<size_t>(y) * 4096 + last_i) * 8];
+          fprintf(stderr, " [n=%lld start=%lld hist=%lld group=%lld rank=%lld chain=%lld]", e[6], e[0] - t0, e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3]);
+        }
+        fprintf(stderr, "\n");
+      }
+    }
+#else
     hipLaunchKernelGGL(k_bin_apply, dim3(1024, P.levels), dim3(kBinThreads), 0, s, P, rk, rv);
+#endif
   }
   HG_HIP_CHECK(hipGetLastError());
   if (want_stats) {
