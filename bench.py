@@ -97,14 +97,30 @@ def cpu_baseline(args, map_scans, query_scans):
 
 def main():
     args = parse_args()
+    # libraries (RCCL banner, ...) may write to fd 1: keep stdout for the single JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        result = run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("HG_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -190,7 +206,7 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return
+        return None
 
     total_scans = args.steps * world
     value = total_scans / elapsed
@@ -241,9 +257,9 @@ def main():
         out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
         out["cpu_baseline"]["cores_available"] = os.cpu_count()
         out["gpu_over_cpu"] = value / world / base["value"]
-    print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

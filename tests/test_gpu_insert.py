@@ -225,3 +225,27 @@ def test_far_points_use_wide_keys(po, hg, ctx):
     st = hg.TSDFRangeDataInserter3D(hg.InsertOpts(**kw)).Insert(hg.RangeData([0, 0, 0], pts), gg)
     assert (st.num_hits, st.num_updates) == a
     assert_grids_equal(og, gg)
+
+
+def test_block_arrays_roundtrip_through_torch(po, hg, ctx):
+    """The multi-GPU gather ships (keys, voxels) of the block pool as torch tensors aliasing library
+    memory; importing them into a fresh grid must reproduce the grid exactly."""
+    torch = pytest.importorskip("torch")
+    from hectorgrapher_amd import distributed as hgd
+    pose = synth.pose_k(2)
+    pts = synth.transform_points(pose, synth.generate_scan(pose, 16, 300, stream=2))
+    src = hg.HybridGridTSDF(ctx, 0.1, max_blocks=1 << 14)
+    hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(pose[:3], pts), src)
+    ctx.synchronize()
+    keys, vox = hgd.grid_block_tensors(src, torch.device("cuda:0"))
+    assert keys.shape[0] == src.num_blocks() and vox.shape == (keys.shape[0], 512)
+    k2, v2 = keys.clone(), vox.clone()
+    torch.cuda.synchronize()
+    dst = hg.HybridGridTSDF(ctx, 0.1, max_blocks=1 << 14)
+    dst.import_blocks(k2, v2)
+    a, b = src.export(), dst.export()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # host path too
+    dst2 = hg.HybridGridTSDF(ctx, 0.1, max_blocks=1 << 14)
+    dst2.import_blocks(k2.cpu().numpy().view(np.uint64), v2.cpu().numpy().view(np.uint32))
+    assert all(np.array_equal(x, y) for x, y in zip(a, dst2.export()))
