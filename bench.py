@@ -37,6 +37,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3)
     ap.add_argument("--max-blocks", type=int, default=1 << 18)
+    ap.add_argument("--workload", default="register", choices=["register", "insert_stream"],
+                    help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
+                         "configs[2]: B scans with known poses inserted per step in one batched call")
+    ap.add_argument("--stream-scans", type=int, default=64)
     return ap.parse_args()
 
 
@@ -111,7 +115,74 @@ def main():
         print(json.dumps(result), flush=True)
 
 
+def run_insert_stream(args):
+    """BASELINE configs[2]: TSDFRangeDataInserter3D on a 100k-pt scan stream, 3 hashed-block grids.
+    One step = args.stream_scans scans (known poses) inserted by ONE hg_pyramid_insert_batch call."""
+    import torch
+    from hectorgrapher_amd import api, synth
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0)
+    n_pts = args.rings * args.cols
+    B = args.stream_scans
+    scans = make_scans(args.rings, args.cols, 0, B, 0)
+    xyz = torch.from_numpy(np.concatenate([p for _, p in scans])).to(dev)
+    poses = np.array([pose for pose, _ in scans], np.float32)
+    origins = np.zeros((B, 3), np.float32)
+    offs = np.arange(B + 1, dtype=np.uint64) * n_pts
+    torch.cuda.synchronize()
+    grids = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+    ins = api.TSDFRangeDataInserter3D()
+    L = api._lib.load()
+    import ctypes as C
+    garr = (C.c_void_p * 3)(*[g._h for g in grids])
+    opts = (api.InsertOpts * 3)(*[api.InsertOpts() for _ in grids])
+    st = (api.InsertStats * 3)()
+
+    def step(stats):
+        api.check(L.hg_pyramid_insert_batch(garr, opts, 3, origins.ctypes.data_as(C.c_void_p), xyz.data_ptr(),
+                                            offs.ctypes.data_as(C.c_void_p), B, 0,
+                                            poses.ctypes.data_as(C.c_void_p), 0, 1, st if stats else None),
+                  "hg_pyramid_insert_batch")
+
+    for _ in range(args.warmup):
+        step(False)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    step(True)
+    U = sum(s_.num_updates for s_ in st)
+    N_in = sum(s_.num_hits for s_ in st)
+    t_fam = sum(prof[k][1] for k in ("ray_count", "scan", "ray_expand", "sort", "alloc", "apply"))
+    avg_ms = t_fam / max(1, prof["apply"][0])
+    bytes_per = 12.0 * N_in + 8.0 * U
+    launches = max(1, prof["apply"][0])
+    achieved = bytes_per * (args.steps / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {
+        "metric": "scans/s (100k-pt scan stream, exact TSDF insert into 3 hashed-block grids)",
+        "value": args.steps * B / elapsed, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32/u16", "data": "synthetic",
+        "config": {"workload": "insert_stream: %d scans x %d pts per batched call, 3-res TSDF, exact mode"
+                               % (B, n_pts), "updates_per_step": U, "hits_per_step": N_in},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "insert family (expand+sort+alloc+apply) per chunk launch",
+                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_step": bytes_per,
+                     "per_kernel_ms_total": {k: round(v[1], 3) for k, v in prof.items()},
+                     "per_kernel_launches": {k: v[0] for k, v in prof.items()}},
+    }
+
+
 def run(args):
+    if args.workload == "insert_stream":
+        return run_insert_stream(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,9 +302,21 @@ def run(args):
     }
     dom = max(fam, key=lambda k: fam[k][2])
     avg_ms, bytes_per, _ = fam[dom]
+    # HBM traffic of the dominant kernel from the committed PMC passes of this same command
+    # (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)["kernels"]
+        if dom == "k_tsdf_residuals":
+            traffic = pmc["hg::k_tsdf_residuals"]["traffic_bytes"]
+        else:
+            traffic = sum(pmc[k]["traffic_bytes"] for k in pmc if k.startswith("hg::k_bin_"))
+    except Exception:
+        traffic = None
     achieved = bytes_per / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per,
                 "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
                 "per_kernel_launches": {k: v[0] for k, v in prof.items()}}

@@ -212,6 +212,38 @@ __device__ inline float round_nonneg(float t) {
   return (t - r >= 0.5f) ? r + 1.0f : r;
 }
 
+// Incremental form of the same chain: begin(code) ... step(u) ... end() == update_cell in a loop
+// with update weight 1.
+struct UnitChain {
+  float d, w, rt, rw;
+  uint32_t code0;
+  bool any;
+  __device__ inline void begin(const GridView& g, uint32_t code) {
+    const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
+    d = tc == 0 ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
+    w = wc == 0 ? 0.f : static_cast<float>(wc) * g.weight_scale + g.weight_offset;
+    rt = rw = 0.f;
+    code0 = code;
+    any = false;
+  }
+  __device__ inline void step(const GridView& g, float maximum_weight, float u) {
+    float uw = w + 1.0f;
+    const float ud = (d * w + u) / uw;
+    uw = (maximum_weight < uw) ? maximum_weight : uw;
+    rt = round_nonneg((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * g.tsd_resolution);
+    rw = round_nonneg((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * g.weight_resolution);
+    d = (rt + 1.0f) * g.tsd_scale + g.tsd_offset;
+    w = (rw + 1.0f) * g.weight_scale + g.weight_offset;
+    any = true;
+  }
+  __device__ inline uint32_t end() const {
+    if (!any) return code0;
+    const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt)) + 1u;
+    const uint32_t nw = static_cast<uint32_t>(static_cast<int>(rw)) + 1u;
+    return (nt + kUpdateMarker) | (nw << 16);
+  }
+};
+
 // `count` consecutive UpdateCell calls with update weight 1 on one voxel (values vals[0..count)),
 // bit-identical to calling update_cell in a loop: codes stay in float form (code - 1 as a float)
 // between updates, so the dependent chain per update is ~35 instructions instead of ~75.
@@ -455,6 +487,8 @@ __global__ __launch_bounds__(256) void k_apply_wave(PyramidIns P, const K* __res
     uint32_t* cell = nullptr;
     uint32_t code = 0;
     const LevelIns& L = P.lv[lvl];
+    constexpr bool kUnit = sizeof(V) == 4;  // 32-bit values: every update weight is 1
+    UnitChain chain;
     if (head) {
       const unsigned long long rest = (lane == 63) ? 0ull : (heads >> (lane + 1));
       const int next = rest ? lane + 1 + __builtin_ctzll(rest) : kWave;
@@ -465,31 +499,43 @@ __global__ __launch_bounds__(256) void k_apply_wave(PyramidIns P, const K* __res
         code = *cell;
       }
     }
+    chain.begin(L.g, code);
     for (int s = 0; __ballot(head && s < len); ++s) {
       const V vs = __shfl(v, lane + s);
-      if (head && s < len)
-        code = update_cell(L.g, L.p.maximum_weight, code, ValCodec<V>::tsd(vs), ValCodec<V>::weight(vs));
+      if (head && s < len) {
+        if (kUnit) chain.step(L.g, L.p.maximum_weight, ValCodec<V>::tsd(vs));
+        else code = update_cell(L.g, L.p.maximum_weight, code, ValCodec<V>::tsd(vs), ValCodec<V>::weight(vs));
+      }
     }
     // continuation of the chunk's last run into the following chunks
     if (heads != 0ull && nv == kWave) {
       const int hl = 63 - __builtin_clzll(heads);
       const K krun = __shfl(k, 63);
       unsigned long long nb = base + kWave;
+      bool raised = false;
       while (nb < n) {
         const unsigned long long i2 = nb + lane;
         const K k2 = (i2 < n) ? keys[i2] : KeyCodec<K>::kInvalid;
         const V v2 = (i2 < n) ? vals[i2] : V(0);
         const unsigned long long mm = __ballot(k2 == krun);
         const int cnt = (mm == ~0ull) ? kWave : __builtin_ctzll(~mm);
+        if (cnt == kWave && !raised) {  // a long per-voxel chain is the critical path of the call
+          __builtin_amdgcn_s_setprio(3);
+          raised = true;
+        }
         for (int j = 0; j < cnt; ++j) {
           const V vj = __shfl(v2, j);
-          if (lane == hl)
-            code = update_cell(L.g, L.p.maximum_weight, code, ValCodec<V>::tsd(vj), ValCodec<V>::weight(vj));
+          if (lane == hl) {
+            if (kUnit) chain.step(L.g, L.p.maximum_weight, ValCodec<V>::tsd(vj));
+            else code = update_cell(L.g, L.p.maximum_weight, code, ValCodec<V>::tsd(vj), ValCodec<V>::weight(vj));
+          }
         }
         if (cnt < kWave) break;
         nb += kWave;
       }
+      if (raised) __builtin_amdgcn_s_setprio(0);
     }
+    if (kUnit) code = chain.end();
     if (head && cell) *cell = code;
   }
   __syncthreads();
