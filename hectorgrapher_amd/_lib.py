@@ -25,6 +25,7 @@ SYMBOLS = [
     "hg_grid_set_cells", "hg_grid_read_cells", "hg_grid_count", "hg_grid_export",
     "hg_grid_num_blocks", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
     "hg_grid_insert_batch", "hg_pyramid_insert", "hg_pyramid_insert_batch", "hg_grid_status",
+    "hg_voxel_filter", "hg_adaptive_voxel_filter", "hg_filter_last_device",
     "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
     "hg_problem_set_pose", "hg_problem_get_pose", "hg_problem_add_block",
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
@@ -146,6 +147,9 @@ def load():
     L.hg_pyramid_insert.argtypes = [vp, vp, i32, vp, vp, sz, sz, vp, i32, i32, vp]
     L.hg_pyramid_insert_batch.argtypes = [vp, vp, i32, vp, vp, vp, sz, sz, vp, i32, i32, vp]
     L.hg_grid_status.argtypes = [vp, P(InsertStats)]
+    L.hg_voxel_filter.argtypes = [vp, f32, vp, sz, i32, i32, vp, P(sz)]
+    L.hg_adaptive_voxel_filter.argtypes = [vp, f32, f32, f32, vp, sz, i32, i32, vp, P(sz)]
+    L.hg_filter_last_device.argtypes = [vp, P(vp), P(vp), P(sz)]
     L.hg_problem_create.argtypes = [vp, P(vp)]
     L.hg_problem_destroy.argtypes = [vp]
     L.hg_problem_reset.argtypes = [vp]

@@ -270,6 +270,54 @@ class TSDFRangeDataInserter3D:
         return st
 
 
+class VoxelFilter:
+    """sensor::VoxelFilter(size).Filter: first point of every voxel, input order preserved."""
+
+    def __init__(self, ctx, size):
+        self.ctx, self.size = ctx, float(size)
+
+    def Filter(self, point_cloud):
+        """Returns the indices of the kept points (numpy uint32, ascending)."""
+        L = _lib.load()
+        n = C.c_size_t()
+        if _is_device(point_cloud):
+            m, stride = point_cloud.shape
+            out = np.empty(m, np.uint32)
+            check(L.hg_voxel_filter(self.ctx._h, self.size, point_cloud.data_ptr(), m, stride,
+                                    _lib.HG_DEVICE, _p(out), C.byref(n)), "hg_voxel_filter")
+        else:
+            pts = np.ascontiguousarray(point_cloud, np.float32)
+            m, stride = pts.shape
+            out = np.empty(m, np.uint32)
+            check(L.hg_voxel_filter(self.ctx._h, self.size, _p(pts), m, stride, _lib.HG_HOST, _p(out),
+                                    C.byref(n)), "hg_voxel_filter")
+        return out[:n.value].copy()
+
+
+class AdaptiveVoxelFilter:
+    """sensor::AdaptiveVoxelFilter (max_length, min_num_points, max_range)."""
+
+    def __init__(self, ctx, max_length, min_num_points, max_range):
+        self.ctx = ctx
+        self.max_length, self.min_num_points, self.max_range = float(max_length), float(min_num_points), float(max_range)
+
+    def Filter(self, point_cloud):
+        L = _lib.load()
+        n = C.c_size_t()
+        if _is_device(point_cloud):
+            m, stride = point_cloud.shape
+            ptr, space = point_cloud.data_ptr(), _lib.HG_DEVICE
+        else:
+            point_cloud = np.ascontiguousarray(point_cloud, np.float32)
+            m, stride = point_cloud.shape
+            ptr, space = _p(point_cloud), _lib.HG_HOST
+        out = np.empty(m, np.uint32)
+        check(L.hg_adaptive_voxel_filter(self.ctx._h, self.max_length, self.min_num_points,
+                                         self.max_range, ptr, m, stride, space, _p(out), C.byref(n)),
+              "hg_adaptive_voxel_filter")
+        return out[:n.value].copy()
+
+
 def insert_pyramid(inserters, range_data, grids, pose_tq=None, want_stats=True):
     """Submap3D::InsertData shape (submap_3d.cc:427-452): the same range data goes through
     inserters[l] into grids[l] (high resolution, low resolution, ...) in one fused device pass.

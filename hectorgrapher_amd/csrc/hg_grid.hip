@@ -167,7 +167,7 @@ int hg_ctx_destroy(hg_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DeviceBuffer* b : {&c->ws_points, &c->ws_scan_table, &c->ws_gate, &c->ws_counts,
                           &c->ws_offsets, &c->ws_keys_a, &c->ws_keys_b, &c->ws_vals_a,
-                          &c->ws_vals_b, &c->ws_temp, &c->ws_misc})
+                          &c->ws_vals_b, &c->ws_temp, &c->ws_misc, &c->ws_filter})
     b->release();
   prof_resolve(c);
   for (hipEvent_t e : c->prof_free_events) (void)hipEventDestroy(e);

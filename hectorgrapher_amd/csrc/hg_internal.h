@@ -71,7 +71,10 @@ struct hg_ctx {
   bool own_stream = false;
   // insertion workspace
   hg::DeviceBuffer ws_points, ws_scan_table, ws_gate, ws_counts, ws_offsets, ws_keys_a, ws_keys_b,
-      ws_vals_a, ws_vals_b, ws_temp, ws_misc;
+      ws_vals_a, ws_vals_b, ws_temp, ws_misc, ws_filter;
+  const uint32_t* filter_idx = nullptr;  // results of the last voxel-filter call (device)
+  const float* filter_xyz = nullptr;
+  size_t filter_count = 0;
   void* pinned = nullptr;  // small pinned host staging (4 KiB)
 };
 

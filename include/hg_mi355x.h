@@ -178,6 +178,24 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
 /* Synchronises and returns the counters of the last insert call + sticky error flags. */
 int hg_grid_status(hg_grid* grid, hg_insert_stats* stats);
 
+/* ---- voxel filters (the step before matching) ------------------------------------------- */
+/* VoxelFilter(resolution).Filter (sensor/internal/voxel_filter.cc:26-37): keeps the first point
+ * of every voxel, input order preserved. pts: n points of `stride` floats (3 = PointCloud, 4 =
+ * TimedPointCloud, time ignored). indices_out (host, capacity n, may be NULL) receives the kept
+ * indices; *count their number. Device key = 3 x 21-bit cell indices: |cell| >= 2^20 returns
+ * HG_ERR_RANGE (the reference uses 3 x 32 bits). */
+int hg_voxel_filter(hg_ctx* ctx, float resolution, const float* pts, size_t n, int stride,
+                    int memspace, uint32_t* indices_out, size_t* count);
+/* AdaptiveVoxelFilter::Filter (sensor/internal/adaptive_voxel_filter.h:33-110): FilterByMaxRange,
+ * then the binary search on the voxel edge length for >= min_num_points points. */
+int hg_adaptive_voxel_filter(hg_ctx* ctx, float max_length, float min_num_points, float max_range,
+                             const float* pts, size_t n, int stride, int memspace,
+                             uint32_t* indices_out, size_t* count);
+/* Device-resident results of the last filter call of this context (valid until the next one):
+ * kept indices and the gathered xyz (3 floats per kept point), e.g. for hg_problem_add_block. */
+int hg_filter_last_device(hg_ctx* ctx, const uint32_t** indices_dev, const float** xyz_dev,
+                          size_t* count);
+
 /* ---- scan matching: ceres::Problem over TSDF cost functions ----------------------------- */
 int hg_problem_create(hg_ctx* ctx, hg_problem** out);
 int hg_problem_destroy(hg_problem* p);

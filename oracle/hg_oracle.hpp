@@ -29,6 +29,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <unordered_set>
 #include <vector>
 
 namespace hgo {
@@ -583,6 +584,72 @@ inline void TransformPointsF(const Rigid3<float>& T, const float* in, size_t n, 
     out[3 * i + 1] = p.y;
     out[3 * i + 2] = p.z;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Voxel filters. ref: sensor/internal/voxel_filter.{h,cc}:26-77,
+// sensor/internal/adaptive_voxel_filter.h:33-110
+// ---------------------------------------------------------------------------
+struct CellKey {
+  int x, y, z;
+  bool operator==(const CellKey& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct CellKeyHash {
+  size_t operator()(const CellKey& k) const {
+    uint64_t h = static_cast<uint32_t>(k.x) * 0x9E3779B97F4A7C15ull;
+    h ^= static_cast<uint32_t>(k.y) * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    h ^= static_cast<uint32_t>(k.z) * 0x165667B19E3779F9ull + (h << 6) + (h >> 2);
+    return static_cast<size_t>(h);
+  }
+};
+
+// VoxelFilter::Filter: indices of the first point that falls into each voxel, in input order.
+// `stride` floats per point (3 = PointCloud, 4 = TimedPointCloud; time is ignored).
+inline std::vector<uint32_t> VoxelFilterIndices(float resolution, const float* pts, size_t n,
+                                                int stride, const std::vector<uint32_t>* subset = nullptr) {
+  std::unordered_set<CellKey, CellKeyHash> voxel_set;
+  std::vector<uint32_t> out;
+  const size_t m = subset ? subset->size() : n;
+  for (size_t j = 0; j < m; ++j) {
+    const uint32_t i = subset ? (*subset)[j] : static_cast<uint32_t>(j);
+    const float* p = pts + static_cast<size_t>(i) * stride;
+    const CellKey k{RoundToInt(p[0] / resolution), RoundToInt(p[1] / resolution),
+                    RoundToInt(p[2] / resolution)};
+    if (voxel_set.insert(k).second) out.push_back(i);
+  }
+  return out;
+}
+
+// AdaptiveVoxelFilter::Filter = AdaptivelyVoxelFiltered(options, FilterByMaxRange(cloud, max_range)).
+inline std::vector<uint32_t> AdaptiveVoxelFilterIndices(float max_length, float min_num_points,
+                                                        float max_range, const float* pts, size_t n,
+                                                        int stride) {
+  std::vector<uint32_t> in;  // FilterByMaxRange (:33-44)
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = pts + i * stride;
+    if (Norm(Vec3f{p[0], p[1], p[2]}) <= max_range) in.push_back(static_cast<uint32_t>(i));
+  }
+  if (in.size() <= min_num_points) return in;  // already sparse enough (:50-53)
+  std::vector<uint32_t> result = VoxelFilterIndices(max_length, pts, n, stride, &in);
+  if (result.size() >= min_num_points) return result;
+  for (float high_length = max_length; high_length > 1e-2f * max_length; high_length /= 2.f) {
+    float low_length = high_length / 2.f;
+    result = VoxelFilterIndices(low_length, pts, n, stride, &in);
+    if (result.size() >= min_num_points) {
+      while ((high_length - low_length) / low_length > 1e-1f) {
+        const float mid_length = (low_length + high_length) / 2.f;
+        const std::vector<uint32_t> candidate = VoxelFilterIndices(mid_length, pts, n, stride, &in);
+        if (candidate.size() >= min_num_points) {
+          low_length = mid_length;
+          result = candidate;
+        } else {
+          high_length = mid_length;
+        }
+      }
+      return result;
+    }
+  }
+  return result;
 }
 
 // ---------------------------------------------------------------------------

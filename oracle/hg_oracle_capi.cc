@@ -179,6 +179,19 @@ int hgo_grid_insert(void* g, const hgo_insert_opts* opts, const float* origin, c
   return 0;
 }
 
+// ---- voxel filters --------------------------------------------------------
+size_t hgo_voxel_filter(float resolution, const float* pts, size_t n, int stride, uint32_t* out) {
+  const std::vector<uint32_t> r = VoxelFilterIndices(resolution, pts, n, stride);
+  if (out) std::memcpy(out, r.data(), r.size() * sizeof(uint32_t));
+  return r.size();
+}
+size_t hgo_adaptive_voxel_filter(float max_length, float min_num_points, float max_range,
+                                 const float* pts, size_t n, int stride, uint32_t* out) {
+  const std::vector<uint32_t> r = AdaptiveVoxelFilterIndices(max_length, min_num_points, max_range, pts, n, stride);
+  if (out) std::memcpy(out, r.data(), r.size() * sizeof(uint32_t));
+  return r.size();
+}
+
 // ---- interpolation --------------------------------------------------------
 // value + gradient of (multi-res) interpolated TSD at m double points.
 void hgo_interp_tsd(void* const* grids, int levels, int multi_res, const double* xyz, size_t m,

@@ -117,6 +117,10 @@ def lib():
     L.hgo_grid_export.argtypes = [vp, vp, vp, vp, sz]
     L.hgo_grid_insert.restype = C.c_int
     L.hgo_grid_insert.argtypes = [vp, P(InsertOpts), vp, vp, sz, sz, vp, vp]
+    L.hgo_voxel_filter.restype = sz
+    L.hgo_voxel_filter.argtypes = [f32, vp, sz, C.c_int, vp]
+    L.hgo_adaptive_voxel_filter.restype = sz
+    L.hgo_adaptive_voxel_filter.argtypes = [f32, f32, f32, vp, sz, C.c_int, vp]
     L.hgo_interp_tsd.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, vp]
     L.hgo_interpolate_transform.argtypes = [vp, vp, f64, vp]
     L.hgo_quaternion_plus.argtypes = [vp, vp, vp]
@@ -241,6 +245,24 @@ class Grid:
         if rc != 0:
             raise RuntimeError("oracle insert failed rc=%d" % rc)
         return int(st[0]), int(st[1])
+
+
+def voxel_filter(resolution, pts):
+    """VoxelFilter(resolution).Filter: indices of the kept points (first per voxel, input order)."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    stride = pts.shape[1]
+    out = np.empty(len(pts), np.uint32)
+    n = lib().hgo_voxel_filter(resolution, _ptr(pts), len(pts), stride, _ptr(out))
+    return out[:n].copy()
+
+
+def adaptive_voxel_filter(max_length, min_num_points, max_range, pts):
+    pts = np.ascontiguousarray(pts, np.float32)
+    stride = pts.shape[1]
+    out = np.empty(len(pts), np.uint32)
+    n = lib().hgo_adaptive_voxel_filter(max_length, min_num_points, max_range, _ptr(pts), len(pts),
+                                        stride, _ptr(out))
+    return out[:n].copy()
 
 
 def interp_tsd(grids, xyz, multi_res=False):

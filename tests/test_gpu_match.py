@@ -158,3 +158,34 @@ def test_register_scan_equals_solve_then_insert(po, hg, ctx):
     else:
         for o, g in zip(og, gg):
             assert abs(o.count() - g.count()) < 0.01 * o.count()
+
+
+def test_sliding_window_three_control_points(po, hg, ctx, maps):
+    """Window of 3 control points (first constant, oltb.cc:1268-1275) with four scans: one exactly on
+    a control point (TSDFSpaceCostFunction3D), three between control points (interpolated blocks),
+    high- and low-resolution grids as separate blocks (oltb.cc:392-502). 12 free columns."""
+    og, gg = maps
+    poses = [synth.pose_k(8), synth.pose_mul(synth.pose_k(9), synth.perturbation()),
+             synth.pose_mul(synth.pose_k(10), synth.perturbation())]
+    const = [True, False, False]
+    clouds = [synth.generate_scan(synth.pose_k(k), 16, 200, stream=40 + i)
+              for i, k in enumerate((9, 9, 10, 10))]
+    # (cloud, grid level, pose_a, pose_b, factor)
+    blocks = [(0, 1, 1, -1, 0.0), (1, 2, 0, 1, 0.6), (2, 1, 1, 2, 0.5), (3, 2, 1, 2, 0.9)]
+    op, gp = po.Problem(), hg.Problem(ctx)
+    for tq, c in zip(poses, const):
+        op.add_pose(tq, c)
+        gp.add_pose(tq, c)
+    for ci, lvl, a, b, f in blocks:
+        s = (1.0 if lvl == 1 else 0.5) / np.sqrt(len(clouds[ci]))
+        op.add_block(clouds[ci], [og[lvl]], s, a, b, f)
+        gp.add_block(clouds[ci], [gg[lvl]], s, a, b, f)
+    assert gp.num_columns() == 12 and gp.num_residuals() == op.evaluate()[1].shape[0]
+    compare_evaluate(op, gp)
+    so, sg = op.solve(), gp.solve()
+    assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
+    for i in range(3):
+        a, b = op.get_pose(i), gp.get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+        assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+    np.testing.assert_array_equal(gp.get_pose(0), poses[0])

@@ -203,3 +203,25 @@ def test_jet_jacobian_matches_finite_differences(po):
         pr.set_pose(i, base)
         err = np.abs((r2 - r) / eps - J[:, col])
         assert np.median(err) < 1e-5 and (err > 1e-3).mean() < 0.02      # isolated branch flips only
+
+
+def test_voxel_filter_reference_kats(po):
+    """sensor/internal/voxel_filter_test.cc:30-56."""
+    pc = np.array([[0, 0, 0], [0.1, -0.1, 0.1], [0.3, -0.1, 0], [0, 0, 0.1]], np.float32)
+    assert po.voxel_filter(0.3, pc).tolist() == [0, 2]                         # first point per voxel
+    pc = np.array([[100000., 0, 0], [100000.001, -0.0001, 0.0001], [100000.003, -0.0001, 0],
+                   [-200000., 0, 0]], np.float32)
+    assert po.voxel_filter(0.01, pc).tolist() == [0, 3]                        # large coordinates
+    timed = np.array([[-100.0, 0.3, 0.4, float(i)] for i in range(100)], np.float32)
+    assert po.voxel_filter(0.3, timed).tolist() == [0]                         # ignores time
+
+
+def test_adaptive_voxel_filter_properties(po):
+    """adaptive_voxel_filter.h:46-86: sparse clouds pass through, dense ones keep >= min points."""
+    from hectorgrapher_amd import synth
+    pts = synth.generate_scan(synth.pose_k(0), 16, 625)
+    keep = po.adaptive_voxel_filter(2.0, 150, 15.0, pts)
+    r = np.linalg.norm(pts[keep], axis=1)
+    assert 150 <= len(keep) < 400 and np.all(r <= 15.0) and np.all(np.diff(keep.astype(np.int64)) > 0)
+    few = pts[:100]
+    assert po.adaptive_voxel_filter(2.0, 150, 60.0, few).tolist() == list(range(100))
