@@ -32,10 +32,15 @@ struct InsertParams {
   float epsilon, sigma;
   int free_space;             // num_free_space_voxels > 0                        (:303)
   int has_pose;
+  int project_normals;        // project_sdf_distance_to_scan_normal, CLOUD_STRUCTURE normals (:502-607)
+  unsigned vertical_stride;   // normal_computation_vertical_stride
+  unsigned horizontal_stride; // normal_computation_horizontal_stride * width
+  unsigned width;
 };
 
 struct ScanTable {        // per scan of a batch
   unsigned long long begin;  // first point index
+  unsigned long long count;  // number of points of the scan
   float origin[3];
   float pose[7];          // t xyz, q wxyz (float Rigid3f)
 };
@@ -47,6 +52,10 @@ struct Ray {
   float range;
   float ox, oy, oz;  // origin (grid frame)
   bool valid;
+  bool use_normal;   // InsertHitWithNormal: tsd measured along the normal through the hit
+  float hx, hy, hz;  // hit
+  float nx, ny, nz;  // unit normal
+  float ndir;        // normal_direction
 };
 
 __device__ inline float norm3(float x, float y, float z) {
@@ -93,17 +102,70 @@ __device__ inline Ray ray_setup(const GridView& g, const InsertParams& p, const 
   if (static_cast<double>(r0) > p.max_range) return r;
   const float range = r0;  // same expression in InsertHit
   const float tau = p.truncation_distance;
-  if (range < tau) return r;
-  const float ratio = tau / range;
-  float b_x, b_y, b_z;
-  if (p.free_space) {
-    b_x = ox; b_y = oy; b_z = oz;
+  r.use_normal = false;
+  float b_x, b_y, b_z, e_x, e_y, e_z;
+  if (p.project_normals) {
+    // CLOUD_STRUCTURE normal from the structured neighbours (:502-607), then InsertHitWithNormal
+    // (:197-241). Neighbour indices stay inside the scan [0, count).
+    const unsigned long long li = i - sc.begin, cnt = sc.count;
+    const float max_range_delta = 1.f * g.resolution / 0.05f;
+    auto load = [&](unsigned long long j, float& x, float& y, float& z) {
+      x = xyz[3 * (sc.begin + j)]; y = xyz[3 * (sc.begin + j) + 1]; z = xyz[3 * (sc.begin + j) + 2];
+      if (p.has_pose) transform_point(sc.pose, x, y, z);
+    };
+    auto bad = [&](unsigned long long j) {
+      float x, y, z;
+      load(j, x, y, z);
+      if (isnan(x) || isnan(y) || isnan(z)) return true;
+      return fabsf(r0 - norm3(x - ox, y - oy, z - oz)) > max_range_delta;
+    };
+    unsigned long long off = p.vertical_stride;
+    while (off > 0 && ((li + off >= cnt) || bad(li + off))) --off;
+    const unsigned long long i_vu = li + off;
+    off = p.vertical_stride;
+    // the reference tests `point_idx - offset < 0` on size_t (:548, always false, then reads out
+    // of bounds); like the oracle this treats an index before the scan as "no neighbour"
+    while (off > 0 && ((li < off) || bad(li - off))) --off;
+    const unsigned long long i_vl = li - off;
+    if (i_vl == i_vu || p.width == 0) return r;
+    off = p.horizontal_stride;
+    while (off > 0 && ((li + off >= cnt) || bad(li + off))) off -= p.width;
+    const unsigned long long i_hu = li + off;
+    off = p.horizontal_stride;
+    while (off > 0 && ((li < off) || bad(li - off))) off -= p.width;
+    const unsigned long long i_hl = li - off;
+    if (i_hl == i_hu) return r;
+    float ax, ay, az, bx2, by2, bz2, cx, cy, cz, dx, dy, dz;
+    load(i_hl, ax, ay, az); load(i_hu, bx2, by2, bz2); load(i_vl, cx, cy, cz); load(i_vu, dx, dy, dz);
+    const float hx_ = ax - bx2, hy_ = ay - by2, hz_ = az - bz2;
+    const float vx_ = cx - dx, vy_ = cy - dy, vz_ = cz - dz;
+    if ((hx_ == 0.f && hy_ == 0.f && hz_ == 0.f) || (vx_ == 0.f && vy_ == 0.f && vz_ == 0.f)) return r;
+    float nx = hy_ * vz_ - hz_ * vy_, ny = hz_ * vx_ - hx_ * vz_, nz = hx_ * vy_ - hy_ * vx_;
+    const float nn = norm3(nx, ny, nz);
+    if (nn > 0.f) { nx = nx / nn; ny = ny / nn; nz = nz / nn; }
+    if (nx == 0.f && ny == 0.f && nz == 0.f) return r;
+    if (range < tau) return r;
+    float ndir = 1.f;
+    if (nx * rx + (ny * ry + nz * rz) > 0.f) ndir = -1.f;
+    const float s = ndir * tau;
+    b_x = hx - s * nx; b_y = hy - s * ny; b_z = hz - s * nz;
+    e_x = hx + s * nx; e_y = hy + s * ny; e_z = hz + s * nz;
+    r.use_normal = true;
+    r.hx = hx; r.hy = hy; r.hz = hz;
+    r.nx = nx; r.ny = ny; r.nz = nz;
+    r.ndir = ndir;
   } else {
-    const float s = 1.0f - ratio;
-    b_x = ox + s * rx; b_y = oy + s * ry; b_z = oz + s * rz;
+    if (range < tau) return r;
+    const float ratio = tau / range;
+    if (p.free_space) {
+      b_x = ox; b_y = oy; b_z = oz;
+    } else {
+      const float s = 1.0f - ratio;
+      b_x = ox + s * rx; b_y = oy + s * ry; b_z = oz + s * rz;
+    }
+    const float e = 1.0f + ratio;
+    e_x = ox + e * rx; e_y = oy + e * ry; e_z = oz + e * rz;
   }
-  const float e = 1.0f + ratio;
-  const float e_x = ox + e * rx, e_y = oy + e * ry, e_z = oz + e * rz;
   r.bx = cell_index_1d(b_x, g.resolution);
   r.by = cell_index_1d(b_y, g.resolution);
   r.bz = cell_index_1d(b_z, g.resolution);
@@ -126,10 +188,15 @@ __device__ inline void ray_sample(const GridView& g, const InsertParams& p, cons
   const float ccx = static_cast<float>(cx) * g.resolution;
   const float ccy = static_cast<float>(cy) * g.resolution;
   const float ccz = static_cast<float>(cz) * g.resolution;
-  const float dist = norm3(ccx - r.ox, ccy - r.oy, ccz - r.oz);
   const float tau = p.truncation_distance;
-  tsd = clampf(r.range - dist, -tau, tau);
   weight = 1.0f;
+  if (r.use_normal) {  // :235-239
+    const float dx = ccx - r.hx, dy = ccy - r.hy, dz = ccz - r.hz;
+    tsd = clampf(r.ndir * (dx * r.nx + (dy * r.ny + dz * r.nz)), -tau, tau);
+    return;
+  }
+  const float dist = norm3(ccx - r.ox, ccy - r.oy, ccz - r.oz);
+  tsd = clampf(r.range - dist, -tau, tau);
   const float normalized = tsd / tau;
   if (normalized < -p.epsilon) {
     // :333-340, evaluated in double as std::exp/std::pow promote
@@ -1048,8 +1115,12 @@ void build_gate(double ratio, size_t n, uint8_t* out) {
   }
 }
 
-InsertParams make_params(const hg_insert_opts& o, const hg_grid* grid, bool has_pose) {
+InsertParams make_params(const hg_insert_opts& o, const hg_grid* grid, bool has_pose, size_t width) {
   InsertParams p;
+  p.project_normals = o.project_sdf_distance_to_scan_normal ? 1 : 0;
+  p.vertical_stride = static_cast<unsigned>(std::max(0, o.normal_computation_vertical_stride));
+  p.horizontal_stride = static_cast<unsigned>(std::max(0, o.normal_computation_horizontal_stride)) * static_cast<unsigned>(width);
+  p.width = static_cast<unsigned>(width);
   p.min_range = o.min_range;
   p.max_range = o.max_range;
   p.truncation_distance =
@@ -1334,7 +1405,6 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
                             const float* origins, const float* xyz, const uint64_t* scan_offsets,
                             size_t n_scans, size_t width, const float* poses_tq,
                             const double* d_pose_tq, int mode, int memspace, hg_insert_stats* stats) {
-  (void)width;
   if (d_pose_tq && (n_scans != 1 || !poses_tq)) return HG_ERR_INVALID;
   if (!grids || !opts || levels < 1 || levels > kMaxInsLevels || !origins || !scan_offsets || n_scans == 0)
     return HG_ERR_INVALID;
@@ -1343,8 +1413,8 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   if (!c) return HG_ERR_INVALID;
   for (int l = 0; l < levels; ++l) {
     if (!grids[l] || grids[l]->ctx != c) return HG_ERR_INVALID;
-    if (opts[l].project_sdf_distance_to_scan_normal) {
-      set_last_error("project_sdf_distance_to_scan_normal is not implemented on the device path");
+    if (opts[l].project_sdf_distance_to_scan_normal && opts[l].normal_computation_method != 1) {
+      set_last_error("only normal_computation_method = CLOUD_STRUCTURE is implemented on the device path");
       return HG_ERR_UNSUPPORTED;
     }
   }
@@ -1425,7 +1495,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   for (int l = 0; l < levels; ++l) {
     LevelIns& L = P.lv[l];
     L.g = grids[l]->view;
-    L.p = make_params(opts[l], grids[l], poses_tq != nullptr);
+    L.p = make_params(opts[l], grids[l], poses_tq != nullptr, width);
     L.gate = d_gate[l];
     const float res = L.g.resolution;
     for (int a = 0; a < 3; ++a) {
@@ -1453,6 +1523,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     while (s1 < n_scans && (s1 == s0 || pts + (scan_offsets[s1 + 1] - scan_offsets[s1]) <= kMaxChunkPoints)) {
       ScanTable t;
       t.begin = scan_offsets[s1] - scan_offsets[s0];
+      t.count = scan_offsets[s1 + 1] - scan_offsets[s1];
       std::memcpy(t.origin, origins + 3 * s1, sizeof(t.origin));
       if (poses_tq) std::memcpy(t.pose, poses_tq + 7 * s1, sizeof(t.pose));
       else std::memset(t.pose, 0, sizeof(t.pose));

@@ -249,3 +249,30 @@ def test_block_arrays_roundtrip_through_torch(po, hg, ctx):
     dst2 = hg.HybridGridTSDF(ctx, 0.1, max_blocks=1 << 14)
     dst2.import_blocks(k2.cpu().numpy().view(np.uint64), v2.cpu().numpy().view(np.uint32))
     assert all(np.array_equal(x, y) for x, y in zip(a, dst2.export()))
+
+
+@pytest.mark.parametrize("res,hs,vs", [(0.10, 5, 1), (0.20, 20, 4), (0.05, 2, 2)])
+def test_project_sdf_to_cloud_structure_normals(po, hg, ctx, res, hs, vs):
+    """a7: project_sdf_distance_to_scan_normal with CLOUD_STRUCTURE normals (:502-607) and
+    InsertHitWithNormal (:197-241) on the structured synthetic cloud (width = rings)."""
+    rings, cols = 16, 400
+    kw = dict(project_sdf_distance_to_scan_normal=1, normal_computation_method=1,
+              normal_computation_horizontal_stride=hs, normal_computation_vertical_stride=vs)
+    og = po.Grid(res)
+    gg = hg.HybridGridTSDF(ctx, res, max_blocks=1 << 15)
+    ins = hg.TSDFRangeDataInserter3D(hg.InsertOpts(**kw))
+    assert ins.RequiresStructuredData()
+    for k in range(3):
+        pose = synth.pose_k(k)
+        pts = synth.generate_scan(pose, rings, cols, stream=k)
+        pts[::97] = np.nan
+        loc = synth.transform_points(pose, pts)
+        a = og.insert(pose[:3], loc, po.InsertOpts(**kw), width=rings)
+        st = ins.Insert(hg.RangeData(pose[:3], loc, width=rings), gg)
+        assert (st.num_hits, st.num_updates) == a and a[1] > 1000
+    assert_grids_equal(og, gg)
+    # PCL / Open3D / TRIANGLE_FILL_IN normals are refused, not approximated
+    bad = hg.TSDFRangeDataInserter3D(hg.InsertOpts(project_sdf_distance_to_scan_normal=1,
+                                                   normal_computation_method=0))
+    with pytest.raises(hg.HgError):
+        bad.Insert(hg.RangeData([0, 0, 0], pts, width=rings), gg)
