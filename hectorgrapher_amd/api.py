@@ -201,6 +201,29 @@ class HybridGridTSDF:
               "hg_grid_export")
         return ijk, t, w
 
+    def ToProto(self):
+        """Serialised proto::HybridGridTSDF (bytes), as HybridGridTSDF::ToProto().SerializeAsString()."""
+        n = C.c_size_t()
+        check(self._L.hg_grid_to_proto(self._h, None, 0, C.byref(n)), "hg_grid_to_proto")
+        buf = (C.c_uint8 * max(1, n.value))()
+        check(self._L.hg_grid_to_proto(self._h, buf, n.value, C.byref(n)), "hg_grid_to_proto")
+        return bytes(buf[:n.value])
+
+    @classmethod
+    def FromProto(cls, ctx, data, max_blocks=1 << 16):
+        """HybridGridTSDF(const proto::HybridGridTSDF&)."""
+        L = _lib.load()
+        h = C.c_void_p()
+        arr = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+        check(L.hg_grid_from_proto(ctx._h, arr, len(data), int(max_blocks), C.byref(h)), "hg_grid_from_proto")
+        g = cls.__new__(cls)
+        g._L, g.ctx, g._h = L, ctx, h
+        ctx._children.add(g)
+        g._resolution = np.float32(L.hg_grid_resolution(h))
+        g.max_blocks = int(max_blocks)
+        g.max_tsd = g.min_tsd = g.max_weight = None  # set by the caller if float decoding is needed
+        return g
+
     def block_arrays(self):
         """Device pointers (keys u64[nb], voxels u32[nb*512]) and nb, for the multi-GPU gather."""
         k, v, n = C.c_void_p(), C.c_void_p(), C.c_uint32()

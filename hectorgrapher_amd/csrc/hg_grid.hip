@@ -7,8 +7,10 @@
 // The reference's DynamicGrid/NestedGrid pointer tree (:144-407) is replaced
 // by this flat pool; export restores the tree's iteration order.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <numeric>
+#include <vector>
 
 #include "hg_internal.h"
 
@@ -17,21 +19,21 @@ namespace hg {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 
-__global__ void k_set_cells_serial(GridView g, const int* ijk, size_t m, const float* tsd,
-                                   const float* weight) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  for (size_t i = 0; i < m; ++i) {
-    const int x = ijk[3 * i], y = ijk[3 * i + 1], z = ijk[3 * i + 2];
-    if (!cell_in_range(x, y, z)) {
-      atomicOr(&g.counters[1], kFlagRange);
-      continue;
-    }
-    const uint32_t slot = insert_block_unique(g, block_key(x, y, z));
-    if (slot >= g.max_blocks) continue;
-    // SetCell: hybrid_grid_tsdf.h:87-92
-    const uint32_t code = (tsd_to_value(g, tsd[i]) + kUpdateMarker) | (weight_to_value(g, weight[i]) << 16);
-    g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + voxel_in_block(x, y, z)] = code;
+// SetCell for m cells, one thread per cell (blocks shared by several cells are inserted once:
+// insert_block_shared). Duplicate cells in one call: last writer wins in no particular order.
+__global__ void k_set_cells(GridView g, const int* ijk, size_t m, const float* tsd, const float* weight) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= m) return;
+  const int x = ijk[3 * i], y = ijk[3 * i + 1], z = ijk[3 * i + 2];
+  if (!cell_in_range(x, y, z)) {
+    atomicOr(&g.counters[1], kFlagRange);
+    return;
   }
+  const uint32_t slot = insert_block_shared(g, block_key(x, y, z));
+  if (slot >= g.max_blocks) return;
+  // SetCell: hybrid_grid_tsdf.h:87-92
+  const uint32_t code = (tsd_to_value(g, tsd[i]) + kUpdateMarker) | (weight_to_value(g, weight[i]) << 16);
+  g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + voxel_in_block(x, y, z)] = code;
 }
 
 __global__ void k_read_cells(GridView g, const int* ijk, size_t m, uint16_t* tsd, uint16_t* weight) {
@@ -317,7 +319,7 @@ int hg_grid_set_cells(hg_grid* g, const int32_t* ijk, size_t m, const float* tsd
   HG_HIP_CHECK(hipMemcpyAsync(base, ijk, bytes_ijk, hipMemcpyHostToDevice, s));
   HG_HIP_CHECK(hipMemcpyAsync(base + bytes_ijk, tsd, bytes_f, hipMemcpyHostToDevice, s));
   HG_HIP_CHECK(hipMemcpyAsync(base + bytes_ijk + bytes_f, weight, bytes_f, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_set_cells_serial, dim3(1), dim3(64), 0, s, g->view,
+  hipLaunchKernelGGL(k_set_cells, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, s, g->view,
                      reinterpret_cast<const int*>(base), m,
                      reinterpret_cast<const float*>(base + bytes_ijk),
                      reinterpret_cast<const float*>(base + bytes_ijk + bytes_f));
@@ -465,6 +467,161 @@ int hg_grid_import_blocks(hg_grid* g, const void* keys, const void* voxels, uint
   int rc = read_counters(g, c);
   if (rc != HG_OK) return rc;
   if (c[1] & kFlagCapacity) return HG_ERR_CAPACITY;
+  return HG_OK;
+}
+
+
+// ---- wire format: proto::HybridGridTSDF (mapping/proto/3d/hybrid_grid_tsdf.proto:19-31) ------
+// Written exactly as HybridGridTSDF::ToProto does (hybrid_grid_tsdf.h:119-134): cells in iterator
+// order, raw codes (update marker included), and — reference quirk — field 8
+// "relative_truncation_distance" holds ValueConverter().getMaxTSD(), not the relative distance.
+}  // extern "C"
+namespace {
+void put_varint(std::vector<uint8_t>& b, uint64_t v) {
+  while (v >= 0x80) { b.push_back(static_cast<uint8_t>(v) | 0x80); v >>= 7; }
+  b.push_back(static_cast<uint8_t>(v));
+}
+void put_float_field(std::vector<uint8_t>& b, int field, float f) {
+  if (f == 0.f && !std::signbit(f)) return;  // proto3: default values are not serialised
+  put_varint(b, (static_cast<uint64_t>(field) << 3) | 5);
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  for (int i = 0; i < 4; ++i) b.push_back(static_cast<uint8_t>(u >> (8 * i)));
+}
+template <typename It, typename F>
+void put_packed(std::vector<uint8_t>& b, int field, It begin, It end, size_t stride, F enc) {
+  if (begin == end) return;
+  std::vector<uint8_t> body;
+  for (It it = begin; it != end; it += stride) put_varint(body, enc(*it));
+  put_varint(b, (static_cast<uint64_t>(field) << 3) | 2);
+  put_varint(b, body.size());
+  b.insert(b.end(), body.begin(), body.end());
+}
+bool get_varint(const uint8_t*& p, const uint8_t* end, uint64_t* v) {
+  uint64_t r = 0;
+  for (int shift = 0; shift < 64 && p < end; shift += 7) {
+    const uint8_t c = *p++;
+    r |= static_cast<uint64_t>(c & 0x7F) << shift;
+    if (!(c & 0x80)) { *v = r; return true; }
+  }
+  return false;
+}
+}  // namespace
+
+extern "C" {
+
+int hg_grid_to_proto(hg_grid* g, uint8_t* buf, size_t cap, size_t* len) {
+  if (!g || !len) return HG_ERR_INVALID;
+  size_t n = 0;
+  int rc = hg_grid_count(g, &n);
+  if (rc != HG_OK) return rc;
+  std::vector<int32_t> ijk(3 * std::max<size_t>(n, 1));
+  std::vector<uint16_t> t(std::max<size_t>(n, 1)), w(std::max<size_t>(n, 1));
+  if (n) {
+    rc = hg_grid_export(g, ijk.data(), t.data(), w.data(), n, &n);
+    if (rc != HG_OK) return rc;
+  }
+  std::vector<uint8_t> b;
+  b.reserve(16 + n * 12);
+  put_float_field(b, 1, g->view.resolution);
+  auto zz = [](int32_t v) { return static_cast<uint64_t>((static_cast<uint32_t>(v) << 1) ^ static_cast<uint32_t>(v >> 31)); };
+  auto pos = [](uint16_t v) { return static_cast<uint64_t>(v); };
+  put_packed(b, 3, ijk.data(), ijk.data() + 3 * n, 3, zz);
+  put_packed(b, 4, ijk.data() + 1, ijk.data() + 1 + 3 * n, 3, zz);
+  put_packed(b, 5, ijk.data() + 2, ijk.data() + 2 + 3 * n, 3, zz);
+  put_packed(b, 6, t.data(), t.data() + n, 1, pos);
+  put_packed(b, 7, w.data(), w.data() + n, 1, pos);
+  put_float_field(b, 8, g->view.max_tsd);  // sic: ToProto stores getMaxTSD() here
+  put_float_field(b, 9, g->view.max_weight);
+  *len = b.size();
+  if (buf) {
+    if (cap < b.size()) return HG_ERR_CAPACITY;
+    std::memcpy(buf, b.data(), b.size());
+  }
+  return HG_OK;
+}
+
+// HybridGridTSDF(const proto::HybridGridTSDF&) (hybrid_grid_tsdf.h:69-83): a grid with
+// (proto.resolution, proto.relative_truncation_distance, proto.max_weight) whose cells are set by
+// SetCell(index, ValueToTSD(values_tsd[i]), ValueToWeight(values_weight[i])).
+int hg_grid_from_proto(hg_ctx* ctx, const uint8_t* buf, size_t len, uint32_t max_blocks, hg_grid** out) {
+  if (!ctx || (!buf && len) || !out) return HG_ERR_INVALID;
+  float resolution = 0.f, rel_trunc = 0.f, max_weight = 0.f;
+  std::vector<int32_t> xs, ys, zs;
+  std::vector<uint32_t> ts, ws;
+  const uint8_t* p = buf;
+  const uint8_t* end = buf + len;
+  while (p < end) {
+    uint64_t tag;
+    if (!get_varint(p, end, &tag)) return HG_ERR_INVALID;
+    const int field = static_cast<int>(tag >> 3), wire = static_cast<int>(tag & 7);
+    auto take = [&](uint64_t v) {
+      const int32_t s32 = static_cast<int32_t>((static_cast<uint32_t>(v) >> 1) ^ (~(static_cast<uint32_t>(v) & 1) + 1));
+      switch (field) {
+        case 3: xs.push_back(s32); break;
+        case 4: ys.push_back(s32); break;
+        case 5: zs.push_back(s32); break;
+        case 6: ts.push_back(static_cast<uint32_t>(v)); break;
+        case 7: ws.push_back(static_cast<uint32_t>(v)); break;
+        default: break;
+      }
+    };
+    if (wire == 5) {
+      if (end - p < 4) return HG_ERR_INVALID;
+      uint32_t u = p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24);
+      p += 4;
+      float f;
+      std::memcpy(&f, &u, 4);
+      if (field == 1) resolution = f;
+      else if (field == 8) rel_trunc = f;
+      else if (field == 9) max_weight = f;
+    } else if (wire == 2) {
+      uint64_t l;
+      if (!get_varint(p, end, &l) || static_cast<uint64_t>(end - p) < l) return HG_ERR_INVALID;
+      const uint8_t* q = p;
+      const uint8_t* qe = p + l;
+      while (q < qe) {
+        uint64_t v;
+        if (!get_varint(q, qe, &v)) return HG_ERR_INVALID;
+        take(v);
+      }
+      p = qe;
+    } else if (wire == 0) {
+      uint64_t v;
+      if (!get_varint(p, end, &v)) return HG_ERR_INVALID;
+      take(v);
+    } else if (wire == 1) {
+      if (end - p < 8) return HG_ERR_INVALID;
+      p += 8;
+    } else {
+      return HG_ERR_INVALID;
+    }
+  }
+  const size_t n = ts.size();
+  if (xs.size() != n || ys.size() != n || zs.size() != n || ws.size() != n) {  // the reference CHECK_EQs
+    set_last_error("proto::HybridGridTSDF: index / value arrays differ in length");
+    return HG_ERR_INVALID;
+  }
+  hg_grid* g = nullptr;
+  int rc = hg_grid_create(ctx, resolution, rel_trunc, max_weight, max_blocks, &g);
+  if (rc != HG_OK) return rc;
+  if (n) {
+    const GridView& v = g->view;
+    std::vector<int32_t> ijk(3 * n);
+    std::vector<float> tf(n), wf(n);
+    for (size_t i = 0; i < n; ++i) {
+      ijk[3 * i] = xs[i]; ijk[3 * i + 1] = ys[i]; ijk[3 * i + 2] = zs[i];
+      const uint32_t tc = ts[i] & 0x7FFFu, wc = ws[i] & 0x7FFFu;  // LUT lookups of the new converter
+      tf[i] = tc == 0 ? v.min_tsd : static_cast<float>(tc) * v.tsd_scale + v.tsd_offset;
+      wf[i] = wc == 0 ? 0.f : static_cast<float>(wc) * v.weight_scale + v.weight_offset;
+    }
+    rc = hg_grid_set_cells(g, ijk.data(), n, tf.data(), wf.data());
+    if (rc != HG_OK) {
+      hg_grid_destroy(g);
+      return rc;
+    }
+  }
+  *out = g;
   return HG_OK;
 }
 

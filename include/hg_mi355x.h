@@ -150,6 +150,14 @@ int hg_grid_block_arrays(hg_grid* grid, void** keys_dev, void** voxels_dev, uint
 int hg_grid_import_blocks(hg_grid* grid, const void* keys, const void* voxels, uint32_t num_blocks,
                           int memspace);
 
+/* proto::HybridGridTSDF wire bytes (mapping/proto/3d/hybrid_grid_tsdf.proto:19-31) as
+ * HybridGridTSDF::ToProto / the proto constructor produce and consume them
+ * (mapping/3d/hybrid_grid_tsdf.h:69-83,119-134), including the reference's habit of storing
+ * getMaxTSD() in the relative_truncation_distance field. buf == NULL: only *len is returned. */
+int hg_grid_to_proto(hg_grid* grid, uint8_t* buf, size_t cap, size_t* len);
+int hg_grid_from_proto(hg_ctx* ctx, const uint8_t* buf, size_t len, uint32_t max_blocks,
+                       hg_grid** out);
+
 /* ---- insertion: TSDFRangeDataInserter3D::Insert ----------------------------------------- */
 /* xyz: n x 3 floats in the grid (submap) frame, or — when pose_tq != NULL — in the frame that
  * pose_tq (float[7], = local_pose().inverse().cast<float>()) maps into the grid frame; the origin
