@@ -48,7 +48,11 @@ def make_scans(rings, cols, first, count, stream_base):
     from hectorgrapher_amd import synth
     out = []
     for k in range(first, first + count):
-        pose = synth.pose_k(k)
+        # SURVEY §8d poses P_k; long runs fold k back and forth over [0, 60] so the sensor stays
+        # inside the room (P_k leaves it beyond k ~ 90)
+        kk = k % 120
+        kk = kk if kk <= 60 else 120 - kk
+        pose = synth.pose_k(kk)
         pts = synth.generate_scan(pose, rings, cols, stream=stream_base + k)
         out.append((pose, pts))
     return out
@@ -267,12 +271,16 @@ def run(args):
     # one-shot exchange at the end of mapping: gather finished TSDF blocks to rank 0
     gather_ms = None
     if dist is not None:
-        barrier()
-        tg = time.perf_counter()
-        gathered = hgd.gather_grids(grids, dist, rank, world, dev)
-        barrier()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        del gathered
+        try:
+            barrier()
+            tg = time.perf_counter()
+            gathered = hgd.gather_grids(grids, dist, rank, world, dev)
+            barrier()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+            del gathered
+        except Exception as e:  # the exchange is reported separately; never lose the timed result
+            sys.stderr.write("gather of TSDF blocks failed: %r\n" % (e,))
+            gather_ms = None
 
     if rank != 0:
         if dist is not None:
@@ -283,7 +291,7 @@ def run(args):
     value = total_scans / elapsed
 
     base = None
-    if not args.no_cpu_baseline and world >= 1:
+    if not args.no_cpu_baseline and world == 1:  # timed on rank 0 at N = 1 only
         base = cpu_baseline(args, map_scans, query[args.warmup:])
 
     # ---- roofline of the dominant kernel family (HIP-event time on the ctx stream) ----

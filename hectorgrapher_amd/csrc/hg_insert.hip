@@ -1021,8 +1021,73 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
       __syncthreads();
       unsigned hi = s_hi;
       unsigned cnt = 0;
-      if (hi == lo) {  // a single voxel exceeds the pass capacity: not supported on this path
-        if (tid == 0) atomicOr(&g.counters[1], kFlagBinOverflow);
+      if (hi == lo) {
+        // One voxel alone holds more records than an LDS pass (degenerate geometry: thousands of
+        // rays through one voxel). Its chain is applied in rounds of <= kBinCap records in seq
+        // order: each round bisects the seq threshold that admits the next <= kBinCap records.
+        const unsigned total_v = hist[lo];
+        unsigned done_v = 0;
+        uint32_t last = 0;  // records with (key & seq_mask) < last are already applied
+        const uint32_t seq_mask = (1u << kSeqBits) - 1u;
+        uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + lo;
+        UnitChain chain;
+        if (tid == 0) chain.begin(g, *cell);
+        // number of this voxel's records with seq in [last, T)
+        auto count_below = [&](uint32_t T) {
+          __syncthreads();
+          if (tid == 0) s_hi = 0;
+          __syncthreads();
+          unsigned c = 0;
+          for (unsigned i = tid; i < n; i += kBinThreads) {
+            const uint32_t k = bk[i];
+            const uint32_t sq = k & seq_mask;
+            if ((k >> kSeqBits) == lo && sq >= last && sq < T) ++c;
+          }
+          if (c) atomicAdd(&s_hi, c);
+          __syncthreads();
+          return s_hi;
+        };
+        while (done_v < total_v) {
+          // largest T with count(seq in [last, T)) <= kBinCap; T = last + 1 always qualifies (seq unique)
+          uint32_t t_ok = last + 1u, t_bad = seq_mask + 1u;
+          if (count_below(t_bad) <= static_cast<unsigned>(kBinCap)) {
+            t_ok = t_bad;
+          } else {
+            while (t_bad - t_ok > 1u) {
+              const uint32_t mid = t_ok + (t_bad - t_ok) / 2u;
+              if (count_below(mid) <= static_cast<unsigned>(kBinCap)) t_ok = mid; else t_bad = mid;
+            }
+          }
+          const uint32_t T = t_ok;
+          __syncthreads();
+          // gather the admitted records (seq in [last, T)), order by seq, apply
+          if (tid == 0) s_hi = 0;
+          __syncthreads();
+          for (unsigned i = tid; i < n; i += kBinThreads) {
+            const uint32_t k = bk[i];
+            const uint32_t sq = k & seq_mask;
+            if ((k >> kSeqBits) == lo && sq >= last && sq < T) {
+              const unsigned p = atomicAdd(&s_hi, 1u);
+              if (p < static_cast<unsigned>(kBinCap)) { gk[p] = k; gv[p] = bv[i]; }
+            }
+          }
+          __syncthreads();
+          const unsigned m = min(s_hi, static_cast<unsigned>(kBinCap));
+          for (unsigned i = tid; i < m; i += kBinThreads) {
+            const uint32_t k = gk[i];
+            unsigned rank = 0;
+            for (unsigned j = 0; j < m; ++j) rank += (gk[j] < k) ? 1u : 0u;
+            sv[rank] = gv[i];
+          }
+          __syncthreads();
+          if (tid == 0)
+            for (unsigned j = 0; j < m; ++j) chain.step(g, L.p.maximum_weight, __uint_as_float(sv[j]));
+          __syncthreads();
+          done_v += m;
+          last = T;
+          if (T > seq_mask) break;  // all seq values covered
+        }
+        if (tid == 0) *cell = chain.end();
         hi = lo + 1;
       } else {
         cnt = base[hi - 1] + hist[hi - 1] - b_lo;

@@ -276,3 +276,17 @@ def test_project_sdf_to_cloud_structure_normals(po, hg, ctx, res, hs, vs):
                                                    normal_computation_method=0))
     with pytest.raises(hg.HgError):
         bad.Insert(hg.RangeData([0, 0, 0], pts, width=rings), gg)
+
+
+def test_thousands_of_rays_through_one_voxel(po, hg, ctx):
+    """Degenerate geometry: 5000 near-identical returns put > 2048 updates (one LDS pass of the
+    binned path) on single voxels; the chain is then applied in seq-ordered rounds."""
+    rng = np.random.default_rng(11)
+    pts = (np.array([[2.01, 0.03, -0.02]], np.float32) + (rng.standard_normal((5000, 3)) * 2e-3).astype(np.float32))
+    for res in (0.05, 0.2):
+        og = po.Grid(res)
+        gg = hg.HybridGridTSDF(ctx, res, max_blocks=256)
+        a = og.insert([0, 0, 0], pts)
+        st = hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], pts), gg)
+        assert (st.num_hits, st.num_updates) == a
+        assert_grids_equal(og, gg)
