@@ -27,7 +27,8 @@ SYMBOLS = [
     "hg_grid_insert_batch", "hg_pyramid_insert", "hg_pyramid_insert_batch", "hg_grid_status",
     "hg_voxel_filter", "hg_adaptive_voxel_filter", "hg_filter_last_device",
     "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
-    "hg_problem_set_pose", "hg_problem_get_pose", "hg_problem_add_block",
+    "hg_problem_set_pose", "hg_problem_get_pose", "hg_problem_set_velocity", "hg_problem_get_velocity",
+    "hg_problem_add_odometry_block", "hg_problem_add_imu_block", "hg_problem_add_block",
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
     "hg_solver_default_opts", "hg_problem_solve", "hg_problem_solve_async", "hg_problem_fetch",
     "hg_register_scan", "hg_match_evaluate", "hg_match_solve",
@@ -158,6 +159,10 @@ def load():
     L.hg_problem_add_pose.argtypes = [vp, vp, i32]
     L.hg_problem_set_pose.argtypes = [vp, i32, vp]
     L.hg_problem_get_pose.argtypes = [vp, i32, vp]
+    L.hg_problem_set_velocity.argtypes = [vp, i32, vp, i32]
+    L.hg_problem_get_velocity.argtypes = [vp, i32, vp]
+    L.hg_problem_add_odometry_block.argtypes = [vp, i32, i32, f64, f64, vp]
+    L.hg_problem_add_imu_block.argtypes = [vp, i32, i32, f64, f64, f64, f64, vp]
     L.hg_problem_add_block.argtypes = [vp, vp, sz, i32, vp, i32, i32, f64, i32, i32, f64]
     L.hg_problem_num_residuals.argtypes = [vp]
     L.hg_problem_num_columns.argtypes = [vp]

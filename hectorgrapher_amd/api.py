@@ -403,6 +403,26 @@ class Problem:
         check(self._L.hg_problem_get_pose(self._h, idx, _p(out)), "get_pose")
         return out
 
+    def set_velocity(self, idx, v, constant=False):
+        v = _host(v, np.float64)
+        check(self._L.hg_problem_set_velocity(self._h, idx, _p(v), int(constant)), "set_velocity")
+
+    def get_velocity(self, idx):
+        out = np.empty(3, np.float64)
+        check(self._L.hg_problem_get_velocity(self._h, idx, _p(out)), "get_velocity")
+        return out
+
+    def add_odometry_block(self, a, b, translation_weight, rotation_weight, delta_tq):
+        d = _host(delta_tq, np.float64)
+        return check(self._L.hg_problem_add_odometry_block(self._h, a, b, float(translation_weight),
+                                                           float(rotation_weight), _p(d)), "add_odometry_block")
+
+    def add_imu_block(self, a, b, translation_weight, velocity_weight, rotation_weight, dt, delta_q):
+        d = _host(delta_q, np.float64)
+        return check(self._L.hg_problem_add_imu_block(self._h, a, b, float(translation_weight),
+                                                      float(velocity_weight), float(rotation_weight),
+                                                      float(dt), _p(d)), "add_imu_block")
+
     def add_block(self, xyz, grids, scaling_factor, pose_a, pose_b=-1, interpolation_ratio=0.0,
                   multi_res=False):
         arr = (C.c_void_p * len(grids))(*[g._h for g in grids])

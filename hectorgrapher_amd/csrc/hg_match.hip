@@ -30,7 +30,9 @@ namespace hg {
 
 constexpr int kMaxLevels = 4;
 constexpr int kMaxPoses = 6;
-constexpr int kMaxCols = 6 * kMaxPoses;
+constexpr int kState = 10;              // per control point: t(3) q(4) v(3)
+constexpr int kMaxCols = 9 * kMaxPoses;  // 6 pose + 3 velocity columns per control point
+constexpr int kMaxSmall = 16;           // odometry / IMU blocks
 constexpr int kMaxBlocks = 16;
 constexpr int kAcc = 36;  // 28 (upper triangle of 7x7) + 7 + 1
 constexpr int kEvalThreads = 512;
@@ -64,6 +66,25 @@ struct BlockInfo {
 enum { PHASE_INIT = 0, PHASE_CANDIDATE = 1 };
 enum { MODE_PREPARE = 0, MODE_STEP = 1, MODE_ASSEMBLE = 2 };
 
+// Odometry (RelativeTranslationAndYawCostFunction, 6 residuals) or IMU pre-integration
+// (PredictionImuPreintegrationCostFunctor, 9 residuals) block between control points a and b.
+struct SmallBlockDev {
+  int type, a, b, active;
+  unsigned row_offset, pad;
+  double w[3];
+  double dt;
+  double delta[7];
+};
+
+// Per small block: J^T J (18 x 18 over the local columns [pose_a 6 | vel_a 3 | pose_b 6 | vel_b 3]),
+// J^T r and r^T r, written by k_small_blocks, consumed by the LM step.
+struct SmallOut {
+  double H[18 * 18];
+  double g[18];
+  double c;
+  double pad;
+};
+
 // Scalars and small vectors of the solver; lives in global memory between launches and in LDS
 // while k_lm runs.
 struct LmHead {
@@ -74,10 +95,14 @@ struct LmHead {
   hg_solver_opts opt;
   double radius, decrease_factor;
   double x_cost, cand_cost, model_cost_change, gradient_max_norm, initial_cost;
-  double x[kMaxPoses][7];
-  double cand[kMaxPoses][7];
+  double x[kMaxPoses][kState];
+  double cand[kMaxPoses][kState];
   int constant[kMaxPoses];
   int col[kMaxPoses];
+  int vfree[kMaxPoses];  // velocity is a free parameter block
+  int vcol[kMaxPoses];
+  int num_small, pad0;
+  SmallBlockDev small[kMaxSmall];
   double scale[kMaxCols], diagonal[kMaxCols], g[kMaxCols], step[kMaxCols], delta[kMaxCols];
   double gc[kMaxCols];
   BlockInfo blocks[kMaxBlocks];
@@ -474,7 +499,7 @@ __device__ inline void quaternion_plus_jacobian(const double* x, double* j /*4x3
 // Block transform and its derivative w.r.t. the local parameters of its pose(s) at `poses`.
 // Single pose: T = pose_a. Two poses: InterpolateTransform (transform/timestamped_transform.h:41-51)
 // = lerp of translations + Eigen 3.3 Quaternion::slerp.
-__device__ void prepare_block(const BlockInfo& b, const double (*poses)[7], BlockXform* xf) {
+__device__ void prepare_block(const BlockInfo& b, const double (*poses)[kState], BlockXform* xf) {
   for (int i = 0; i < 7 * 12; ++i) xf->M[i] = 0.0;
   const double* pa = poses[b.pose_a];
   double pja[12];
@@ -558,18 +583,21 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-__device__ inline void pose_plus(const LmHead& h, const double (*x)[7], const double* delta,
-                                 double (*out)[7], int lane) {
+__device__ inline void pose_plus(const LmHead& h, const double (*x)[kState], const double* delta,
+                                 double (*out)[kState], int lane) {
   if (lane < h.num_poses) {
     const int p = lane;
-    if (h.constant[p]) {
-      for (int k = 0; k < 7; ++k) out[p][k] = x[p][k];
-    } else {
+    for (int k = 0; k < kState; ++k) out[p][k] = x[p][k];
+    if (!h.constant[p]) {
       const double* d = delta + h.col[p];
       for (int k = 0; k < 3; ++k) out[p][k] = x[p][k] + d[k];
       double q[4];
       quaternion_plus(x[p] + 3, d + 3, q);
       for (int k = 0; k < 4; ++k) out[p][3 + k] = q[k];
+    }
+    if (h.vfree[p]) {
+      const double* d = delta + h.vcol[p];
+      for (int k = 0; k < 3; ++k) out[p][7 + k] = x[p][7 + k] + d[k];
     }
   }
   wave_sync();
@@ -675,13 +703,18 @@ __device__ inline void finish(LmHead& h, int type, int reason) {
 __device__ double gradient_max_norm(const LmHead& h) {
   double m = 0.0;
   for (int p = 0; p < h.num_poses; ++p) {
-    if (h.constant[p]) continue;
-    const double* g = h.g + h.col[p];
-    const double neg[6] = {-g[0], -g[1], -g[2], -g[3], -g[4], -g[5]};
-    for (int k = 0; k < 3; ++k) m = fmax(m, fabs(h.x[p][k] - (h.x[p][k] + neg[k])));
-    double q[4];
-    quaternion_plus(h.x[p] + 3, neg + 3, q);
-    for (int k = 0; k < 4; ++k) m = fmax(m, fabs(h.x[p][3 + k] - q[k]));
+    if (!h.constant[p]) {
+      const double* g = h.g + h.col[p];
+      const double neg[6] = {-g[0], -g[1], -g[2], -g[3], -g[4], -g[5]};
+      for (int k = 0; k < 3; ++k) m = fmax(m, fabs(h.x[p][k] - (h.x[p][k] + neg[k])));
+      double q[4];
+      quaternion_plus(h.x[p] + 3, neg + 3, q);
+      for (int k = 0; k < 4; ++k) m = fmax(m, fabs(h.x[p][3 + k] - q[k]));
+    }
+    if (h.vfree[p]) {
+      const double* g = h.g + h.vcol[p];
+      for (int k = 0; k < 3; ++k) m = fmax(m, fabs(h.x[p][7 + k] - (h.x[p][7 + k] - g[k])));
+    }
   }
   return m;
 }
@@ -816,7 +849,8 @@ __device__ void reduce_partials(LmShared& S, const double* partials) {
 }
 
 // Maps the per-block 7x7 sums through M into Hc / gc / cand_cost.
-__device__ void assemble(LmShared& S, const BlockXform* xf, const double* partials, int lane) {
+__device__ void assemble(LmShared& S, const BlockXform* xf, const double* partials,
+                         const SmallOut* small_out, int lane) {
   LmHead& h = S.h;
   const int n = h.ncols;
   // S.sums was filled by reduce_partials (all 256 threads) before the other waves retired
@@ -865,6 +899,29 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
     }
     wave_sync();
   }
+  // odometry / IMU blocks: their 18 x 18 local systems were computed by k_small_blocks
+  for (int b = 0; b < h.num_small; ++b) {
+    const SmallBlockDev& sb = h.small[b];
+    if (!sb.active) continue;
+    const SmallOut& so = small_out[b];
+    cost += so.c;
+    // local column -> global column: [pose_a 6 | vel_a 3 | pose_b 6 | vel_b 3]
+    auto gcol = [&](int c) {
+      if (c < 6) return h.constant[sb.a] ? -1 : h.col[sb.a] + c;
+      if (c < 9) return h.vfree[sb.a] ? h.vcol[sb.a] + (c - 6) : -1;
+      if (c < 15) return h.constant[sb.b] ? -1 : h.col[sb.b] + (c - 9);
+      return h.vfree[sb.b] ? h.vcol[sb.b] + (c - 15) : -1;
+    };
+    for (int idx = lane; idx < 18 * 18; idx += kLmThreads) {
+      const int g1 = gcol(idx / 18), g2 = gcol(idx % 18);
+      if (g1 >= 0 && g2 >= 0) S.Hc[g1 * n + g2] += so.H[idx];
+    }
+    if (lane < 18) {
+      const int g1 = gcol(lane);
+      if (g1 >= 0) h.gc[g1] += so.g[lane];
+    }
+    wave_sync();
+  }
   if (lane == 0) h.cand_cost = 0.5 * cost;
   wave_sync();
 }
@@ -872,7 +929,8 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
 // One LM iteration by the calling workgroup (any size >= 64): loads the solver head, sums the
 // partials, and lets wavefront 0 advance the state machine. Called from k_lm and from the tail of
 // the last k_tsdf_residuals workgroup of an iteration.
-__device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* partials, int mode) {
+__device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* partials,
+                        const SmallOut* small_out, int mode) {
   const int lane = threadIdx.x;
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
@@ -894,7 +952,7 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
   reduce_partials(S, partials);
   if (threadIdx.x >= kLmThreads) return;  // retired waves no longer take part in barriers
   HG_STAMP(S, 1);
-  assemble(S, xf, partials, lane);
+  assemble(S, xf, partials, small_out, lane);
   HG_STAMP(S, 2);
   if (mode == MODE_ASSEMBLE) {
     for (int i = lane; i < n * n; i += kLmThreads) G->Hc[i] = S.Hc[i];
@@ -929,8 +987,8 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
     // candidate evaluated: ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful
     double sn = 0.0, xn = 0.0;
     for (int p = 0; p < h.num_poses; ++p) {
-      if (h.constant[p]) continue;
-      for (int k = 0; k < 7; ++k) {
+      const int k0 = h.constant[p] ? 7 : 0, k1 = h.vfree[p] ? kState : 7;
+      for (int k = k0; k < k1; ++k) {
         const double d = h.x[p][k] - h.cand[p][k];
         sn += d * d;
         xn += h.x[p][k] * h.x[p][k];
@@ -956,7 +1014,7 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
         for (int i = lane; i < n * n; i += kLmThreads) S.H[i] = S.Hc[i];
         for (int i = lane; i < n; i += kLmThreads) h.g[i] = h.gc[i];
         if (lane < h.num_poses)
-          for (int k = 0; k < 7; ++k) h.x[lane][k] = h.cand[lane][k];
+          for (int k = 0; k < kState; ++k) h.x[lane][k] = h.cand[lane][k];
         h_changed = true;
         wave_sync();
         const double gmn = gradient_max_norm(h);
@@ -999,6 +1057,170 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
     for (int i = lane; i < n * n; i += kLmThreads) G->H[i] = S.H[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Odometry / IMU residual blocks: one wavefront per block, lane k carries d/d(parameter k) of
+// every intermediate (forward-mode differentiation spread over the lanes; scalar parts are
+// computed redundantly). Parameter lanes: t_a 0-2, v_a 3-5, q_a 6-9, t_b 10-12, v_b 13-15,
+// q_b 16-19 (Ceres Jet arithmetic, jet.h).
+// ------------------------------------------------------------------------------------------
+struct LJ {
+  double a, v;
+};
+__device__ inline LJ lj(double a) { return {a, 0.0}; }
+__device__ inline LJ operator+(const LJ& f, const LJ& g) { return {f.a + g.a, f.v + g.v}; }
+__device__ inline LJ operator-(const LJ& f, const LJ& g) { return {f.a - g.a, f.v - g.v}; }
+__device__ inline LJ operator-(const LJ& f) { return {-f.a, -f.v}; }
+__device__ inline LJ operator*(const LJ& f, const LJ& g) { return {f.a * g.a, f.a * g.v + f.v * g.a}; }
+__device__ inline LJ operator*(double s, const LJ& f) { return {f.a * s, f.v * s}; }
+__device__ inline LJ operator/(const LJ& f, const LJ& g) {
+  const double gi = 1.0 / g.a, fg = f.a * gi;
+  return {fg, (f.v - fg * g.v) * gi};
+}
+__device__ inline LJ lj_sqrt(const LJ& f) {
+  const double t = sqrt(f.a);
+  return {t, f.v * (1.0 / (2.0 * t))};
+}
+__device__ inline LJ lj_atan2(const LJ& g, const LJ& f) {
+  const double tmp = 1.0 / (f.a * f.a + g.a * g.a);
+  return {atan2(g.a, f.a), tmp * (-g.a * f.v + f.a * g.v)};
+}
+__device__ inline LJ lj_asin(const LJ& f) {
+  const double tmp = 1.0 / sqrt(1.0 - f.a * f.a);
+  return {asin(f.a), tmp * f.v};
+}
+struct LJ3 { LJ x, y, z; };
+struct LJ4 { LJ w, x, y, z; };
+__device__ inline LJ3 lj_cross(const LJ3& a, const LJ3& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ inline LJ3 lj_rotate(const LJ4& q, const LJ3& v) {  // Eigen _transformVector
+  const LJ3 u{q.x, q.y, q.z};
+  LJ3 uv = lj_cross(u, v);
+  uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+  const LJ3 c = lj_cross(u, uv);
+  return {v.x + q.w * uv.x + c.x, v.y + q.w * uv.y + c.y, v.z + q.w * uv.z + c.z};
+}
+__device__ inline LJ4 lj_qmul(const LJ4& a, const LJ4& b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+__device__ inline LJ4 lj_qnormalized(const LJ4& q) {
+  const LJ n = lj_sqrt((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+  return {q.w / n, q.x / n, q.y / n, q.z / n};
+}
+struct LJRigid { LJ3 t; LJ4 q; };
+__device__ inline LJRigid lj_inverse(const LJRigid& r) {  // rigid_transform.h:159-163
+  const LJ4 rc{r.q.w, -r.q.x, -r.q.y, -r.q.z};
+  const LJ3 t = lj_rotate(rc, r.t);
+  return {{-t.x, -t.y, -t.z}, rc};
+}
+__device__ inline LJRigid lj_mul(const LJRigid& a, const LJRigid& b) {  // :184-190
+  const LJ3 t = lj_rotate(a.q, b.t);
+  return {{t.x + a.t.x, t.y + a.t.y, t.z + a.t.z}, lj_qnormalized(lj_qmul(a.q, b.q))};
+}
+
+__global__ __launch_bounds__(kWave) void k_small_blocks(LmState* G, SmallOut* out, double* residuals) {
+  if (G->h.done) return;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const SmallBlockDev sb = G->h.small[b];
+  if (!sb.active) return;
+  __shared__ double Ja[9][20];   // ambient Jacobian rows
+  __shared__ double Jl[9][18];   // local Jacobian rows
+  __shared__ double rs[9];
+  const double* A = G->h.cand[sb.a];
+  const double* B = G->h.cand[sb.b];
+  auto var = [&](double a, int k) { return LJ{a, lane == k ? 1.0 : 0.0}; };
+  const LJ3 ta{var(A[0], 0), var(A[1], 1), var(A[2], 2)};
+  const LJ3 va{var(A[7], 3), var(A[8], 4), var(A[9], 5)};
+  const LJ4 qa{var(A[3], 6), var(A[4], 7), var(A[5], 8), var(A[6], 9)};
+  const LJ3 tb{var(B[0], 10), var(B[1], 11), var(B[2], 12)};
+  const LJ3 vb{var(B[7], 13), var(B[8], 14), var(B[9], 15)};
+  const LJ4 qb{var(B[3], 16), var(B[4], 17), var(B[5], 18), var(B[6], 19)};
+  LJ r[9];
+  int rows;
+  if (sb.type == 1) {
+    // relative_translation_and_yaw_cost_function.h:41-63
+    rows = 6;
+    const LJRigid delta = lj_mul(lj_inverse({tb, qb}), {ta, qa});
+    const LJRigid dc{{lj(sb.delta[0]), lj(sb.delta[1]), lj(sb.delta[2])},
+                     {lj(sb.delta[3]), lj(sb.delta[4]), lj(sb.delta[5]), lj(sb.delta[6])}};
+    const LJRigid e = lj_mul(lj_inverse(delta), dc);
+    r[0] = sb.w[0] * e.t.x;
+    r[1] = sb.w[0] * e.t.y;
+    r[2] = sb.w[0] * e.t.z;
+    const LJ4& q = e.q;
+    r[3] = sb.w[1] * lj_atan2(lj(2.0) * (q.w * q.x + q.y * q.z), lj(1.0) - lj(2.0) * (q.x * q.x + q.y * q.y));
+    const LJ sinp = lj(2.0) * (q.w * q.y - q.z * q.x);
+    r[4] = sb.w[1] * ((fabs(sinp.a) >= 1.0) ? lj(M_PI / 2) : lj_asin(sinp));
+    const LJ3 d = lj_rotate(q, {lj(1.0), lj(0.0), lj(0.0)});
+    r[5] = sb.w[1] * lj_atan2(d.y, d.x);
+    r[6] = r[7] = r[8] = lj(0.0);
+  } else {
+    // prediction_imu_preintegration_cost_functor.h:49-101
+    rows = 9;
+    const LJ dt = lj(sb.dt);
+    r[0] = sb.w[0] * (tb.x - ta.x - dt * va.x);
+    r[1] = sb.w[0] * (tb.y - ta.y - dt * va.y);
+    r[2] = sb.w[0] * (tb.z - ta.z - dt * va.z);
+    r[3] = sb.w[1] * (vb.x - va.x);
+    r[4] = sb.w[1] * (vb.y - va.y);
+    r[5] = sb.w[1] * (vb.z - va.z);
+    const LJ4 qbc{qb.w, -qb.x, -qb.y, -qb.z};
+    const LJ4 dq{lj(sb.delta[3]), lj(sb.delta[4]), lj(sb.delta[5]), lj(sb.delta[6])};
+    const LJ4 re = lj_qmul(lj_qmul(qbc, qa), dq);
+    r[6] = sb.w[2] * re.x;
+    r[7] = sb.w[2] * re.y;
+    r[8] = sb.w[2] * re.z;
+  }
+  if (lane < 20)
+    for (int i = 0; i < 9; ++i) Ja[i][lane] = (i < rows) ? r[i].v : 0.0;
+  if (lane == 0)
+    for (int i = 0; i < 9; ++i) rs[i] = (i < rows) ? r[i].a : 0.0;
+  __syncthreads();
+  // ambient -> local columns [t_a 3 | rot_a 3 | v_a 3 | t_b 3 | rot_b 3 | v_b 3]
+  if (lane < 18) {
+    double pj[12];
+    const int c = lane;
+    for (int i = 0; i < 9; ++i) {
+      double v;
+      if (c < 3) v = Ja[i][c];
+      else if (c < 6) {
+        quaternion_plus_jacobian(A + 3, pj);
+        v = 0.0;
+        for (int j = 0; j < 4; ++j) v += Ja[i][6 + j] * pj[j * 3 + (c - 3)];
+      } else if (c < 9) v = Ja[i][3 + (c - 6)];
+      else if (c < 12) v = Ja[i][10 + (c - 9)];
+      else if (c < 15) {
+        quaternion_plus_jacobian(B + 3, pj);
+        v = 0.0;
+        for (int j = 0; j < 4; ++j) v += Ja[i][16 + j] * pj[j * 3 + (c - 12)];
+      } else v = Ja[i][13 + (c - 15)];
+      Jl[i][c] = v;
+    }
+  }
+  __syncthreads();
+  SmallOut& o = out[b];
+  for (int idx = lane; idx < 18 * 18; idx += kWave) {
+    const int c1 = idx / 18, c2 = idx % 18;
+    double s = 0.0;
+    for (int i = 0; i < 9; ++i) s += Jl[i][c1] * Jl[i][c2];
+    o.H[idx] = s;
+  }
+  if (lane < 18) {
+    double s = 0.0;
+    for (int i = 0; i < 9; ++i) s += Jl[i][lane] * rs[i];
+    o.g[lane] = s;
+  }
+  if (lane == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 9; ++i) s += rs[i] * rs[i];
+    o.c = s;
+    if (residuals)
+      for (int i = 0; i < rows; ++i) residuals[sb.row_offset + i] = rs[i];
+  }
+}
+
+
 // Residual kernel of one block. With `G` set, the last workgroup of the iteration (a ticket counts
 // the workgroups of all blocks' launches) runs the LM step in its tail, so an iteration is ONE
 // launch: release/acquire at agent scope around the ticket makes the other workgroups' partials
@@ -1007,7 +1229,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
     PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
     double* __restrict__ residuals, LmState* G, BlockXform* xf_all, const double* partials_all,
-    unsigned* ticket, unsigned total_wg) {
+    const SmallOut* small_out, unsigned* ticket, unsigned total_wg) {
   if (G && G->h.done) return;
   tsdf_residuals_body(pv, xyz, n, scaling, xf, partials, residuals);
   if (!G) return;
@@ -1029,13 +1251,14 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
   }
   __syncthreads();
   __shared__ LmShared S;
-  lm_step(S, G, xf_all, partials_all, MODE_STEP);
+  lm_step(S, G, xf_all, partials_all, small_out, MODE_STEP);
 }
 
-__global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials, int mode) {
+__global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
+                                                 const SmallOut* small_out, int mode) {
   __shared__ LmShared S;
   if (mode == MODE_STEP && G->h.done) return;
-  lm_step(S, G, xf, partials, mode);
+  lm_step(S, G, xf, partials, small_out, mode);
 }
 
 }  // namespace hg
@@ -1057,6 +1280,10 @@ struct hg_problem {
   std::vector<Block> blocks;
   std::vector<std::array<double, 7>> poses;
   std::vector<int> constant;
+  std::vector<std::array<double, 3>> velocity;
+  std::vector<int> vfree;  // 1: velocity set and not constant
+  std::vector<SmallBlockDev> small;
+  SmallOut* d_small = nullptr;
   // device state
   LmState* d_state = nullptr;
   unsigned* d_ticket = nullptr;
@@ -1085,9 +1312,13 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   int col = 0;
   for (int i = 0; i < S.num_poses; ++i) {
     for (int k = 0; k < 7; ++k) S.x[i][k] = S.cand[i][k] = p->poses[i][k];
+    for (int k = 0; k < 3; ++k) S.x[i][7 + k] = S.cand[i][7 + k] = p->velocity[i][k];
     S.constant[i] = p->constant[i];
     S.col[i] = p->constant[i] ? -1 : col;
     if (!p->constant[i]) col += 6;
+    S.vfree[i] = p->vfree[i];
+    S.vcol[i] = p->vfree[i] ? col : -1;
+    if (p->vfree[i]) col += 3;
   }
   S.ncols = col;
   if (opts) S.opt = *opts; else hg_solver_default_opts(&S.opt);
@@ -1110,6 +1341,16 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
     wg_off += bi.num_wg;
     if (bi.active) row += bi.n;
   }
+  S.num_small = static_cast<int>(p->small.size());
+  for (int b = 0; b < S.num_small; ++b) {
+    SmallBlockDev sb = p->small[b];
+    const bool free_pose = !p->constant[sb.a] || !p->constant[sb.b];
+    const bool free_vel = sb.type == 2 && (p->vfree[sb.a] || p->vfree[sb.b]);
+    sb.active = (free_pose || free_vel) ? 1 : 0;
+    sb.row_offset = row;
+    if (sb.active) row += (sb.type == 1 ? 6u : 9u);
+    S.small[b] = sb;
+  }
   int rc = p->partials.reserve(static_cast<size_t>(std::max(1u, wg_off)) * kAcc * sizeof(double));
   if (rc != HG_OK) return rc;
   // the pinned buffer may still be the source of the previous (finished) upload: solves are
@@ -1122,6 +1363,12 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
 int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
   hipStream_t s = p->ctx->stream;
   const LmHead& S = p->h_state.h;
+  if (S.num_small > 0) {
+    // odometry / IMU blocks at the candidate; stream order puts their results before the LM step
+    hipLaunchKernelGGL(k_small_blocks, dim3(S.num_small), dim3(kWave), 0, s, p->d_state, p->d_small,
+                       d_residuals);
+    HG_HIP_CHECK(hipGetLastError());
+  }
   unsigned total_wg = 0;
   for (int b = 0; b < S.num_blocks; ++b) total_wg += S.blocks[b].num_wg;
   for (int b = 0; b < S.num_blocks; ++b) {
@@ -1139,7 +1386,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
                        p->partials.as<double>() + static_cast<size_t>(bi.partial_offset) * kAcc,
                        d_residuals ? d_residuals + bi.row_offset : nullptr,
                        fused_lm ? p->d_state : nullptr, p->d_xf, p->partials.as<double>(),
-                       p->d_ticket, total_wg);
+                       p->d_small, p->d_ticket, total_wg);
     HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
@@ -1174,6 +1421,7 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(LmState));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_xf), sizeof(BlockXform) * kMaxBlocks);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 256);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_small), sizeof(SmallOut) * kMaxSmall);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_pin), sizeof(LmState));
   if (e == hipSuccess) e = hipMemset(p->d_ticket, 0, 256);
   if (e != hipSuccess) {
@@ -1194,6 +1442,7 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->d_state) (void)hipFree(p->d_state);
   if (p->d_xf) (void)hipFree(p->d_xf);
   if (p->d_ticket) (void)hipFree(p->d_ticket);
+  if (p->d_small) (void)hipFree(p->d_small);
   if (p->h_pin) (void)hipHostFree(p->h_pin);
   p->partials.release();
   p->residuals.release();
@@ -1211,6 +1460,9 @@ int hg_problem_reset(hg_problem* p) {
   p->blocks.clear();
   p->poses.clear();
   p->constant.clear();
+  p->velocity.clear();
+  p->vfree.clear();
+  p->small.clear();
   return HG_OK;
 }
 
@@ -1224,6 +1476,8 @@ int hg_problem_add_pose(hg_problem* p, const double tq[7], int constant) {
   std::memcpy(a.data(), tq, sizeof(double) * 7);
   p->poses.push_back(a);
   p->constant.push_back(constant ? 1 : 0);
+  p->velocity.push_back({{0.0, 0.0, 0.0}});
+  p->vfree.push_back(0);
   return static_cast<int>(p->poses.size()) - 1;
 }
 
@@ -1237,6 +1491,54 @@ int hg_problem_get_pose(hg_problem* p, int index, double tq[7]) {
   if (!p || !tq || index < 0 || index >= static_cast<int>(p->poses.size())) return HG_ERR_INVALID;
   std::memcpy(tq, p->poses[index].data(), sizeof(double) * 7);
   return HG_OK;
+}
+
+int hg_problem_set_velocity(hg_problem* p, int index, const double v[3], int constant) {
+  if (!p || !v || index < 0 || index >= static_cast<int>(p->poses.size())) return HG_ERR_INVALID;
+  std::memcpy(p->velocity[index].data(), v, sizeof(double) * 3);
+  p->vfree[index] = constant ? 0 : 1;
+  return HG_OK;
+}
+
+int hg_problem_get_velocity(hg_problem* p, int index, double v[3]) {
+  if (!p || !v || index < 0 || index >= static_cast<int>(p->poses.size())) return HG_ERR_INVALID;
+  std::memcpy(v, p->velocity[index].data(), sizeof(double) * 3);
+  return HG_OK;
+}
+
+static int add_small(hg_problem* p, const SmallBlockDev& sb) {
+  const int np = static_cast<int>(p->poses.size());
+  if (sb.a < 0 || sb.a >= np || sb.b < 0 || sb.b >= np || sb.a == sb.b) return HG_ERR_INVALID;
+  if (p->small.size() >= static_cast<size_t>(kMaxSmall)) {
+    set_last_error("too many odometry / IMU blocks");
+    return HG_ERR_CAPACITY;
+  }
+  p->small.push_back(sb);
+  return static_cast<int>(p->small.size()) - 1;
+}
+
+int hg_problem_add_odometry_block(hg_problem* p, int pose_a, int pose_b, double translation_weight,
+                                  double rotation_weight, const double delta_tq[7]) {
+  if (!p || !delta_tq) return HG_ERR_INVALID;
+  SmallBlockDev sb;
+  std::memset(&sb, 0, sizeof(sb));
+  sb.type = 1; sb.a = pose_a; sb.b = pose_b;
+  sb.w[0] = translation_weight; sb.w[1] = rotation_weight;
+  std::memcpy(sb.delta, delta_tq, sizeof(double) * 7);
+  return add_small(p, sb);
+}
+
+int hg_problem_add_imu_block(hg_problem* p, int pose_a, int pose_b, double translation_weight,
+                             double velocity_weight, double rotation_weight, double delta_time_seconds,
+                             const double delta_rotation_wxyz[4]) {
+  if (!p || !delta_rotation_wxyz) return HG_ERR_INVALID;
+  SmallBlockDev sb;
+  std::memset(&sb, 0, sizeof(sb));
+  sb.type = 2; sb.a = pose_a; sb.b = pose_b;
+  sb.w[0] = translation_weight; sb.w[1] = velocity_weight; sb.w[2] = rotation_weight;
+  sb.dt = delta_time_seconds;
+  std::memcpy(sb.delta + 3, delta_rotation_wxyz, sizeof(double) * 4);
+  return add_small(p, sb);
 }
 
 int hg_problem_add_block(hg_problem* p, const float* xyz, size_t n, int memspace,
@@ -1289,14 +1591,21 @@ int hg_problem_num_residuals(hg_problem* p) {
   size_t n = 0;
   for (const auto& b : p->blocks)
     if (block_active(p, b)) n += b.n;
+  for (const auto& sb : p->small) {
+    const bool free_pose = !p->constant[sb.a] || !p->constant[sb.b];
+    const bool free_vel = sb.type == 2 && (p->vfree[sb.a] || p->vfree[sb.b]);
+    if (free_pose || free_vel) n += (sb.type == 1 ? 6 : 9);
+  }
   return static_cast<int>(n);
 }
 
 int hg_problem_num_columns(hg_problem* p) {
   if (!p) return HG_ERR_INVALID;
   int c = 0;
-  for (int k : p->constant)
-    if (!k) c += 6;
+  for (size_t i = 0; i < p->constant.size(); ++i) {
+    if (!p->constant[i]) c += 6;
+    if (p->vfree[i]) c += 3;
+  }
   return c;
 }
 
@@ -1313,11 +1622,11 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
     if (rc != HG_OK) return rc;
     d_res = p->residuals.as<double>();
   }
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_PREPARE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE);
   HG_HIP_CHECK(hipGetLastError());
   rc = launch_eval(p, d_res, false);
   if (rc != HG_OK) return rc;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_ASSEMBLE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_ASSEMBLE);
   HG_HIP_CHECK(hipGetLastError());
   HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmState), hipMemcpyDeviceToHost, s));
   if (d_res) HG_HIP_CHECK(hipMemcpyAsync(residuals, d_res, sizeof(double) * nres, hipMemcpyDeviceToHost, s));
@@ -1339,18 +1648,23 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
   p->solve_pending = true;
   if (S0.ncols == 0) return HG_OK;
   const int max_it = S0.opt.max_num_iterations;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_PREPARE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE);
   HG_HIP_CHECK(hipGetLastError());
   bool any_active = false;
   for (int b = 0; b < S0.num_blocks; ++b) any_active = any_active || S0.blocks[b].active;
   for (int it = 0; it <= max_it; ++it) {
+    if (!any_active && S0.num_small > 0) {
+      hipLaunchKernelGGL(k_small_blocks, dim3(S0.num_small), dim3(kWave), 0, s, p->d_state, p->d_small,
+                         static_cast<double*>(nullptr));
+      HG_HIP_CHECK(hipGetLastError());
+    }
     if (any_active) {
       // residuals of every block at the candidate + (tail of the last workgroup) one LM step
       rc = launch_eval(p, nullptr, true);
       if (rc != HG_OK) return rc;
     } else {
       ProfScope ps(p->ctx, HG_K_LM, 1);
-      hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), MODE_STEP);
+      hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_STEP);
       HG_HIP_CHECK(hipGetLastError());
     }
   }
@@ -1374,7 +1688,10 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
   for (int i = 1; i < 8; ++i) fprintf(stderr, " [%d]%lld", i, S.stamps[i] - S.stamps[i - 1]);
   fprintf(stderr, "\n");
 #endif
-  for (int i = 0; i < S.num_poses; ++i) std::memcpy(p->poses[i].data(), S.x[i], sizeof(double) * 7);
+  for (int i = 0; i < S.num_poses; ++i) {
+    std::memcpy(p->poses[i].data(), S.x[i], sizeof(double) * 7);
+    std::memcpy(p->velocity[i].data(), S.x[i] + 7, sizeof(double) * 3);
+  }
   if (summary) {
     summary->initial_cost = S.initial_cost;
     summary->final_cost = S.x_cost;

@@ -223,6 +223,23 @@ int hg_problem_add_block(hg_problem* p, const float* xyz, size_t n, int memspace
                          hg_grid* const* pyramid, int levels, int multi_res,
                          double scaling_factor, int pose_a, int pose_b,
                          double interpolation_ratio);
+/* Sliding-window blocks that are not TSDF lookups (oltb.cc:928-1074). Control point `index` may
+ * carry a velocity parameter block (state.h:11-31); constant != 0 = SetParameterBlockConstant.
+ * Columns per control point: 6 pose (if free) then 3 velocity (if free). */
+int hg_problem_set_velocity(hg_problem* p, int index, const double v[3], int constant);
+int hg_problem_get_velocity(hg_problem* p, int index, double v[3]);
+/* RelativeTranslationAndYawCostFunction(translation_weight, rotation_weight, delta_pose) between the
+ * previous (a) and next (b) control point: 6 residuals
+ * (mapping/internal/3d/scan_matching/relative_translation_and_yaw_cost_function.h:41-63). */
+int hg_problem_add_odometry_block(hg_problem* p, int pose_a, int pose_b, double translation_weight,
+                                  double rotation_weight, const double delta_tq[7]);
+/* PredictionImuPreintegrationCostFunctor(translation_w, velocity_w, rotation_w, delta_time,
+ * pre-integrated delta_rotation): 9 residuals over (t, v, q) of a and b
+ * (…/scan_matching/prediction_imu_preintegration_cost_functor.h:49-101). Needs velocities on both
+ * control points. */
+int hg_problem_add_imu_block(hg_problem* p, int pose_a, int pose_b, double translation_weight,
+                             double velocity_weight, double rotation_weight, double delta_time_seconds,
+                             const double delta_rotation_wxyz[4]);
 int hg_problem_num_residuals(hg_problem* p);
 int hg_problem_num_columns(hg_problem* p);
 /* ceres::Problem::Evaluate shape: cost = 0.5 |r|^2; residuals[num_residuals]; gradient and JtJ in

@@ -729,6 +729,24 @@ template <int N> inline Jet<N> jacos(const Jet<N>& f) {
   Jet<N> r; r.a = std::acos(f.a); for (int i = 0; i < N; ++i) r.v[i] = tmp * f.v[i]; return r;
 }
 template <int N> inline Jet<N> jabs(const Jet<N>& f) { return f.a < 0.0 ? -f : f; }
+template <int N> inline Jet<N> jasin(const Jet<N>& f) {
+  const double tmp = 1.0 / std::sqrt(1.0 - f.a * f.a);
+  Jet<N> r; r.a = std::asin(f.a); for (int i = 0; i < N; ++i) r.v[i] = tmp * f.v[i]; return r;
+}
+template <int N> inline Jet<N> jatan2(const Jet<N>& g, const Jet<N>& f) {  // atan2(g, f)
+  const double tmp = 1.0 / (f.a * f.a + g.a * g.a);
+  Jet<N> r; r.a = std::atan2(g.a, f.a);
+  for (int i = 0; i < N; ++i) r.v[i] = tmp * (-g.a * f.v[i] + f.a * g.v[i]);
+  return r;
+}
+template <int N> inline Jet<N> jsqrt(const Jet<N>& f) {
+  const double tmp = std::sqrt(f.a);
+  const double two_a_inverse = 1.0 / (2.0 * tmp);
+  Jet<N> r; r.a = tmp; for (int i = 0; i < N; ++i) r.v[i] = f.v[i] * two_a_inverse; return r;
+}
+inline double jasin(double x) { return std::asin(x); }
+inline double jatan2(double y, double x) { return std::atan2(y, x); }
+inline double jsqrt(double x) { return std::sqrt(x); }
 inline double jsin(double x) { return std::sin(x); }
 inline double jacos(double x) { return std::acos(x); }
 inline double jabs(double x) { return std::fabs(x); }
@@ -889,11 +907,80 @@ inline T InterpolatedMultiResGetTSD(const std::vector<const HybridGridTSDF*>& py
 // 1238-1291 (block wiring, scaling, constant first control point,
 // QuaternionParameterization).
 // ---------------------------------------------------------------------------
-struct PoseBlock {
+struct PoseBlock {  // one control point: pose (+ optional velocity, state.h:11-31)
   double t[3];
   double q[4];  // w x y z
   bool constant = false;
+  double v[3] = {0.0, 0.0, 0.0};
+  bool has_velocity = false;
+  bool v_constant = false;
 };
+
+// Non-TSDF residual blocks of the sliding window (oltb.cc:928-1074).
+struct SmallBlock {
+  int type = 0;  // 1: RelativeTranslationAndYawCostFunction (6 residuals), 2: PredictionImuPreintegrationCostFunctor (9)
+  int a = 0, b = 0;          // previous / next control point
+  double w[3] = {0, 0, 0};   // type 1: translation, rotation scaling; type 2: translation, velocity, rotation
+  double dt = 0.0;           // type 2: delta_time_seconds
+  double delta[7] = {0, 0, 0, 1, 0, 0, 0};  // type 1: delta pose (t, q wxyz); type 2: delta_rotation in [3..6]
+};
+
+// ref transform/rigid_transform.h:159-163,184-190 and transform/transform.h:43-96 on generic T.
+template <typename T> inline Quat<T> QuatNormalized(const Quat<T>& q) {
+  const T n = jsqrt((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+  return {q.w / n, q.x / n, q.y / n, q.z / n};
+}
+template <typename T> inline Rigid3<T> RigidInverse(const Rigid3<T>& r) {
+  const Quat<T> rc{r.q.w, -r.q.x, -r.q.y, -r.q.z};
+  return {-Rotate(rc, r.t), rc};
+}
+template <typename T> inline Rigid3<T> RigidMul(const Rigid3<T>& a, const Rigid3<T>& b) {
+  return {Rotate(a.q, b.t) + a.t, QuatNormalized(QuatMul(a.q, b.q))};
+}
+template <typename T> inline T GetRoll(const Quat<T>& q) {
+  const T sinr_cosp = T(2.0) * (q.w * q.x + q.y * q.z);
+  const T cosr_cosp = T(1.0) - T(2.0) * (q.x * q.x + q.y * q.y);
+  return jatan2(sinr_cosp, cosr_cosp);
+}
+template <typename T> inline T GetPitch(const Quat<T>& q) {
+  const T sinp = T(2.0) * (q.w * q.y - q.z * q.x);
+  if (ScalarPart(jabs(sinp)) >= 1.0) return T(M_PI / 2);
+  return jasin(sinp);
+}
+template <typename T> inline T GetYaw(const Quat<T>& q) {
+  const Vec3<T> d = Rotate(q, Vec3<T>{T(1.0), T(0.0), T(0.0)});
+  return jatan2(d.y, d.x);
+}
+
+// ref relative_translation_and_yaw_cost_function.h:41-63
+template <typename T>
+inline void OdometryResiduals(const SmallBlock& sb, const Rigid3<T>& start, const Rigid3<T>& end, T* r) {
+  const Rigid3<T> delta = RigidMul(RigidInverse(end), start);
+  const Rigid3<T> delta_c{{T(sb.delta[0]), T(sb.delta[1]), T(sb.delta[2])},
+                          {T(sb.delta[3]), T(sb.delta[4]), T(sb.delta[5]), T(sb.delta[6])}};
+  const Rigid3<T> error = RigidMul(RigidInverse(delta), delta_c);
+  r[0] = sb.w[0] * error.t.x;
+  r[1] = sb.w[0] * error.t.y;
+  r[2] = sb.w[0] * error.t.z;
+  r[3] = sb.w[1] * GetRoll(error.q);
+  r[4] = sb.w[1] * GetPitch(error.q);
+  r[5] = sb.w[1] * GetYaw(error.q);
+}
+
+// ref prediction_imu_preintegration_cost_functor.h:49-101 (the live, un-commented form)
+template <typename T>
+inline void ImuPreintegrationResiduals(const SmallBlock& sb, const Vec3<T>& t0, const Vec3<T>& v0,
+                                       const Quat<T>& q0, const Vec3<T>& t1, const Vec3<T>& v1,
+                                       const Quat<T>& q1, T* r) {
+  const Vec3<T> te = t1 - t0 - T(sb.dt) * v0;
+  const Vec3<T> ve = v1 - v0;
+  const Quat<T> q1c{q1.w, -q1.x, -q1.y, -q1.z};
+  const Quat<T> dq{T(sb.delta[3]), T(sb.delta[4]), T(sb.delta[5]), T(sb.delta[6])};
+  const Quat<T> re = QuatMul(QuatMul(q1c, q0), dq);
+  r[0] = sb.w[0] * te.x; r[1] = sb.w[0] * te.y; r[2] = sb.w[0] * te.z;
+  r[3] = sb.w[1] * ve.x; r[4] = sb.w[1] * ve.y; r[5] = sb.w[1] * ve.z;
+  r[6] = sb.w[2] * re.x; r[7] = sb.w[2] * re.y; r[8] = sb.w[2] * re.z;
+}
 
 struct ResidualBlock {
   const float* points = nullptr;  // n x 3
@@ -964,19 +1051,39 @@ class Problem {
  public:
   std::vector<PoseBlock> poses;
   std::vector<ResidualBlock> blocks;
+  std::vector<SmallBlock> small_blocks;
   LookupStats lookup_stats;
 
+  static int SmallRows(const SmallBlock& sb) { return sb.type == 1 ? 6 : 9; }
+  bool VelFree(int i) const { return poses[i].has_velocity && !poses[i].v_constant; }
+  bool SmallActive(const SmallBlock& sb) const {
+    if (!poses[sb.a].constant || !poses[sb.b].constant) return true;
+    return sb.type == 2 && (VelFree(sb.a) || VelFree(sb.b));
+  }
   int NumResiduals() const {
     int n = 0;
     for (const auto& b : blocks) if (BlockActive(b)) n += static_cast<int>(b.n);
+    for (const auto& sb : small_blocks) if (SmallActive(sb)) n += SmallRows(sb);
     return n;
   }
-  // Column layout of the reduced program: 6 local columns per non-constant pose
-  // (3 translation, 3 rotation tangent), in pose order.
+  // Column layout of the reduced program, per control point in order: 6 local columns of a
+  // non-constant pose (3 translation, 3 rotation tangent), then 3 of a non-constant velocity.
   int NumEffectiveParameters() const {
     int c = 0;
-    for (const auto& p : poses) if (!p.constant) c += 6;
+    for (size_t i = 0; i < poses.size(); ++i) {
+      if (!poses[i].constant) c += 6;
+      if (VelFree(static_cast<int>(i))) c += 3;
+    }
     return c;
+  }
+  std::vector<int> VelocityOffsets() const {
+    std::vector<int> off(poses.size(), -1);
+    int c = 0;
+    for (size_t i = 0; i < poses.size(); ++i) {
+      if (!poses[i].constant) c += 6;
+      if (VelFree(static_cast<int>(i))) { off[i] = c; c += 3; }
+    }
+    return off;
   }
   int NumParameters() const {
     int c = 0;
@@ -986,8 +1093,10 @@ class Problem {
   std::vector<int> ColumnOffsets() const {
     std::vector<int> off(poses.size(), -1);
     int c = 0;
-    for (size_t i = 0; i < poses.size(); ++i)
+    for (size_t i = 0; i < poses.size(); ++i) {
       if (!poses[i].constant) { off[i] = c; c += 6; }
+      if (VelFree(static_cast<int>(i))) c += 3;
+    }
     return off;
   }
   bool BlockActive(const ResidualBlock& b) const {
@@ -1029,6 +1138,21 @@ class Problem {
       }
       row0 += static_cast<int>(b.n);
     }
+    const std::vector<int> voff = VelocityOffsets();
+    for (const auto& sb : small_blocks) {
+      if (!SmallActive(sb)) continue;
+      const int rows = SmallRows(sb);
+      double rr[9];
+      double* r = residuals ? residuals + row0 : rr;
+      double* J = jacobian ? jacobian + static_cast<size_t>(row0) * ncols : nullptr;
+      if (J) std::fill(J, J + rows * static_cast<size_t>(ncols), 0.0);
+      EvalSmall(sb, x, off, voff, ncols, r, J);
+      for (int i = 0; i < rows; ++i) c += r[i] * r[i];
+      if (gradient && J)
+        for (int i = 0; i < rows; ++i)
+          for (int k = 0; k < ncols; ++k) gradient[k] += J[i * ncols + k] * r[i];
+      row0 += rows;
+    }
     *cost = 0.5 * c;
   }
 
@@ -1037,6 +1161,53 @@ class Problem {
   SolverSummary Solve(const SolverOptions& opt);
 
  private:
+  // Jet<20> layout: t_a(0-2) v_a(3-5) q_a(6-9) t_b(10-12) v_b(13-15) q_b(16-19), as the parameter
+  // block order of the IMU functor; the odometry functor uses t/q of both.
+  void EvalSmall(const SmallBlock& sb, const std::vector<PoseBlock>& x, const std::vector<int>& off,
+                 const std::vector<int>& voff, int ncols, double* r, double* J) {
+    const PoseBlock& A = x[sb.a];
+    const PoseBlock& B = x[sb.b];
+    const int rows = SmallRows(sb);
+    if (!J) {
+      const Rigid3<double> Ta{{A.t[0], A.t[1], A.t[2]}, {A.q[0], A.q[1], A.q[2], A.q[3]}};
+      const Rigid3<double> Tb{{B.t[0], B.t[1], B.t[2]}, {B.q[0], B.q[1], B.q[2], B.q[3]}};
+      if (sb.type == 1) OdometryResiduals<double>(sb, Ta, Tb, r);
+      else ImuPreintegrationResiduals<double>(sb, Ta.t, Vec3d{A.v[0], A.v[1], A.v[2]}, Ta.q, Tb.t,
+                                              Vec3d{B.v[0], B.v[1], B.v[2]}, Tb.q, r);
+      return;
+    }
+    using JT = Jet<20>;
+    const Vec3<JT> ta{JT(A.t[0], 0), JT(A.t[1], 1), JT(A.t[2], 2)};
+    const Vec3<JT> va{JT(A.v[0], 3), JT(A.v[1], 4), JT(A.v[2], 5)};
+    const Quat<JT> qa{JT(A.q[0], 6), JT(A.q[1], 7), JT(A.q[2], 8), JT(A.q[3], 9)};
+    const Vec3<JT> tb{JT(B.t[0], 10), JT(B.t[1], 11), JT(B.t[2], 12)};
+    const Vec3<JT> vb{JT(B.v[0], 13), JT(B.v[1], 14), JT(B.v[2], 15)};
+    const Quat<JT> qb{JT(B.q[0], 16), JT(B.q[1], 17), JT(B.q[2], 18), JT(B.q[3], 19)};
+    JT res[9];
+    if (sb.type == 1) OdometryResiduals<JT>(sb, Rigid3<JT>{ta, qa}, Rigid3<JT>{tb, qb}, res);
+    else ImuPreintegrationResiduals<JT>(sb, ta, va, qa, tb, vb, qb, res);
+    double pja[12], pjb[12];
+    QuaternionPlusJacobian(A.q, pja);
+    QuaternionPlusJacobian(B.q, pjb);
+    for (int i = 0; i < rows; ++i) {
+      r[i] = res[i].a;
+      double* row = J + static_cast<size_t>(i) * ncols;
+      auto put_pose = [&](int col, int tbase, int qbase, const double* pj) {
+        if (col < 0) return;
+        for (int k = 0; k < 3; ++k) row[col + k] = res[i].v[tbase + k];
+        for (int k = 0; k < 3; ++k) {
+          double s2 = 0.0;
+          for (int j = 0; j < 4; ++j) s2 += res[i].v[qbase + j] * pj[j * 3 + k];
+          row[col + 3 + k] = s2;
+        }
+      };
+      put_pose(A.constant ? -1 : off[sb.a], 0, 6, pja);
+      put_pose(B.constant ? -1 : off[sb.b], 10, 16, pjb);
+      if (voff[sb.a] >= 0) for (int k = 0; k < 3; ++k) row[voff[sb.a] + k] = res[i].v[3 + k];
+      if (voff[sb.b] >= 0) for (int k = 0; k < 3; ++k) row[voff[sb.b] + k] = res[i].v[13 + k];
+    }
+  }
+
   template <typename T>
   T BlockTSD(const ResidualBlock& b, const T& wx, const T& wy, const T& wz) {
     if (b.multi_res) return InterpolatedMultiResGetTSD(b.pyramid, wx, wy, wz, &lookup_stats);
@@ -1150,19 +1321,27 @@ inline void PosePlus(const std::vector<PoseBlock>& x, const double* delta,
   *out = x;
   int c = 0;
   for (size_t i = 0; i < x.size(); ++i) {
-    if (x[i].constant) continue;
-    for (int k = 0; k < 3; ++k) (*out)[i].t[k] = x[i].t[k] + delta[c + k];
-    QuaternionPlus(x[i].q, delta + c + 3, (*out)[i].q);
-    c += 6;
+    if (!x[i].constant) {
+      for (int k = 0; k < 3; ++k) (*out)[i].t[k] = x[i].t[k] + delta[c + k];
+      QuaternionPlus(x[i].q, delta + c + 3, (*out)[i].q);
+      c += 6;
+    }
+    if (x[i].has_velocity && !x[i].v_constant) {
+      for (int k = 0; k < 3; ++k) (*out)[i].v[k] = x[i].v[k] + delta[c + k];
+      c += 3;
+    }
   }
 }
 
 inline double AmbientNorm(const std::vector<PoseBlock>& x) {
   double s = 0.0;
   for (const auto& p : x) {
-    if (p.constant) continue;
-    for (int k = 0; k < 3; ++k) s += p.t[k] * p.t[k];
-    for (int k = 0; k < 4; ++k) s += p.q[k] * p.q[k];
+    if (!p.constant) {
+      for (int k = 0; k < 3; ++k) s += p.t[k] * p.t[k];
+      for (int k = 0; k < 4; ++k) s += p.q[k] * p.q[k];
+    }
+    if (p.has_velocity && !p.v_constant)
+      for (int k = 0; k < 3; ++k) s += p.v[k] * p.v[k];
   }
   return std::sqrt(s);
 }
@@ -1170,15 +1349,21 @@ inline void AmbientDiffNorms(const std::vector<PoseBlock>& a, const std::vector<
                              double* l2, double* linf) {
   double s = 0.0, m = 0.0;
   for (size_t i = 0; i < a.size(); ++i) {
-    if (a[i].constant) continue;
-    for (int k = 0; k < 3; ++k) {
-      const double d = a[i].t[k] - b[i].t[k];
-      s += d * d; m = std::max(m, std::fabs(d));
+    if (!a[i].constant) {
+      for (int k = 0; k < 3; ++k) {
+        const double d = a[i].t[k] - b[i].t[k];
+        s += d * d; m = std::max(m, std::fabs(d));
+      }
+      for (int k = 0; k < 4; ++k) {
+        const double d = a[i].q[k] - b[i].q[k];
+        s += d * d; m = std::max(m, std::fabs(d));
+      }
     }
-    for (int k = 0; k < 4; ++k) {
-      const double d = a[i].q[k] - b[i].q[k];
-      s += d * d; m = std::max(m, std::fabs(d));
-    }
+    if (a[i].has_velocity && !a[i].v_constant)
+      for (int k = 0; k < 3; ++k) {
+        const double d = a[i].v[k] - b[i].v[k];
+        s += d * d; m = std::max(m, std::fabs(d));
+      }
   }
   *l2 = std::sqrt(s);
   *linf = m;

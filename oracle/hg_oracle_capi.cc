@@ -242,6 +242,35 @@ void hgo_problem_get_pose(void* p, int idx, double* tq) {
   for (int k = 0; k < 3; ++k) tq[k] = b.t[k];
   for (int k = 0; k < 4; ++k) tq[3 + k] = b.q[k];
 }
+void hgo_problem_set_velocity(void* p, int idx, const double* v, int constant) {
+  PoseBlock& b = static_cast<Problem*>(p)->poses[idx];
+  for (int k = 0; k < 3; ++k) b.v[k] = v[k];
+  b.has_velocity = true;
+  b.v_constant = constant != 0;
+}
+void hgo_problem_get_velocity(void* p, int idx, double* v) {
+  const PoseBlock& b = static_cast<Problem*>(p)->poses[idx];
+  for (int k = 0; k < 3; ++k) v[k] = b.v[k];
+}
+// RelativeTranslationAndYawCostFunction(translation_w, rotation_w, delta_pose) between a and b
+int hgo_problem_add_odometry_block(void* p, int a, int b, double wt, double wr, const double* delta_tq) {
+  SmallBlock sb;
+  sb.type = 1; sb.a = a; sb.b = b; sb.w[0] = wt; sb.w[1] = wr;
+  for (int k = 0; k < 7; ++k) sb.delta[k] = delta_tq[k];
+  auto* P = static_cast<Problem*>(p);
+  P->small_blocks.push_back(sb);
+  return static_cast<int>(P->small_blocks.size()) - 1;
+}
+// PredictionImuPreintegrationCostFunctor(translation_w, velocity_w, rotation_w, dt, delta_rotation)
+int hgo_problem_add_imu_block(void* p, int a, int b, double wt, double wv, double wr, double dt,
+                              const double* delta_q_wxyz) {
+  SmallBlock sb;
+  sb.type = 2; sb.a = a; sb.b = b; sb.w[0] = wt; sb.w[1] = wv; sb.w[2] = wr; sb.dt = dt;
+  for (int k = 0; k < 4; ++k) sb.delta[3 + k] = delta_q_wxyz[k];
+  auto* P = static_cast<Problem*>(p);
+  P->small_blocks.push_back(sb);
+  return static_cast<int>(P->small_blocks.size()) - 1;
+}
 // points must stay alive while the problem is used (the reference functors
 // hold references too).
 int hgo_problem_add_block(void* p, const float* xyz, size_t n, void* const* grids, int levels,

@@ -130,6 +130,12 @@ def lib():
     L.hgo_problem_add_pose.argtypes = [vp, vp, C.c_int]
     L.hgo_problem_set_pose.argtypes = [vp, C.c_int, vp]
     L.hgo_problem_get_pose.argtypes = [vp, C.c_int, vp]
+    L.hgo_problem_set_velocity.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.hgo_problem_get_velocity.argtypes = [vp, C.c_int, vp]
+    L.hgo_problem_add_odometry_block.restype = C.c_int
+    L.hgo_problem_add_odometry_block.argtypes = [vp, C.c_int, C.c_int, f64, f64, vp]
+    L.hgo_problem_add_imu_block.restype = C.c_int
+    L.hgo_problem_add_imu_block.argtypes = [vp, C.c_int, C.c_int, f64, f64, f64, f64, vp]
     L.hgo_problem_add_block.restype = C.c_int
     L.hgo_problem_add_block.argtypes = [vp, vp, sz, vp, C.c_int, C.c_int, f64, C.c_int, C.c_int,
                                         f64]
@@ -315,6 +321,26 @@ class Problem:
         out = np.empty(7, np.float64)
         lib().hgo_problem_get_pose(self._h, idx, _ptr(out))
         return out
+
+    def set_velocity(self, idx, v, constant=False):
+        v = np.ascontiguousarray(v, np.float64)
+        lib().hgo_problem_set_velocity(self._h, idx, _ptr(v), int(constant))
+
+    def get_velocity(self, idx):
+        out = np.empty(3, np.float64)
+        lib().hgo_problem_get_velocity(self._h, idx, _ptr(out))
+        return out
+
+    def add_odometry_block(self, a, b, translation_weight, rotation_weight, delta_tq):
+        d = np.ascontiguousarray(delta_tq, np.float64)
+        return lib().hgo_problem_add_odometry_block(self._h, a, b, float(translation_weight),
+                                                    float(rotation_weight), _ptr(d))
+
+    def add_imu_block(self, a, b, translation_weight, velocity_weight, rotation_weight, dt, delta_q):
+        d = np.ascontiguousarray(delta_q, np.float64)
+        return lib().hgo_problem_add_imu_block(self._h, a, b, float(translation_weight),
+                                               float(velocity_weight), float(rotation_weight),
+                                               float(dt), _ptr(d))
 
     def add_block(self, xyz, grids, scaling_factor, pose_a, pose_b=-1, interpolation_ratio=0.0,
                   multi_res=False):

@@ -189,3 +189,51 @@ def test_sliding_window_three_control_points(po, hg, ctx, maps):
         assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
         assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
     np.testing.assert_array_equal(gp.get_pose(0), poses[0])
+
+
+def _window_with_imu_and_odometry(po, hg, ctx, maps, with_tsdf):
+    og, gg = maps
+    n_cp = 4
+    poses = [synth.pose_k(7 + i) if i == 0 else synth.pose_mul(synth.pose_k(7 + i), synth.perturbation())
+             for i in range(n_cp)]
+    vels = [np.array([0.5, 0.2, 0.0]) + 0.05 * i for i in range(n_cp)]
+    op, gp = po.Problem(), hg.Problem(ctx)
+    for i in range(n_cp):
+        for pr in (op, gp):
+            pr.add_pose(poses[i], i == 0)
+            pr.set_velocity(i, vels[i], i == 0)        # oltb.cc:1268-1275: first state constant
+    for i in range(1, n_cp):
+        delta = synth.pose_mul(synth.pose_inverse(synth.pose_k(7 + i)), synth.pose_k(6 + i))
+        dq = synth.pose_mul(synth.pose_inverse(synth.pose_k(6 + i)), synth.pose_k(7 + i))[3:]
+        for pr in (op, gp):
+            pr.add_odometry_block(i - 1, i, 12.0, 30.0, delta)
+            pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, dq)
+    if with_tsdf:
+        for i in range(1, n_cp):
+            pts = synth.generate_scan(synth.pose_k(7 + i), 16, 150, stream=60 + i)
+            s = 1.0 / np.sqrt(len(pts))
+            op.add_block(pts, [og[1]], s, i)
+            gp.add_block(pts, [gg[1]], s, i)
+    return op, gp, n_cp
+
+
+@pytest.mark.parametrize("with_tsdf", [False, True])
+def test_imu_preintegration_and_odometry_blocks(po, hg, ctx, maps, with_tsdf):
+    """the non-TSDF blocks of the sliding window (oltb.cc:928-1074) on the device —
+    9 columns per free control point (pose 6 + velocity 3)."""
+    op, gp, n_cp = _window_with_imu_and_odometry(po, hg, ctx, maps, with_tsdf)
+    assert gp.num_columns() == 9 * (n_cp - 1) == 27
+    c0, r0, J0, g0 = op.evaluate()
+    c1, r1, g1, H1 = gp.evaluate()
+    assert abs(c0 - c1) <= 1e-11 * max(1.0, abs(c0))
+    np.testing.assert_allclose(r1, r0, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(H1, J0.T @ J0, rtol=1e-9, atol=1e-10)
+    so, sg = op.solve(), gp.solve()
+    assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
+    assert abs(so.final_cost - sg.final_cost) <= 1e-8 * max(1e-12, so.final_cost) + 1e-15
+    for i in range(n_cp):
+        a, b = op.get_pose(i), gp.get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+        assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+        np.testing.assert_allclose(gp.get_velocity(i), op.get_velocity(i), atol=1e-6)
