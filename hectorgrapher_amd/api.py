@@ -437,6 +437,26 @@ class Problem:
                                                   int(multi_res), float(scaling_factor), pose_a,
                                                   pose_b, float(interpolation_ratio)), "add_block")
 
+    def add_unwarped_block(self, xyz, interpolation_ratios, grids, scaling_factor, pose_a, pose_b,
+                           multi_res=False):
+        """All returns bracketed by control points (pose_a, pose_b), each with its own ratio."""
+        arr = (C.c_void_p * len(grids))(*[g._h for g in grids])
+        if _is_device(xyz):
+            if not _is_device(interpolation_ratios):
+                raise HgError("device points need device interpolation ratios (float64)")
+            n, ptr, fptr, space = xyz.shape[0], xyz.data_ptr(), interpolation_ratios.data_ptr(), _lib.HG_DEVICE
+            self._keep.append((xyz, interpolation_ratios))
+        else:
+            xyz = _host(xyz, np.float32, 3)
+            f = _host(interpolation_ratios, np.float64)
+            if len(f) != len(xyz):
+                raise HgError("one interpolation ratio per return expected")
+            n, ptr, fptr, space = len(xyz), _p(xyz), _p(f), _lib.HG_HOST
+        self._keep.append(grids)
+        return check(self._L.hg_problem_add_unwarped_block(self._h, ptr, fptr, n, space, arr, len(grids),
+                                                           int(multi_res), float(scaling_factor),
+                                                           pose_a, pose_b), "add_unwarped_block")
+
     def num_residuals(self):
         return check(self._L.hg_problem_num_residuals(self._h))
 
@@ -486,6 +506,67 @@ def register_scan(problem, pose_index, inserters, range_data, grids, **solver_kw
                              _p(range_data.origin), ptr, n, range_data.width, space, _p(pose),
                              C.byref(s)), "hg_register_scan")
     return pose, s
+
+
+def from_seconds(seconds):
+    """common::FromSeconds (common/time.cc:30-33): 100 ns ticks, truncated toward zero."""
+    return int(float(seconds) * 1e7)
+
+
+def to_seconds(ticks):
+    """common::ToSeconds (common/time.cc:35-38)."""
+    return float(ticks) / 1e7
+
+
+def per_point_subdivisions(point_times, cloud_time, control_times, num_points_per_subdivision):
+    """Bracketing of AddPerPointMatchingResiduals (oltb.cc:521-565): subdivisions of
+    `num_points_per_subdivision` consecutive returns, timed at the mean of their first and last
+    return; a subdivision outside (front, back) of the control points is omitted. Times are
+    universal 100 ns ticks (cloud_time, control_times) and seconds relative to the cloud
+    (point_times). Returns [(start, end_exclusive, prev_index, next_index, ratio)]."""
+    ct = [int(t) for t in control_times]
+    n = len(point_times)
+    out = []
+    step = int(num_points_per_subdivision)
+    for start in range(0, n, step):
+        end = min(start + step - 1, n - 1)
+        center = 0.5 * (float(point_times[start]) + float(point_times[end]))
+        t = int(cloud_time) + from_seconds(center)
+        if not (ct[0] < t < ct[-1]):
+            continue
+        nxt = 1
+        while ct[nxt] <= t:   # first control point later than t (exists: t < back)
+            nxt += 1
+        duration = to_seconds(ct[nxt] - ct[nxt - 1])
+        ratio = min(max(to_seconds(t - ct[nxt - 1]) / duration, 0.0), 1.0)
+        out.append((start, end + 1, nxt - 1, nxt, ratio))
+    return out
+
+
+def add_per_point_matching_residuals(problem, pose_ids, control_times, clouds, grids, weight,
+                                     num_points_per_subdivision, multi_res=True):
+    """use_per_point_unwarping branch of OptimizingLocalTrajectoryBuilder (oltb.cc:513-612): every
+    subdivision gets its own interpolation ratio; on the device the subdivisions of one cloud that
+    share a control-point pair are ONE unwarped block. clouds: [(cloud_time_ticks, xyz[n,3],
+    point_times[n])]. Scaling = weight / sqrt(cloud size) (:573-577). Returns, per block added,
+    (cloud index, prev, next, return indices, ratios) in residual order."""
+    added = []
+    for ci, (cloud_time, xyz, times) in enumerate(clouds):
+        xyz = _host(xyz, np.float32, 3)
+        subs = per_point_subdivisions(times, cloud_time, control_times, num_points_per_subdivision)
+        scale = weight / np.sqrt(float(len(xyz)))
+        pairs = {}
+        for (s0, s1, a, b, ratio) in subs:
+            idx, f = pairs.setdefault((a, b), ([], []))
+            idx.extend(range(s0, s1))
+            f.extend([ratio] * (s1 - s0))
+        for (a, b) in sorted(pairs):
+            idx = np.asarray(pairs[(a, b)][0], np.int64)
+            f = np.asarray(pairs[(a, b)][1], np.float64)
+            problem.add_unwarped_block(xyz[idx], f, grids, scale, pose_ids[a], pose_ids[b],
+                                       multi_res=multi_res)
+            added.append((ci, a, b, idx, f))
+    return added
 
 
 class CeresScanMatcher3D:

@@ -16,6 +16,7 @@
 #ifndef HG_ADAPTER_H_
 #define HG_ADAPTER_H_
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -233,6 +234,47 @@ class TsdfScanMatcher3D {
   hg_solver_opts solver_;
   hg_problem* problem_ = nullptr;
 };
+
+// use_per_point_unwarping branch of AddPerPointMatchingResiduals (oltb.cc:513-612): subdivisions of
+// `num_points_per_subdivision` consecutive returns, each timed at the mean of its first and last
+// return and interpolated between the control points that bracket that time; subdivisions outside
+// (front, back) are omitted. Times: universal 100 ns ticks for the cloud and control points, seconds
+// relative to the cloud for the returns (TimedRangefinderPoint::time). The subdivisions of this
+// cloud that share a control-point pair become one hg_problem_add_unwarped_block.
+inline int64_t FromSecondsTicks(double seconds) { return static_cast<int64_t>(seconds * 1e7); }  // common/time.cc:30-33
+inline double TicksToSeconds(int64_t ticks) { return static_cast<double>(ticks) / 1e7; }         // :35-38
+
+inline void AddPerPointMatchingResiduals(hg_problem* problem, const std::vector<int>& pose_ids,
+                                         const std::vector<int64_t>& control_times, int64_t cloud_time,
+                                         const std::vector<Point>& points, const std::vector<float>& point_times,
+                                         hg_grid* const* pyramid, int levels, bool multi_res, double weight,
+                                         int num_points_per_subdivision) {
+  const size_t n = points.size();
+  const size_t pairs = control_times.size() < 2 ? 0 : control_times.size() - 1;
+  std::vector<std::vector<float>> xyz(pairs);
+  std::vector<std::vector<double>> ratios(pairs);
+  for (size_t start = 0; start < n; start += num_points_per_subdivision) {
+    const size_t end = std::min(start + num_points_per_subdivision - 1, n - 1);
+    const double center = 0.5 * (static_cast<double>(point_times[start]) + static_cast<double>(point_times[end]));
+    const int64_t t = cloud_time + FromSecondsTicks(center);
+    if (!(t < control_times.back() && t > control_times.front())) continue;
+    size_t next = 1;
+    while (control_times[next] <= t) ++next;
+    const double duration = TicksToSeconds(control_times[next] - control_times[next - 1]);
+    const double ratio = std::min(1.0, std::max(0.0, TicksToSeconds(t - control_times[next - 1]) / duration));
+    for (size_t i = start; i <= end; ++i) {
+      xyz[next - 1].insert(xyz[next - 1].end(), points[i].begin(), points[i].end());
+      ratios[next - 1].push_back(ratio);
+    }
+  }
+  const double scaling = weight / std::sqrt(static_cast<double>(n));  // :573-577
+  for (size_t k = 0; k < pairs; ++k) {
+    if (ratios[k].empty()) continue;
+    Check(hg_problem_add_unwarped_block(problem, xyz[k].data(), ratios[k].data(), ratios[k].size(), HG_HOST,
+                                        pyramid, levels, multi_res ? 1 : 0, scaling, pose_ids[k], pose_ids[k + 1]),
+          "hg_problem_add_unwarped_block");
+  }
+}
 
 }  // namespace scan_matching
 

@@ -35,6 +35,7 @@ constexpr int kMaxCols = 9 * kMaxPoses;  // 6 pose + 3 velocity columns per cont
 constexpr int kMaxSmall = 16;           // odometry / IMU blocks
 constexpr int kMaxBlocks = 16;
 constexpr int kAcc = 36;  // 28 (upper triangle of 7x7) + 7 + 1
+constexpr int kAccU = 91;  // unwarped blocks: 78 (upper triangle of 12x12) + 12 + 1
 constexpr int kEvalThreads = 512;
 constexpr int kLmThreads = 64;   // the LM state machine runs in one wavefront
 constexpr int kLmBlock = 256;    // waves 1-3 only help summing the workgroup partials
@@ -58,9 +59,10 @@ struct BlockInfo {
   double scaling;
   unsigned n;
   unsigned num_wg;
-  unsigned partial_offset;  // in units of workgroups
+  unsigned partial_offset;  // in doubles
   unsigned row_offset;
   int active;
+  int acc;  // partial sums per workgroup: kAcc, or kAccU for a block with per-return factors
 };
 
 enum { PHASE_INIT = 0, PHASE_CANDIDATE = 1 };
@@ -323,6 +325,40 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
   c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// One return at transform (t, q): row8 = [d r / d(t, q) (7) | r]. The world point follows Eigen's
+// QuaternionBase::_transformVector, then + translation (rigid_transform.h:193-197).
+__device__ __forceinline__ void return_row(const PyramidView& pv, const double* t, const double* q,
+                                           const double* v, double scaling, double* row8) {
+  const double qw = q[0];
+  const double u[3] = {q[1], q[2], q[3]};
+  double uv[3], c2[3];
+  cross3(u, v, uv);
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  cross3(u, uv, c2);
+  const double wx = (v[0] + qw * uv[0] + c2[0]) + t[0];
+  const double wy = (v[1] + qw * uv[1] + c2[1]) + t[1];
+  const double wz = (v[2] + qw * uv[2] + c2[2]) + t[2];
+  const D3 tsd = pyramid_tsd(pv, wx, wy, wz);
+  const double r = scaling * tsd.a;
+  const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
+  // d world / d q = [uv | w*duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v)
+  row8[0] = g[0]; row8[1] = g[1]; row8[2] = g[2];
+  row8[3] = g[0] * uv[0] + g[1] * uv[1] + g[2] * uv[2];
+  const double ekv[3][3] = {{0.0, -v[2], v[1]}, {v[2], 0.0, -v[0]}, {-v[1], v[0], 0.0}};
+  const double eku[3][3] = {{0.0, -uv[2], uv[1]}, {uv[2], 0.0, -uv[0]}, {-uv[1], uv[0], 0.0}};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double duv[3] = {2.0 * ekv[k][0], 2.0 * ekv[k][1], 2.0 * ekv[k][2]};
+    double ud[3];
+    cross3(u, duv, ud);
+    const double c0 = qw * duv[0] + eku[k][0] + ud[0];
+    const double c1 = qw * duv[1] + eku[k][1] + ud[1];
+    const double c2k = qw * duv[2] + eku[k][2] + ud[2];
+    row8[4 + k] = g[0] * c0 + g[1] * c1 + g[2] * c2k;
+  }
+  row8[7] = r;
+}
+
 // residuals of one block at its current transform + 36 partial sums per workgroup
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
@@ -331,41 +367,10 @@ __device__ __forceinline__ void tsdf_residuals_body(
   const unsigned i = blockIdx.x * kEvalThreads + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (i < n) {
-    const double qw = xf->q[0];
-    const double u[3] = {xf->q[1], xf->q[2], xf->q[3]};
     const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
                          static_cast<double>(xyz[3 * i + 2])};
-    // Eigen QuaternionBase::_transformVector, then + translation (rigid_transform.h:193-197)
-    double uv[3], c2[3];
-    cross3(u, v, uv);
-    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
-    cross3(u, uv, c2);
-    const double wx = (v[0] + qw * uv[0] + c2[0]) + xf->t[0];
-    const double wy = (v[1] + qw * uv[1] + c2[1]) + xf->t[1];
-    const double wz = (v[2] + qw * uv[2] + c2[2]) + xf->t[2];
-    const D3 tsd = pyramid_tsd(pv, wx, wy, wz);
-    const double r = scaling * tsd.a;
-    if (residuals) residuals[i] = r;
-    const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
-    // d world / d q = [uv | w*duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v)
-    double row[7];
-    row[0] = g[0]; row[1] = g[1]; row[2] = g[2];
-    row[3] = g[0] * uv[0] + g[1] * uv[1] + g[2] * uv[2];
-    const double ekv[3][3] = {{0.0, -v[2], v[1]}, {v[2], 0.0, -v[0]}, {-v[1], v[0], 0.0}};
-    const double eku[3][3] = {{0.0, -uv[2], uv[1]}, {uv[2], 0.0, -uv[0]}, {-uv[1], uv[0], 0.0}};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double duv[3] = {2.0 * ekv[k][0], 2.0 * ekv[k][1], 2.0 * ekv[k][2]};
-      double ud[3];
-      cross3(u, duv, ud);
-      const double c0 = qw * duv[0] + eku[k][0] + ud[0];
-      const double c1 = qw * duv[1] + eku[k][1] + ud[1];
-      const double c2k = qw * duv[2] + eku[k][2] + ud[2];
-      row[4 + k] = g[0] * c0 + g[1] * c1 + g[2] * c2k;
-    }
-#pragma unroll
-    for (int a = 0; a < 7; ++a) row8[a] = row[a];
-    row8[7] = r;
+    return_row(pv, xf->t, xf->q, v, scaling, row8);
+    if (residuals) residuals[i] = row8[7];
   }
   // J^T J accumulation on the matrix cores: per wavefront X = [row | r] is 64 x 8 (padded to 16
   // columns); 16 x v_mfma_f64_16x16x4_f64 accumulate X^T X, whose upper-left 8 x 8 block holds
@@ -497,9 +502,37 @@ __device__ inline void quaternion_plus_jacobian(const double* x, double* j /*4x3
 }
 
 // Block transform and its derivative w.r.t. the local parameters of its pose(s) at `poses`.
+// Eigen 3.3 Quaternion::slerp(t, b) of a (Geometry/Quaternion.h) in Jet arithmetic; variables: the
+// coefficients (w,x,y,z) of a -> 0..3, of b -> 4..7.
+__device__ inline void slerp_jets(const double* qa, const double* qb, double f, DJ<8>* q) {
+  typedef DJ<8> J;
+  J aw = dj_var<8>(qa[0], 0), ax = dj_var<8>(qa[1], 1), ay = dj_var<8>(qa[2], 2), az = dj_var<8>(qa[3], 3);
+  J bw = dj_var<8>(qb[0], 4), bx = dj_var<8>(qb[1], 5), by = dj_var<8>(qb[2], 6), bz = dj_var<8>(qb[3], 7);
+  const J t = dj_const<8>(f);
+  const double one = 1.0 - 2.220446049250313e-16;
+  const J d = (ax * bx + ay * by) + (az * bz + aw * bw);
+  const J absd = d.a < 0.0 ? -d : d;
+  J s0, s1;
+  if (absd.a >= one) {
+    s0 = dj_const<8>(1.0) - t;
+    s1 = t;
+  } else {
+    const J theta = dj_acos(absd);
+    const J sin_theta = dj_sin(theta);
+    s0 = dj_sin((dj_const<8>(1.0) - t) * theta) / sin_theta;
+    s1 = dj_sin(t * theta) / sin_theta;
+  }
+  if (d.a < 0.0) s1 = -s1;
+  q[0] = s0 * aw + s1 * bw;
+  q[1] = s0 * ax + s1 * bx;
+  q[2] = s0 * ay + s1 * by;
+  q[3] = s0 * az + s1 * bz;
+}
+
 // Single pose: T = pose_a. Two poses: InterpolateTransform (transform/timestamped_transform.h:41-51)
 // = lerp of translations + Eigen 3.3 Quaternion::slerp.
 __device__ void prepare_block(const BlockInfo& b, const double (*poses)[kState], BlockXform* xf) {
+  if (b.acc == kAccU) return;  // per-return factors: the residual kernel interpolates itself
   for (int i = 0; i < 7 * 12; ++i) xf->M[i] = 0.0;
   const double* pa = poses[b.pose_a];
   double pja[12];
@@ -521,26 +554,8 @@ __device__ void prepare_block(const BlockInfo& b, const double (*poses)[kState],
     xf->M[k * 12 + k] = 1.0 + (0.0 - 1.0) * f;
     xf->M[k * 12 + 6 + k] = (1.0 - 0.0) * f;
   }
-  typedef DJ<8> J;
-  // quaternion coefficients as variables: a = (w,x,y,z) -> 0..3, b -> 4..7
-  J aw = dj_var<8>(pa[3], 0), ax = dj_var<8>(pa[4], 1), ay = dj_var<8>(pa[5], 2), az = dj_var<8>(pa[6], 3);
-  J bw = dj_var<8>(pb[3], 4), bx = dj_var<8>(pb[4], 5), by = dj_var<8>(pb[5], 6), bz = dj_var<8>(pb[6], 7);
-  const J t = dj_const<8>(f);
-  const double one = 1.0 - 2.220446049250313e-16;
-  const J d = (ax * bx + ay * by) + (az * bz + aw * bw);
-  const J absd = d.a < 0.0 ? -d : d;
-  J s0, s1;
-  if (absd.a >= one) {
-    s0 = dj_const<8>(1.0) - t;
-    s1 = t;
-  } else {
-    const J theta = dj_acos(absd);
-    const J sin_theta = dj_sin(theta);
-    s0 = dj_sin((dj_const<8>(1.0) - t) * theta) / sin_theta;
-    s1 = dj_sin(t * theta) / sin_theta;
-  }
-  if (d.a < 0.0) s1 = -s1;
-  const J q[4] = {s0 * aw + s1 * bw, s0 * ax + s1 * bx, s0 * ay + s1 * by, s0 * az + s1 * bz};
+  DJ<8> q[4];
+  slerp_jets(pa + 3, pb + 3, f, q);
   for (int r = 0; r < 4; ++r) {
     xf->q[r] = q[r].a;
     for (int c = 0; c < 3; ++c) {
@@ -552,6 +567,93 @@ __device__ void prepare_block(const BlockInfo& b, const double (*poses)[kState],
       xf->M[(3 + r) * 12 + 3 + c] = sa;
       xf->M[(3 + r) * 12 + 9 + c] = sb;
     }
+  }
+}
+
+// Block with one interpolation factor per return (per-point unwarping: the subdivision blocks of
+// AddPerPointMatchingResiduals, optimizing_local_trajectory_builder.cc:513-612, and
+// InterpolatedTSDFPerPointSpaceCostFunction3D): every lane interpolates its own transform between
+// control points a and b and forms its Jacobian row directly over the 12 local columns
+// [pose_a 6 | pose_b 6]; X = [row12 | r] (64 x 13, padded to 16) goes through the same MFMA X^T X
+// reduction. 91 partial sums per workgroup: upper triangle of the 12 x 12 block, J^T r, r^T r.
+__device__ __forceinline__ void tsdf_residuals_unwarp_body(
+    const PyramidView& pv, const float* __restrict__ xyz, const double* __restrict__ factor,
+    unsigned n, double scaling, const double* pa, const double* pb, double* __restrict__ partials,
+    double* __restrict__ residuals, double (*xs)[kWave][16], double (*cs)[256]) {
+  const unsigned i = blockIdx.x * kEvalThreads + threadIdx.x;
+  double row[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) row[k] = 0.0;
+  if (i < n) {
+    const double f = factor[i];
+    double pja[12], pjb[12];
+    quaternion_plus_jacobian(pa + 3, pja);
+    quaternion_plus_jacobian(pb + 3, pjb);
+    double t[3], q[4];
+    for (int k = 0; k < 3; ++k) t[k] = pa[k] + (pb[k] - pa[k]) * f;
+    DJ<8> qj[4];
+    slerp_jets(pa + 3, pb + 3, f, qj);
+    for (int r = 0; r < 4; ++r) q[r] = qj[r].a;
+    const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
+                         static_cast<double>(xyz[3 * i + 2])};
+    double row8[8];
+    return_row(pv, t, q, v, scaling, row8);
+    if (residuals) residuals[i] = row8[7];
+    const double ma = 1.0 + (0.0 - 1.0) * f, mb = (1.0 - 0.0) * f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      row[c] = row8[c] * ma;
+      row[6 + c] = row8[c] * mb;
+      double ja = 0.0, jb = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sa += qj[r].v[j] * pja[j * 3 + c];
+          sb += qj[r].v[4 + j] * pjb[j * 3 + c];
+        }
+        ja += row8[3 + r] * sa;
+        jb += row8[3 + r] * sb;
+      }
+      row[3 + c] = ja;
+      row[9 + c] = jb;
+    }
+    row[12] = row8[7];
+  }
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) xs[wave][lane][c] = c < 13 ? row[c] : 0.0;
+  __syncthreads();
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 cacc = {0.0, 0.0, 0.0, 0.0};
+  const int mj = lane & 15, mk = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const double a = xs[wave][4 * s + mk][mj];
+    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) cs[wave][(mk + 4 * r) * 16 + mj] = cacc[r];  // D[l/16 + 4v][l%16]
+  __syncthreads();
+  if (threadIdx.x < kAccU) {
+    int a, b;
+    if (threadIdx.x < 78) {
+      int t = threadIdx.x;
+      a = 0;
+      while (t >= 12 - a) { t -= 12 - a; ++a; }
+      b = a + t;
+    } else if (threadIdx.x < 90) {
+      a = threadIdx.x - 78;
+      b = 12;
+    } else {
+      a = 12;
+      b = 12;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += cs[wv][a * 16 + b];
+    partials[static_cast<size_t>(blockIdx.x) * kAccU + threadIdx.x] = s;
   }
 }
 
@@ -570,7 +672,7 @@ struct LmShared {
   double Hc[kMaxCols * kMaxCols];
   double A[kMaxCols * kMaxCols];
   double rhs[kMaxCols], y[kMaxCols];
-  double sums[kMaxBlocks * kAcc];
+  double sums[kMaxBlocks * kAccU];
   double AM[7 * 12];
   double M[kMaxBlocks * 7 * 12];  // d(t,q)/d(local) of every block, staged from xf
   double red[kLmThreads];
@@ -817,32 +919,33 @@ __device__ void compute_next_candidate(LmShared& S, int lane) {
 __device__ void reduce_partials(LmShared& S, const double* partials) {
   const LmHead& h = S.h;
   const int t = threadIdx.x;
-  const int stripes = min(static_cast<int>(blockDim.x) / kAcc, kMaxStripes);
-  const int j = t / kAcc, k = t % kAcc;
   for (int b = 0; b < h.num_blocks; ++b) {
     const BlockInfo& bi = h.blocks[b];
+    const int acc_n = bi.acc;
+    const int stripes = min(static_cast<int>(blockDim.x) / acc_n, kMaxStripes);
+    const int j = t / acc_n, k = t % acc_n;
     if (j < stripes) {
       double acc = 0.0;
       if (bi.active) {
-        const double* p = partials + static_cast<size_t>(bi.partial_offset) * kAcc + k;
+        const double* p = partials + bi.partial_offset + k;
         for (unsigned w = j; w < bi.num_wg; w += 8 * stripes) {
           double v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {  // 8 independent loads in flight, masked at the end
             const unsigned idx = w + u * stripes;
-            v[u] = idx < bi.num_wg ? p[static_cast<size_t>(idx) * kAcc] : 0.0;
+            v[u] = idx < bi.num_wg ? p[static_cast<size_t>(idx) * acc_n] : 0.0;
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc += v[u];
         }
       }
-      S.stripe[j * kAcc + k] = acc;
+      S.stripe[j * acc_n + k] = acc;
     }
     __syncthreads();
-    if (t < kAcc) {
+    if (t < acc_n) {
       double s = 0.0;
-      for (int jj = 0; jj < stripes; ++jj) s += S.stripe[jj * kAcc + t];
-      S.sums[b * kAcc + t] = s;
+      for (int jj = 0; jj < stripes; ++jj) s += S.stripe[jj * acc_n + t];
+      S.sums[b * kAccU + t] = s;
     }
     __syncthreads();
   }
@@ -861,7 +964,26 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
   for (int b = 0; b < h.num_blocks; ++b) {
     const BlockInfo& bi = h.blocks[b];
     if (!bi.active) continue;
-    const double* sm = S.sums + b * kAcc;
+    const double* sm = S.sums + b * kAccU;
+    const int ca = h.constant[bi.pose_a] ? -1 : h.col[bi.pose_a];
+    const int cb = (bi.pose_b >= 0 && !h.constant[bi.pose_b]) ? h.col[bi.pose_b] : -1;
+    if (bi.acc == kAccU) {  // already over the 12 local columns
+      cost += sm[90];
+      for (int idx = lane; idx < 12 * 12; idx += kLmThreads) {
+        const int c1 = idx / 12, c2 = idx % 12;
+        const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
+        const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
+        if (g1 < 0 || g2 < 0) continue;
+        const int lo = c1 < c2 ? c1 : c2, hi = c1 < c2 ? c2 : c1;
+        S.Hc[g1 * n + g2] += sm[lo * 12 - (lo * (lo - 1)) / 2 + (hi - lo)];
+      }
+      if (lane < 12) {
+        const int g1 = lane < 6 ? (ca < 0 ? -1 : ca + lane) : (cb < 0 ? -1 : cb + lane - 6);
+        if (g1 >= 0) h.gc[g1] += sm[78 + lane];
+      }
+      wave_sync();
+      continue;
+    }
     cost += sm[35];
     const double* M = S.M + b * 84;
     // AM = A7 * M (7 x 12)
@@ -877,8 +999,6 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
       S.AM[idx] = s;
     }
     wave_sync();
-    const int ca = h.constant[bi.pose_a] ? -1 : h.col[bi.pose_a];
-    const int cb = (bi.pose_b >= 0 && !h.constant[bi.pose_b]) ? h.col[bi.pose_b] : -1;
     for (int idx = lane; idx < 12 * 12; idx += kLmThreads) {
       const int c1 = idx / 12, c2 = idx % 12;
       const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
@@ -1254,6 +1374,42 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
   lm_step(S, G, xf_all, partials_all, small_out, MODE_STEP);
 }
 
+// Same launch protocol for a block with per-return interpolation factors. The staging tiles of
+// the X^T X reduction and the LM tail's working set share one LDS allocation.
+__global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals_unwarp(
+    PyramidView pv, const float* __restrict__ xyz, const double* __restrict__ factor, unsigned n,
+    double scaling, int pose_a, int pose_b, double* __restrict__ partials,
+    double* __restrict__ residuals, LmState* G, BlockXform* xf_all, const double* partials_all,
+    const SmallOut* small_out, unsigned* ticket, unsigned total_wg) {
+  if (G->h.done) return;
+  __shared__ __align__(16) unsigned char smem[sizeof(LmShared)];
+  static_assert(sizeof(LmShared) >= (kEvalThreads / kWave) * (kWave * 16 + 256) * sizeof(double),
+                "LDS tile aliasing");
+  double (*xs)[kWave][16] = reinterpret_cast<double (*)[kWave][16]>(smem);
+  double (*cs)[256] = reinterpret_cast<double (*)[256]>(smem + (kEvalThreads / kWave) * kWave * 16 * sizeof(double));
+  tsdf_residuals_unwarp_body(pv, xyz, factor, n, scaling, G->h.cand[pose_a], G->h.cand[pose_b],
+                             partials, residuals, xs, cs);
+  if (!ticket) return;
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last = (t == total_wg - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *ticket = 0u;
+  }
+  __syncthreads();
+  lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
+}
+
 __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
                                                  const SmallOut* small_out, int mode) {
   __shared__ LmShared S;
@@ -1276,6 +1432,7 @@ struct hg_problem {
     double scaling = 1.0;
     int pose_a = 0, pose_b = -1;
     double factor = 0.0;
+    const double* d_factor = nullptr;  // per-return interpolation factors (unwarped block)
   };
   std::vector<Block> blocks;
   std::vector<std::array<double, 7>> poses;
@@ -1335,10 +1492,11 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
     bi.scaling = hb.scaling;
     bi.n = static_cast<unsigned>(hb.n);
     bi.active = block_active(p, hb) ? 1 : 0;
+    bi.acc = hb.d_factor ? kAccU : kAcc;
     bi.num_wg = bi.active ? (bi.n + kEvalThreads - 1) / kEvalThreads : 0;
     bi.partial_offset = wg_off;
     bi.row_offset = row;
-    wg_off += bi.num_wg;
+    wg_off += bi.num_wg * bi.acc;
     if (bi.active) row += bi.n;
   }
   S.num_small = static_cast<int>(p->small.size());
@@ -1351,7 +1509,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
     if (sb.active) row += (sb.type == 1 ? 6u : 9u);
     S.small[b] = sb;
   }
-  int rc = p->partials.reserve(static_cast<size_t>(std::max(1u, wg_off)) * kAcc * sizeof(double));
+  int rc = p->partials.reserve(static_cast<size_t>(std::max(1u, wg_off)) * sizeof(double));
   if (rc != HG_OK) return rc;
   // the pinned buffer may still be the source of the previous (finished) upload: solves are
   // synchronised by their fetch before the next upload
@@ -1381,9 +1539,19 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
     pv.multi_res = hb.multi_res;
     for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
     ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n);
+    if (hb.d_factor) {
+      hipLaunchKernelGGL(k_tsdf_residuals_unwarp, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
+                         hb.d_xyz, hb.d_factor, bi.n, bi.scaling, bi.pose_a, bi.pose_b,
+                         p->partials.as<double>() + bi.partial_offset,
+                         d_residuals ? d_residuals + bi.row_offset : nullptr, p->d_state, p->d_xf,
+                         p->partials.as<double>(), p->d_small, fused_lm ? p->d_ticket : nullptr,
+                         total_wg);
+      HG_HIP_CHECK(hipGetLastError());
+      continue;
+    }
     hipLaunchKernelGGL(k_tsdf_residuals, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv, hb.d_xyz,
                        bi.n, bi.scaling, p->d_xf + b,
-                       p->partials.as<double>() + static_cast<size_t>(bi.partial_offset) * kAcc,
+                       p->partials.as<double>() + bi.partial_offset,
                        d_residuals ? d_residuals + bi.row_offset : nullptr,
                        fused_lm ? p->d_state : nullptr, p->d_xf, p->partials.as<double>(),
                        p->d_small, p->d_ticket, total_wg);
@@ -1541,9 +1709,9 @@ int hg_problem_add_imu_block(hg_problem* p, int pose_a, int pose_b, double trans
   return add_small(p, sb);
 }
 
-int hg_problem_add_block(hg_problem* p, const float* xyz, size_t n, int memspace,
-                         hg_grid* const* pyramid, int levels, int multi_res, double scaling_factor,
-                         int pose_a, int pose_b, double interpolation_ratio) {
+static int add_block_impl(hg_problem* p, const float* xyz, const double* factors, size_t n,
+                          int memspace, hg_grid* const* pyramid, int levels, int multi_res,
+                          double scaling_factor, int pose_a, int pose_b, double interpolation_ratio) {
   if (!p || !pyramid || levels < 1 || levels > kMaxLevels || (n && !xyz)) return HG_ERR_INVALID;
   const int np = static_cast<int>(p->poses.size());
   if (pose_a < 0 || pose_a >= np || pose_b >= np) return HG_ERR_INVALID;
@@ -1569,9 +1737,15 @@ int hg_problem_add_block(hg_problem* p, const float* xyz, size_t n, int memspace
   b.pose_b = pose_b < 0 ? -1 : pose_b;
   b.factor = interpolation_ratio;
   if (memspace == HG_HOST && n) {
+    // one allocation: xyz (padded to 8 bytes), then the per-return factors
+    const size_t xyz_bytes = (n * 3 * sizeof(float) + 7) & ~static_cast<size_t>(7);
+    const size_t bytes = xyz_bytes + (factors ? n * sizeof(double) : 0);
     HG_HIP_CHECK(hipSetDevice(p->ctx->device));
-    HG_HIP_CHECK(hipMalloc(&b.owned, n * 3 * sizeof(float)));
+    HG_HIP_CHECK(hipMalloc(&b.owned, bytes));
     hipError_t e = hipMemcpyAsync(b.owned, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, p->ctx->stream);
+    if (e == hipSuccess && factors)
+      e = hipMemcpyAsync(static_cast<char*>(b.owned) + xyz_bytes, factors, n * sizeof(double),
+                         hipMemcpyHostToDevice, p->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
     if (e != hipSuccess) {
       (void)hipFree(b.owned);
@@ -1579,11 +1753,32 @@ int hg_problem_add_block(hg_problem* p, const float* xyz, size_t n, int memspace
       return HG_ERR_HIP;
     }
     b.d_xyz = static_cast<const float*>(b.owned);
+    if (factors) b.d_factor = reinterpret_cast<const double*>(static_cast<char*>(b.owned) + xyz_bytes);
   } else {
     b.d_xyz = xyz;
+    b.d_factor = factors;
   }
   p->blocks.push_back(b);
   return static_cast<int>(p->blocks.size()) - 1;
+}
+
+int hg_problem_add_block(hg_problem* p, const float* xyz, size_t n, int memspace,
+                         hg_grid* const* pyramid, int levels, int multi_res, double scaling_factor,
+                         int pose_a, int pose_b, double interpolation_ratio) {
+  return add_block_impl(p, xyz, nullptr, n, memspace, pyramid, levels, multi_res, scaling_factor,
+                        pose_a, pose_b, interpolation_ratio);
+}
+
+int hg_problem_add_unwarped_block(hg_problem* p, const float* xyz, const double* interpolation_ratios,
+                                  size_t n, int memspace, hg_grid* const* pyramid, int levels,
+                                  int multi_res, double scaling_factor, int pose_a, int pose_b) {
+  if (!p || pose_b < 0 || pose_a == pose_b || (n && !interpolation_ratios)) return HG_ERR_INVALID;
+  if (n == 0) {
+    set_last_error("unwarped block without returns");
+    return HG_ERR_INVALID;
+  }
+  return add_block_impl(p, xyz, interpolation_ratios, n, memspace, pyramid, levels, multi_res,
+                        scaling_factor, pose_a, pose_b, 0.0);
 }
 
 int hg_problem_num_residuals(hg_problem* p) {

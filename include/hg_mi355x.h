@@ -223,6 +223,17 @@ int hg_problem_add_block(hg_problem* p, const float* xyz, size_t n, int memspace
                          hg_grid* const* pyramid, int levels, int multi_res,
                          double scaling_factor, int pose_a, int pose_b,
                          double interpolation_ratio);
+/* Per-point unwarping (use_per_point_unwarping, oltb.cc:513-612 and :613-683): the reference adds
+ * one Interpolated[MultiResolution]TSDFSpaceCostFunction3D per subdivision of
+ * num_points_per_subdivision returns, and one InterpolatedTSDFPerPointSpaceCostFunction3D
+ * (…/scan_matching/interpolated_tsdf_per_point_space_cost_function_3d.h:36-82) per low-resolution
+ * return, each with its own interpolation ratio between the SAME two control points. Here all
+ * returns bracketed by (pose_a, pose_b) form one block; interpolation_ratios[i] is return i's ratio
+ * (returns of one subdivision repeat their subdivision's ratio). Residual order = return order.
+ * n >= 1, pose_a != pose_b >= 0. */
+int hg_problem_add_unwarped_block(hg_problem* p, const float* xyz, const double* interpolation_ratios,
+                                  size_t n, int memspace, hg_grid* const* pyramid, int levels,
+                                  int multi_res, double scaling_factor, int pose_a, int pose_b);
 /* Sliding-window blocks that are not TSDF lookups (oltb.cc:928-1074). Control point `index` may
  * carry a velocity parameter block (state.h:11-31); constant != 0 = SetParameterBlockConstant.
  * Columns per control point: 6 pose (if free) then 3 velocity (if free). */

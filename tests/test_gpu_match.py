@@ -237,3 +237,100 @@ def test_imu_preintegration_and_odometry_blocks(po, hg, ctx, maps, with_tsdf):
         assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
         assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
         np.testing.assert_allclose(gp.get_velocity(i), op.get_velocity(i), atol=1e-6)
+
+
+def _unwarped_window(po, hg, ctx, maps, levels, multi, per_sub):
+    """Three control points 0.1 s apart (first constant); two clouds whose returns are spread over
+    the sweep time so that they straddle control points and partly fall outside the window."""
+    from hectorgrapher_amd import api
+    og, gg = maps
+    tick0 = 636_000_000_000_000_000
+    control = [tick0, tick0 + api.from_seconds(0.1), tick0 + api.from_seconds(0.2)]
+    poses = [synth.pose_k(8), synth.pose_mul(synth.pose_k(9), synth.perturbation()),
+             synth.pose_mul(synth.pose_k(10), synth.perturbation())]
+    clouds = []
+    for ci, (k, t_cloud, t0, t1) in enumerate([(9, 0.02, -0.05, 0.13), (10, 0.12, -0.04, 0.11)]):
+        pts = synth.generate_scan(synth.pose_k(k), 16, 120, stream=80 + ci)
+        times = np.linspace(t0, t1, len(pts)).astype(np.float32)
+        clouds.append((tick0 + api.from_seconds(t_cloud), pts, times))
+    op, gp = po.Problem(), hg.Problem(ctx)
+    for i, tq in enumerate(poses):
+        op.add_pose(tq, i == 0)
+        gp.add_pose(tq, i == 0)
+    added = api.add_per_point_matching_residuals(gp, [0, 1, 2], control, clouds, [gg[l] for l in levels],
+                                                 1.3, per_sub, multi_res=multi)
+    # the reference's problem: one block per subdivision, in cloud / subdivision order
+    order = []
+    for ci, (t_cloud, pts, times) in enumerate(clouds):
+        s = 1.3 / np.sqrt(len(pts))
+        for (s0, s1, a, b, ratio) in api.per_point_subdivisions(times, t_cloud, control, per_sub):
+            op.add_block(pts[s0:s1], [og[l] for l in levels], s, a, b, ratio, multi)
+            order.extend((ci, i) for i in range(s0, s1))
+    dev_order = [(ci, int(i)) for (ci, a, b, idx, f) in added for i in idx]
+    return op, gp, order, dev_order, poses
+
+
+@pytest.mark.parametrize("levels,multi,per_sub", [([0, 1, 2], True, 4), ([2], False, 1), ([1], False, 7)])
+def test_per_point_unwarping_blocks(po, hg, ctx, maps, levels, multi, per_sub):
+    """SURVEY 8f-2 (use_per_point_unwarping, oltb.cc:513-683): subdivision blocks with their own
+    interpolation ratio; per_sub == 1 on one grid is InterpolatedTSDFPerPointSpaceCostFunction3D."""
+    op, gp, order, dev_order, poses = _unwarped_window(po, hg, ctx, maps, levels, multi, per_sub)
+    assert sorted(order) == sorted(dev_order) and 0 < len(order) < 2 * 16 * 120
+    c0, r0, J0, g0 = op.evaluate()
+    c1, r1, g1, H1 = gp.evaluate()
+    assert gp.num_columns() == 12 and gp.num_residuals() == len(r0) == len(order)
+    pos = {key: i for i, key in enumerate(order)}
+    perm = np.array([pos[key] for key in dev_order])
+    np.testing.assert_allclose(r1, r0[perm], rtol=0, atol=1e-13)
+    assert abs(c0 - c1) <= 1e-12 * max(1.0, abs(c0))
+    np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(H1, J0.T @ J0, rtol=1e-9, atol=1e-12)
+    so, sg = op.solve(), gp.solve()
+    assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
+    assert abs(so.final_cost - sg.final_cost) <= 1e-8 * max(1e-12, so.final_cost) + 1e-15
+    for i in range(3):
+        a, b = op.get_pose(i), gp.get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+        assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+    np.testing.assert_array_equal(gp.get_pose(0), poses[0])
+
+
+def test_unwarped_block_mixed_with_per_scan_blocks(po, hg, ctx, maps):
+    """An unwarped block and ordinary per-scan blocks in one problem share the iteration's ticket."""
+    og, gg = maps
+    poses = [synth.pose_k(8), synth.pose_mul(synth.pose_k(9), synth.perturbation())]
+    pts = synth.generate_scan(synth.pose_k(9), 16, 100, stream=91)
+    f = np.linspace(0.0, 1.0, len(pts))
+    op, gp = po.Problem(), hg.Problem(ctx)
+    for i, tq in enumerate(poses):
+        op.add_pose(tq, False)
+        gp.add_pose(tq, False)
+    s = 1.0 / np.sqrt(len(pts))
+    gp.add_block(pts, [gg[1]], s, 1)
+    gp.add_unwarped_block(pts, f, [gg[0], gg[1], gg[2]], s, 0, 1, multi_res=True)
+    gp.add_block(pts, [gg[2]], 0.5 * s, 0, 1, 0.25)
+    op.add_block(pts, [og[1]], s, 1)
+    for i in range(len(pts)):
+        op.add_block(pts[i:i + 1], [og[0], og[1], og[2]], s, 0, 1, float(f[i]), True)
+    op.add_block(pts, [og[2]], 0.5 * s, 0, 1, 0.25)
+    compare_evaluate(op, gp)
+    so, sg = op.solve(), gp.solve()
+    assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
+    for i in range(2):
+        a, b = op.get_pose(i), gp.get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+        assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+
+
+def test_unwarped_block_argument_errors(hg, ctx, maps):
+    _, gg = maps
+    p = hg.Problem(ctx)
+    p.add_pose(synth.pose_k(0))
+    p.add_pose(synth.pose_k(1))
+    pts = np.zeros((4, 3), np.float32)
+    with pytest.raises(hg.HgError):
+        p.add_unwarped_block(pts, np.zeros(4), [gg[0]], 1.0, 0, -1)     # needs two control points
+    with pytest.raises(hg.HgError):
+        p.add_unwarped_block(pts, np.zeros(4), [gg[0]], 1.0, 0, 0)
+    with pytest.raises(hg.HgError):
+        p.add_unwarped_block(pts, np.zeros(3), [gg[0]], 1.0, 0, 1)      # one ratio per return
