@@ -29,11 +29,15 @@
 namespace hg {
 
 constexpr int kMaxLevels = 4;
-constexpr int kMaxPoses = 6;
+constexpr int kMaxPoses = 10;           // ct_window_horizon / ct_window_rate ~ 9 control points
 constexpr int kState = 10;              // per control point: t(3) q(4) v(3)
 constexpr int kMaxCols = 9 * kMaxPoses;  // 6 pose + 3 velocity columns per control point
-constexpr int kMaxSmall = 16;           // odometry / IMU blocks
-constexpr int kMaxBlocks = 16;
+constexpr int kMaxSmall = 20;           // odometry / IMU blocks
+constexpr int kMaxBlocks = 32;
+// The normal equations are stored as a symmetric band (lower part, row i holds columns
+// i-bw..i): blocks couple neighbouring control points only, so the system is block-tridiagonal
+// (SURVEY 8a16). n * (bw + 1) <= kHCap: a 90-column window with bw <= 35, or dense up to 56 x 56.
+constexpr int kHCap = 3240;
 constexpr int kAcc = 36;  // 28 (upper triangle of 7x7) + 7 + 1
 constexpr int kAccU = 91;  // unwarped blocks: 78 (upper triangle of 12x12) + 12 + 1
 constexpr int kEvalThreads = 512;
@@ -103,7 +107,8 @@ struct LmHead {
   int col[kMaxPoses];
   int vfree[kMaxPoses];  // velocity is a free parameter block
   int vcol[kMaxPoses];
-  int num_small, pad0;
+  int num_small;
+  int bw;  // half bandwidth of J^T J (max column distance coupled by any block)
   SmallBlockDev small[kMaxSmall];
   double scale[kMaxCols], diagonal[kMaxCols], g[kMaxCols], step[kMaxCols], delta[kMaxCols];
   double gc[kMaxCols];
@@ -115,9 +120,16 @@ struct LmHead {
 
 struct LmState {
   LmHead h;
-  double H[kMaxCols * kMaxCols];   // J^T J at x (unscaled), n x n used
-  double Hc[kMaxCols * kMaxCols];  // J^T J at the candidate
+  double H[kHCap];   // J^T J at x (unscaled), band storage n x (bw + 1)
+  double Hc[kHCap];  // J^T J at the candidate
 };
+
+// band storage: entry (i, j), j <= i, i - j <= bw, of a symmetric matrix; W = bw + 1
+__device__ __host__ inline int band_index(int i, int j, int W) { return i * W + (W - 1) - (i - j); }
+__device__ inline double band_get(const double* B, int i, int j, int W) {
+  const int hi = i > j ? i : j, lo = i > j ? j : i;
+  return (hi - lo < W) ? B[band_index(hi, lo, W)] : 0.0;
+}
 
 // ------------------------------------------------------------------------------------------
 // per-return residual + row
@@ -363,7 +375,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const double* 
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
-    double* __restrict__ residuals) {
+    double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64]) {
   const unsigned i = blockIdx.x * kEvalThreads + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (i < n) {
@@ -377,8 +389,6 @@ __device__ __forceinline__ void tsdf_residuals_body(
   // J^T J (7x7), J^T r (column 7) and r^T r. Operand layout: lane l feeds A[i = l%16][k = l/16] and
   // B[k = l/16][j = l%16] — here the same element X[4s + l/16][l%16]; D[l/16 + 4v][l%16] comes back
   // in accumulator register v (verified against the CPU oracle by the parity tests).
-  __shared__ double xs[kEvalThreads / kWave][kWave][8];
-  __shared__ double cs[kEvalThreads / kWave][64];
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   {
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -668,9 +678,9 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
 struct LmShared {
   double stripe[kMaxStripes * kAcc];
   LmHead h;
-  double H[kMaxCols * kMaxCols];
-  double Hc[kMaxCols * kMaxCols];
-  double A[kMaxCols * kMaxCols];
+  double H[kHCap];
+  double Hc[kHCap];
+  double A[kHCap];
   double rhs[kMaxCols], y[kMaxCols];
   double sums[kMaxBlocks * kAccU];
   double AM[7 * 12];
@@ -705,38 +715,45 @@ __device__ inline void pose_plus(const LmHead& h, const double (*x)[kState], con
   wave_sync();
 }
 
-// Right-looking Cholesky + column-oriented substitutions on an n x n LDS matrix (n <= 36).
-// Term order per entry equals the sequential left-looking form (k ascending).
-__device__ bool cholesky_solve_wave(int n, double* A, const double* b, double* x, double* y, int lane) {
+// Right-looking band Cholesky + column-oriented substitutions on an LDS band matrix (W = bw + 1).
+// Entries outside the band stay exactly zero in the dense factorisation, so skipping them changes
+// nothing; term order per entry equals the sequential left-looking form (k ascending).
+__device__ bool cholesky_solve_wave(int n, int W, double* A, const double* b, double* x, double* y, int lane) {
+  const int bw = W - 1;
   for (int j = 0; j < n; ++j) {
-    const double d = A[j * n + j];
+    const double d = A[band_index(j, j, W)];
     if (!(d > 0.0) || !isfinite(d)) return false;  // uniform
     const double l = sqrt(d);
     wave_sync();
-    if (lane == 0) A[j * n + j] = l;
-    for (int i = j + 1 + lane; i < n; i += kLmThreads) A[i * n + j] = A[i * n + j] / l;
+    const int m = min(bw, n - j - 1);  // rows below the diagonal inside the band
+    if (lane == 0) A[band_index(j, j, W)] = l;
+    for (int r = lane; r < m; r += kLmThreads) {
+      const int i = j + 1 + r;
+      A[band_index(i, j, W)] = A[band_index(i, j, W)] / l;
+    }
     wave_sync();
-    const int m = n - j - 1;
     for (int idx = lane; idx < m * m; idx += kLmThreads) {
       const int i = j + 1 + idx / m, k = j + 1 + idx % m;
-      if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
+      if (k <= i) A[band_index(i, k, W)] -= A[band_index(i, j, W)] * A[band_index(k, j, W)];
     }
     wave_sync();
   }
   for (int i = lane; i < n; i += kLmThreads) y[i] = b[i];
   wave_sync();
   for (int i = 0; i < n; ++i) {
-    if (lane == 0) y[i] = y[i] / A[i * n + i];
+    if (lane == 0) y[i] = y[i] / A[band_index(i, i, W)];
     wave_sync();
     const double yi = y[i];
-    for (int r = i + 1 + lane; r < n; r += kLmThreads) y[r] -= A[r * n + i] * yi;
+    const int m = min(bw, n - i - 1);
+    for (int r = lane; r < m; r += kLmThreads) y[i + 1 + r] -= A[band_index(i + 1 + r, i, W)] * yi;
     wave_sync();
   }
   for (int i = n - 1; i >= 0; --i) {
-    if (lane == 0) x[i] = y[i] / A[i * n + i];
+    if (lane == 0) x[i] = y[i] / A[band_index(i, i, W)];
     wave_sync();
     const double xi = x[i];
-    for (int r = lane; r < i; r += kLmThreads) y[r] -= A[i * n + r] * xi;
+    const int m = min(bw, i);
+    for (int r = lane; r < m; r += kLmThreads) y[i - 1 - r] -= A[band_index(i, i - 1 - r, W)] * xi;
     wave_sync();
   }
   bool ok = true;
@@ -747,12 +764,12 @@ __device__ bool cholesky_solve_wave(int n, double* A, const double* b, double* x
 // Small systems: every lane factorises its own register copy (no LDS round trips, no barriers);
 // same left-looking term order as the sequential reference form.
 template <int N>
-__device__ bool cholesky_solve_regs(const double* A_lds, const double* b_lds, double* x_lds, int lane) {
+__device__ bool cholesky_solve_regs(const double* A_lds, int W, const double* b_lds, double* x_lds, int lane) {
   double L[N][N], y[N], x[N];
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
-    for (int j = 0; j <= i; ++j) L[i][j] = A_lds[i * N + j];
+    for (int j = 0; j <= i; ++j) L[i][j] = band_get(A_lds, i, j, W);
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -826,7 +843,7 @@ __device__ double gradient_max_norm(const LmHead& h) {
 // or terminates. Scalar updates of `h` are done by lane 0 between syncs; every lane reads them.
 __device__ void compute_next_candidate(LmShared& S, int lane) {
   LmHead& h = S.h;
-  const int n = h.ncols;
+  const int n = h.ncols, W = h.bw + 1;
   while (true) {
     wave_sync();
     // FinalizeIterationAndCheckIfMinimizerCanContinue (all lanes evaluate the same predicates)
@@ -849,26 +866,29 @@ __device__ void compute_next_candidate(LmShared& S, int lane) {
     if (stop_iter || stop_grad || stop_rad) return;
     if (!h.reuse_diagonal) {
       for (int k = lane; k < n; k += kLmThreads) {
-        const double s = S.H[k * n + k] * h.scale[k] * h.scale[k];
+        const double s = S.H[band_index(k, k, W)] * h.scale[k] * h.scale[k];
         h.diagonal[k] = fmin(fmax(s, h.opt.min_lm_diagonal), h.opt.max_lm_diagonal);
       }
     }
     wave_sync();
-    for (int idx = lane; idx < n * n; idx += kLmThreads) {
-      const int a = idx / n, b = idx % n;
-      double v = S.H[idx] * h.scale[a] * h.scale[b];
-      if (a == b) {
-        const double lm = sqrt(h.diagonal[a] / h.radius);
-        v += lm * lm;
+    for (int idx = lane; idx < n * W; idx += kLmThreads) {
+      const int a = idx / W, b = a - (W - 1) + idx % W;
+      double v = 0.0;
+      if (b >= 0) {
+        v = S.H[idx] * h.scale[a] * h.scale[b];
+        if (a == b) {
+          const double lm = sqrt(h.diagonal[a] / h.radius);
+          v += lm * lm;
+        }
       }
       S.A[idx] = v;
     }
     for (int a = lane; a < n; a += kLmThreads) S.rhs[a] = h.g[a] * h.scale[a];
     wave_sync();
     HG_STAMP(S, 4);
-    bool valid = (n == 6)    ? cholesky_solve_regs<6>(S.A, S.rhs, h.step, lane)
-                 : (n == 12) ? cholesky_solve_regs<12>(S.A, S.rhs, h.step, lane)
-                             : cholesky_solve_wave(n, S.A, S.rhs, h.step, S.y, lane);
+    bool valid = (n == 6)    ? cholesky_solve_regs<6>(S.A, W, S.rhs, h.step, lane)
+                 : (n == 12) ? cholesky_solve_regs<12>(S.A, W, S.rhs, h.step, lane)
+                             : cholesky_solve_wave(n, W, S.A, S.rhs, h.step, S.y, lane);
     HG_STAMP(S, 5);
     wave_sync();
     double mcc = 0.0;
@@ -879,7 +899,8 @@ __device__ void compute_next_candidate(LmShared& S, int lane) {
       double part = 0.0;
       for (int a = lane; a < n; a += kLmThreads) {
         double row = 0.0;
-        for (int b = 0; b < n; ++b) row += S.H[a * n + b] * h.scale[a] * h.scale[b] * h.step[b];
+        const int b0 = max(0, a - (W - 1)), b1 = min(n - 1, a + (W - 1));
+        for (int b = b0; b <= b1; ++b) row += band_get(S.H, a, b, W) * h.scale[a] * h.scale[b] * h.step[b];
         part += h.step[a] * (h.g[a] * h.scale[a]) + 0.5 * (h.step[a] * row);
       }
       mcc = -wave_sum(part);
@@ -955,9 +976,9 @@ __device__ void reduce_partials(LmShared& S, const double* partials) {
 __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partials,
                          const SmallOut* small_out, int lane) {
   LmHead& h = S.h;
-  const int n = h.ncols;
+  const int n = h.ncols, W = h.bw + 1;
   // S.sums was filled by reduce_partials (all 256 threads) before the other waves retired
-  for (int i = lane; i < n * n; i += kLmThreads) S.Hc[i] = 0.0;
+  for (int i = lane; i < n * W; i += kLmThreads) S.Hc[i] = 0.0;
   for (int i = lane; i < n; i += kLmThreads) h.gc[i] = 0.0;
   wave_sync();
   double cost = 0.0;
@@ -973,9 +994,9 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
         const int c1 = idx / 12, c2 = idx % 12;
         const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
         const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
-        if (g1 < 0 || g2 < 0) continue;
+        if (g1 < 0 || g2 < 0 || g2 > g1) continue;  // lower band only
         const int lo = c1 < c2 ? c1 : c2, hi = c1 < c2 ? c2 : c1;
-        S.Hc[g1 * n + g2] += sm[lo * 12 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        S.Hc[band_index(g1, g2, W)] += sm[lo * 12 - (lo * (lo - 1)) / 2 + (hi - lo)];
       }
       if (lane < 12) {
         const int g1 = lane < 6 ? (ca < 0 ? -1 : ca + lane) : (cb < 0 ? -1 : cb + lane - 6);
@@ -1003,10 +1024,10 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
       const int c1 = idx / 12, c2 = idx % 12;
       const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
       const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
-      if (g1 < 0 || g2 < 0) continue;
+      if (g1 < 0 || g2 < 0 || g2 > g1) continue;  // lower band only
       double s = 0.0;
       for (int k = 0; k < 7; ++k) s += M[k * 12 + c1] * S.AM[k * 12 + c2];
-      S.Hc[g1 * n + g2] += s;  // (g1, g2) is unique per lane within this block
+      S.Hc[band_index(g1, g2, W)] += s;  // (g1, g2) is unique per lane within this block
     }
     if (lane < 12) {
       const int c1 = lane;
@@ -1034,7 +1055,7 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
     };
     for (int idx = lane; idx < 18 * 18; idx += kLmThreads) {
       const int g1 = gcol(idx / 18), g2 = gcol(idx % 18);
-      if (g1 >= 0 && g2 >= 0) S.Hc[g1 * n + g2] += so.H[idx];
+      if (g1 >= 0 && g2 >= 0 && g2 <= g1) S.Hc[band_index(g1, g2, W)] += so.H[idx];
     }
     if (lane < 18) {
       const int g1 = gcol(lane);
@@ -1059,7 +1080,7 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
   }
   __syncthreads();
   LmHead& h = S.h;
-  const int n = h.ncols;
+  const int n = h.ncols, nW = n * (h.bw + 1);
   if (mode == MODE_PREPARE) {
     if (lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &xf[lane]);
     return;
@@ -1068,14 +1089,14 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
   // stage M (all blocks) and H into LDS; these loads and the first partial loads overlap
   for (int i = threadIdx.x; i < h.num_blocks * 84; i += blockDim.x) S.M[i] = xf[i / 84].M[i % 84];
   if (h.phase != PHASE_INIT)
-    for (int i = threadIdx.x; i < n * n; i += blockDim.x) S.H[i] = G->H[i];
+    for (int i = threadIdx.x; i < nW; i += blockDim.x) S.H[i] = G->H[i];
   reduce_partials(S, partials);
   if (threadIdx.x >= kLmThreads) return;  // retired waves no longer take part in barriers
   HG_STAMP(S, 1);
   assemble(S, xf, partials, small_out, lane);
   HG_STAMP(S, 2);
   if (mode == MODE_ASSEMBLE) {
-    for (int i = lane; i < n * n; i += kLmThreads) G->Hc[i] = S.Hc[i];
+    for (int i = lane; i < nW; i += kLmThreads) G->Hc[i] = S.Hc[i];
     for (int i = lane; i < n; i += kLmThreads) G->h.gc[i] = h.gc[i];
     if (lane == 0) G->h.cand_cost = h.cand_cost;
     return;
@@ -1083,11 +1104,11 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
   bool h_changed = false;
   if (h.phase == PHASE_INIT) {
     // IterationZero: EvaluateGradientAndJacobian at x (= cand)
-    for (int i = lane; i < n * n; i += kLmThreads) S.H[i] = S.Hc[i];
+    for (int i = lane; i < nW; i += kLmThreads) S.H[i] = S.Hc[i];
     for (int i = lane; i < n; i += kLmThreads) h.g[i] = h.gc[i];
     wave_sync();
     for (int k = lane; k < n; k += kLmThreads)
-      h.scale[k] = h.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(S.H[k * n + k])) : 1.0;
+      h.scale[k] = h.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(S.H[band_index(k, k, h.bw + 1)])) : 1.0;
     wave_sync();
     const double gmn = gradient_max_norm(h);
     wave_sync();
@@ -1131,7 +1152,7 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
     } else {
       if (accept) {
         // HandleSuccessfulStep: the candidate's normal equations become x's
-        for (int i = lane; i < n * n; i += kLmThreads) S.H[i] = S.Hc[i];
+        for (int i = lane; i < nW; i += kLmThreads) S.H[i] = S.Hc[i];
         for (int i = lane; i < n; i += kLmThreads) h.g[i] = h.gc[i];
         if (lane < h.num_poses)
           for (int k = 0; k < kState; ++k) h.x[lane][k] = h.cand[lane][k];
@@ -1174,7 +1195,7 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
     for (unsigned i = lane; i < sizeof(LmHead) / 8; i += kLmThreads) dst[i] = src[i];
   }
   if (h_changed)
-    for (int i = lane; i < n * n; i += kLmThreads) G->H[i] = S.H[i];
+    for (int i = lane; i < nW; i += kLmThreads) G->H[i] = S.H[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1351,7 +1372,13 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
     double* __restrict__ residuals, LmState* G, BlockXform* xf_all, const double* partials_all,
     const SmallOut* small_out, unsigned* ticket, unsigned total_wg) {
   if (G && G->h.done) return;
-  tsdf_residuals_body(pv, xyz, n, scaling, xf, partials, residuals);
+  // the staging tiles of the X^T X reduction and the LM tail's working set share one LDS allocation
+  __shared__ __align__(16) unsigned char smem[sizeof(LmShared)];
+  static_assert(sizeof(LmShared) >= (kEvalThreads / kWave) * (kWave * 8 + 64) * sizeof(double),
+                "LDS tile aliasing");
+  tsdf_residuals_body(pv, xyz, n, scaling, xf, partials, residuals,
+                      reinterpret_cast<double (*)[kWave][8]>(smem),
+                      reinterpret_cast<double (*)[64]>(smem + (kEvalThreads / kWave) * kWave * 8 * sizeof(double)));
   if (!G) return;
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
@@ -1370,8 +1397,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
     *ticket = 0u;  // ready for the next iteration's launches
   }
   __syncthreads();
-  __shared__ LmShared S;
-  lm_step(S, G, xf_all, partials_all, small_out, MODE_STEP);
+  lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
 }
 
 // Same launch protocol for a block with per-return interpolation factors. The staging tiles of
@@ -1508,6 +1534,28 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
     sb.row_offset = row;
     if (sb.active) row += (sb.type == 1 ? 6u : 9u);
     S.small[b] = sb;
+  }
+  // half bandwidth: the largest column distance any active block couples
+  int bw = 0;
+  auto couple = [&](std::initializer_list<int> ids, bool with_velocity) {
+    int lo = 1 << 30, hi = -1;
+    for (int i : ids) {
+      if (i < 0) continue;
+      if (!S.constant[i]) { lo = std::min(lo, S.col[i]); hi = std::max(hi, S.col[i] + 5); }
+      if (with_velocity && S.vfree[i]) { lo = std::min(lo, S.vcol[i]); hi = std::max(hi, S.vcol[i] + 2); }
+    }
+    if (hi >= 0) bw = std::max(bw, hi - lo);
+  };
+  for (int i = 0; i < S.num_poses; ++i) couple({i}, false);  // keeps the diagonal blocks in band
+  for (int b = 0; b < S.num_blocks; ++b)
+    if (S.blocks[b].active) couple({S.blocks[b].pose_a, S.blocks[b].pose_b}, false);
+  for (int b = 0; b < S.num_small; ++b)
+    if (S.small[b].active) couple({S.small[b].a, S.small[b].b}, S.small[b].type == 2);
+  S.bw = bw;
+  if (static_cast<long long>(S.ncols) * (bw + 1) > kHCap) {
+    set_last_error("normal equations exceed the band capacity (n * (bandwidth + 1) > " +
+                   std::to_string(kHCap) + "): blocks must couple nearby control points");
+    return HG_ERR_CAPACITY;
   }
   int rc = p->partials.reserve(static_cast<size_t>(std::max(1u, wg_off)) * sizeof(double));
   if (rc != HG_OK) return rc;
@@ -1829,7 +1877,14 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
   const LmHead& S = p->h_state.h;
   if (cost) *cost = S.cand_cost;
   if (gradient) std::memcpy(gradient, S.gc, sizeof(double) * S.ncols);
-  if (JtJ) std::memcpy(JtJ, p->h_state.Hc, sizeof(double) * S.ncols * S.ncols);
+  if (JtJ) {  // band -> dense
+    const int n = S.ncols, W = S.bw + 1;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) {
+        const int hi = std::max(i, j), lo = std::min(i, j);
+        JtJ[i * n + j] = (hi - lo < W) ? p->h_state.Hc[band_index(hi, lo, W)] : 0.0;
+      }
+  }
   return HG_OK;
 }
 

@@ -334,3 +334,57 @@ def test_unwarped_block_argument_errors(hg, ctx, maps):
         p.add_unwarped_block(pts, np.zeros(4), [gg[0]], 1.0, 0, 0)
     with pytest.raises(hg.HgError):
         p.add_unwarped_block(pts, np.zeros(3), [gg[0]], 1.0, 0, 1)      # one ratio per return
+
+
+def test_window_of_ten_control_points(po, hg, ctx, maps):
+    """ct_window_horizon / ct_window_rate ~ 9 control points -> 81 free columns
+    (first state constant); block-tridiagonal normal equations in band storage on the device."""
+    og, gg = maps
+    n_cp = 10
+    poses = [synth.pose_k(3 + i) if i == 0 else synth.pose_mul(synth.pose_k(3 + i), synth.perturbation())
+             for i in range(n_cp)]
+    op, gp = po.Problem(), hg.Problem(ctx)
+    for i in range(n_cp):
+        for pr in (op, gp):
+            pr.add_pose(poses[i], i == 0)
+            pr.set_velocity(i, np.array([0.5, 0.2, 0.0]) + 0.01 * i, i == 0)
+    for i in range(1, n_cp):
+        delta = synth.pose_mul(synth.pose_inverse(synth.pose_k(3 + i)), synth.pose_k(2 + i))
+        dq = synth.pose_mul(synth.pose_inverse(synth.pose_k(2 + i)), synth.pose_k(3 + i))[3:]
+        for pr in (op, gp):
+            pr.add_odometry_block(i - 1, i, 12.0, 30.0, delta)
+            pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, dq)
+    for i in range(1, n_cp):   # one scan on each control point, one between each pair
+        pts = synth.generate_scan(synth.pose_k(3 + i), 16, 60, stream=120 + i)
+        s = 1.0 / np.sqrt(len(pts))
+        for pr, g in ((op, og), (gp, gg)):
+            pr.add_block(pts, [g[0], g[1], g[2]], s, i, -1, 0.0, True)
+            pr.add_block(pts, [g[1]], 0.5 * s, i - 1, i, 0.4)
+    assert gp.num_columns() == 81
+    c0, r0, J0, g0 = op.evaluate()
+    c1, r1, g1, H1 = gp.evaluate()
+    assert abs(c0 - c1) <= 1e-11 * max(1.0, abs(c0))
+    np.testing.assert_allclose(r1, r0, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(H1, J0.T @ J0, rtol=1e-9, atol=1e-10)
+    so, sg = op.solve(), gp.solve()
+    assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
+    assert abs(so.final_cost - sg.final_cost) <= 1e-8 * max(1e-12, so.final_cost) + 1e-15
+    for i in range(n_cp):
+        a, b = op.get_pose(i), gp.get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+        assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+        np.testing.assert_allclose(gp.get_velocity(i), op.get_velocity(i), atol=1e-6)
+
+
+def test_band_capacity_is_reported(hg, ctx, maps):
+    """A block that couples the two ends of a 10-state window does not fit the band storage."""
+    _, gg = maps
+    p = hg.Problem(ctx)
+    for i in range(10):
+        p.add_pose(synth.pose_k(i), i == 0)
+        p.set_velocity(i, np.zeros(3), i == 0)
+    pts = synth.generate_scan(synth.pose_k(5), 16, 20, stream=7)
+    p.add_block(pts, [gg[1]], 1.0, 1, 9, 0.5)
+    with pytest.raises(hg.HgError):
+        p.evaluate()
