@@ -19,6 +19,7 @@
 //                     tolerances) entirely on the device.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -93,6 +94,7 @@ struct SmallOut {
 
 // Scalars and small vectors of the solver; lives in global memory between launches and in LDS
 // while k_lm runs.
+struct PinBox;
 struct LmHead {
   int num_poses, num_blocks, ncols, done;
   int iteration, phase, step_is_successful, reuse_diagonal;
@@ -113,6 +115,10 @@ struct LmHead {
   double scale[kMaxCols], diagonal[kMaxCols], g[kMaxCols], step[kMaxCols], delta[kMaxCols];
   double gc[kMaxCols];
   BlockInfo blocks[kMaxBlocks];
+  // host mailbox (mapped pinned memory): the step that terminates the solve stores the head there
+  // and then `seq` into its flag word, so the host neither copies nor synchronises the stream
+  struct PinBox* box;
+  unsigned long long seq;
 #ifdef HG_LM_STAMPS
   long long stamps[16];  // diagnostic build only: s_memtime at phase boundaries of the last LM step
 #endif
@@ -122,6 +128,11 @@ struct LmState {
   LmHead h;
   double H[kHCap];   // J^T J at x (unscaled), band storage n x (bw + 1)
   double Hc[kHCap];  // J^T J at the candidate
+};
+
+struct PinBox {
+  LmHead h;                 // upload source (host writes, k_lm MODE_PREPARE reads) and result
+  unsigned long long flag;  // == h.seq once the result of solve `seq` is complete
 };
 
 // band storage: entry (i, j), j <= i, i - j <= bw, of a symmetric matrix; W = bw + 1
@@ -230,7 +241,6 @@ __device__ inline void fetch_voxels(const GridView& g, LevelFetch& f) {
                     ? g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + f.vox[c]] : 0u;
   }
 }
-
 // Codec constants + geometry + codes of the level a lane interpolates on.
 struct LevelSel {
   double x1, y1, z1, x2, y2, z2;
@@ -541,9 +551,9 @@ __device__ inline void slerp_jets(const double* qa, const double* qb, double f, 
 
 // Single pose: T = pose_a. Two poses: InterpolateTransform (transform/timestamped_transform.h:41-51)
 // = lerp of translations + Eigen 3.3 Quaternion::slerp.
+// xf->M must be zero on entry (only the structural non-zeros are written).
 __device__ void prepare_block(const BlockInfo& b, const double (*poses)[kState], BlockXform* xf) {
   if (b.acc == kAccU) return;  // per-return factors: the residual kernel interpolates itself
-  for (int i = 0; i < 7 * 12; ++i) xf->M[i] = 0.0;
   const double* pa = poses[b.pose_a];
   double pja[12];
   quaternion_plus_jacobian(pa + 3, pja);
@@ -670,7 +680,7 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
 // Everything below runs in ONE wavefront: scalars are computed redundantly by every lane,
 // vectors/matrices live in LDS and their loops are spread over the lanes.
 #ifdef HG_LM_STAMPS
-#define HG_STAMP(S, i) do { if (threadIdx.x == 0) (S).h.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define HG_STAMP(S, i) do { if (threadIdx.x == 0 && (S).h.stamps[15]) (S).h.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define HG_STAMP(S, i) do {} while (0)
 #endif
@@ -683,8 +693,7 @@ struct LmShared {
   double A[kHCap];
   double rhs[kMaxCols], y[kMaxCols];
   double sums[kMaxBlocks * kAccU];
-  double AM[7 * 12];
-  double M[kMaxBlocks * 7 * 12];  // d(t,q)/d(local) of every block, staged from xf
+  BlockXform xfs[kMaxBlocks];  // transform + d(t,q)/d(local) of every block
   double red[kLmThreads];
 };
 
@@ -762,10 +771,10 @@ __device__ bool cholesky_solve_wave(int n, int W, double* A, const double* b, do
 }
 
 // Small systems: every lane factorises its own register copy (no LDS round trips, no barriers);
-// same left-looking term order as the sequential reference form.
+// left-looking term order; one reciprocal per column instead of a division per entry.
 template <int N>
 __device__ bool cholesky_solve_regs(const double* A_lds, int W, const double* b_lds, double* x_lds, int lane) {
-  double L[N][N], y[N], x[N];
+  double L[N][N], inv[N], y[N], x[N];
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -779,12 +788,13 @@ __device__ bool cholesky_solve_regs(const double* A_lds, int W, const double* b_
     ok = ok && (d > 0.0) && isfinite(d);
     const double l = sqrt(d);
     L[j][j] = l;
+    inv[j] = 1.0 / l;
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
       double s = L[i][j];
 #pragma unroll
       for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-      L[i][j] = s / l;
+      L[i][j] = s * inv[j];
     }
   }
 #pragma unroll
@@ -792,14 +802,14 @@ __device__ bool cholesky_solve_regs(const double* A_lds, int W, const double* b_
     double s = b_lds[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
-    y[i] = s / L[i][i];
+    y[i] = s * inv[i];
   }
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
     double s = y[i];
 #pragma unroll
     for (int k = i + 1; k < N; ++k) s -= L[k][i] * x[k];
-    x[i] = s / L[i][i];
+    x[i] = s * inv[i];
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) ok = ok && isfinite(x[i]);
@@ -949,15 +959,15 @@ __device__ void reduce_partials(LmShared& S, const double* partials) {
       double acc = 0.0;
       if (bi.active) {
         const double* p = partials + bi.partial_offset + k;
-        for (unsigned w = j; w < bi.num_wg; w += 8 * stripes) {
-          double v[8];
+        for (unsigned w = j; w < bi.num_wg; w += 16 * stripes) {
+          double v[16];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {  // 8 independent loads in flight, masked at the end
+          for (int u = 0; u < 16; ++u) {  // 16 independent loads in flight, masked at the end
             const unsigned idx = w + u * stripes;
             v[u] = idx < bi.num_wg ? p[static_cast<size_t>(idx) * acc_n] : 0.0;
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) acc += v[u];
+          for (int u = 0; u < 16; ++u) acc += v[u];
         }
       }
       S.stripe[j * acc_n + k] = acc;
@@ -1006,36 +1016,44 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
       continue;
     }
     cost += sm[35];
-    const double* M = S.M + b * 84;
-    // AM = A7 * M (7 x 12)
-    for (int idx = lane; idx < 7 * 12; idx += kLmThreads) {
-      const int a = idx / 12, c = idx % 12;
-      double s = 0.0;
-      for (int k = 0; k < 7; ++k) {
-        const int lo = a < k ? a : k, hi = a < k ? k : a;
-        // upper-triangle index of (lo, hi): rows 0..lo-1 hold 7,6,.. entries
-        const int tri = lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo);
-        s += sm[tri] * M[k * 12 + c];
-      }
-      S.AM[idx] = s;
-    }
-    wave_sync();
-    for (int idx = lane; idx < 12 * 12; idx += kLmThreads) {
-      const int c1 = idx / 12, c2 = idx % 12;
-      const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
-      const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
-      if (g1 < 0 || g2 < 0 || g2 > g1) continue;  // lower band only
-      double s = 0.0;
-      for (int k = 0; k < 7; ++k) s += M[k * 12 + c1] * S.AM[k * 12 + c2];
-      S.Hc[band_index(g1, g2, W)] += s;  // (g1, g2) is unique per lane within this block
-    }
-    if (lane < 12) {
-      const int c1 = lane;
-      const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
-      if (g1 >= 0) {
-        double gs = 0.0;
-        for (int k = 0; k < 7; ++k) gs += M[k * 12 + c1] * sm[28 + k];
-        h.gc[g1] += gs;
+    // J^T J = M^T A7 M over the block's local columns: one lane per lower-triangle entry keeps
+    // column c1 of M in registers, forms t = M[:,c1]^T A7 and contracts it with column c2
+    const double* M = S.xfs[b].M;
+    const int nc = bi.pose_b >= 0 ? 12 : 6;
+    const int ne = nc * (nc + 1) / 2;
+    for (int it = lane; it < ne + nc; it += kLmThreads) {
+      if (it < ne) {
+        int c1 = 0, e = it;
+        while (e > c1) { e -= c1 + 1; ++c1; }
+        const int c2 = e;  // c2 <= c1
+        const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
+        const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
+        if (g1 < 0 || g2 < 0) continue;
+        double m1[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) m1[k] = M[k * 12 + c1];
+        double v = 0.0;
+#pragma unroll
+        for (int l = 0; l < 7; ++l) {
+          double t = 0.0;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) {
+            const int lo = k < l ? k : l, hi = k < l ? l : k;
+            t += m1[k] * sm[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)];
+          }
+          v += t * M[l * 12 + c2];
+        }
+        const int hi_g = g1 > g2 ? g1 : g2, lo_g = g1 > g2 ? g2 : g1;
+        S.Hc[band_index(hi_g, lo_g, W)] += v;  // unique per lane within this block
+      } else {
+        const int c1 = it - ne;
+        const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
+        if (g1 >= 0) {
+          double gs = 0.0;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) gs += M[k * 12 + c1] * sm[28 + k];
+          h.gc[g1] += gs;
+        }
       }
     }
     wave_sync();
@@ -1067,27 +1085,65 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
   wave_sync();
 }
 
+// Transforms of every block at the candidate: built in LDS (M zeroed cooperatively, one lane per
+// block fills the non-zeros), then copied out coalesced. Runs in wavefront 0.
+__device__ void prepare_all(LmShared& S, BlockXform* xf) {
+  const LmHead& h = S.h;
+  const int lane = threadIdx.x;
+  if (lane >= kLmThreads) return;
+  const int per = static_cast<int>(sizeof(BlockXform) / sizeof(double));
+  double* buf = reinterpret_cast<double*>(S.xfs);
+  for (int i = lane; i < h.num_blocks * per; i += kLmThreads) buf[i] = 0.0;
+  wave_sync();
+  if (lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &S.xfs[lane]);
+  wave_sync();
+  double* dst = reinterpret_cast<double*>(xf);
+  for (int i = lane; i < h.num_blocks * per; i += kLmThreads) dst[i] = buf[i];
+}
+
 // One LM iteration by the calling workgroup (any size >= 64): loads the solver head, sums the
 // partials, and lets wavefront 0 advance the state machine. Called from k_lm and from the tail of
 // the last k_tsdf_residuals workgroup of an iteration.
 __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* partials,
-                        const SmallOut* small_out, int mode) {
+                        const SmallOut* small_out, int mode, const LmHead* host_head = nullptr) {
   const int lane = threadIdx.x;
+#ifdef HG_LM_STAMPS
+  const long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
   {
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
+    // MODE_PREPARE reads the head the host left in the mailbox (zero-copy upload)
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(
+        (mode == MODE_PREPARE && host_head) ? host_head : &G->h);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&S.h);
     for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
   LmHead& h = S.h;
   const int n = h.ncols, nW = n * (h.bw + 1);
+#ifdef HG_LM_STAMPS
+  if (threadIdx.x == 0) {
+    h.stamps[15] = (h.iteration == 3) ? 1 : 0;
+    if (h.stamps[15]) h.stamps[8] = t_entry;
+  }
+  __syncthreads();
+#endif
   if (mode == MODE_PREPARE) {
-    if (lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &xf[lane]);
+    if (host_head) {
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&G->h);
+      for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
+    }
+    prepare_all(S, xf);
     return;
   }
   HG_STAMP(S, 0);
   // stage M (all blocks) and H into LDS; these loads and the first partial loads overlap
-  for (int i = threadIdx.x; i < h.num_blocks * 84; i += blockDim.x) S.M[i] = xf[i / 84].M[i % 84];
+  {
+    const double* src = reinterpret_cast<const double*>(xf);
+    double* dst = reinterpret_cast<double*>(S.xfs);
+    const int cnt = h.num_blocks * static_cast<int>(sizeof(BlockXform) / sizeof(double));
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
+  }
   if (h.phase != PHASE_INIT)
     for (int i = threadIdx.x; i < nW; i += blockDim.x) S.H[i] = G->H[i];
   reduce_partials(S, partials);
@@ -1185,7 +1241,7 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
   }
   wave_sync();
   HG_STAMP(S, 6);
-  if (!h.done && lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &xf[lane]);
+  if (!h.done) prepare_all(S, xf);
   HG_STAMP(S, 7);
   wave_sync();
   // store the head and (if it changed) H
@@ -1196,6 +1252,382 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
   }
   if (h_changed)
     for (int i = lane; i < nW; i += kLmThreads) G->H[i] = S.H[i];
+  if (h.done && h.box) {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&h.box->h);
+    for (unsigned i = lane; i < sizeof(LmHead) / 8; i += kLmThreads) dst[i] = src[i];
+    __threadfence_system();
+    wave_sync();
+    if (lane == 0) {
+      *reinterpret_cast<volatile unsigned long long*>(&h.box->flag) = h.seq;
+      __threadfence_system();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Single free pose, one per-scan block, no velocity / odometry / IMU blocks (CeresScanMatcher3D and
+// the per-scan registration step): the same state machine as lm_step with n = 6, but every lane of
+// wavefront 0 keeps the whole solver state in registers and advances it redundantly — no LDS
+// round trips or barriers after the partial reduction. The general path's LDS/loop overhead is
+// ~40k cycles per iteration; this is the launch-latency-bound inner loop of the registration.
+// `scratch` needs (blockDim / 36) * 36 + 36 doubles of LDS.
+// ------------------------------------------------------------------------------------------
+#ifdef HG_EVAL_STAMPS
+__device__ unsigned long long g_tail_stamps[8];
+#define TAIL_STAMP(i) do { if (threadIdx.x == 0 && g_tail_stamps[7] == 3) g_tail_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TAIL_STAMP(i) do {} while (0)
+#endif
+__device__ inline int b6(int i, int j) { return i * 6 + 5 - (i - j); }  // band_index(i, j, W = 6), j <= i
+
+__device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, BlockXform* xf, const double* partials,
+                               unsigned num_wg) {
+  const int t = threadIdx.x;
+  LmHead& gh = G->h;
+  TAIL_STAMP(0);
+  // --- partial sums: thread (stripe j, column k), <= 16 loads in flight, fixed-order stripe sum ---
+  {
+    const int stripes = static_cast<int>(blockDim.x) / kAcc;
+    const int j = t / kAcc, k = t % kAcc;
+    if (j < stripes) {
+      double acc = 0.0;
+      const double* p = partials + k;
+      for (unsigned w = j; w < num_wg; w += 16 * stripes) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const unsigned idx = w + u * stripes;
+          v[u] = idx < num_wg ? p[static_cast<size_t>(idx) * kAcc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+      }
+      scratch[j * kAcc + k] = acc;
+    }
+    __syncthreads();
+    if (t < kAcc) {
+      double sum = 0.0;
+      for (int jj = 0; jj < stripes; ++jj) sum += scratch[jj * kAcc + t];
+      scratch[stripes * kAcc + t] = sum;
+    }
+    __syncthreads();
+    if (t >= kLmThreads) return;
+    scratch += stripes * kAcc;
+  }
+  TAIL_STAMP(1);
+  // --- solver state (uniform loads) ---
+  const hg_solver_opts opt = gh.opt;
+  PinBox* const box = gh.box;
+  const unsigned long long seq = gh.seq;
+  int iteration = gh.iteration, phase = gh.phase, step_is_successful = gh.step_is_successful;
+  int reuse_diagonal = gh.reuse_diagonal, invalid_steps = gh.invalid_steps;
+  int num_iterations = gh.num_iterations, num_successful = gh.num_successful;
+  int num_unsuccessful = gh.num_unsuccessful, num_cost_evals = gh.num_cost_evals;
+  int num_jac_evals = gh.num_jac_evals;
+  int done = 0, termination_type = gh.termination_type, termination_reason = gh.termination_reason;
+  double radius = gh.radius, decrease_factor = gh.decrease_factor, x_cost = gh.x_cost;
+  double model_cost_change = gh.model_cost_change, gradient_max = gh.gradient_max_norm;
+  double initial_cost = gh.initial_cost;
+  double x[7], cand[7], scale[6], diagonal[6], g[6], H[21];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { x[k] = gh.x[0][k]; cand[k] = gh.cand[0][k]; }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { scale[k] = gh.scale[k]; diagonal[k] = gh.diagonal[k]; g[k] = gh.g[k]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) H[i * (i + 1) / 2 + j] = G->H[b6(i, j)];
+
+  TAIL_STAMP(2);
+  // A7 (symmetric 7 x 7), b7 = J^T r, c = r^T r from the 36 sums (constant indices after unrolling)
+  double A7m[7][7], b7[7];
+  {
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+      for (int b = a; b < 7; ++b) {
+        const double v = scratch[idx++];
+        A7m[a][b] = v;
+        A7m[b][a] = v;
+      }
+#pragma unroll
+    for (int a = 0; a < 7; ++a) b7[a] = scratch[28 + a];
+  }
+  const double rtr = scratch[35];
+#define A7(a, b) A7m[a][b]
+
+  // --- assemble at the candidate: Hc = M^T A7 M, gc = M^T b7, M = diag(I3, dq/dlocal(cand q)) ---
+  double P[12];
+  quaternion_plus_jacobian(cand + 3, P);
+  double Hc[21], gc[6];
+  double AP[7][3];  // A7[:, 3:7] * P
+#pragma unroll
+  for (int a = 0; a < 7; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double v = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v += A7(a, 3 + r) * P[r * 3 + c];
+      AP[a][c] = v;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) Hc[i * (i + 1) / 2 + j] = A7(i, j);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Hc[(3 + c) * (4 + c) / 2 + j] = AP[j][c];
+#pragma unroll
+    for (int c2 = 0; c2 <= c; ++c2) {
+      double v = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v += P[r * 3 + c] * AP[3 + r][c2];
+      Hc[(3 + c) * (4 + c) / 2 + 3 + c2] = v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) gc[i] = b7[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v += P[r * 3 + c] * b7[3 + r];
+    gc[3 + c] = v;
+  }
+  const double cand_cost = 0.5 * rtr;
+#undef A7
+
+  auto finish_ = [&](int type, int reason) { done = 1; termination_type = type; termination_reason = reason; };
+  // |x - Plus(x, -g)|_inf (TrustRegionMinimizer::EvaluateGradientAndJacobian)
+  auto gradient_max_norm_ = [&]() {
+    double m = 0.0;
+    const double neg[6] = {-g[0], -g[1], -g[2], -g[3], -g[4], -g[5]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) m = fmax(m, fabs(x[k] - (x[k] + neg[k])));
+    double q[4];
+    quaternion_plus(x + 3, neg + 3, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = fmax(m, fabs(x[3 + k] - q[k]));
+    return m;
+  };
+  bool h_changed = false;
+  bool want_candidate = false;
+  TAIL_STAMP(3);
+  if (phase == PHASE_INIT) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) H[i] = Hc[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      g[k] = gc[k];
+      scale[k] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[k * (k + 1) / 2 + k])) : 1.0;
+    }
+    ++num_cost_evals;
+    ++num_jac_evals;
+    x_cost = cand_cost;
+    initial_cost = cand_cost;
+    gradient_max = gradient_max_norm_();
+    step_is_successful = 1;
+    num_iterations = 1;
+    phase = PHASE_CANDIDATE;
+    h_changed = true;
+    want_candidate = true;
+  } else {
+    double sn = 0.0, xn = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const double d = x[k] - cand[k];
+      sn += d * d;
+      xn += x[k] * x[k];
+    }
+    sn = sqrt(sn);
+    xn = sqrt(xn);
+    const double cost_change = x_cost - cand_cost;
+    const bool ptol = sn <= opt.parameter_tolerance * (xn + opt.parameter_tolerance);
+    const bool ftol = fabs(cost_change) <= opt.function_tolerance * x_cost;
+    const double relative_decrease = cost_change / model_cost_change;
+    const bool accept = relative_decrease > opt.min_relative_decrease;
+    ++num_cost_evals;
+    if (ptol) {
+      finish_(0, 2);
+    } else if (ftol) {
+      finish_(0, 3);
+    } else {
+      if (accept) {
+#pragma unroll
+        for (int i = 0; i < 21; ++i) H[i] = Hc[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[k] = gc[k];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) x[k] = cand[k];
+        h_changed = true;
+        x_cost = cand_cost;
+        ++num_jac_evals;
+        gradient_max = gradient_max_norm_();
+        step_is_successful = 1;
+        const double tt = 2.0 * relative_decrease - 1.0;
+        radius = radius / fmax(1.0 / 3.0, 1.0 - tt * tt * tt);
+        radius = fmin(opt.max_trust_region_radius, radius);
+        decrease_factor = 2.0;
+        reuse_diagonal = 0;
+      } else {
+        radius = radius / decrease_factor;
+        decrease_factor *= 2.0;
+        reuse_diagonal = 1;
+      }
+      want_candidate = true;
+    }
+  }
+  TAIL_STAMP(4);
+  // LevenbergMarquardtStrategy::ComputeStep + ComputeTrustRegionStep (see compute_next_candidate)
+  while (want_candidate) {
+    const bool stop_iter = iteration >= opt.max_num_iterations;
+    const bool stop_grad = step_is_successful && gradient_max <= opt.gradient_tolerance;
+    const bool stop_rad = radius <= opt.min_trust_region_radius;
+    if (step_is_successful) ++num_successful; else ++num_unsuccessful;
+    if (stop_iter) { finish_(1, 4); break; }
+    if (stop_grad) { finish_(0, 1); break; }
+    if (stop_rad) { finish_(0, 5); break; }
+    ++iteration;
+    ++num_iterations;
+    step_is_successful = 0;
+    if (!reuse_diagonal) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double sd = H[k * (k + 1) / 2 + k] * scale[k] * scale[k];
+        diagonal[k] = fmin(fmax(sd, opt.min_lm_diagonal), opt.max_lm_diagonal);
+      }
+    }
+    double L[6][6], inv[6], rhs[6], y[6], step[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        double v = H[a * (a + 1) / 2 + b] * scale[a] * scale[b];
+        if (a == b) {
+          const double lm = sqrt(diagonal[a] / radius);
+          v += lm * lm;
+        }
+        L[a][b] = v;
+      }
+      rhs[a] = g[a] * scale[a];
+    }
+    bool valid = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double d = L[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+      valid = valid && (d > 0.0) && isfinite(d);
+      const double l = sqrt(d);
+      L[j][j] = l;
+      inv[j] = 1.0 / l;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double v = L[i][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+        L[i][j] = v * inv[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double v = rhs[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+      y[i] = v * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double v = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) v -= L[k][i] * step[k];
+      step[i] = v * inv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) valid = valid && isfinite(step[i]);
+    double mcc = 0.0;
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) step[k] = -step[k];
+      // model_cost_change = -(step.J^T r + step^T J^T J step / 2) on the scaled system
+      double part = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double row = 0.0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          const int hi = a > b ? a : b, lo = a > b ? b : a;
+          row += H[hi * (hi + 1) / 2 + lo] * scale[a] * scale[b] * step[b];
+        }
+        part += step[a] * (g[a] * scale[a]) + 0.5 * (step[a] * row);
+      }
+      mcc = -part;
+      valid = mcc > 0.0;
+    }
+    if (!valid) {
+      const bool fail = (invalid_steps + 1) >= 5;  // max_num_consecutive_invalid_steps
+      ++invalid_steps;
+      reuse_diagonal = 1;
+      if (fail) { finish_(2, 6); break; }
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      continue;
+    }
+    reuse_diagonal = 1;
+    invalid_steps = 0;
+    model_cost_change = mcc;
+    double delta[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) delta[k] = step[k] * scale[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cand[k] = x[k] + delta[k];
+    quaternion_plus(x + 3, delta + 3, cand + 3);
+    break;
+  }
+  if (done) {
+    // the general path leaves cand = x's last candidate; nothing reads it after termination
+  }
+  TAIL_STAMP(5);
+  // --- write back (lane 0; every lane holds the same values) ---
+  if (t == 0) {
+    auto store_fields = [&](LmHead& d) {
+      d.iteration = iteration; d.phase = phase; d.step_is_successful = step_is_successful;
+      d.reuse_diagonal = reuse_diagonal; d.invalid_steps = invalid_steps;
+      d.num_iterations = num_iterations; d.num_successful = num_successful;
+      d.num_unsuccessful = num_unsuccessful; d.num_cost_evals = num_cost_evals;
+      d.num_jac_evals = num_jac_evals; d.done = done;
+      d.termination_type = termination_type; d.termination_reason = termination_reason;
+      d.radius = radius; d.decrease_factor = decrease_factor; d.x_cost = x_cost;
+      d.cand_cost = cand_cost; d.model_cost_change = model_cost_change;
+      d.gradient_max_norm = gradient_max; d.initial_cost = initial_cost;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { d.x[0][k] = x[k]; d.cand[0][k] = cand[k]; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { d.scale[k] = scale[k]; d.diagonal[k] = diagonal[k]; d.g[k] = g[k]; d.gc[k] = gc[k]; }
+    };
+    store_fields(gh);
+    if (h_changed) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) G->H[b6(i, j)] = H[i * (i + 1) / 2 + j];
+    }
+    if (!done) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xf[0].t[k] = cand[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xf[0].q[k] = cand[3 + k];
+    } else if (box) {
+      // the mailbox head still holds the uploaded state: only the fields this path changes go out
+      store_fields(box->h);
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned long long*>(&box->flag) = seq;
+      __threadfence_system();
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1366,12 +1798,24 @@ __global__ __launch_bounds__(kWave) void k_small_blocks(LmState* G, SmallOut* ou
 // the workgroups of all blocks' launches) runs the LM step in its tail, so an iteration is ONE
 // launch: release/acquire at agent scope around the ticket makes the other workgroups' partials
 // visible to it (cdna_hip_programming.md Guideline 16).
+#ifdef HG_EVAL_STAMPS
+// diagnostic build only: per-workgroup timeline of the last k_tsdf_residuals launch (100 MHz clock)
+__device__ unsigned long long g_eval_stamps[1024][4];
+#define EVAL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && eval_it == 3) g_eval_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EVAL_STAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
     PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
     double* __restrict__ residuals, LmState* G, BlockXform* xf_all, const double* partials_all,
-    const SmallOut* small_out, unsigned* ticket, unsigned total_wg) {
+    const SmallOut* small_out, unsigned* ticket, unsigned total_wg, int single_pose) {
   if (G && G->h.done) return;
+#ifdef HG_EVAL_STAMPS
+  const int eval_it = G ? G->h.iteration : -1;
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_tail_stamps[7] = eval_it;
+#endif
+  EVAL_STAMP(0);
   // the staging tiles of the X^T X reduction and the LM tail's working set share one LDS allocation
   __shared__ __align__(16) unsigned char smem[sizeof(LmShared)];
   static_assert(sizeof(LmShared) >= (kEvalThreads / kWave) * (kWave * 8 + 64) * sizeof(double),
@@ -1380,6 +1824,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
                       reinterpret_cast<double (*)[kWave][8]>(smem),
                       reinterpret_cast<double (*)[64]>(smem + (kEvalThreads / kWave) * kWave * 8 * sizeof(double)));
   if (!G) return;
+  EVAL_STAMP(1);
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
   __syncthreads();
@@ -1397,7 +1842,12 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
     *ticket = 0u;  // ready for the next iteration's launches
   }
   __syncthreads();
-  lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
+  EVAL_STAMP(2);
+  if (single_pose)
+    lm_step_single(reinterpret_cast<double*>(smem), G, xf_all, partials_all, total_wg);
+  else
+    lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
+  EVAL_STAMP(3);
 }
 
 // Same launch protocol for a block with per-return interpolation factors. The staging tiles of
@@ -1437,10 +1887,11 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals_unwarp(
 }
 
 __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
-                                                 const SmallOut* small_out, int mode) {
+                                                 const SmallOut* small_out, int mode,
+                                                 const LmHead* host_head) {
   __shared__ LmShared S;
   if (mode == MODE_STEP && G->h.done) return;
-  lm_step(S, G, xf, partials, small_out, mode);
+  lm_step(S, G, xf, partials, small_out, mode, host_head);
 }
 
 }  // namespace hg
@@ -1473,7 +1924,9 @@ struct hg_problem {
   BlockXform* d_xf = nullptr;
   DeviceBuffer partials, residuals;
   bool solve_pending = false;
-  LmState* h_pin = nullptr;  // pinned staging for uploads / read-backs
+  PinBox* h_box = nullptr;   // mapped pinned mailbox: upload source and result sink
+  PinBox* d_box = nullptr;   // its device address
+  unsigned long long seq = 0;
   LmState h_state;            // host copy
 };
 
@@ -1561,8 +2014,11 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   if (rc != HG_OK) return rc;
   // the pinned buffer may still be the source of the previous (finished) upload: solves are
   // synchronised by their fetch before the next upload
-  std::memcpy(&p->h_pin->h, &ST.h, sizeof(LmHead));
-  HG_HIP_CHECK(hipMemcpyAsync(p->d_state, p->h_pin, sizeof(LmHead), hipMemcpyHostToDevice, p->ctx->stream));
+  S.box = p->d_box;
+  S.seq = ++p->seq;
+  // zero-copy upload: k_lm MODE_PREPARE reads the head from the mailbox. The previous solve's
+  // fetch has seen its result, so the device no longer reads or writes the mailbox.
+  std::memcpy(&p->h_box->h, &ST.h, sizeof(LmHead));
   return HG_OK;
 }
 
@@ -1577,6 +2033,11 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
   }
   unsigned total_wg = 0;
   for (int b = 0; b < S.num_blocks; ++b) total_wg += S.blocks[b].num_wg;
+  // register-resident LM tail: one free pose without velocity, one per-scan block, nothing else
+  const int single_pose = (S.num_poses == 1 && !S.constant[0] && !S.vfree[0] && S.num_blocks == 1 &&
+                           S.blocks[0].active && S.blocks[0].acc == kAcc && S.blocks[0].pose_b < 0 &&
+                           S.num_small == 0 && S.ncols == 6 && S.bw == 5 &&
+                           std::getenv("HG_LM_GENERAL") == nullptr) ? 1 : 0;
   for (int b = 0; b < S.num_blocks; ++b) {
     const BlockInfo& bi = S.blocks[b];
     if (!bi.active) continue;
@@ -1602,7 +2063,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
                        p->partials.as<double>() + bi.partial_offset,
                        d_residuals ? d_residuals + bi.row_offset : nullptr,
                        fused_lm ? p->d_state : nullptr, p->d_xf, p->partials.as<double>(),
-                       p->d_small, p->d_ticket, total_wg);
+                       p->d_small, p->d_ticket, total_wg, single_pose);
     HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
@@ -1638,7 +2099,12 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_xf), sizeof(BlockXform) * kMaxBlocks);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 256);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_small), sizeof(SmallOut) * kMaxSmall);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_pin), sizeof(LmState));
+  if (e == hipSuccess)
+    e = hipHostMalloc(reinterpret_cast<void**>(&p->h_box), sizeof(PinBox), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) {
+    std::memset(p->h_box, 0, sizeof(PinBox));
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_box), p->h_box, 0);
+  }
   if (e == hipSuccess) e = hipMemset(p->d_ticket, 0, 256);
   if (e != hipSuccess) {
     set_last_error(std::string("hipMalloc problem: ") + hipGetErrorString(e));
@@ -1659,7 +2125,7 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->d_xf) (void)hipFree(p->d_xf);
   if (p->d_ticket) (void)hipFree(p->d_ticket);
   if (p->d_small) (void)hipFree(p->d_small);
-  if (p->h_pin) (void)hipHostFree(p->h_pin);
+  if (p->h_box) (void)hipHostFree(p->h_box);
   p->partials.release();
   p->residuals.release();
   delete p;
@@ -1865,11 +2331,11 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
     if (rc != HG_OK) return rc;
     d_res = p->residuals.as<double>();
   }
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, &p->d_box->h);
   HG_HIP_CHECK(hipGetLastError());
   rc = launch_eval(p, d_res, false);
   if (rc != HG_OK) return rc;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_ASSEMBLE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_ASSEMBLE, static_cast<const LmHead*>(nullptr));
   HG_HIP_CHECK(hipGetLastError());
   HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmState), hipMemcpyDeviceToHost, s));
   if (d_res) HG_HIP_CHECK(hipMemcpyAsync(residuals, d_res, sizeof(double) * nres, hipMemcpyDeviceToHost, s));
@@ -1898,7 +2364,7 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
   p->solve_pending = true;
   if (S0.ncols == 0) return HG_OK;
   const int max_it = S0.opt.max_num_iterations;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, &p->d_box->h);
   HG_HIP_CHECK(hipGetLastError());
   bool any_active = false;
   for (int b = 0; b < S0.num_blocks; ++b) any_active = any_active || S0.blocks[b].active;
@@ -1914,7 +2380,7 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
       if (rc != HG_OK) return rc;
     } else {
       ProfScope ps(p->ctx, HG_K_LM, 1);
-      hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_STEP);
+      hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_STEP, static_cast<const LmHead*>(nullptr));
       HG_HIP_CHECK(hipGetLastError());
     }
   }
@@ -1929,12 +2395,55 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
     if (summary) std::memset(summary, 0, sizeof(*summary));
     return HG_OK;
   }
-  HG_HIP_CHECK(hipMemcpyAsync(p->h_pin, p->d_state, sizeof(LmHead), hipMemcpyDeviceToHost, s));
-  HG_HIP_CHECK(hipStreamSynchronize(s));
-  std::memcpy(&p->h_state.h, &p->h_pin->h, sizeof(LmHead));
+  {
+    // the terminating LM step stores the head into the mailbox and then its sequence number; work
+    // enqueued behind the solve (the insertion of hg_register_scan) keeps running meanwhile
+    volatile unsigned long long* flag = &p->h_box->flag;
+    bool arrived = false;
+    for (unsigned long long spin = 0; !arrived; ++spin) {
+      if (*flag == p->seq) { arrived = true; break; }
+      if ((spin & 0x3FFFu) == 0x3FFFu) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) break;  // stream drained: decide below
+        if (q != hipErrorNotReady) {
+          set_last_error(std::string("solve: ") + hipGetErrorString(q));
+          return HG_ERR_HIP;
+        }
+      }
+    }
+    if (!arrived) arrived = (*flag == p->seq);
+    if (arrived) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      std::memcpy(&p->h_state.h, &p->h_box->h, sizeof(LmHead));
+    } else {
+      // stream finished without a terminating step (cannot happen with max_it + 1 launches): read back
+      HG_HIP_CHECK(hipMemcpy(&p->h_state.h, p->d_state, sizeof(LmHead), hipMemcpyDeviceToHost));
+    }
+  }
   const LmHead& S = p->h_state.h;
+#ifdef HG_EVAL_STAMPS
+  {
+    static unsigned long long st[1024][4];
+    (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_eval_stamps), sizeof(st));
+    unsigned long long t0 = ~0ull, body_end = 0, tail0 = 0, tail1 = 0, last_start = 0;
+    const unsigned nwg = std::min(1024u, p->h_state.h.blocks[0].num_wg);
+    for (unsigned w = 0; w < nwg; ++w) {
+      t0 = std::min(t0, st[w][0]);
+      last_start = std::max(last_start, st[w][0]);
+      body_end = std::max(body_end, st[w][1]);
+      if (st[w][3] > tail1) { tail1 = st[w][3]; tail0 = st[w][2]; }
+    }
+    fprintf(stderr, "eval timeline (us from first WG start): last WG start %.2f, last body end %.2f, tail start %.2f, tail end %.2f\n",
+            (last_start - t0) * 0.01, (body_end - t0) * 0.01, (tail0 - t0) * 0.01, (tail1 - t0) * 0.01);
+    unsigned long long ts[8];
+    (void)hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_tail_stamps), sizeof(ts));
+    fprintf(stderr, "  fast tail (us): reduce %.2f, state %.2f, assemble %.2f, decide %.2f, solve %.2f\n",
+            (ts[1] - ts[0]) * 0.01, (ts[2] - ts[1]) * 0.01, (ts[3] - ts[2]) * 0.01, (ts[4] - ts[3]) * 0.01, (ts[5] - ts[4]) * 0.01);
+  }
+#endif
 #ifdef HG_LM_STAMPS
   fprintf(stderr, "lm stamps (cycles of the last step):");
+  fprintf(stderr, " [load]%lld", S.stamps[0] - S.stamps[8]);
   for (int i = 1; i < 8; ++i) fprintf(stderr, " [%d]%lld", i, S.stamps[i] - S.stamps[i - 1]);
   fprintf(stderr, "\n");
 #endif
