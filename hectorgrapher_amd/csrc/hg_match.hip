@@ -149,6 +149,15 @@ struct D3 {  // value + gradient w.r.t. world (x, y, z); mirrors ceres::Jet<doub
   double a, d0, d1, d2;
 };
 
+#ifdef HG_EVAL_STAMPS
+// diagnostic build only: phase timeline of every workgroup's wave 0 in the residual body (100 MHz)
+__device__ unsigned long long g_body_stamps[1024][8];
+#define BODY_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_body_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BODY_STAMP(i) do {} while (0)
+#endif
+
 // InterpolateLinear (interpolated_tsdf.h:30-46 / interpolated_multi_resolution_tsdf.h:30-46)
 __device__ inline void interpolate_linear(double both_invalid, const D3& q1, const D3& q2, double w1,
                                           double w2, const D3& r, D3& q, double& w) {
@@ -300,10 +309,13 @@ __device__ inline D3 pyramid_tsd_n(const PyramidView& pv, double x, double y, do
   LevelFetch f[LEVELS];
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) fetch_setup(pv.level[l], x, y, z, f[l]);
+  BODY_STAMP(1);
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) fetch_probe(pv.level[l], f[l]);
+  BODY_STAMP(2);
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) fetch_voxels(pv.level[l], f[l]);
+  BODY_STAMP(3);
   LevelSel s;
   select_level(pv.level[0], f[0], s);
   if (!pv.multi_res) {
@@ -388,12 +400,14 @@ __device__ __forceinline__ void tsdf_residuals_body(
     double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64]) {
   const unsigned i = blockIdx.x * kEvalThreads + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  BODY_STAMP(0);
   if (i < n) {
     const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
                          static_cast<double>(xyz[3 * i + 2])};
     return_row(pv, xf->t, xf->q, v, scaling, row8);
     if (residuals) residuals[i] = row8[7];
   }
+  BODY_STAMP(4);
   // J^T J accumulation on the matrix cores: per wavefront X = [row | r] is 64 x 8 (padded to 16
   // columns); 16 x v_mfma_f64_16x16x4_f64 accumulate X^T X, whose upper-left 8 x 8 block holds
   // J^T J (7x7), J^T r (column 7) and r^T r. Operand layout: lane l feeds A[i = l%16][k = l/16] and
@@ -440,6 +454,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
     for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += cs[wv][a * 8 + b];
     partials[static_cast<size_t>(blockIdx.x) * kAcc + threadIdx.x] = s;
   }
+  BODY_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1279,6 +1294,11 @@ __device__ unsigned long long g_tail_stamps[8];
 #else
 #define TAIL_STAMP(i) do {} while (0)
 #endif
+__device__ inline double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ inline int b6(int i, int j) { return i * 6 + 5 - (i - j); }  // band_index(i, j, W = 6), j <= i
 
 __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, BlockXform* xf, const double* partials,
@@ -1286,6 +1306,17 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   const int t = threadIdx.x;
   LmHead& gh = G->h;
   TAIL_STAMP(0);
+  // the solver head and H are staged through LDS by all threads while the partial loads are in
+  // flight (one memory round trip for both); layout: [stripes*36 | 36 sums | head | 36 H entries]
+  const int stripes0 = static_cast<int>(blockDim.x) / kAcc;
+  LmHead& sh = *reinterpret_cast<LmHead*>(scratch + (stripes0 + 1) * kAcc);
+  double* sH = reinterpret_cast<double*>(&sh + 1);
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&gh);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&sh);
+    for (unsigned i = t; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
+    if (t < 36) sH[t] = G->H[t];
+  }
   // --- partial sums: thread (stripe j, column k), <= 16 loads in flight, fixed-order stripe sum ---
   {
     const int stripes = static_cast<int>(blockDim.x) / kAcc;
@@ -1317,27 +1348,27 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   }
   TAIL_STAMP(1);
   // --- solver state (uniform loads) ---
-  const hg_solver_opts opt = gh.opt;
-  PinBox* const box = gh.box;
-  const unsigned long long seq = gh.seq;
-  int iteration = gh.iteration, phase = gh.phase, step_is_successful = gh.step_is_successful;
-  int reuse_diagonal = gh.reuse_diagonal, invalid_steps = gh.invalid_steps;
-  int num_iterations = gh.num_iterations, num_successful = gh.num_successful;
-  int num_unsuccessful = gh.num_unsuccessful, num_cost_evals = gh.num_cost_evals;
-  int num_jac_evals = gh.num_jac_evals;
-  int done = 0, termination_type = gh.termination_type, termination_reason = gh.termination_reason;
-  double radius = gh.radius, decrease_factor = gh.decrease_factor, x_cost = gh.x_cost;
-  double model_cost_change = gh.model_cost_change, gradient_max = gh.gradient_max_norm;
-  double initial_cost = gh.initial_cost;
+  const hg_solver_opts opt = sh.opt;
+  PinBox* const box = sh.box;
+  const unsigned long long seq = sh.seq;
+  int iteration = sh.iteration, phase = sh.phase, step_is_successful = sh.step_is_successful;
+  int reuse_diagonal = sh.reuse_diagonal, invalid_steps = sh.invalid_steps;
+  int num_iterations = sh.num_iterations, num_successful = sh.num_successful;
+  int num_unsuccessful = sh.num_unsuccessful, num_cost_evals = sh.num_cost_evals;
+  int num_jac_evals = sh.num_jac_evals;
+  int done = 0, termination_type = sh.termination_type, termination_reason = sh.termination_reason;
+  double radius = sh.radius, decrease_factor = sh.decrease_factor, x_cost = sh.x_cost;
+  double model_cost_change = sh.model_cost_change, gradient_max = sh.gradient_max_norm;
+  double initial_cost = sh.initial_cost;
   double x[7], cand[7], scale[6], diagonal[6], g[6], H[21];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) { x[k] = gh.x[0][k]; cand[k] = gh.cand[0][k]; }
+  for (int k = 0; k < 7; ++k) { x[k] = sh.x[0][k]; cand[k] = sh.cand[0][k]; }
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { scale[k] = gh.scale[k]; diagonal[k] = gh.diagonal[k]; g[k] = gh.g[k]; }
+  for (int k = 0; k < 6; ++k) { scale[k] = sh.scale[k]; diagonal[k] = sh.diagonal[k]; g[k] = sh.g[k]; }
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = 0; j <= i; ++j) H[i * (i + 1) / 2 + j] = G->H[b6(i, j)];
+    for (int j = 0; j <= i; ++j) H[i * (i + 1) / 2 + j] = sH[b6(i, j)];
 
   TAIL_STAMP(2);
   // A7 (symmetric 7 x 7), b7 = J^T r, c = r^T r from the 36 sums (constant indices after unrolling)
@@ -1501,15 +1532,24 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
       }
     }
     double L[6][6], inv[6], rhs[6], y[6], step[6];
+    // lm_a^2 = sqrt(diagonal_a / radius)^2: lane a evaluates entry a, the wavefront reads them back
+    double lm2[6];
+    {
+      const int ln = t & 63;
+      double mine = diagonal[0];
+#pragma unroll
+      for (int a = 1; a < 6; ++a) mine = (ln == a) ? diagonal[a] : mine;
+      const double lm = sqrt(mine / radius);
+      const double sq = lm * lm;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) lm2[a] = readlane_f64(sq, a);
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
       for (int b = 0; b <= a; ++b) {
         double v = H[a * (a + 1) / 2 + b] * scale[a] * scale[b];
-        if (a == b) {
-          const double lm = sqrt(diagonal[a] / radius);
-          v += lm * lm;
-        }
+        if (a == b) v += lm2[a];
         L[a][b] = v;
       }
       rhs[a] = g[a] * scale[a];
@@ -1521,9 +1561,8 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
 #pragma unroll
       for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
       valid = valid && (d > 0.0) && isfinite(d);
-      const double l = sqrt(d);
-      L[j][j] = l;
-      inv[j] = 1.0 / l;
+      inv[j] = rsqrt(d);
+      L[j][j] = d * inv[j];
 #pragma unroll
       for (int i = j + 1; i < 6; ++i) {
         double v = L[i][j];
@@ -2435,6 +2474,19 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
     }
     fprintf(stderr, "eval timeline (us from first WG start): last WG start %.2f, last body end %.2f, tail start %.2f, tail end %.2f\n",
             (last_start - t0) * 0.01, (body_end - t0) * 0.01, (tail0 - t0) * 0.01, (tail1 - t0) * 0.01);
+    {
+      static unsigned long long bs[1024][8];
+      (void)hipMemcpyFromSymbol(bs, HIP_SYMBOL(g_body_stamps), sizeof(bs));
+      double acc[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
+      for (unsigned w = 0; w < nwg; ++w)
+        for (int k = 1; k <= 5; ++k) {
+          const double d = (bs[w][k] - bs[w][k - 1]) * 0.01;
+          acc[k] += d / nwg;
+          mx[k] = std::max(mx[k], d);
+        }
+      fprintf(stderr, "  body wave0 (us) mean/max: setup %.2f/%.2f, probes %.2f/%.2f, voxels %.2f/%.2f, interp+row %.2f/%.2f, reduce %.2f/%.2f\n",
+              acc[1], mx[1], acc[2], mx[2], acc[3], mx[3], acc[4], mx[4], acc[5], mx[5]);
+    }
     unsigned long long ts[8];
     (void)hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_tail_stamps), sizeof(ts));
     fprintf(stderr, "  fast tail (us): reduce %.2f, state %.2f, assemble %.2f, decide %.2f, solve %.2f\n",
