@@ -279,13 +279,43 @@ __device__ inline float round_nonneg(float t) {
   return (t - r >= 0.5f) ? r + 1.0f : r;
 }
 
+// lround(t) + 1 for t = v * resolution >= 0, given y = v * (2 * resolution) = 2t (scaling by two
+// commutes with the rounding of the product): floor(y) = 2n + [frac(t) >= 0.5] for t = n + frac, so
+// floor((floor(y) + 1) / 2) = lround(t); every step is exact in fp32 for t < 2^22. Four
+// instructions instead of the six of trunc / subtract / compare / select / add.
+__device__ inline float round_nonneg_plus1(float y) {
+  return floorf(__builtin_fmaf(floorf(y), 0.5f, 1.5f));
+}
+
+// num / den, correctly rounded, for the operands of the unit-weight update chain: den = w + 1 in
+// [1, maximum_weight + 1], |num| <= (|tsd| * w + |update|) — far inside the range where
+// v_div_scale_f32 leaves both operands unscaled and v_div_fixup_f32 has nothing to fix. This is the
+// Newton-Raphson sequence the compiler emits for an IEEE fdiv without those two wrappers (same
+// instructions, same operands, hence the same bits); only the sign of a zero quotient can differ,
+// which the quantisation that follows does not see. The reciprocal depends on the weight chain
+// only, so the dependent chain through the TSD value is 5 FMAs instead of 10 instructions.
+__device__ inline bool div_in_range_ok(const GridView& g) {
+  return g.max_weight <= 1.0e6f && g.max_tsd <= 1.0e3f && g.min_tsd >= -1.0e3f;
+}
+__device__ inline float div_in_range(float num, float den) {
+  const float r0 = __builtin_amdgcn_rcpf(den);
+  const float e0 = __builtin_fmaf(-den, r0, 1.0f);
+  const float r = __builtin_fmaf(e0, r0, r0);
+  const float q0 = num * r;
+  const float rem0 = __builtin_fmaf(-den, q0, num);
+  const float q1 = __builtin_fmaf(rem0, r, q0);
+  const float rem1 = __builtin_fmaf(-den, q1, num);
+  return __builtin_fmaf(rem1, r, q1);
+}
+
 // Incremental form of the same chain: begin(code) ... step(u) ... end() == update_cell in a loop
 // with update weight 1.
 struct UnitChain {
   float d, w, rt, rw;
   uint32_t code0;
-  bool any;
+  bool any, fast;
   __device__ inline void begin(const GridView& g, uint32_t code) {
+    fast = div_in_range_ok(g);
     const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
     d = tc == 0 ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
     w = wc == 0 ? 0.f : static_cast<float>(wc) * g.weight_scale + g.weight_offset;
@@ -293,49 +323,71 @@ struct UnitChain {
     code0 = code;
     any = false;
   }
-  __device__ inline void step(const GridView& g, float maximum_weight, float u) {
+  template <bool FAST>
+  __device__ inline void step_t(const GridView& g, float maximum_weight, float u) {
     float uw = w + 1.0f;
-    const float ud = (d * w + u) / uw;
+    const float ud = FAST ? div_in_range(d * w + u, uw) : (d * w + u) / uw;
     uw = (maximum_weight < uw) ? maximum_weight : uw;
-    rt = round_nonneg((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * g.tsd_resolution);
-    rw = round_nonneg((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * g.weight_resolution);
-    d = (rt + 1.0f) * g.tsd_scale + g.tsd_offset;
-    w = (rw + 1.0f) * g.weight_scale + g.weight_offset;
+    rt = round_nonneg_plus1((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * (2.0f * g.tsd_resolution));
+    rw = round_nonneg_plus1((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * (2.0f * g.weight_resolution));
+    d = rt * g.tsd_scale + g.tsd_offset;  // rt, rw hold code = lround(..) + 1
+    w = rw * g.weight_scale + g.weight_offset;
     any = true;
+  }
+  __device__ inline void step(const GridView& g, float maximum_weight, float u) {
+    if (fast) step_t<true>(g, maximum_weight, u); else step_t<false>(g, maximum_weight, u);
+  }
+  // `count` consecutive steps on LDS values
+  __device__ inline void run(const GridView& g, float maximum_weight, const uint32_t* vals, unsigned count) {
+    if (fast) {
+      for (unsigned j = 0; j < count; ++j) step_t<true>(g, maximum_weight, __uint_as_float(vals[j]));
+    } else {
+      for (unsigned j = 0; j < count; ++j) step_t<false>(g, maximum_weight, __uint_as_float(vals[j]));
+    }
   }
   __device__ inline uint32_t end() const {
     if (!any) return code0;
-    const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt)) + 1u;
-    const uint32_t nw = static_cast<uint32_t>(static_cast<int>(rw)) + 1u;
+    const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt));
+    const uint32_t nw = static_cast<uint32_t>(static_cast<int>(rw));
     return (nt + kUpdateMarker) | (nw << 16);
   }
 };
 
 // `count` consecutive UpdateCell calls with update weight 1 on one voxel (values vals[0..count)),
 // bit-identical to calling update_cell in a loop: codes stay in float form (code - 1 as a float)
-// between updates, so the dependent chain per update is ~35 instructions instead of ~75.
-__device__ inline uint32_t update_chain_unit(const GridView& g, float maximum_weight, uint32_t code,
-                                             const uint32_t* vals, unsigned count) {
-  if (count == 0) return code;
+// between updates, so the dependent chain per update is ~30 instructions instead of ~75.
+template <bool FAST>
+__device__ inline uint32_t update_chain_unit_t(const GridView& g, float maximum_weight, uint32_t code,
+                                               const uint32_t* vals, unsigned count) {
   const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
   float d = tc == 0 ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
   float w = wc == 0 ? 0.f : static_cast<float>(wc) * g.weight_scale + g.weight_offset;
   float rt = 0.f, rw = 0.f;
+  const float res2_t = 2.0f * g.tsd_resolution, res2_w = 2.0f * g.weight_resolution;
+  uint32_t next = vals[0];
   for (unsigned j = 0; j < count; ++j) {
-    const float u = __uint_as_float(vals[j]);
+    const float u = __uint_as_float(next);
+    if (j + 1 < count) next = vals[j + 1];  // LDS read one update ahead of its use
     float uw = w + 1.0f;
-    const float ud = (d * w + u) / uw;            // u * 1.0f == u
+    const float ud = FAST ? div_in_range(d * w + u, uw) : (d * w + u) / uw;  // u * 1.0f == u
     uw = (maximum_weight < uw) ? maximum_weight : uw;
-    // TSDToValue / WeightToValue (values are finite: med3 == the reference's two-sided clamp)
-    rt = round_nonneg((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * g.tsd_resolution);
-    rw = round_nonneg((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * g.weight_resolution);
-    // ValueToTSD / ValueToWeight of the codes rt + 1, rw + 1 (never 0)
-    d = (rt + 1.0f) * g.tsd_scale + g.tsd_offset;
-    w = (rw + 1.0f) * g.weight_scale + g.weight_offset;
+    // TSDToValue / WeightToValue (values are finite: med3 == the reference's two-sided clamp);
+    // rt, rw hold the codes lround(..) + 1 as floats
+    rt = round_nonneg_plus1((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * res2_t);
+    rw = round_nonneg_plus1((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * res2_w);
+    // ValueToTSD / ValueToWeight of the codes (never 0)
+    d = rt * g.tsd_scale + g.tsd_offset;
+    w = rw * g.weight_scale + g.weight_offset;
   }
-  const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt)) + 1u;
-  const uint32_t nw = static_cast<uint32_t>(static_cast<int>(rw)) + 1u;
+  const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt));
+  const uint32_t nw = static_cast<uint32_t>(static_cast<int>(rw));
   return (nt + kUpdateMarker) | (nw << 16);
+}
+__device__ inline uint32_t update_chain_unit(const GridView& g, float maximum_weight, uint32_t code,
+                                             const uint32_t* vals, unsigned count) {
+  if (count == 0) return code;
+  return div_in_range_ok(g) ? update_chain_unit_t<true>(g, maximum_weight, code, vals, count)
+                            : update_chain_unit_t<false>(g, maximum_weight, code, vals, count);
 }
 
 __global__ void k_apply_runs(GridView g, InsertParams p, const unsigned long long* keys,
@@ -941,9 +993,33 @@ __global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const float* 
   }
 }
 
+// Bitonic sort of m (power of two) key/value pairs in LDS by all kBinThreads threads. Keys are
+// unique ((voxel, seq) records; padding is 0xFFFFFFFF), so the result is the (voxel, seq) order.
+__device__ inline void bitonic_sort_kv(uint32_t* k, uint32_t* v, unsigned m, unsigned tid) {
+  for (unsigned size = 2; size <= m; size <<= 1) {
+    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+      for (unsigned t = tid; t < (m >> 1); t += kBinThreads) {
+        const unsigned i = ((t & ~(stride - 1u)) << 1) | (t & (stride - 1u));
+        const unsigned j = i | stride;
+        const bool up = (i & size) == 0u;
+        const uint32_t a = k[i], b = k[j];
+        if ((a > b) == up) {
+          k[i] = b;
+          k[j] = a;
+          const uint32_t va = v[i];
+          v[i] = v[j];
+          v[j] = va;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+constexpr unsigned kRankMaxGroup = 1024;  // larger per-voxel groups are ordered by the bitonic sort (break-even ~1100)
+
 // grid (G, levels), 512 threads, loops over the level's work items (block, voxel range).
 #ifdef HG_BIN_STAMPS
-#define BIN_STAMP(i) do { if (threadIdx.x == 0) stamps[(static_cast<size_t>(blockIdx.y) * 4096 + wi) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BIN_STAMP(i) do { if (threadIdx.x == 0) stamps[(static_cast<size_t>(blockIdx.y) * 4096 + wi) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define BIN_STAMP(i) do {} while (0)
 #endif
@@ -1023,68 +1099,77 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
       unsigned cnt = 0;
       if (hi == lo) {
         // One voxel alone holds more records than an LDS pass (degenerate geometry: thousands of
-        // rays through one voxel). Its chain is applied in rounds of <= kBinCap records in seq
-        // order: each round bisects the seq threshold that admits the next <= kBinCap records.
+        // rays through one voxel). Its chain is applied in seq-ordered rounds of <= kBinCap records:
+        // a 512-bucket histogram of the remaining seq range picks each round's threshold (if even
+        // the first bucket is too large, the histogram is refined inside it; seq is unique, so
+        // buckets of one seq value hold at most one record), the round is gathered, sorted, applied.
         const unsigned total_v = hist[lo];
         unsigned done_v = 0;
-        uint32_t last = 0;  // records with (key & seq_mask) < last are already applied
         const uint32_t seq_mask = (1u << kSeqBits) - 1u;
         uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + lo;
         UnitChain chain;
         if (tid == 0) chain.begin(g, *cell);
-        // number of this voxel's records with seq in [last, T)
-        auto count_below = [&](uint32_t T) {
-          __syncthreads();
-          if (tid == 0) s_hi = 0;
-          __syncthreads();
-          unsigned c = 0;
-          for (unsigned i = tid; i < n; i += kBinThreads) {
-            const uint32_t k = bk[i];
-            const uint32_t sq = k & seq_mask;
-            if ((k >> kSeqBits) == lo && sq >= last && sq < T) ++c;
-          }
-          if (c) atomicAdd(&s_hi, c);
-          __syncthreads();
-          return s_hi;
-        };
+        uint32_t cur_lo = 0;  // records with seq < cur_lo are applied
+        unsigned* bucket = sv;            // 512 counters (sv is free until a round is sorted)
+        unsigned* bucket_pre = sv + 512;  // their exclusive prefix
         while (done_v < total_v) {
-          // largest T with count(seq in [last, T)) <= kBinCap; T = last + 1 always qualifies (seq unique)
-          uint32_t t_ok = last + 1u, t_bad = seq_mask + 1u;
-          if (count_below(t_bad) <= static_cast<unsigned>(kBinCap)) {
-            t_ok = t_bad;
-          } else {
-            while (t_bad - t_ok > 1u) {
-              const uint32_t mid = t_ok + (t_bad - t_ok) / 2u;
-              if (count_below(mid) <= static_cast<unsigned>(kBinCap)) t_ok = mid; else t_bad = mid;
+          uint32_t range_hi = seq_mask + 1u;
+          uint32_t T = range_hi;
+          while (true) {
+            unsigned S = 0;
+            while (((range_hi - cur_lo - 1u) >> S) >= 512u) ++S;
+            __syncthreads();
+            bucket[tid] = 0;
+            if (tid == 0) s_hi = 0;
+            __syncthreads();
+            for (unsigned i = tid; i < n; i += kBinThreads) {
+              const uint32_t k = bk[i];
+              const uint32_t sq = k & seq_mask;
+              if ((k >> kSeqBits) == lo && sq >= cur_lo && sq < range_hi) atomicAdd(&bucket[(sq - cur_lo) >> S], 1u);
             }
+            __syncthreads();
+            {
+              unsigned tot;
+              const unsigned excl = block_exclusive_scan(bucket[tid], cursor, &tot);
+              bucket_pre[tid] = excl;
+              // number of leading buckets whose records fit one pass
+              if (excl + bucket[tid] <= static_cast<unsigned>(kBinCap)) atomicMax(&s_hi, tid + 1u);
+            }
+            __syncthreads();
+            // s_hi counts buckets b with prefix_incl(b) <= cap; prefix sums are monotone, so these
+            // are exactly the first s_hi buckets
+            const unsigned nb = s_hi;
+            if (nb == 0u) {  // the first bucket alone is too large: refine inside it
+              range_hi = cur_lo + (1u << S);
+              continue;
+            }
+            const unsigned long long t_end = static_cast<unsigned long long>(cur_lo) +
+                                             (static_cast<unsigned long long>(nb) << S);
+            T = t_end < range_hi ? static_cast<uint32_t>(t_end) : range_hi;
+            break;
           }
-          const uint32_t T = t_ok;
           __syncthreads();
-          // gather the admitted records (seq in [last, T)), order by seq, apply
           if (tid == 0) s_hi = 0;
           __syncthreads();
           for (unsigned i = tid; i < n; i += kBinThreads) {
             const uint32_t k = bk[i];
             const uint32_t sq = k & seq_mask;
-            if ((k >> kSeqBits) == lo && sq >= last && sq < T) {
+            if ((k >> kSeqBits) == lo && sq >= cur_lo && sq < T) {
               const unsigned p = atomicAdd(&s_hi, 1u);
               if (p < static_cast<unsigned>(kBinCap)) { gk[p] = k; gv[p] = bv[i]; }
             }
           }
           __syncthreads();
           const unsigned m = min(s_hi, static_cast<unsigned>(kBinCap));
-          for (unsigned i = tid; i < m; i += kBinThreads) {
-            const uint32_t k = gk[i];
-            unsigned rank = 0;
-            for (unsigned j = 0; j < m; ++j) rank += (gk[j] < k) ? 1u : 0u;
-            sv[rank] = gv[i];
-          }
+          unsigned m2 = 2;
+          while (m2 < m) m2 <<= 1;
+          for (unsigned i = m + tid; i < m2; i += kBinThreads) gk[i] = 0xFFFFFFFFu;
           __syncthreads();
-          if (tid == 0)
-            for (unsigned j = 0; j < m; ++j) chain.step(g, L.p.maximum_weight, __uint_as_float(sv[j]));
+          bitonic_sort_kv(gk, gv, m2, tid);
+          if (tid == 0) chain.run(g, L.p.maximum_weight, gv, m);
           __syncthreads();
           done_v += m;
-          last = T;
+          cur_lo = T;
           if (T > seq_mask) break;  // all seq values covered
         }
         if (tid == 0) *cell = chain.end();
@@ -1119,8 +1204,21 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
             }
           }
         }
+        if (tid == 0) s_hi = 0;
         __syncthreads();
         BIN_STAMP(2);
+        if (tid >= lo && tid < hi && hist[tid] > kRankMaxGroup) s_hi = 1;  // benign race: same value
+        __syncthreads();
+        if (s_hi) {
+          // large groups: one bitonic sort of the whole pass by (voxel, seq); the groups keep their
+          // places because the grouped layout is already ordered by voxel
+          unsigned m2 = 2;
+          while (m2 < cnt) m2 <<= 1;
+          for (unsigned i = cnt + tid; i < m2; i += kBinThreads) gk[i] = 0xFFFFFFFFu;
+          __syncthreads();
+          bitonic_sort_kv(gk, gv, m2, tid);
+          for (unsigned i = tid; i < cnt; i += kBinThreads) sv[i] = gv[i];
+        } else
         // order each group by seq: rank = number of group members with a smaller key
         for (unsigned i = tid; i < cnt; i += kBinThreads) {
           const uint32_t k = gk[i];
@@ -1157,6 +1255,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
       lo = hi;
     }
     __syncthreads();
+    BIN_STAMP(5);
   }
 }
 
@@ -1381,6 +1480,31 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P, const float* d_xyz, unsi
           for (int k = 1; k <= 4; ++k) if (e[k]) sum[k] += double(e[k] - e[k - 1]);
           long long end = e[4] ? e[4] : e[1];
           if (end > last_end) { last_end = end; last_i = w; }
+        }
+        {
+          long long first = -1, lastend = 0, longest = 0; int li = -1;
+          for (int w = 0; w < 4096; ++w) {
+            const long long* e = &h[(static_cast<size_t>(y) * 4096 + w) * 8];
+            if (!e[0] || !e[5]) continue;
+            if (first < 0 || e[0] < first) first = e[0];
+            if (e[5] > lastend) lastend = e[5];
+            if (e[5] - e[0] > longest) { longest = e[5] - e[0]; li = w; }
+          }
+          const long long* e = &h[(static_cast<size_t>(y) * 4096 + (li < 0 ? 0 : li)) * 8];
+          fprintf(stderr, "bin y=%d span %lld..%lld (x10ns from kernel start); longest item %d: %lld (n=%lld) starts %lld hist=%lld last-pass[group=%lld rank=%lld chain=%lld]\n", y,
+                  first - t0, lastend - t0, li, longest, e[6], e[0] - t0, e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3]);
+          // the 5 items that end last
+          for (int rep = 0; rep < 5; ++rep) {
+            long long best = 0; int bi = -1;
+            for (int w = 0; w < 4096; ++w) {
+              const long long* q = &h[(static_cast<size_t>(y) * 4096 + w) * 8];
+              if (q[0] && q[5] > best && q[5] < (rep ? lastend : lastend + 1)) { best = q[5]; bi = w; }
+            }
+            if (bi < 0) break;
+            const long long* q = &h[(static_cast<size_t>(y) * 4096 + bi) * 8];
+            fprintf(stderr, "   late item %d: start %lld end %lld n=%lld\n", bi, q[0] - t0, q[5] - t0, q[6]);
+            lastend = best;
+          }
         }
         fprintf(stderr, "bin y=%d items=%d mean cycles hist=%.0f group=%.0f rank=%.0f chain=%.0f; last item %d ends at %lld",
                 y, cnt, cnt ? sum[1] / cnt : 0, cnt ? sum[2] / cnt : 0, cnt ? sum[3] / cnt : 0, cnt ? sum[4] / cnt : 0, last_i, last_end - t0);

@@ -10,7 +10,7 @@ ctx = api.Context(0)
 dev = torch.device("cuda", 0)
 grids = [api.HybridGridTSDF(ctx, r, max_blocks=1 << 18) for r in bench.RESOLUTIONS]
 ins = [api.TSDFRangeDataInserter3D() for _ in grids]
-ks = list(range(0, 121, 10))
+ks = [int(a) for a in sys.argv[1:]] or list(range(0, 121, 10))
 for k in ks:
     scans = bench.make_scans(50, 2000, k, 1, 0)
     pose, pts = scans[0]

@@ -290,3 +290,20 @@ def test_thousands_of_rays_through_one_voxel(po, hg, ctx):
         st = hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], pts), gg)
         assert (st.num_hits, st.num_updates) == a
         assert_grids_equal(og, gg)
+
+
+def test_giant_voxel_rounds_with_gaps_and_dense_runs(po, hg, ctx):
+    """Giant-voxel rounds of the binned path: 20000 returns through the same voxels with two far
+    apart index clusters (empty seq buckets between them) embedded in an ordinary scan."""
+    rng = np.random.default_rng(5)
+    hot = np.array([[1.51, -0.52, 0.11]], np.float32)
+    cluster = lambda m: hot + (rng.standard_normal((m, 3)) * 1.5e-3).astype(np.float32)
+    filler = synth.generate_scan(synth.pose_k(0), 16, 500, stream=3)
+    pts = np.concatenate([cluster(9000), filler[:4000], cluster(300), filler[4000:], cluster(11000)])
+    for res in (0.05, 0.2):
+        og = po.Grid(res)
+        gg = hg.HybridGridTSDF(ctx, res, max_blocks=1 << 14)
+        a = og.insert([0, 0, 0], pts)
+        st = hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], pts), gg)
+        assert (st.num_hits, st.num_updates) == a
+        assert_grids_equal(og, gg)
