@@ -131,8 +131,13 @@ struct LmState {
 };
 
 struct PinBox {
-  LmHead h;                 // upload source (host writes, k_lm MODE_PREPARE reads) and result
+  LmHead h;                 // uploaded state (host copy) and result of the terminating LM step
   unsigned long long flag;  // == h.seq once the result of solve `seq` is complete
+  // compact upload read by k_lm MODE_PREPARE over the host link in ONE round trip: the non-zero
+  // 8-byte words of the head and their word indices (~150 of 1170 words; small uncached host reads
+  // are slow). The number of words is a kernel argument.
+  unsigned long long up_val[sizeof(LmHead) / 8];
+  unsigned up_idx[sizeof(LmHead) / 8];
 };
 
 // band storage: entry (i, j), j <= i, i - j <= bw, of a symmetric matrix; W = bw + 1
@@ -1120,15 +1125,30 @@ __device__ void prepare_all(LmShared& S, BlockXform* xf) {
 // partials, and lets wavefront 0 advance the state machine. Called from k_lm and from the tail of
 // the last k_tsdf_residuals workgroup of an iteration.
 __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* partials,
-                        const SmallOut* small_out, int mode, const LmHead* host_head = nullptr) {
+                        const SmallOut* small_out, int mode, const PinBox* host_up = nullptr,
+                        unsigned up_words = 0) {
   const int lane = threadIdx.x;
 #ifdef HG_LM_STAMPS
   const long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
-  {
-    // MODE_PREPARE reads the head the host left in the mailbox (zero-copy upload)
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(
-        (mode == MODE_PREPARE && host_head) ? host_head : &G->h);
+  if (mode == MODE_PREPARE && host_up) {
+    // zero-copy upload: scatter the non-zero words the host left in the mailbox
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&S.h);
+    unsigned long long val[5];
+    unsigned idx[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {  // all host reads in flight together (5 * 256 >= words of the head)
+      const unsigned w = threadIdx.x + u * blockDim.x;
+      idx[u] = w < up_words ? host_up->up_idx[w] : 0xFFFFFFFFu;
+      val[u] = w < up_words ? host_up->up_val[w] : 0ull;
+    }
+    for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+      if (idx[u] < sizeof(LmHead) / 8) dst[idx[u]] = val[u];
+  } else {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&S.h);
     for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
   }
@@ -1143,7 +1163,7 @@ __device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* p
   __syncthreads();
 #endif
   if (mode == MODE_PREPARE) {
-    if (host_head) {
+    if (host_up) {
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
       unsigned long long* dst = reinterpret_cast<unsigned long long*>(&G->h);
       for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
@@ -1927,10 +1947,11 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals_unwarp(
 
 __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
                                                  const SmallOut* small_out, int mode,
-                                                 const LmHead* host_head) {
+                                                 const PinBox* host_up, unsigned up_words) {
   __shared__ LmShared S;
+  static_assert(5 * kLmBlock >= sizeof(LmHead) / 8, "upload words per thread");
   if (mode == MODE_STEP && G->h.done) return;
-  lm_step(S, G, xf, partials, small_out, mode, host_head);
+  lm_step(S, G, xf, partials, small_out, mode, host_up, up_words);
 }
 
 }  // namespace hg
@@ -1966,6 +1987,7 @@ struct hg_problem {
   PinBox* h_box = nullptr;   // mapped pinned mailbox: upload source and result sink
   PinBox* d_box = nullptr;   // its device address
   unsigned long long seq = 0;
+  unsigned up_words = 0;
   LmState h_state;            // host copy
 };
 
@@ -2058,6 +2080,18 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   // zero-copy upload: k_lm MODE_PREPARE reads the head from the mailbox. The previous solve's
   // fetch has seen its result, so the device no longer reads or writes the mailbox.
   std::memcpy(&p->h_box->h, &ST.h, sizeof(LmHead));
+  {
+    // compact form: the non-zero words and their indices
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&ST.h);
+    unsigned n = 0;
+    for (unsigned i = 0; i < sizeof(LmHead) / 8; ++i)
+      if (w[i] != 0ull) {
+        p->h_box->up_idx[n] = i;
+        p->h_box->up_val[n] = w[i];
+        ++n;
+      }
+    p->up_words = n;
+  }
   return HG_OK;
 }
 
@@ -2370,11 +2404,11 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
     if (rc != HG_OK) return rc;
     d_res = p->residuals.as<double>();
   }
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, &p->d_box->h);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
   HG_HIP_CHECK(hipGetLastError());
   rc = launch_eval(p, d_res, false);
   if (rc != HG_OK) return rc;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_ASSEMBLE, static_cast<const LmHead*>(nullptr));
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_ASSEMBLE, static_cast<const PinBox*>(nullptr), 0u);
   HG_HIP_CHECK(hipGetLastError());
   HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmState), hipMemcpyDeviceToHost, s));
   if (d_res) HG_HIP_CHECK(hipMemcpyAsync(residuals, d_res, sizeof(double) * nres, hipMemcpyDeviceToHost, s));
@@ -2403,7 +2437,7 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
   p->solve_pending = true;
   if (S0.ncols == 0) return HG_OK;
   const int max_it = S0.opt.max_num_iterations;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, &p->d_box->h);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
   HG_HIP_CHECK(hipGetLastError());
   bool any_active = false;
   for (int b = 0; b < S0.num_blocks; ++b) any_active = any_active || S0.blocks[b].active;
@@ -2419,7 +2453,7 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
       if (rc != HG_OK) return rc;
     } else {
       ProfScope ps(p->ctx, HG_K_LM, 1);
-      hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_STEP, static_cast<const LmHead*>(nullptr));
+      hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_STEP, static_cast<const PinBox*>(nullptr), 0u);
       HG_HIP_CHECK(hipGetLastError());
     }
   }
