@@ -227,15 +227,18 @@ def run(args):
     torch.cuda.synchronize()
     problem = api.Problem(ctx)
     scale = 1.0 / np.sqrt(float(n_pts))
-    stats = {"U": 0, "N_in": 0}
+    stats = {"U": 0, "N_in": 0, "evals": 0}
     errs = []
+    sampling = [False]
 
     def step(i):
         problem.reset()
         pi = problem.add_pose(guesses[i])
         problem.add_block(d_scans[i], grids, scale, pi, multi_res=True)
-        est, _ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i]), grids)
+        est, summ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i]), grids)
         errs.append(float(np.linalg.norm(est[:3] - query[i][0][:3])))
+        if sampling[0]:
+            stats["evals"] += summ.num_cost_evaluations  # launches that evaluated (the rest exit early)
 
     def barrier():
         ctx.synchronize()
@@ -247,14 +250,15 @@ def run(args):
 
     for i in range(args.warmup):
         step(i)
-    stats = {"U": 0, "N_in": 0}
+    stats = {"U": 0, "N_in": 0, "evals": 0}
     errs.clear()
     ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         # kernel durations are sampled with HIP events on every prof_every-th step of the timed region
-        ctx.prof_enable(args.prof_every > 0 and (i - args.warmup) % args.prof_every == 0)
+        sampling[0] = args.prof_every > 0 and (i - args.warmup) % args.prof_every == 0
+        ctx.prof_enable(sampling[0])
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -307,7 +311,10 @@ def run(args):
     lbar = base["mean_levels_probed"] if base else 1.0
     # insert 12*N_in + 8*U bytes per (scan, level); match N_m*(12 + 32*Lbar) per evaluation
     ins_bytes_per_launch = 12.0 * stats["N_in"] + 8.0 * stats["U"]  # summed over the 3 levels
-    res_bytes_per_launch = n_pts * (12.0 + 32.0 * lbar)
+    # a solve enqueues max_num_iterations + 1 launches; those after termination exit at once and move
+    # no data, so the per-launch average is scaled by the share of launches that evaluated
+    active_share = min(1.0, stats["evals"] / n_resid) if n_resid else 1.0
+    res_bytes_per_launch = n_pts * (12.0 + 32.0 * lbar) * active_share
     fam = {
         "insert(expand+sort+alloc+apply, 3 levels fused)": (t_insert / max(1, n_insert_calls), ins_bytes_per_launch, t_insert),
         "k_tsdf_residuals": (t_resid / max(1, n_resid), res_bytes_per_launch, t_resid),
@@ -332,7 +339,8 @@ def run(args):
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per,
                 "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
                 "per_kernel_launches": {k: v[0] for k, v in prof.items()},
-                "hip_event_sampling": "every %d-th of the %d timed steps" % (max(1, args.prof_every), args.steps)}
+                "hip_event_sampling": "every %d-th of the %d timed steps" % (max(1, args.prof_every), args.steps),
+                "residual_launches_evaluating": active_share}
 
     out = {
         "metric": "scans/s (100k-pt scan, 3-res TSDF registration)",
