@@ -140,6 +140,7 @@ struct PinBox {
   unsigned up_idx[sizeof(LmHead) / 8];
 };
 
+typedef __attribute__((address_space(3))) double lds_f64;
 // band storage: entry (i, j), j <= i, i - j <= bw, of a symmetric matrix; W = bw + 1
 __device__ __host__ inline int band_index(int i, int j, int W) { return i * W + (W - 1) - (i - j); }
 __device__ inline double band_get(const double* B, int i, int j, int W) {
@@ -402,8 +403,8 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const double* 
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
-    double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64]) {
-  const unsigned i = blockIdx.x * kEvalThreads + threadIdx.x;
+    double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64], unsigned wg) {
+  const unsigned i = wg * kEvalThreads + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   BODY_STAMP(0);
   if (i < n) {
@@ -457,7 +458,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += cs[wv][a * 8 + b];
-    partials[static_cast<size_t>(blockIdx.x) * kAcc + threadIdx.x] = s;
+    partials[static_cast<size_t>(wg) * kAcc + threadIdx.x] = s;
   }
   BODY_STAMP(5);
 }
@@ -572,7 +573,7 @@ __device__ inline void slerp_jets(const double* qa, const double* qb, double f, 
 // Single pose: T = pose_a. Two poses: InterpolateTransform (transform/timestamped_transform.h:41-51)
 // = lerp of translations + Eigen 3.3 Quaternion::slerp.
 // xf->M must be zero on entry (only the structural non-zeros are written).
-__device__ void prepare_block(const BlockInfo& b, const double (*poses)[kState], BlockXform* xf) {
+__device__ __forceinline__ void prepare_block(const BlockInfo& b, const double (*poses)[kState], BlockXform* xf) {
   if (b.acc == kAccU) return;  // per-return factors: the residual kernel interpolates itself
   const double* pa = poses[b.pose_a];
   double pja[12];
@@ -619,8 +620,8 @@ __device__ void prepare_block(const BlockInfo& b, const double (*poses)[kState],
 __device__ __forceinline__ void tsdf_residuals_unwarp_body(
     const PyramidView& pv, const float* __restrict__ xyz, const double* __restrict__ factor,
     unsigned n, double scaling, const double* pa, const double* pb, double* __restrict__ partials,
-    double* __restrict__ residuals, double (*xs)[kWave][16], double (*cs)[256]) {
-  const unsigned i = blockIdx.x * kEvalThreads + threadIdx.x;
+    double* __restrict__ residuals, double (*xs)[kWave][16], double (*cs)[256], unsigned wg) {
+  const unsigned i = wg * kEvalThreads + threadIdx.x;
   double row[13];
 #pragma unroll
   for (int k = 0; k < 13; ++k) row[k] = 0.0;
@@ -693,7 +694,7 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += cs[wv][a * 16 + b];
-    partials[static_cast<size_t>(blockIdx.x) * kAccU + threadIdx.x] = s;
+    partials[static_cast<size_t>(wg) * kAccU + threadIdx.x] = s;
   }
 }
 
@@ -706,25 +707,38 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
 #endif
 
 struct LmShared {
-  double stripe[kMaxStripes * kAcc];
+  double stripe[2][kMaxStripes * kAcc];  // double-buffered: block b + 1 is summed while b is combined
   LmHead h;
   double H[kHCap];
   double Hc[kHCap];
   double A[kHCap];
   double rhs[kMaxCols], y[kMaxCols];
+  double invd[kMaxCols];  // reciprocals of the Cholesky diagonal
+  int colmap[18];         // local -> global column of the odometry / IMU block being assembled
   double sums[kMaxBlocks * kAccU];
   BlockXform xfs[kMaxBlocks];  // transform + d(t,q)/d(local) of every block
   double red[kLmThreads];
 };
 
-__device__ inline void wave_sync() { __syncthreads(); }  // 64-thread workgroup
+// The LM state machine runs in ONE wavefront (the others have returned): a wavefront executes its
+// LDS instructions in order, so lanes only need the compiler not to move accesses across the point.
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
+__device__ inline double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ inline double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
 
-__device__ inline void pose_plus(const LmHead& h, const double (*x)[kState], const double* delta,
+__device__ __forceinline__ void pose_plus(const LmHead& h, const double (*x)[kState], const double* delta,
                                  double (*out)[kState], int lane) {
   if (lane < h.num_poses) {
     const int p = lane;
@@ -747,58 +761,174 @@ __device__ inline void pose_plus(const LmHead& h, const double (*x)[kState], con
 // Right-looking band Cholesky + column-oriented substitutions on an LDS band matrix (W = bw + 1).
 // Entries outside the band stay exactly zero in the dense factorisation, so skipping them changes
 // nothing; term order per entry equals the sequential left-looking form (k ascending).
-__device__ bool cholesky_solve_wave(int n, int W, double* A, const double* b, double* x, double* y, int lane) {
+// noinline: its register allocation must not be squeezed by the 12 x 12 register solver. The
+// matrices live in LDS; the address-space-qualified pointers keep the accesses ds_read / ds_write
+// across the call (a generic pointer would turn every access into a flat load + full waitcnt).
+__device__ __attribute__((noinline)) bool cholesky_solve_wave(int n, int W, lds_f64* A, const lds_f64* b,
+                                                             lds_f64* x, lds_f64* y, lds_f64* invd,
+                                                             int lane, long long* dbg = nullptr) {
   const int bw = W - 1;
-  for (int j = 0; j < n; ++j) {
-    const double d = A[band_index(j, j, W)];
-    if (!(d > 0.0) || !isfinite(d)) return false;  // uniform
-    const double l = sqrt(d);
-    wave_sync();
-    const int m = min(bw, n - j - 1);  // rows below the diagonal inside the band
-    if (lane == 0) A[band_index(j, j, W)] = l;
-    for (int r = lane; r < m; r += kLmThreads) {
-      const int i = j + 1 + r;
-      A[band_index(i, j, W)] = A[band_index(i, j, W)] / l;
+  if (bw > 40) {
+    // dense systems up to 56 x 56 (blocks coupling far-apart control points): plain loop
+    for (int j = 0; j < n; ++j) {
+      const double d = A[band_index(j, j, W)];
+      if (!(d > 0.0) || !isfinite(d)) return false;
+      const double inv = rsqrt(d);
+      const int m = min(bw, n - j - 1);
+      wave_sync();
+      if (lane == 0) { A[band_index(j, j, W)] = d * inv; invd[j] = inv; }
+      for (int r = lane; r < m; r += kLmThreads) A[band_index(j + 1 + r, j, W)] *= inv;
+      wave_sync();
+      for (int idx = lane; idx < m * m; idx += kLmThreads) {
+        const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+        if (k <= i) A[band_index(i, k, W)] -= A[band_index(i, j, W)] * A[band_index(k, j, W)];
+      }
+      wave_sync();
     }
-    wave_sync();
-    for (int idx = lane; idx < m * m; idx += kLmThreads) {
-      const int i = j + 1 + idx / m, k = j + 1 + idx % m;
-      if (k <= i) A[band_index(i, k, W)] -= A[band_index(i, j, W)] * A[band_index(k, j, W)];
+  } else {
+    // One LDS round trip per column: every lane reads the pivot, the (unscaled) column entries
+    // and the targets of its share of the trailing triangle, then the updates and the scaled
+    // column are written. (a * inv) * (b * inv) has the same bits as the product of the stored
+    // scaled entries. Entry p = lane + 64 e of the triangle {(r, k): 0 <= k <= r < bw} belongs to
+    // lane `lane`; band_index(j + 1 + r, j) etc. are j * W + constant, hoisted out of the loop.
+    constexpr int kEnt = 12;  // ceil(40 * 41 / 2 / 64) + 1
+    const int Wm = W - 1;
+    const int tri = bw * (bw + 1) / 2;
+    int o_li[kEnt], o_lk[kEnt], o_tg[kEnt], er[kEnt];
+#pragma unroll
+    for (int e = 0; e < kEnt; ++e) {
+      const int pidx = lane + 64 * e;
+      int r = static_cast<int>((sqrtf(8.0f * static_cast<float>(pidx) + 1.0f) - 1.0f) * 0.5f);
+      while (r * (r + 1) / 2 > pidx) --r;
+      while ((r + 1) * (r + 2) / 2 <= pidx) ++r;
+      const int k = pidx - r * (r + 1) / 2;
+      const bool in = pidx < tri;
+      er[e] = in ? r : 0x7FFFFFFF;  // entry exists in this column iff er < m
+      o_li[e] = in ? (1 + r) * Wm + Wm : 0;
+      o_lk[e] = in ? (1 + k) * Wm + Wm : 0;
+      o_tg[e] = in ? (1 + r) * Wm + Wm + 1 + k : 0;
     }
-    wave_sync();
+    const int ne = (tri + 63) / 64;  // entries per lane in use (uniform)
+    const int o_col = (1 + lane) * Wm + Wm;
+    int jW = 0;  // j * W
+    for (int j = 0; j < n; ++j, jW += W) {
+      const double d = A[jW + Wm];  // band_index(j, j)
+      if (!(d > 0.0) || !isfinite(d)) return false;  // uniform
+      const int m = min(bw, n - j - 1);  // rows below the diagonal inside the band
+      // reads of entries outside this column's triangle (er >= m) stay inside the LDS arrays
+      // (offsets are bounded by the full-band triangle) and are discarded
+      double li[kEnt], lk[kEnt], tg[kEnt];
+#pragma unroll
+      for (int e = 0; e < kEnt; ++e) {
+        if (e < ne) {
+          const int base = min(jW, (n - 1 - bw > 0 ? n - 1 - bw : 0) * W);  // keep the reads in range
+          const bool live = er[e] < m;
+          li[e] = A[(live ? jW : base) + o_li[e]];
+          lk[e] = A[(live ? jW : base) + o_lk[e]];
+          tg[e] = A[(live ? jW : base) + o_tg[e]];
+        }
+      }
+      const double cj = A[min(jW + o_col, kHCap - 1)];
+      const double inv = rsqrt(d);  // l = d * inv, rows *= inv
+#pragma unroll
+      for (int e = 0; e < kEnt; ++e) {
+        if (e < ne) {
+          if (er[e] < m) A[jW + o_tg[e]] = tg[e] - (li[e] * inv) * (lk[e] * inv);
+        }
+      }
+      if (lane < m) A[jW + o_col] = cj * inv;
+      if (lane == 0) {
+        A[jW + Wm] = d * inv;
+        invd[j] = inv;
+      }
+      wave_sync();
+    }
   }
-  for (int i = lane; i < n; i += kLmThreads) y[i] = b[i];
+  if (dbg && lane == 0) dbg[9] = __builtin_amdgcn_s_memtime();
+  // Substitutions with the vector in registers: lane l holds entries l and l + 64 (n <= 128); the
+  // pivot entry travels by v_readlane, so the dependent chain per row is a few ALU instructions
+  // instead of two LDS round trips. L's entries for the next row are loaded one row ahead; their
+  // addresses are linear in the row (band_index(r, i) = r * (W - 1) + (W - 1) + i).
+  (void)y;
+  const int Wm1 = W - 1;
+  double v0 = lane < n ? b[lane] : 0.0, v1 = lane + 64 < n ? b[lane + 64] : 0.0;
+  const double iv0 = lane < n ? invd[lane] : 0.0, iv1 = lane + 64 < n ? invd[lane + 64] : 0.0;
+  const int r0 = lane, r1 = lane + 64;
+  {
+    // forward, column oriented: after y_i is final, rows i < r <= i + bw subtract L[r][i] * y_i
+    const int f0 = r0 * Wm1 + Wm1, f1 = r1 * Wm1 + Wm1;  // + i
+    auto col = [&](int i, double& c0, double& c1) {
+      c0 = (static_cast<unsigned>(r0 - i - 1) < static_cast<unsigned>(bw) && r0 < n) ? A[f0 + i] : 0.0;
+      c1 = (static_cast<unsigned>(r1 - i - 1) < static_cast<unsigned>(bw) && r1 < n) ? A[f1 + i] : 0.0;
+    };
+    double c0, c1;
+    col(0, c0, c1);
+    const int n_lo = min(n, 64);
+    for (int i = 0; i < n_lo; ++i) {
+      double n0, n1;
+      col(i + 1, n0, n1);
+      const double yi = readlane_f64(v0, i) * readlane_f64(iv0, i);
+      v0 = (lane == i) ? yi : v0 - c0 * yi;  // c = 0 outside the band / above the pivot row
+      v1 -= c1 * yi;
+      c0 = n0;
+      c1 = n1;
+    }
+    for (int i = 64; i < n; ++i) {
+      double n0, n1;
+      col(i + 1, n0, n1);
+      const double yi = readlane_f64(v1, i - 64) * readlane_f64(iv1, i - 64);
+      v1 = (lane == i - 64) ? yi : v1 - c1 * yi;
+      c1 = n1;
+      (void)n0;
+    }
+  }
+  if (dbg && lane == 0) dbg[10] = __builtin_amdgcn_s_memtime();
+  {
+    // backward: after x_i is final, rows i - bw <= r < i subtract L[i][r] * x_i;
+    // band_index(i, r) = i * (W - 1) + (W - 1) + r
+    auto rowv = [&](int i, double& c0, double& c1) {
+      const int base = i * Wm1 + Wm1;
+      c0 = (static_cast<unsigned>(i - r0 - 1) < static_cast<unsigned>(bw)) ? A[base + r0] : 0.0;
+      c1 = (static_cast<unsigned>(i - r1 - 1) < static_cast<unsigned>(bw)) ? A[base + r1] : 0.0;
+    };
+    double c0 = 0.0, c1 = 0.0;
+    if (n > 0) rowv(n - 1, c0, c1);
+    for (int i = n - 1; i >= 64; --i) {
+      double n0, n1;
+      rowv(i - 1, n0, n1);
+      const double xi = readlane_f64(v1, i - 64) * readlane_f64(iv1, i - 64);
+      v1 = (lane == i - 64) ? xi : v1 - c1 * xi;
+      v0 -= c0 * xi;
+      c0 = n0;
+      c1 = n1;
+    }
+    for (int i = min(n, 64) - 1; i >= 0; --i) {
+      double n0 = 0.0, n1 = 0.0;
+      if (i > 0) rowv(i - 1, n0, n1);
+      const double xi = readlane_f64(v0, i) * readlane_f64(iv0, i);
+      v0 = (lane == i) ? xi : v0 - c0 * xi;
+      c0 = n0;
+      (void)n1;
+    }
+  }
+  bool ok = isfinite(v0) && isfinite(v1);
+  ok = __all(ok);
+  if (lane < n) x[lane] = v0;
+  if (lane + 64 < n) x[lane + 64] = v1;
   wave_sync();
-  for (int i = 0; i < n; ++i) {
-    if (lane == 0) y[i] = y[i] / A[band_index(i, i, W)];
-    wave_sync();
-    const double yi = y[i];
-    const int m = min(bw, n - i - 1);
-    for (int r = lane; r < m; r += kLmThreads) y[i + 1 + r] -= A[band_index(i + 1 + r, i, W)] * yi;
-    wave_sync();
-  }
-  for (int i = n - 1; i >= 0; --i) {
-    if (lane == 0) x[i] = y[i] / A[band_index(i, i, W)];
-    wave_sync();
-    const double xi = x[i];
-    const int m = min(bw, i);
-    for (int r = lane; r < m; r += kLmThreads) y[i - 1 - r] -= A[band_index(i, i - 1 - r, W)] * xi;
-    wave_sync();
-  }
-  bool ok = true;
-  for (int i = 0; i < n; ++i) ok = ok && isfinite(x[i]);
   return ok;
 }
 
 // Small systems: every lane factorises its own register copy (no LDS round trips, no barriers);
 // left-looking term order; one reciprocal per column instead of a division per entry.
 template <int N>
-__device__ bool cholesky_solve_regs(const double* A_lds, int W, const double* b_lds, double* x_lds, int lane) {
+__device__ __attribute__((noinline)) bool cholesky_solve_regs(const lds_f64* A_lds, int W, const lds_f64* b_lds,
+                                                              lds_f64* x_lds, int lane) {
   double L[N][N], inv[N], y[N], x[N];
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
-    for (int j = 0; j <= i; ++j) L[i][j] = band_get(A_lds, i, j, W);
+    for (int j = 0; j <= i; ++j) L[i][j] = (i - j < W) ? A_lds[band_index(i, j, W)] : 0.0;
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -849,7 +979,7 @@ __device__ inline void finish(LmHead& h, int type, int reason) {
 }
 
 // |x - Plus(x, -g)|_inf in the ambient space (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-__device__ double gradient_max_norm(const LmHead& h) {
+__device__ __forceinline__ double gradient_max_norm(const LmHead& h) {
   double m = 0.0;
   for (int p = 0; p < h.num_poses; ++p) {
     if (!h.constant[p]) {
@@ -871,7 +1001,7 @@ __device__ double gradient_max_norm(const LmHead& h) {
 // LevenbergMarquardtStrategy::ComputeStep + TrustRegionMinimizer::ComputeTrustRegionStep,
 // looping over invalid steps (each one is an iteration). Leaves the next candidate in h.cand
 // or terminates. Scalar updates of `h` are done by lane 0 between syncs; every lane reads them.
-__device__ void compute_next_candidate(LmShared& S, int lane) {
+__device__ __forceinline__ void compute_next_candidate(LmShared& S, int lane) {
   LmHead& h = S.h;
   const int n = h.ncols, W = h.bw + 1;
   while (true) {
@@ -916,9 +1046,16 @@ __device__ void compute_next_candidate(LmShared& S, int lane) {
     for (int a = lane; a < n; a += kLmThreads) S.rhs[a] = h.g[a] * h.scale[a];
     wave_sync();
     HG_STAMP(S, 4);
-    bool valid = (n == 6)    ? cholesky_solve_regs<6>(S.A, W, S.rhs, h.step, lane)
-                 : (n == 12) ? cholesky_solve_regs<12>(S.A, W, S.rhs, h.step, lane)
-                             : cholesky_solve_wave(n, W, S.A, S.rhs, h.step, S.y, lane);
+    bool valid = (n == 6)    ? cholesky_solve_regs<6>((const lds_f64*)S.A, W, (const lds_f64*)S.rhs, (lds_f64*)h.step, lane)
+                 : (n == 12) ? cholesky_solve_regs<12>((const lds_f64*)S.A, W, (const lds_f64*)S.rhs, (lds_f64*)h.step, lane)
+#ifdef HG_LM_STAMPS
+                             : cholesky_solve_wave(n, W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step,
+                                                   (lds_f64*)S.y, (lds_f64*)S.invd, lane,
+                                                   h.stamps[15] ? h.stamps : nullptr);
+#else
+                             : cholesky_solve_wave(n, W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step,
+                                                   (lds_f64*)S.y, (lds_f64*)S.invd, lane);
+#endif
     HG_STAMP(S, 5);
     wave_sync();
     double mcc = 0.0;
@@ -967,43 +1104,54 @@ __device__ void compute_next_candidate(LmShared& S, int lane) {
 
 // All threads of the workgroup: thread (stripe j, column k) sums every stripes-th workgroup
 // partial of column k with up to 8 loads in flight; the stripes are then added in a fixed order.
-__device__ void reduce_partials(LmShared& S, const double* partials) {
+__device__ __forceinline__ void reduce_partials(LmShared& S, const double* partials) {
   const LmHead& h = S.h;
   const int t = threadIdx.x;
-  for (int b = 0; b < h.num_blocks; ++b) {
+  // stripe sum of block b for this thread; the loads of block b + 1 are issued before block b is
+  // combined, so one memory round trip is exposed for the whole window instead of one per block
+  auto stripe_sum = [&](int b) {
     const BlockInfo& bi = h.blocks[b];
     const int acc_n = bi.acc;
     const int stripes = min(static_cast<int>(blockDim.x) / acc_n, kMaxStripes);
     const int j = t / acc_n, k = t % acc_n;
-    if (j < stripes) {
-      double acc = 0.0;
-      if (bi.active) {
-        const double* p = partials + bi.partial_offset + k;
-        for (unsigned w = j; w < bi.num_wg; w += 16 * stripes) {
-          double v[16];
+    double acc = 0.0;
+    if (j < stripes && bi.active) {
+      const double* p = partials + bi.partial_offset + k;
+      for (unsigned w = j; w < bi.num_wg; w += 16 * stripes) {
+        double v[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {  // 16 independent loads in flight, masked at the end
-            const unsigned idx = w + u * stripes;
-            v[u] = idx < bi.num_wg ? p[static_cast<size_t>(idx) * acc_n] : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < 16; ++u) acc += v[u];
+        for (int u = 0; u < 16; ++u) {  // 16 independent loads in flight, masked at the end
+          const unsigned idx = w + u * stripes;
+          v[u] = idx < bi.num_wg ? p[static_cast<size_t>(idx) * acc_n] : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
       }
-      S.stripe[j * acc_n + k] = acc;
     }
+    return acc;
+  };
+  double next = h.num_blocks > 0 ? stripe_sum(0) : 0.0;
+  for (int b = 0; b < h.num_blocks; ++b) {
+    const double acc = next;
+    if (b + 1 < h.num_blocks) next = stripe_sum(b + 1);
+    const int acc_n = h.blocks[b].acc;
+    const int stripes = min(static_cast<int>(blockDim.x) / acc_n, kMaxStripes);
+    double* buf = S.stripe[b & 1];
+    if (t / acc_n < stripes) buf[t] = acc;  // t = j * acc_n + k
     __syncthreads();
     if (t < acc_n) {
-      double s = 0.0;
-      for (int jj = 0; jj < stripes; ++jj) s += S.stripe[jj * acc_n + t];
-      S.sums[b * kAccU + t] = s;
+      double sum = 0.0;
+      for (int jj = 0; jj < stripes; ++jj) sum += buf[jj * acc_n + t];
+      S.sums[b * kAccU + t] = sum;
     }
-    __syncthreads();
+    // no second barrier: the next block writes the other buffer, and the barrier of that block
+    // orders this block's reads before the buffer is written again
   }
+  __syncthreads();
 }
 
 // Maps the per-block 7x7 sums through M into Hc / gc / cand_cost.
-__device__ void assemble(LmShared& S, const BlockXform* xf, const double* partials,
+__device__ __forceinline__ void assemble(LmShared& S, const BlockXform* xf, const double* partials,
                          const SmallOut* small_out, int lane) {
   LmHead& h = S.h;
   const int n = h.ncols, W = h.bw + 1;
@@ -1078,28 +1226,61 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
     }
     wave_sync();
   }
-  // odometry / IMU blocks: their 18 x 18 local systems were computed by k_small_blocks
-  for (int b = 0; b < h.num_small; ++b) {
-    const SmallBlockDev& sb = h.small[b];
-    if (!sb.active) continue;
-    const SmallOut& so = small_out[b];
-    cost += so.c;
-    // local column -> global column: [pose_a 6 | vel_a 3 | pose_b 6 | vel_b 3]
-    auto gcol = [&](int c) {
-      if (c < 6) return h.constant[sb.a] ? -1 : h.col[sb.a] + c;
-      if (c < 9) return h.vfree[sb.a] ? h.vcol[sb.a] + (c - 6) : -1;
-      if (c < 15) return h.constant[sb.b] ? -1 : h.col[sb.b] + (c - 9);
-      return h.vfree[sb.b] ? h.vcol[sb.b] + (c - 15) : -1;
+  // odometry / IMU blocks: their 18 x 18 local systems were computed by k_small_blocks. Each lane
+  // owns entries lane, lane + 64, ... of the block; the next block's entries are loaded while the
+  // current block is added (the loads come from global memory).
+  {
+    auto fetch = [&](int b, double* v, double& gv, double& cv) {
+      const SmallOut& so = small_out[b];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int idx = lane + u * kLmThreads;
+        v[u] = idx < 18 * 18 ? so.H[idx] : 0.0;
+      }
+      gv = lane < 18 ? so.g[lane] : 0.0;
+      cv = so.c;
     };
-    for (int idx = lane; idx < 18 * 18; idx += kLmThreads) {
-      const int g1 = gcol(idx / 18), g2 = gcol(idx % 18);
-      if (g1 >= 0 && g2 >= 0 && g2 <= g1) S.Hc[band_index(g1, g2, W)] += so.H[idx];
+    int b = 0;
+    while (b < h.num_small && !h.small[b].active) ++b;
+    double cur[6], cg = 0.0, cc = 0.0;
+    if (b < h.num_small) fetch(b, cur, cg, cc);
+    while (b < h.num_small) {
+      int nb = b + 1;
+      while (nb < h.num_small && !h.small[nb].active) ++nb;
+      double nxt[6], ng = 0.0, nc = 0.0;
+      if (nb < h.num_small) fetch(nb, nxt, ng, nc);
+      const SmallBlockDev& sb = h.small[b];
+      // local column -> global column: [pose_a 6 | vel_a 3 | pose_b 6 | vel_b 3]
+      if (lane < 18) {
+        const int c = lane;
+        int gcol;
+        if (c < 6) gcol = h.constant[sb.a] ? -1 : h.col[sb.a] + c;
+        else if (c < 9) gcol = h.vfree[sb.a] ? h.vcol[sb.a] + (c - 6) : -1;
+        else if (c < 15) gcol = h.constant[sb.b] ? -1 : h.col[sb.b] + (c - 9);
+        else gcol = h.vfree[sb.b] ? h.vcol[sb.b] + (c - 15) : -1;
+        S.colmap[c] = gcol;
+      }
+      wave_sync();
+      cost += cc;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int idx = lane + u * kLmThreads;
+        if (idx < 18 * 18) {
+          const int g1 = S.colmap[idx / 18], g2 = S.colmap[idx % 18];
+          if (g1 >= 0 && g2 >= 0 && g2 <= g1) S.Hc[band_index(g1, g2, W)] += cur[u];
+        }
+      }
+      if (lane < 18) {
+        const int g1 = S.colmap[lane];
+        if (g1 >= 0) h.gc[g1] += cg;
+      }
+      wave_sync();
+#pragma unroll
+      for (int u = 0; u < 6; ++u) cur[u] = nxt[u];
+      cg = ng;
+      cc = nc;
+      b = nb;
     }
-    if (lane < 18) {
-      const int g1 = gcol(lane);
-      if (g1 >= 0) h.gc[g1] += so.g[lane];
-    }
-    wave_sync();
   }
   if (lane == 0) h.cand_cost = 0.5 * cost;
   wave_sync();
@@ -1107,7 +1288,7 @@ __device__ void assemble(LmShared& S, const BlockXform* xf, const double* partia
 
 // Transforms of every block at the candidate: built in LDS (M zeroed cooperatively, one lane per
 // block fills the non-zeros), then copied out coalesced. Runs in wavefront 0.
-__device__ void prepare_all(LmShared& S, BlockXform* xf) {
+__device__ __forceinline__ void prepare_all(LmShared& S, BlockXform* xf) {
   const LmHead& h = S.h;
   const int lane = threadIdx.x;
   if (lane >= kLmThreads) return;
@@ -1124,7 +1305,7 @@ __device__ void prepare_all(LmShared& S, BlockXform* xf) {
 // One LM iteration by the calling workgroup (any size >= 64): loads the solver head, sums the
 // partials, and lets wavefront 0 advance the state machine. Called from k_lm and from the tail of
 // the last k_tsdf_residuals workgroup of an iteration.
-__device__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* partials,
+__device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* partials,
                         const SmallOut* small_out, int mode, const PinBox* host_up = nullptr,
                         unsigned up_words = 0) {
   const int lane = threadIdx.x;
@@ -1314,11 +1495,6 @@ __device__ unsigned long long g_tail_stamps[8];
 #else
 #define TAIL_STAMP(i) do {} while (0)
 #endif
-__device__ inline double readlane_f64(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
 __device__ inline int b6(int i, int j) { return i * 6 + 5 - (i - j); }  // band_index(i, j, W = 6), j <= i
 
 __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, BlockXform* xf, const double* partials,
@@ -1881,7 +2057,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
                 "LDS tile aliasing");
   tsdf_residuals_body(pv, xyz, n, scaling, xf, partials, residuals,
                       reinterpret_cast<double (*)[kWave][8]>(smem),
-                      reinterpret_cast<double (*)[64]>(smem + (kEvalThreads / kWave) * kWave * 8 * sizeof(double)));
+                      reinterpret_cast<double (*)[64]>(smem + (kEvalThreads / kWave) * kWave * 8 * sizeof(double)),
+                      blockIdx.x);
   if (!G) return;
   EVAL_STAMP(1);
   __shared__ int s_last;
@@ -1923,7 +2100,71 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals_unwarp(
   double (*xs)[kWave][16] = reinterpret_cast<double (*)[kWave][16]>(smem);
   double (*cs)[256] = reinterpret_cast<double (*)[256]>(smem + (kEvalThreads / kWave) * kWave * 16 * sizeof(double));
   tsdf_residuals_unwarp_body(pv, xyz, factor, n, scaling, G->h.cand[pose_a], G->h.cand[pose_b],
-                             partials, residuals, xs, cs);
+                             partials, residuals, xs, cs, blockIdx.x);
+  if (!ticket) return;
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last = (t == total_wg - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *ticket = 0u;
+  }
+  __syncthreads();
+  lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
+}
+
+// All residual blocks of a problem in ONE launch per LM iteration (sliding windows: one block per
+// scan in the window): workgroup -> (block, local workgroup) through the device block table.
+struct EvalBlock {
+  PyramidView pv;
+  const float* xyz;
+  const double* factor;  // per-return interpolation ratios, or nullptr
+  double scaling;
+  unsigned n, wg_begin, partial_offset, row_offset;
+  int pose_a, pose_b, index, pad;
+};
+
+__global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals_multi(
+    const EvalBlock* __restrict__ blocks, int num_eval, double* __restrict__ residuals, LmState* G,
+    BlockXform* xf_all, double* partials_all, const SmallOut* small_out, unsigned* ticket,
+    unsigned total_wg) {
+  if (G->h.done) return;
+  __shared__ __align__(16) unsigned char smem[sizeof(LmShared)];
+  // block of this workgroup: every lane reads one table entry's first workgroup, one ballot
+  int b;
+  {
+    const int lane = threadIdx.x % kWave;
+    const bool le = lane < num_eval && blocks[lane].wg_begin <= blockIdx.x;
+    b = __popcll(__ballot(le)) - 1;  // wg_begin ascends; entry 0 starts at 0
+  }
+  // by-value copy: the table entry is read once (uniform loads), not at every use in the body
+  const PyramidView pv = blocks[b].pv;
+  const EvalBlock eb = {PyramidView(), blocks[b].xyz, blocks[b].factor, blocks[b].scaling, blocks[b].n,
+                        blocks[b].wg_begin, blocks[b].partial_offset, blocks[b].row_offset,
+                        blocks[b].pose_a, blocks[b].pose_b, blocks[b].index, 0};
+  const unsigned wg = blockIdx.x - eb.wg_begin;
+  double* res = residuals ? residuals + eb.row_offset : nullptr;
+  if (eb.factor) {
+    double (*xs)[kWave][16] = reinterpret_cast<double (*)[kWave][16]>(smem);
+    double (*cs)[256] = reinterpret_cast<double (*)[256]>(smem + (kEvalThreads / kWave) * kWave * 16 * sizeof(double));
+    tsdf_residuals_unwarp_body(pv, eb.xyz, eb.factor, eb.n, eb.scaling, G->h.cand[eb.pose_a],
+                               G->h.cand[eb.pose_b], partials_all + eb.partial_offset, res, xs, cs, wg);
+  } else {
+    tsdf_residuals_body(pv, eb.xyz, eb.n, eb.scaling, xf_all + eb.index,
+                        partials_all + eb.partial_offset, res,
+                        reinterpret_cast<double (*)[kWave][8]>(smem),
+                        reinterpret_cast<double (*)[64]>(smem + (kEvalThreads / kWave) * kWave * 8 * sizeof(double)),
+                        wg);
+  }
   if (!ticket) return;
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1984,6 +2225,9 @@ struct hg_problem {
   BlockXform* d_xf = nullptr;
   DeviceBuffer partials, residuals;
   bool solve_pending = false;
+  EvalBlock* d_eval = nullptr;  // block table of the fused multi-block launch
+  EvalBlock* h_eval = nullptr;  // pinned staging
+  int num_eval = 0;             // active blocks in the table (>= 2 -> fused launch)
   PinBox* h_box = nullptr;   // mapped pinned mailbox: upload source and result sink
   PinBox* d_box = nullptr;   // its device address
   unsigned long long seq = 0;
@@ -2075,6 +2319,33 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   if (rc != HG_OK) return rc;
   // the pinned buffer may still be the source of the previous (finished) upload: solves are
   // synchronised by their fetch before the next upload
+  // block table of the fused launch (two or more active blocks)
+  p->num_eval = 0;
+  for (int b = 0; b < S.num_blocks; ++b) {
+    const BlockInfo& bi = S.blocks[b];
+    if (!bi.active) continue;
+    const hg_problem::Block& hb = p->blocks[b];
+    EvalBlock& eb = p->h_eval[p->num_eval];
+    std::memset(&eb, 0, sizeof(eb));
+    eb.pv.levels = static_cast<int>(hb.pyramid.size());
+    eb.pv.multi_res = hb.multi_res;
+    for (int l = 0; l < eb.pv.levels; ++l) eb.pv.level[l] = hb.pyramid[l]->view;
+    eb.xyz = hb.d_xyz;
+    eb.factor = hb.d_factor;
+    eb.scaling = bi.scaling;
+    eb.n = bi.n;
+    eb.wg_begin = p->num_eval ? p->h_eval[p->num_eval - 1].wg_begin +
+                                    (p->h_eval[p->num_eval - 1].n + kEvalThreads - 1) / kEvalThreads : 0u;
+    eb.partial_offset = bi.partial_offset;
+    eb.row_offset = bi.row_offset;
+    eb.pose_a = bi.pose_a;
+    eb.pose_b = bi.pose_b;
+    eb.index = b;
+    ++p->num_eval;
+  }
+  if (p->num_eval >= 2)
+    HG_HIP_CHECK(hipMemcpyAsync(p->d_eval, p->h_eval, sizeof(EvalBlock) * p->num_eval,
+                                hipMemcpyHostToDevice, p->ctx->stream));
   S.box = p->d_box;
   S.seq = ++p->seq;
   // zero-copy upload: k_lm MODE_PREPARE reads the head from the mailbox. The previous solve's
@@ -2111,6 +2382,15 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
                            S.blocks[0].active && S.blocks[0].acc == kAcc && S.blocks[0].pose_b < 0 &&
                            S.num_small == 0 && S.ncols == 6 && S.bw == 5 &&
                            std::getenv("HG_LM_GENERAL") == nullptr) ? 1 : 0;
+  if (p->num_eval >= 2) {
+    // all blocks of the window in one launch per iteration
+    ProfScope ps(p->ctx, HG_K_RESIDUALS, 0);
+    hipLaunchKernelGGL(k_tsdf_residuals_multi, dim3(total_wg), dim3(kEvalThreads), 0, s, p->d_eval,
+                       p->num_eval, d_residuals, p->d_state, p->d_xf, p->partials.as<double>(),
+                       p->d_small, fused_lm ? p->d_ticket : nullptr, total_wg);
+    HG_HIP_CHECK(hipGetLastError());
+    return HG_OK;
+  }
   for (int b = 0; b < S.num_blocks; ++b) {
     const BlockInfo& bi = S.blocks[b];
     if (!bi.active) continue;
@@ -2178,6 +2458,8 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
     std::memset(p->h_box, 0, sizeof(PinBox));
     e = hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_box), p->h_box, 0);
   }
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_eval), sizeof(EvalBlock) * kMaxBlocks);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_eval), sizeof(EvalBlock) * kMaxBlocks);
   if (e == hipSuccess) e = hipMemset(p->d_ticket, 0, 256);
   if (e != hipSuccess) {
     set_last_error(std::string("hipMalloc problem: ") + hipGetErrorString(e));
@@ -2199,6 +2481,8 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->d_ticket) (void)hipFree(p->d_ticket);
   if (p->d_small) (void)hipFree(p->d_small);
   if (p->h_box) (void)hipHostFree(p->h_box);
+  if (p->d_eval) (void)hipFree(p->d_eval);
+  if (p->h_eval) (void)hipHostFree(p->h_eval);
   p->partials.release();
   p->residuals.release();
   delete p;
@@ -2531,6 +2815,7 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
   fprintf(stderr, "lm stamps (cycles of the last step):");
   fprintf(stderr, " [load]%lld", S.stamps[0] - S.stamps[8]);
   for (int i = 1; i < 8; ++i) fprintf(stderr, " [%d]%lld", i, S.stamps[i] - S.stamps[i - 1]);
+  fprintf(stderr, " | solve: factor %lld forward %lld backward %lld", S.stamps[9] - S.stamps[4], S.stamps[10] - S.stamps[9], S.stamps[5] - S.stamps[10]);
   fprintf(stderr, "\n");
 #endif
   for (int i = 0; i < S.num_poses; ++i) {
