@@ -761,6 +761,62 @@ __device__ __forceinline__ void pose_plus(const LmHead& h, const double (*x)[kSt
 // Right-looking band Cholesky + column-oriented substitutions on an LDS band matrix (W = bw + 1).
 // Entries outside the band stay exactly zero in the dense factorisation, so skipping them changes
 // nothing; term order per entry equals the sequential left-looking form (k ascending).
+// Right-looking band Cholesky, one LDS round trip per column: every lane reads the pivot, the
+// (unscaled) column entries and the targets of its NE entries of the trailing triangle
+// {(r, k): 0 <= k <= r < bw} (entry p = lane + 64 e), then the updates and the scaled column are
+// written. (a * inv) * (b * inv) has the same bits as the product of the stored scaled entries.
+// band_index(j + 1 + r, j) etc. are j * W + constant, hoisted out of the column loop.
+template <int NE>
+__device__ __forceinline__ bool band_factor(int n, int W, lds_f64* A, lds_f64* invd, int lane) {
+  const int bw = W - 1, Wm = W - 1;
+  const int tri = bw * (bw + 1) / 2;
+  int o_li[NE], o_lk[NE], o_tg[NE], er[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int pidx = lane + 64 * e;
+    int r = static_cast<int>((sqrtf(8.0f * static_cast<float>(pidx) + 1.0f) - 1.0f) * 0.5f);
+    while (r * (r + 1) / 2 > pidx) --r;
+    while ((r + 1) * (r + 2) / 2 <= pidx) ++r;
+    const int k = pidx - r * (r + 1) / 2;
+    const bool in = pidx < tri;
+    er[e] = in ? r : 0x7FFFFFFF;  // entry exists in column j iff er < m
+    o_li[e] = in ? (1 + r) * Wm + Wm : Wm;
+    o_lk[e] = in ? (1 + k) * Wm + Wm : Wm;
+    o_tg[e] = in ? (1 + r) * Wm + Wm + 1 + k : Wm;
+  }
+  const int o_col = (1 + lane) * Wm + Wm;
+  const int last_full = (n - 1 - bw > 0 ? n - 1 - bw : 0) * W;  // j * W of the last full-band column
+  int jW = 0;
+  for (int j = 0; j < n; ++j, jW += W) {
+    const double d = A[jW + Wm];  // band_index(j, j)
+    if (!(d > 0.0) || !isfinite(d)) return false;  // uniform
+    const int m = min(bw, n - j - 1);  // rows below the diagonal inside the band
+    // entries outside this column's triangle (er >= m: the last bw columns) read in-range
+    // addresses of an earlier column and are discarded
+    const int rb = min(jW, last_full);
+    double li[NE], lk[NE], tg[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int base = er[e] < m ? jW : rb;
+      li[e] = A[base + o_li[e]];
+      lk[e] = A[base + o_lk[e]];
+      tg[e] = A[base + o_tg[e]];
+    }
+    const double cj = A[min(jW + o_col, kHCap - 1)];
+    const double inv = rsqrt(d);  // l = d * inv, rows *= inv
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      if (er[e] < m) A[jW + o_tg[e]] = tg[e] - (li[e] * inv) * (lk[e] * inv);
+    if (lane < m) A[jW + o_col] = cj * inv;
+    if (lane == 0) {
+      A[jW + Wm] = d * inv;
+      invd[j] = inv;
+    }
+    wave_sync();
+  }
+  return true;
+}
+
 // noinline: its register allocation must not be squeezed by the 12 x 12 register solver. The
 // matrices live in LDS; the address-space-qualified pointers keep the accesses ds_read / ds_write
 // across the call (a generic pointer would turn every access into a flat load + full waitcnt).
@@ -786,63 +842,19 @@ __device__ __attribute__((noinline)) bool cholesky_solve_wave(int n, int W, lds_
       wave_sync();
     }
   } else {
-    // One LDS round trip per column: every lane reads the pivot, the (unscaled) column entries
-    // and the targets of its share of the trailing triangle, then the updates and the scaled
-    // column are written. (a * inv) * (b * inv) has the same bits as the product of the stored
-    // scaled entries. Entry p = lane + 64 e of the triangle {(r, k): 0 <= k <= r < bw} belongs to
-    // lane `lane`; band_index(j + 1 + r, j) etc. are j * W + constant, hoisted out of the loop.
-    constexpr int kEnt = 12;  // ceil(40 * 41 / 2 / 64) + 1
-    const int Wm = W - 1;
     const int tri = bw * (bw + 1) / 2;
-    int o_li[kEnt], o_lk[kEnt], o_tg[kEnt], er[kEnt];
-#pragma unroll
-    for (int e = 0; e < kEnt; ++e) {
-      const int pidx = lane + 64 * e;
-      int r = static_cast<int>((sqrtf(8.0f * static_cast<float>(pidx) + 1.0f) - 1.0f) * 0.5f);
-      while (r * (r + 1) / 2 > pidx) --r;
-      while ((r + 1) * (r + 2) / 2 <= pidx) ++r;
-      const int k = pidx - r * (r + 1) / 2;
-      const bool in = pidx < tri;
-      er[e] = in ? r : 0x7FFFFFFF;  // entry exists in this column iff er < m
-      o_li[e] = in ? (1 + r) * Wm + Wm : 0;
-      o_lk[e] = in ? (1 + k) * Wm + Wm : 0;
-      o_tg[e] = in ? (1 + r) * Wm + Wm + 1 + k : 0;
+    const int ne = (tri + 63) / 64;  // triangle entries per lane (uniform)
+    bool ok;
+    switch (ne) {
+      case 1: ok = band_factor<1>(n, W, A, invd, lane); break;
+      case 2: ok = band_factor<2>(n, W, A, invd, lane); break;
+      case 3: ok = band_factor<3>(n, W, A, invd, lane); break;
+      case 4: ok = band_factor<4>(n, W, A, invd, lane); break;
+      case 5: case 6: ok = band_factor<6>(n, W, A, invd, lane); break;
+      case 7: case 8: ok = band_factor<8>(n, W, A, invd, lane); break;
+      default: ok = band_factor<13>(n, W, A, invd, lane); break;  // bw <= 40: 820 entries
     }
-    const int ne = (tri + 63) / 64;  // entries per lane in use (uniform)
-    const int o_col = (1 + lane) * Wm + Wm;
-    int jW = 0;  // j * W
-    for (int j = 0; j < n; ++j, jW += W) {
-      const double d = A[jW + Wm];  // band_index(j, j)
-      if (!(d > 0.0) || !isfinite(d)) return false;  // uniform
-      const int m = min(bw, n - j - 1);  // rows below the diagonal inside the band
-      // reads of entries outside this column's triangle (er >= m) stay inside the LDS arrays
-      // (offsets are bounded by the full-band triangle) and are discarded
-      double li[kEnt], lk[kEnt], tg[kEnt];
-#pragma unroll
-      for (int e = 0; e < kEnt; ++e) {
-        if (e < ne) {
-          const int base = min(jW, (n - 1 - bw > 0 ? n - 1 - bw : 0) * W);  // keep the reads in range
-          const bool live = er[e] < m;
-          li[e] = A[(live ? jW : base) + o_li[e]];
-          lk[e] = A[(live ? jW : base) + o_lk[e]];
-          tg[e] = A[(live ? jW : base) + o_tg[e]];
-        }
-      }
-      const double cj = A[min(jW + o_col, kHCap - 1)];
-      const double inv = rsqrt(d);  // l = d * inv, rows *= inv
-#pragma unroll
-      for (int e = 0; e < kEnt; ++e) {
-        if (e < ne) {
-          if (er[e] < m) A[jW + o_tg[e]] = tg[e] - (li[e] * inv) * (lk[e] * inv);
-        }
-      }
-      if (lane < m) A[jW + o_col] = cj * inv;
-      if (lane == 0) {
-        A[jW + Wm] = d * inv;
-        invd[j] = inv;
-      }
-      wave_sync();
-    }
+    if (!ok) return false;
   }
   if (dbg && lane == 0) dbg[9] = __builtin_amdgcn_s_memtime();
   // Substitutions with the vector in registers: lane l holds entries l and l + 64 (n <= 128); the
@@ -1107,20 +1119,40 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S, int lane) {
 __device__ __forceinline__ void reduce_partials(LmShared& S, const double* partials) {
   const LmHead& h = S.h;
   const int t = threadIdx.x;
-  // stripe sum of block b for this thread; the loads of block b + 1 are issued before block b is
-  // combined, so one memory round trip is exposed for the whole window instead of one per block
-  auto stripe_sum = [&](int b) {
+  // Thread (stripe j, column k) of block b sums the partials of workgroups j, j + stripes, ...
+  // The raw loads of block b + 1 are issued before block b is combined (they are only added one
+  // iteration later), so one memory round trip is exposed for the whole window, not one per block.
+  // Blocks with more than 16 * stripes workgroups add the remaining rounds in place.
+  auto issue = [&](int b, double* v) {
+    const BlockInfo& bi = h.blocks[b];
+    const int acc_n = bi.acc;
+    const int stripes = min(static_cast<int>(blockDim.x) / acc_n, kMaxStripes);
+    const int j = t / acc_n, k = t % acc_n;
+    const bool on = j < stripes && bi.active;
+    const double* p = partials + bi.partial_offset + k;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const unsigned idx = j + u * stripes;
+      v[u] = (on && idx < bi.num_wg) ? p[static_cast<size_t>(idx) * acc_n] : 0.0;
+    }
+  };
+  double cur[16], nxt[16];
+  if (h.num_blocks > 0) issue(0, cur);
+  for (int b = 0; b < h.num_blocks; ++b) {
+    if (b + 1 < h.num_blocks) issue(b + 1, nxt);
     const BlockInfo& bi = h.blocks[b];
     const int acc_n = bi.acc;
     const int stripes = min(static_cast<int>(blockDim.x) / acc_n, kMaxStripes);
     const int j = t / acc_n, k = t % acc_n;
     double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += cur[u];
     if (j < stripes && bi.active) {
       const double* p = partials + bi.partial_offset + k;
-      for (unsigned w = j; w < bi.num_wg; w += 16 * stripes) {
+      for (unsigned w = j + 16 * stripes; w < bi.num_wg; w += 16 * stripes) {
         double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {  // 16 independent loads in flight, masked at the end
+        for (int u = 0; u < 16; ++u) {
           const unsigned idx = w + u * stripes;
           v[u] = idx < bi.num_wg ? p[static_cast<size_t>(idx) * acc_n] : 0.0;
         }
@@ -1128,24 +1160,23 @@ __device__ __forceinline__ void reduce_partials(LmShared& S, const double* parti
         for (int u = 0; u < 16; ++u) acc += v[u];
       }
     }
-    return acc;
-  };
-  double next = h.num_blocks > 0 ? stripe_sum(0) : 0.0;
-  for (int b = 0; b < h.num_blocks; ++b) {
-    const double acc = next;
-    if (b + 1 < h.num_blocks) next = stripe_sum(b + 1);
-    const int acc_n = h.blocks[b].acc;
-    const int stripes = min(static_cast<int>(blockDim.x) / acc_n, kMaxStripes);
     double* buf = S.stripe[b & 1];
-    if (t / acc_n < stripes) buf[t] = acc;  // t = j * acc_n + k
+    if (j < stripes) buf[t] = acc;  // t = j * acc_n + k
     __syncthreads();
     if (t < acc_n) {
+      double part[kMaxStripes];
+#pragma unroll
+      for (int jj = 0; jj < kMaxStripes; ++jj)  // all LDS reads in flight; missing stripes add 0
+        part[jj] = jj < stripes ? buf[jj * acc_n + t] : 0.0;
       double sum = 0.0;
-      for (int jj = 0; jj < stripes; ++jj) sum += buf[jj * acc_n + t];
+#pragma unroll
+      for (int jj = 0; jj < kMaxStripes; ++jj) sum += part[jj];
       S.sums[b * kAccU + t] = sum;
     }
     // no second barrier: the next block writes the other buffer, and the barrier of that block
     // orders this block's reads before the buffer is written again
+#pragma unroll
+    for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
   }
   __syncthreads();
 }

@@ -65,8 +65,12 @@ def test_evaluate_interpolated_two_poses(po, hg, ctx, maps):
     compare_evaluate(op, gp)
 
 
+@pytest.mark.parametrize("general_lm", [False, True])
 @pytest.mark.parametrize("levels,multi", [([1], False), ([0, 1, 2], True)])
-def test_solve_single_pose(po, hg, ctx, maps, levels, multi):
+def test_solve_single_pose(po, hg, ctx, maps, levels, multi, general_lm, monkeypatch):
+    """Both LM tails: the register-resident single-pose step and (HG_LM_GENERAL=1) the general one."""
+    if general_lm:
+        monkeypatch.setenv("HG_LM_GENERAL", "1")
     truth, pts, guess = query()
     op, gp = both_problems(po, hg, ctx, maps, levels, multi, pts, [guess], [False])
     so, sg = op.solve(), gp.solve()
