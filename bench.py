@@ -37,7 +37,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3)
     ap.add_argument("--max-blocks", type=int, default=1 << 18)
-    ap.add_argument("--workload", default="register", choices=["register", "insert_stream"],
+    ap.add_argument("--window", type=int, default=10, help="control points of --workload window")
+    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window"],
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
@@ -187,9 +188,105 @@ def run_insert_stream(args):
     }
 
 
+def window_problem(pr, synth, first, n_cp, clouds, pyramid, n_pts):
+    """OptimizingLocalTrajectoryBuilder-shaped problem: n_cp control points (first constant,
+    oltb.cc:1268-1275) with velocities, IMU pre-integration + odometry blocks between neighbours
+    (:928-1074), one multi-resolution scan block per free control point (:343-364)."""
+    for i in range(n_cp):
+        k = first + i
+        tq = synth.pose_k(k) if i == 0 else synth.pose_mul(synth.pose_k(k), synth.perturbation())
+        pr.add_pose(tq, i == 0)
+        pr.set_velocity(i, np.array([0.5, 0.2, 0.0]), i == 0)
+    for i in range(1, n_cp):
+        k = first + i
+        delta = synth.pose_mul(synth.pose_inverse(synth.pose_k(k)), synth.pose_k(k - 1))
+        dq = synth.pose_mul(synth.pose_inverse(synth.pose_k(k - 1)), synth.pose_k(k))[3:]
+        pr.add_odometry_block(i - 1, i, 12.0, 30.0, delta)
+        pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, dq)
+        pr.add_block(clouds[i - 1], pyramid, 1.0 / np.sqrt(float(n_pts)), i, multi_res=True)
+
+
+def run_window(args):
+    """Sliding-window registration (the OptimizingLocalTrajectoryBuilder shape): every step solves
+    a window of --window control points over (window - 1) 100k-point scans against the 3-resolution
+    TSDF, then inserts the scan that leaves the window at its solved pose. Extra workload, not the
+    headline metric."""
+    import torch
+    from hectorgrapher_amd import api, synth
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0)
+    n_pts = args.rings * args.cols
+    n_cp = args.window
+    map_scans = make_scans(args.rings, args.cols, 0, args.map_scans, 0)
+    total = args.warmup + args.steps
+    # poses beyond k = 60 leave the folded range of make_scans: keep windows inside [map_scans, 60]
+    scans = [synth.generate_scan(synth.pose_k(args.map_scans + j), args.rings, args.cols, stream=args.map_scans + j)
+             for j in range(total + n_cp)]
+    grids = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+    inserters = [api.TSDFRangeDataInserter3D() for _ in grids]
+    for pose, pts in map_scans:
+        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                           pose_tq=pose.astype(np.float32))
+    d_scans = [torch.from_numpy(p).to(dev) for p in scans]
+    torch.cuda.synchronize()
+    problem = api.Problem(ctx)
+    its = []
+
+    def step(s):
+        problem.reset()
+        first = args.map_scans - 1 + s  # control point 0 sits on the last inserted scan
+        window_problem(problem, synth, first, n_cp, d_scans[s:s + n_cp - 1], grids, n_pts)
+        summ = problem.solve()
+        its.append(summ.num_iterations)
+        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d_scans[s]), grids,
+                           pose_tq=problem.get_pose(1).astype(np.float32), want_stats=False)
+
+    for s_ in range(args.warmup):
+        step(s_)
+    its.clear()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(args.warmup, total):
+        step(s_)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    base = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        og = [po.Grid(r) for r in RESOLUTIONS]
+        for pose, pts in map_scans:
+            loc = synth.transform_points(pose, pts)
+            for g in og:
+                g.insert(pose[:3], loc)
+        t1 = time.perf_counter()
+        pr = po.Problem()
+        window_problem(pr, synth, args.map_scans - 1, n_cp, scans[:n_cp - 1], og, n_pts)
+        so = pr.solve()
+        est = pr.get_pose(1)
+        loc = synth.transform_points(est, scans[0])
+        for g in og:
+            g.insert(est[:3].astype(np.float32), loc)
+        cpu_s = time.perf_counter() - t1
+        base = {"value": 1.0 / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
+                "sample": "1 window of the same workload (solve %d iterations + insert), oracle -O3 1 thread" % so.num_iterations}
+    return {
+        "metric": "scans/s (sliding window of %d control points over %d x 100k-pt scans, 3-res TSDF)" % (n_cp, n_cp - 1),
+        "value": args.steps / elapsed, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "window: %d control points (81 free columns at 10), %d multi-res scan blocks + IMU/odometry blocks per solve, exact insert of the scan leaving the window"
+                               % (n_cp, n_cp - 1), "mean_lm_iterations": float(np.mean(its))},
+        "roofline": None, "cpu_baseline": base,
+        "gpu_over_cpu": (args.steps / elapsed) / base["value"] if base else None,
+    }
+
+
 def run(args):
     if args.workload == "insert_stream":
         return run_insert_stream(args)
+    if args.workload == "window":
+        return run_window(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
