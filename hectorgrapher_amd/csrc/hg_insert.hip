@@ -432,6 +432,7 @@ struct PyramidIns {
   ScanTable scan0;  // the scan when a call carries exactly one (no table upload needed)
   const double* d_pose;  // optional: pose (t xyz, q wxyz, fp64) in device memory, e.g. the pose a
                          // solve left there; cast to float as Rigid3d::cast<float>() does
+  int accumulate;        // not the first chunk of a call: hit / update counters add up
 };
 
 enum : uint32_t { kFlagStride = 4u };
@@ -684,8 +685,9 @@ __global__ void k_sum_stats(PyramidIns P, const unsigned* wg_hits, unsigned n_ex
       __syncthreads();
     }
     if (threadIdx.x == 0) {
-      P.lv[l].g.counters[2] = static_cast<uint32_t>(hs);
-      if (wg_updates) *reinterpret_cast<unsigned long long*>(&P.lv[l].g.counters[4]) = red[0];
+      unsigned long long* upd = reinterpret_cast<unsigned long long*>(&P.lv[l].g.counters[4]);
+      P.lv[l].g.counters[2] = static_cast<uint32_t>(hs) + (P.accumulate ? P.lv[l].g.counters[2] : 0u);
+      if (wg_updates) *upd = red[0] + (P.accumulate ? *upd : 0ull);
     }
     __syncthreads();
   }
@@ -959,7 +961,8 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
   if (threadIdx.x == 0) {
     L.g.counters[7] = min(s_work, L.g.work_capacity);  // consumed by k_bin_apply
     L.g.counters[6] = 0;                                // next call collects from scratch
-    *reinterpret_cast<unsigned long long*>(&L.g.counters[4]) = s_base;  // U of this call
+    unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
+    *upd = s_base + (P.accumulate ? *upd : 0ull);  // U of this call
   }
 }
 
@@ -1700,7 +1703,10 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     if (!(reach / (8.0 * res) < 62.0)) key32 = false;
   }
 
-  // chunk by scans so the record workspace stays bounded
+  // chunk by scans so the record workspace stays bounded; when the binned path applies every scan
+  // is its own chunk (same per-voxel chain length as one sorted batch, without the global sort)
+  const char* force_sort = getenv("HG_INSERT_SORT");
+  const bool binned_ok = fixed_ok && unit_weight && !(force_sort && force_sort[0] == '1');
   const unsigned long long kMaxChunkPoints = 4ull << 20;
   std::vector<ScanTable> table;
   size_t s0 = 0;
@@ -1709,7 +1715,8 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     size_t s1 = s0;
     unsigned long long pts = 0;
     table.clear();
-    while (s1 < n_scans && (s1 == s0 || pts + (scan_offsets[s1 + 1] - scan_offsets[s1]) <= kMaxChunkPoints)) {
+    while (s1 < n_scans && (s1 == s0 || (!(binned_ok && pts < (1ull << 20)) &&
+                                         pts + (scan_offsets[s1 + 1] - scan_offsets[s1]) <= kMaxChunkPoints))) {
       ScanTable t;
       t.begin = scan_offsets[s1] - scan_offsets[s0];
       t.count = scan_offsets[s1 + 1] - scan_offsets[s1];
@@ -1732,11 +1739,10 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
       const unsigned long long first = scan_offsets[s0] - scan_offsets[0];
       PyramidIns Pc = P;
       Pc.scan0 = table[0];
+      Pc.accumulate = s0 > 0 ? 1 : 0;
       for (int l = 0; l < levels; ++l)
         if (Pc.lv[l].gate) Pc.lv[l].gate += first;
-      const char* force_sort = getenv("HG_INSERT_SORT");
-      if (fixed_ok && unit_weight && table.size() == 1 && pts < (1ull << 20) &&
-          !(force_sort && force_sort[0] == '1')) {
+      if (binned_ok && table.size() == 1 && pts < (1ull << 20)) {
         rc = insert_chunk_binned(c, Pc, d_xyz + 3 * first, pts, stats != nullptr);
       } else if (fixed_ok) {
         const bool ws = stats != nullptr;
