@@ -1203,7 +1203,7 @@ __device__ __forceinline__ void assemble(LmShared& S, const BlockXform* xf, cons
         const int c1 = idx / 12, c2 = idx % 12;
         const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
         const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
-        if (g1 < 0 || g2 < 0 || g2 > g1) continue;  // lower band only
+        if (g1 < 0 || g2 < 0 || g2 > g1 || g1 - g2 >= W) continue;  // lower band only
         const int lo = c1 < c2 ? c1 : c2, hi = c1 < c2 ? c2 : c1;
         S.Hc[band_index(g1, g2, W)] += sm[lo * 12 - (lo * (lo - 1)) / 2 + (hi - lo)];
       }
@@ -1243,7 +1243,7 @@ __device__ __forceinline__ void assemble(LmShared& S, const BlockXform* xf, cons
           v += t * M[l * 12 + c2];
         }
         const int hi_g = g1 > g2 ? g1 : g2, lo_g = g1 > g2 ? g2 : g1;
-        S.Hc[band_index(hi_g, lo_g, W)] += v;  // unique per lane within this block
+        if (hi_g - lo_g < W) S.Hc[band_index(hi_g, lo_g, W)] += v;  // unique per lane within this block
       } else {
         const int c1 = it - ne;
         const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
@@ -1298,7 +1298,9 @@ __device__ __forceinline__ void assemble(LmShared& S, const BlockXform* xf, cons
         const int idx = lane + u * kLmThreads;
         if (idx < 18 * 18) {
           const int g1 = S.colmap[idx / 18], g2 = S.colmap[idx % 18];
-          if (g1 >= 0 && g2 >= 0 && g2 <= g1) S.Hc[band_index(g1, g2, W)] += cur[u];
+          // entries beyond the band are structural zeros (an odometry block has no velocity
+          // columns); their band address would alias another entry, so they must be skipped
+          if (g1 >= 0 && g2 >= 0 && g2 <= g1 && g1 - g2 < W) S.Hc[band_index(g1, g2, W)] += cur[u];
         }
       }
       if (lane < 18) {

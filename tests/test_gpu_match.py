@@ -392,3 +392,28 @@ def test_band_capacity_is_reported(hg, ctx, maps):
     p.add_block(pts, [gg[1]], 1.0, 1, 9, 0.5)
     with pytest.raises(hg.HgError):
         p.evaluate()
+
+
+def test_free_velocity_without_imu_block(po, hg, ctx, maps):
+    """A velocity parameter block that no residual touches (odometry only): its columns are zero and
+    lie outside the band of the coupled columns; the band assembly must skip, not alias, them."""
+    og, gg = maps
+    op, gp = po.Problem(), hg.Problem(ctx)
+    for i in range(2):
+        tq = synth.pose_k(2 + i) if i == 0 else synth.pose_mul(synth.pose_k(2 + i), synth.perturbation())
+        for pr in (op, gp):
+            pr.add_pose(tq, i == 0)
+            pr.set_velocity(i, np.array([0.5, 0.2, 0.0]), i == 0)
+    pts = synth.generate_scan(synth.pose_k(3), 16, 40, stream=77)
+    s = 1.0 / np.sqrt(len(pts))
+    op.add_block(pts, og, s, 1, -1, 0.0, True)
+    gp.add_block(pts, gg, s, 1, -1, 0.0, True)
+    delta = synth.pose_mul(synth.pose_inverse(synth.pose_k(3)), synth.pose_k(2))
+    for pr in (op, gp):
+        pr.add_odometry_block(0, 1, 12.0, 30.0, delta)
+    assert gp.num_columns() == 9
+    compare_evaluate(op, gp)
+    so, sg = op.solve(), gp.solve()
+    assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
+    a, b = op.get_pose(1), gp.get_pose(1)
+    assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M and rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
