@@ -189,7 +189,8 @@ void* hg_ctx_stream(hg_ctx* c) { return c ? static_cast<void*>(c->stream) : null
 
 int hg_prof_enable(hg_ctx* c, int on) {
   if (!c) return HG_ERR_INVALID;
-  prof_resolve(c);
+  // only a flag: pending event pairs are resolved (stream synchronisation) by read / reset, so
+  // sampling can be switched on and off between steps without stalling the stream
   c->prof_on = on != 0;
   return HG_OK;
 }

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -2884,8 +2885,17 @@ int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
   if (!p || !grids || !iopts || !origin || pose_index < 0 ||
       pose_index >= static_cast<int>(p->poses.size()))
     return HG_ERR_INVALID;
+#ifdef HG_HOST_STAMPS
+  static double acc[4] = {0, 0, 0, 0};
+  static int calls = 0;
+  static std::chrono::steady_clock::time_point last_ret;
+  const auto h0 = std::chrono::steady_clock::now();
+#endif
   int rc = hg_problem_solve_async(p, sopts);
   if (rc != HG_OK) return rc;
+#ifdef HG_HOST_STAMPS
+  const auto h1 = std::chrono::steady_clock::now();
+#endif
   // insertion at the pose the solve leaves in device memory; the host only knows the initial
   // guess, which sizes the key window
   float approx[7];
@@ -2894,9 +2904,26 @@ int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
   const uint64_t offsets[2] = {0, n};
   rc = pyramid_insert_impl(grids, iopts, levels, origin, xyz, offsets, 1, width, approx, d_pose,
                            HG_INSERT_EXACT, memspace, nullptr);
+#ifdef HG_HOST_STAMPS
+  const auto h2 = std::chrono::steady_clock::now();
+#endif
   const int rc2 = hg_problem_fetch(p, summary);
   if (rc == HG_OK) rc = rc2;
   if (rc == HG_OK && pose_out) std::memcpy(pose_out, p->poses[pose_index].data(), sizeof(double) * 7);
+#ifdef HG_HOST_STAMPS
+  {
+    const auto h3 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    if (calls > 0) acc[0] += us(last_ret, h0);
+    acc[1] += us(h0, h1); acc[2] += us(h1, h2); acc[3] += us(h2, h3);
+    last_ret = h3;
+    if (++calls % 20 == 0) {
+      fprintf(stderr, "host per step (us): outside call %.1f, enqueue solve %.1f, enqueue insert %.1f, wait for pose %.1f\n",
+              acc[0] / 20, acc[1] / 20, acc[2] / 20, acc[3] / 20);
+      acc[0] = acc[1] = acc[2] = acc[3] = 0;
+    }
+  }
+#endif
   return rc;
 }
 
