@@ -123,7 +123,7 @@ static void prof_resolve(hg_ctx* c) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
       c->prof_ms[r.kernel] += ms;
-      c->prof_launches[r.kernel] += 1;
+      c->prof_launches[r.kernel] += r.launches;
       c->prof_units[r.kernel] += r.units;
     }
     c->prof_free_events.push_back(r.start);

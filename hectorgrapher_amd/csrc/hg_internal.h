@@ -56,6 +56,7 @@ struct ProfRecord {
   int kernel;
   unsigned long long units;
   hipEvent_t start, stop;
+  unsigned launches = 1;  // back-to-back launches bracketed by this pair
 };
 }  // namespace hg
 
@@ -83,11 +84,15 @@ namespace hg {
 struct ProfScope {
   hg_ctx* c;
   hipEvent_t stop = nullptr;
-  ProfScope(hg_ctx* ctx, int kernel, unsigned long long units) : c(ctx) {
-    if (!c->prof_on) return;
+  // `launches` back-to-back launches of the same kernel may share one event pair (every event
+  // costs ~4 us of stream serialisation); `enabled` = false makes the scope a no-op.
+  ProfScope(hg_ctx* ctx, int kernel, unsigned long long units, unsigned launches = 1, bool enabled = true)
+      : c(ctx) {
+    if (!c->prof_on || !enabled) return;
     ProfRecord r;
     r.kernel = kernel;
     r.units = units;
+    r.launches = launches;
     auto get = [&]() {
       hipEvent_t e = nullptr;
       if (!c->prof_free_events.empty()) {

@@ -2266,6 +2266,7 @@ struct hg_problem {
   PinBox* d_box = nullptr;   // its device address
   unsigned long long seq = 0;
   unsigned up_words = 0;
+  bool prof_grouped = false;  // the residual launches of this solve share one event pair
   LmState h_state;            // host copy
 };
 
@@ -2418,7 +2419,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
                            std::getenv("HG_LM_GENERAL") == nullptr) ? 1 : 0;
   if (p->num_eval >= 2) {
     // all blocks of the window in one launch per iteration
-    ProfScope ps(p->ctx, HG_K_RESIDUALS, 0);
+    ProfScope ps(p->ctx, HG_K_RESIDUALS, 0, 1, !p->prof_grouped);
     hipLaunchKernelGGL(k_tsdf_residuals_multi, dim3(total_wg), dim3(kEvalThreads), 0, s, p->d_eval,
                        p->num_eval, d_residuals, p->d_state, p->d_xf, p->partials.as<double>(),
                        p->d_small, fused_lm ? p->d_ticket : nullptr, total_wg);
@@ -2434,7 +2435,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
     pv.levels = static_cast<int>(hb.pyramid.size());
     pv.multi_res = hb.multi_res;
     for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
-    ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n);
+    ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n, 1, !p->prof_grouped);
     if (hb.d_factor) {
       hipLaunchKernelGGL(k_tsdf_residuals_unwarp, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
                          hb.d_xyz, hb.d_factor, bi.n, bi.scaling, bi.pose_a, bi.pose_b,
@@ -2758,7 +2759,21 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
   hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
   HG_HIP_CHECK(hipGetLastError());
   bool any_active = false;
-  for (int b = 0; b < S0.num_blocks; ++b) any_active = any_active || S0.blocks[b].active;
+  unsigned launches_per_it = 0;
+  unsigned long long units_per_it = 0;
+  for (int b = 0; b < S0.num_blocks; ++b) {
+    any_active = any_active || S0.blocks[b].active;
+    if (S0.blocks[b].active) {
+      ++launches_per_it;
+      units_per_it += S0.blocks[b].n;
+    }
+  }
+  if (p->num_eval >= 2) launches_per_it = 1;
+  // without odometry / IMU launches in between, the residual launches of the solve are
+  // back-to-back: one event pair brackets all of them
+  p->prof_grouped = any_active && S0.num_small == 0;
+  ProfScope group(p->ctx, HG_K_RESIDUALS, units_per_it * (max_it + 1), launches_per_it * (max_it + 1),
+                  p->prof_grouped);
   for (int it = 0; it <= max_it; ++it) {
     if (!any_active && S0.num_small > 0) {
       hipLaunchKernelGGL(k_small_blocks, dim3(S0.num_small), dim3(kWave), 0, s, p->d_state, p->d_small,
@@ -2775,6 +2790,7 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
       HG_HIP_CHECK(hipGetLastError());
     }
   }
+  p->prof_grouped = false;
   return HG_OK;
 }
 
