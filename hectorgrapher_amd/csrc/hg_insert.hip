@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
                                                    RunInfo* runs, unsigned* wg_hits) {
   const int level = blockIdx.y;
   const LevelIns& L = P.lv[level];
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;  // see hg_device.h
   const int lane = threadIdx.x & (kWave - 1);
   __shared__ unsigned s_hits;
   if (threadIdx.x == 0) s_hits = 0;
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const float* 
                                                      uint32_t* rec_vals) {
   const int level = blockIdx.y;
   const LevelIns& L = P.lv[level];
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
   if (i >= n) return;
   const RunInfo info = runs[static_cast<size_t>(level) * n + i];
   if (info.packed == 0u) return;

@@ -400,20 +400,6 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const double* 
   row8[7] = r;
 }
 
-// Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8), and each
-// XCD has its own L2. Consecutive returns of a scan touch the same voxel blocks, so workgroup b is
-// given the returns of a contiguous eighth of the block per XCD instead of chunk b: the lines an
-// XCD's workgroups share then live in ONE L2 instead of being replicated in all eight. A bijection
-// on [0, num_wg); the partial sums keep the order of the returns, so results do not change.
-__device__ inline unsigned xcd_chunk(unsigned b, unsigned num_wg) {
-  const unsigned x = b & 7u, k = b >> 3;
-  // workgroups with b % 8 == y: (num_wg - y + 7) / 8
-  unsigned start = 0;
-#pragma unroll
-  for (unsigned y = 0; y < 8; ++y) start += (y < x) ? (num_wg + 7u - y) / 8u : 0u;
-  return start + k;
-}
-
 // residuals of one block at its current transform + 36 partial sums per workgroup
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
