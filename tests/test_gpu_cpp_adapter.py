@@ -1,0 +1,28 @@
+"""The header-only C++ host layer (hectorgrapher_amd/cpp/hg_adapter.h) over the C ABI: the example
+drives a LocalTrajectoryBuilder3D-shaped builder (AddRangeData per scan: match + insert)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "hectorgrapher_amd", "cpp")
+
+
+def test_cpp_local_trajectory_builder_example():
+    exe = os.path.join(CPP, "example_local_slam")
+    if not os.path.exists(exe):   # built by __graft_entry__.build(); rebuild if the tree is fresh
+        subprocess.check_call(["g++", "-std=c++11", "-O2", os.path.join(CPP, "example_local_slam.cc"),
+                               "-L" + os.path.join(ROOT, "hectorgrapher_amd"), "-lhg_mi355x",
+                               "-Wl,-rpath," + os.path.join(ROOT, "hectorgrapher_amd"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    poses = [tuple(float(v) for v in m.groups())
+             for m in re.finditer(r"scan \d+ pose (\S+) (\S+) (\S+)", out.stdout)]
+    assert len(poses) == 5
+    # the sensor moves 5 cm per scan along x; the matched poses follow it
+    for k, (x, y, z) in enumerate(poses):
+        assert abs(x - 0.05 * k) < 0.02 and abs(y) < 0.02 and abs(z) < 0.03
