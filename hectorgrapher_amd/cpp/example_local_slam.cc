@@ -31,6 +31,38 @@ int main() {
       auto result = builder.AddRangeData("lidar", scan);
       if (result) std::printf("scan %d pose %.4f %.4f %.4f\n", k, result->local_pose[0], result->local_pose[1], result->local_pose[2]);
     }
+    // the same trajectory through the sliding-window builder (OptimizingLocalTrajectoryBuilder
+    // shape): window of 3 control points, odometry with an alternating +-1 cm error
+    mapping::OptimizingLocalTrajectoryBuilder::Options wopt;
+    wopt.window = 3;
+    mapping::OptimizingLocalTrajectoryBuilder wbuilder(&ctx, wopt);
+    for (int k = 0; k < 8; ++k) {
+      sensor::TimedPointCloudData scan;
+      scan.time = 0.1 * k;
+      const float sx = 0.05f * k;
+      for (int c = 0; c < 360; ++c)
+        for (int r = 0; r < 16; ++r) {
+          const float az = 6.2831853f * c / 360.f, el = (-15.f + 2.f * r) * 0.01745329f;
+          const float d[3] = {std::cos(el) * std::cos(az), std::cos(el) * std::sin(az), std::sin(el)};
+          float t = 1e9f;
+          const float lo[3] = {-5.f - sx, -4.f, -1.f}, hi[3] = {5.f - sx, 4.f, 3.f};
+          for (int a = 0; a < 3; ++a) {
+            if (d[a] > 1e-6f) t = std::fmin(t, hi[a] / d[a]);
+            if (d[a] < -1e-6f) t = std::fmin(t, lo[a] / d[a]);
+          }
+          scan.ranges.push_back({{d[0] * t, d[1] * t, d[2] * t, 0.f}});
+        }
+      sensor::OdometryData odom;
+      odom.time = scan.time;
+      // (a small lateral offset keeps the predictions off the exact symmetry axis of this synthetic
+      // room, where returns sit exactly on voxel boundaries and the interpolated TSDF cost jumps)
+      odom.pose = Pose{{0.05 * k + ((k & 1) ? 0.01 : -0.01), 0.0013 * (k + 1), 0.0007 * (k + 1), 1.0, 0.0, 0.0, 0.0}};
+      wbuilder.AddOdometryData(odom);
+      auto result = wbuilder.AddRangeData("lidar", scan);
+      if (result)
+        std::printf("window scan %d pose %.4f %.4f %.4f (window %zu)\n", k, result->local_pose[0], result->local_pose[1],
+                    result->local_pose[2], wbuilder.window_size());
+    }
   } catch (const Error& e) {
     std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
     return 1;

@@ -386,6 +386,130 @@ class LocalTrajectoryBuilder3D {
   int num_scans_ = 0;
 };
 
+// OptimizingLocalTrajectoryBuilder-shaped driver (mapping/internal/3d/optimizing_local_trajectory_builder.cc):
+// a sliding window of control points is re-optimised on every scan — AddRangeData (:188-264) queues the
+// cloud and adds a control point, MaybeOptimize (:1114-1413) builds one problem over the window (first
+// state constant :1268-1275, one TSDF block per scan :323-511, odometry blocks between neighbours
+// :1009-1074), solves it on the device, and the scans that leave the window are inserted into the map at
+// their optimised poses (:1332-1404). One control point per scan (the reference spaces them by
+// ct_window_rate and interpolates; that is hg_problem_add_block's pose_b / interpolation_ratio).
+class OptimizingLocalTrajectoryBuilder {
+ public:
+  typedef LocalTrajectoryBuilder3D::MatchingResult MatchingResult;
+  typedef LocalTrajectoryBuilder3D::InsertionResult InsertionResult;
+  struct Options : LocalTrajectoryBuilder3D::Options {
+    int window = 5;  // control points kept in the window (ct_window_horizon / ct_window_rate)
+    double odometry_translation_weight = 1.0, odometry_rotation_weight = 1.0;  // trajectory_builder_3d.lua:126-127
+  };
+
+  OptimizingLocalTrajectoryBuilder(Context* ctx, const Options& options) : ctx_(ctx), options_(options) {
+    for (float r : options.resolutions)
+      grids_.emplace_back(new HybridGridTSDF(ctx, r, options.relative_truncation_distance, options.maximum_weight,
+                                             options.max_blocks));
+    Check(hg_problem_create(ctx->get(), &problem_), "hg_problem_create");
+    hg_solver_default_opts(&solver_);
+    solver_.max_num_iterations = options.max_num_iterations;
+  }
+  ~OptimizingLocalTrajectoryBuilder() { if (problem_) hg_problem_destroy(problem_); }
+
+  void AddImuData(const sensor::ImuData&) {}  // pre-integration is host code: hg_problem_add_imu_block takes its result
+  void AddOdometryData(const sensor::OdometryData& odom) { last_odom_ = odom; have_odom_ = true; }
+
+  std::unique_ptr<MatchingResult> AddRangeData(const std::string& /*sensor_id*/,
+                                               const sensor::TimedPointCloudData& data) {
+    ControlPoint cp;
+    cp.time = data.time;
+    cp.origin = data.origin;
+    for (const auto& p : data.ranges) {  // range crop (:214-227)
+      const float dx = p[0] - data.origin[0], dy = p[1] - data.origin[1], dz = p[2] - data.origin[2];
+      const float r = std::sqrt(dx * dx + dy * dy + dz * dz);
+      if (r >= options_.min_range && r <= options_.max_range) cp.cloud.push_back(Point{{p[0], p[1], p[2]}});
+    }
+    if (cp.cloud.empty()) return nullptr;
+    cp.has_odom = have_odom_;
+    if (have_odom_) cp.odom = last_odom_.pose;
+    // prediction: odometry delta, else constant velocity, else the previous pose (:266-321)
+    if (window_.empty()) cp.pose = Pose{{0, 0, 0, 1, 0, 0, 0}};
+    else if (cp.has_odom && window_.back().has_odom)
+      cp.pose = transform::Multiply(window_.back().pose, transform::Multiply(transform::Inverse(window_.back().odom), cp.odom));
+    else if (window_.size() >= 2)
+      cp.pose = transform::Multiply(window_.back().pose,
+                                    transform::Multiply(transform::Inverse(window_[window_.size() - 2].pose), window_.back().pose));
+    else cp.pose = window_.back().pose;
+    window_.push_back(std::move(cp));
+
+    std::vector<hg_grid*> pyr;
+    for (auto& g : grids_) pyr.push_back(g->get());
+    if (map_has_data_) {
+      // MaybeOptimize: one problem over the window
+      Check(hg_problem_reset(problem_), "hg_problem_reset");
+      for (size_t i = 0; i < window_.size(); ++i)
+        Check(hg_problem_add_pose(problem_, window_[i].pose.data(), i == 0 && window_.size() > 1), "hg_problem_add_pose");
+      for (size_t i = (window_.size() > 1 ? 1 : 0); i < window_.size(); ++i) {
+        const std::vector<Point>& c = window_[i].cloud;
+        Check(hg_problem_add_block(problem_, c[0].data(), c.size(), HG_HOST, pyr.data(), static_cast<int>(pyr.size()),
+                                   pyr.size() > 1, options_.high_resolution_grid_weight / std::sqrt(double(c.size())),
+                                   static_cast<int>(i), -1, 0.0), "hg_problem_add_block");
+        if (i > 0 && window_[i].has_odom && window_[i - 1].has_odom) {
+          // RelativeTranslationAndYawCostFunction: delta = inverse(next odometry) * previous (:1025-1029)
+          const Pose delta = transform::Multiply(transform::Inverse(window_[i].odom), window_[i - 1].odom);
+          Check(hg_problem_add_odometry_block(problem_, static_cast<int>(i) - 1, static_cast<int>(i),
+                                              options_.odometry_translation_weight, options_.odometry_rotation_weight,
+                                              delta.data()), "hg_problem_add_odometry_block");
+        }
+      }
+      hg_solver_summary summary;
+      Check(hg_problem_solve(problem_, &solver_, &summary), "hg_problem_solve");
+      for (size_t i = 0; i < window_.size(); ++i)
+        Check(hg_problem_get_pose(problem_, static_cast<int>(i), window_[i].pose.data()), "hg_problem_get_pose");
+    }
+    std::unique_ptr<MatchingResult> result(new MatchingResult);
+    result->time = data.time;
+    result->local_pose = window_.back().pose;
+    result->range_data_in_local.origin = data.origin;
+    // scans leaving the window (and the very first scan, which seeds the map) are inserted
+    while (!window_.empty() && (!map_has_data_ || static_cast<int>(window_.size()) > options_.window)) {
+      ControlPoint& out = window_.front();
+      if (!out.inserted) {
+        std::vector<hg_insert_opts> opts(grids_.size(), options_.inserter);
+        const std::array<float, 7> pf = transform::ToFloat(out.pose);
+        Check(hg_pyramid_insert(pyr.data(), opts.data(), static_cast<int>(pyr.size()), out.origin.data(),
+                                out.cloud[0].data(), out.cloud.size(), 0, pf.data(), HG_INSERT_EXACT, HG_HOST, nullptr),
+              "hg_pyramid_insert");
+        out.inserted = true;
+        std::unique_ptr<InsertionResult> ins(new InsertionResult);
+        for (auto& g : grids_) ins->insertion_grids.push_back(g.get());
+        result->insertion_result = std::move(ins);
+      }
+      if (!map_has_data_) {  // keep the seeding scan as the constant first state of the next windows
+        map_has_data_ = true;
+        break;
+      }
+      window_.erase(window_.begin());
+    }
+    return result;
+  }
+  const std::vector<std::unique_ptr<HybridGridTSDF>>& grids() const { return grids_; }
+  size_t window_size() const { return window_.size(); }
+
+ private:
+  struct ControlPoint {
+    double time = 0;
+    Pose pose, odom;
+    bool has_odom = false, inserted = false;
+    std::array<float, 3> origin;
+    std::vector<Point> cloud;
+  };
+  Context* ctx_;
+  Options options_;
+  std::vector<std::unique_ptr<HybridGridTSDF>> grids_;
+  hg_problem* problem_ = nullptr;
+  hg_solver_opts solver_;
+  std::vector<ControlPoint> window_;
+  sensor::OdometryData last_odom_{};
+  bool have_odom_ = false, map_has_data_ = false;
+};
+
 }  // namespace mapping
 }  // namespace hg_amd
 #endif  // HG_ADAPTER_H_

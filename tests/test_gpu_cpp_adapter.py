@@ -21,8 +21,17 @@ def test_cpp_local_trajectory_builder_example():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     poses = [tuple(float(v) for v in m.groups())
-             for m in re.finditer(r"scan \d+ pose (\S+) (\S+) (\S+)", out.stdout)]
+             for m in re.finditer(r"^scan \d+ pose (\S+) (\S+) (\S+)", out.stdout, re.M)]
     assert len(poses) == 5
     # the sensor moves 5 cm per scan along x; the matched poses follow it
     for k, (x, y, z) in enumerate(poses):
         assert abs(x - 0.05 * k) < 0.02 and abs(y) < 0.02 and abs(z) < 0.03
+    # sliding-window builder (OptimizingLocalTrajectoryBuilder shape): odometry with an alternating
+    # +-1 cm error (dead reckoning is off by up to 2 cm) and TSDF blocks in a window of 3 control
+    # points; the solved poses stay between the two sources
+    wposes = [tuple(float(v) for v in m.groups())
+              for m in re.finditer(r"^window scan \d+ pose (\S+) (\S+) (\S+)", out.stdout, re.M)]
+    assert len(wposes) == 8
+    for k, (x, y, z) in enumerate(wposes):
+        assert abs(x - 0.05 * k) < 0.021 and abs(y) < 0.02 and abs(z) < 0.02
+    assert "(window 3)" in out.stdout
