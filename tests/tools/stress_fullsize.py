@@ -1,8 +1,8 @@
-"""Full-size exactness check (not part of the product): 100k-point scans along the bench trajectory,
+"""Full-size exactness check (test infrastructure, uses the oracle; not part of the product): 100k-point scans along the bench trajectory,
 including the positions with ~3000-update chains, GPU pyramid insert vs oracle, bit-exact."""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyoracle as po
 from hectorgrapher_amd import api as hg, synth

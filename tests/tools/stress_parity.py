@@ -1,8 +1,8 @@
-"""Randomised parity sweep (GPU vs oracle), broader than the unit tests. Not part of the product.
-usage: python scripts/stress_parity.py [n_insert_cases] [n_solver_cases] [seed]"""
+"""Randomised parity sweep (GPU vs oracle), broader than the unit tests. Test infrastructure (uses the oracle); not part of the product.
+usage: python tests/tools/stress_parity.py [n_insert_cases] [n_solver_cases] [seed]"""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pyoracle as po
 from hectorgrapher_amd import api as hg, synth
