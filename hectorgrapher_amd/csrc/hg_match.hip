@@ -401,11 +401,12 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const double* 
 }
 
 // residuals of one block at its current transform + 36 partial sums per workgroup
+template <int THREADS = kEvalThreads>
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
     double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64], unsigned wg) {
-  const unsigned i = wg * kEvalThreads + threadIdx.x;
+  const unsigned i = wg * THREADS + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   BODY_STAMP(0);
   if (i < n) {
@@ -458,7 +459,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
     }
     double s = 0.0;
 #pragma unroll
-    for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += cs[wv][a * 8 + b];
+    for (int wv = 0; wv < THREADS / kWave; ++wv) s += cs[wv][a * 8 + b];
     partials[static_cast<size_t>(wg) * kAcc + threadIdx.x] = s;
   }
   BODY_STAMP(5);
@@ -2078,7 +2079,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
     PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
     double* __restrict__ residuals, LmState* G, BlockXform* xf_all, const double* partials_all,
-    const SmallOut* small_out, unsigned* ticket, unsigned total_wg, int single_pose) {
+    const SmallOut* small_out, unsigned* ticket, unsigned total_wg) {
   if (G && G->h.done) return;
 #ifdef HG_EVAL_STAMPS
   const int eval_it = G ? G->h.iteration : -1;
@@ -2113,10 +2114,51 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
   }
   __syncthreads();
   EVAL_STAMP(2);
-  if (single_pose)
-    lm_step_single(reinterpret_cast<double*>(smem), G, xf_all, partials_all, total_wg);
-  else
-    lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
+  lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
+  EVAL_STAMP(3);
+}
+
+// The single-pose registration step (one free pose, one per-scan block): the same evaluation with
+// the register-resident LM step in the tail, in a kernel of its own so that its LDS footprint is
+// the X tiles (36 KB) instead of the general solver's working set (139 KB). (256-thread workgroups
+// — 391 of them, on all 256 CUs — were measured slower: twice the partials for the tail to sum.)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
+    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
+    const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket) {
+  if (G->h.done) return;
+#ifdef HG_EVAL_STAMPS
+  const int eval_it = G->h.iteration;
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_tail_stamps[7] = eval_it;
+#endif
+  EVAL_STAMP(0);
+  constexpr size_t kTiles = (THREADS / kWave) * (kWave * 8 + 64) * sizeof(double);
+  constexpr size_t kTail = ((THREADS / kAcc) + 1) * kAcc * sizeof(double) + sizeof(LmHead) + 36 * sizeof(double);
+  __shared__ __align__(16) unsigned char smem[kTiles > kTail ? kTiles : kTail];
+  tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, partials, nullptr,
+                               reinterpret_cast<double (*)[kWave][8]>(smem),
+                               reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
+                               xcd_chunk(blockIdx.x, gridDim.x));
+  EVAL_STAMP(1);
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last = (t == gridDim.x - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *ticket = 0u;  // ready for the next iteration's launch
+  }
+  __syncthreads();
+  EVAL_STAMP(2);
+  lm_step_single(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), partials, gridDim.x);
   EVAL_STAMP(3);
 }
 
@@ -2267,6 +2309,7 @@ struct hg_problem {
   unsigned long long seq = 0;
   unsigned up_words = 0;
   bool prof_grouped = false;  // the residual launches of this solve share one event pair
+  int single_threads = 0;      // > 0: single-pose registration step with this workgroup size
   LmState h_state;            // host copy
 };
 
@@ -2301,6 +2344,14 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   S.radius = S.opt.initial_trust_region_radius;
   S.decrease_factor = 2.0;
   S.phase = PHASE_INIT;
+  // register-resident LM tail: one free pose without velocity, one per-scan block, nothing else
+  // (bw and the activity of the block are checked below, once they are known)
+  p->single_threads = 0;
+  if (opts && S.num_poses == 1 && !p->constant[0] && !p->vfree[0] && S.num_blocks == 1 && p->small.empty() &&
+      !p->blocks[0].d_factor && p->blocks[0].pose_b < 0 && p->blocks[0].n > 0 && std::getenv("HG_LM_GENERAL") == nullptr) {
+    p->single_threads = kEvalThreads;  // 256-thread workgroups were measured 19 % slower per step
+  }
+  const unsigned eval_threads = p->single_threads ? static_cast<unsigned>(p->single_threads) : kEvalThreads;
   unsigned wg_off = 0, row = 0;
   for (int b = 0; b < S.num_blocks; ++b) {
     const hg_problem::Block& hb = p->blocks[b];
@@ -2312,7 +2363,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
     bi.n = static_cast<unsigned>(hb.n);
     bi.active = block_active(p, hb) ? 1 : 0;
     bi.acc = hb.d_factor ? kAccU : kAcc;
-    bi.num_wg = bi.active ? (bi.n + kEvalThreads - 1) / kEvalThreads : 0;
+    bi.num_wg = bi.active ? (bi.n + eval_threads - 1) / eval_threads : 0;
     bi.partial_offset = wg_off;
     bi.row_offset = row;
     wg_off += bi.num_wg * bi.acc;
@@ -2412,11 +2463,20 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
   }
   unsigned total_wg = 0;
   for (int b = 0; b < S.num_blocks; ++b) total_wg += S.blocks[b].num_wg;
-  // register-resident LM tail: one free pose without velocity, one per-scan block, nothing else
-  const int single_pose = (S.num_poses == 1 && !S.constant[0] && !S.vfree[0] && S.num_blocks == 1 &&
-                           S.blocks[0].active && S.blocks[0].acc == kAcc && S.blocks[0].pose_b < 0 &&
-                           S.num_small == 0 && S.ncols == 6 && S.bw == 5 &&
-                           std::getenv("HG_LM_GENERAL") == nullptr) ? 1 : 0;
+  if (fused_lm && p->single_threads && S.ncols == 6 && S.bw == 5 && S.blocks[0].active) {
+    const BlockInfo& bi = S.blocks[0];
+    const hg_problem::Block& hb = p->blocks[0];
+    PyramidView pv;
+    std::memset(&pv, 0, sizeof(pv));
+    pv.levels = static_cast<int>(hb.pyramid.size());
+    pv.multi_res = hb.multi_res;
+    for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
+    ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n, 1, !p->prof_grouped);
+    hipLaunchKernelGGL(k_tsdf_residuals_single<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
+                       hb.d_xyz, bi.n, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket);
+    HG_HIP_CHECK(hipGetLastError());
+    return HG_OK;
+  }
   if (p->num_eval >= 2) {
     // all blocks of the window in one launch per iteration
     ProfScope ps(p->ctx, HG_K_RESIDUALS, 0, 1, !p->prof_grouped);
@@ -2451,7 +2511,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
                        p->partials.as<double>() + bi.partial_offset,
                        d_residuals ? d_residuals + bi.row_offset : nullptr,
                        fused_lm ? p->d_state : nullptr, p->d_xf, p->partials.as<double>(),
-                       p->d_small, p->d_ticket, total_wg, single_pose);
+                       p->d_small, p->d_ticket, total_wg);
     HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
