@@ -923,9 +923,59 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
   __syncthreads();
   // two rounds over the touched list: round 0 assigns offsets and emits the work items of large
   // bins (their long per-voxel chains are the critical path, so they are scheduled first),
-  // round 1 emits the rest
+  // round 1 emits the rest. Up to 4096 touched blocks are held in registers (two dependent memory
+  // round trips for the whole list instead of two per 1024-block chunk and round).
+  constexpr int kRegChunks = 4;
+  const bool in_regs = nt <= 1024u * kRegChunks;
+  unsigned r_slot[kRegChunks], r_cnt[kRegChunks];
+  if (in_regs) {
+#pragma unroll
+    for (int c = 0; c < kRegChunks; ++c) {
+      const unsigned i = c * 1024u + threadIdx.x;
+      r_slot[c] = i < nt ? L.g.touched[i] : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < kRegChunks; ++c) {
+      const unsigned i = c * 1024u + threadIdx.x;
+      r_cnt[c] = i < nt ? L.g.bin_count[r_slot[c]] : 0u;
+    }
+  }
   for (int round = 0; round < 2; ++round) {
-    for (unsigned c0 = 0; c0 < nt; c0 += 1024) {
+#pragma unroll
+    for (int c = 0; c < kRegChunks; ++c) {
+      const unsigned c0 = c * 1024u;
+      if (!in_regs || c0 >= nt) break;
+      const unsigned i = c0 + threadIdx.x;
+      const unsigned slot = r_slot[c], cnt = r_cnt[c];
+      unsigned chunk_total = 0;
+      if (round == 0) {
+        const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
+        if (i < nt) L.g.bin_offset[slot] = blockIdx.x * records_per_level + s_base + excl;
+      }
+      const bool large = cnt > 512u;
+      if (i < nt && ((round == 0) == large)) {
+        unsigned slices = 1;
+        while (slices < 64 && cnt > slices * 1024u) slices <<= 1;
+        const unsigned w0 = atomicAdd(&s_work, slices);
+        const unsigned step = 512u / slices;
+        for (unsigned k = 0; k < slices; ++k) {
+          if (w0 + k < L.g.work_capacity)
+            L.g.work[w0 + k] = static_cast<unsigned long long>(slot) |
+                               (static_cast<unsigned long long>(k * step) << 24) |
+                               (static_cast<unsigned long long>((k + 1) * step) << 34) |
+                               (static_cast<unsigned long long>(cnt) << 44);
+          else
+            atomicOr(&L.g.counters[1], kFlagCapacity);
+        }
+      }
+      if (round == 1 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
+      if (round == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += chunk_total;
+        __syncthreads();
+      }
+    }
+    for (unsigned c0 = 0; !in_regs && c0 < nt; c0 += 1024) {
       const unsigned i = c0 + threadIdx.x;
       const unsigned slot = i < nt ? L.g.touched[i] : 0u;
       unsigned cnt = 0;
