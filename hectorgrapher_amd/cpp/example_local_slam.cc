@@ -63,6 +63,23 @@ int main() {
         std::printf("window scan %d pose %.4f %.4f %.4f (window %zu)\n", k, result->local_pose[0], result->local_pose[1],
                     result->local_pose[2], wbuilder.window_size());
     }
+    // ActiveSubmaps3D: two live submaps, a new one every 3 insertions, the old one finished at 6
+    mapping::ActiveSubmaps3D::Options sopt;
+    sopt.num_range_data = 3;
+    sopt.max_blocks = 1u << 14;
+    mapping::ActiveSubmaps3D active(&ctx, sopt);
+    for (int k = 0; k < 7; ++k) {
+      sensor::RangeData rd;
+      rd.origin = Point{{0.05f * k, 0.f, 0.f}};
+      for (int c = 0; c < 360; ++c) {
+        const float az = 6.2831853f * c / 360.f;
+        rd.returns.push_back(Point{{0.05f * k + 3.f * std::cos(az), 3.f * std::sin(az), 0.1f}});
+      }
+      const auto& live = active.InsertData(rd, {{1.0, 0.0, 0.0, 0.0}});
+      std::printf("submaps after insert %d:", k);
+      for (const auto& sm : live) std::printf(" %d%s", sm->num_range_data(), sm->insertion_finished() ? "(finished)" : "");
+      std::printf("\n");
+    }
   } catch (const Error& e) {
     std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
     return 1;

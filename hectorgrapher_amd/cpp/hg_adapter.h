@@ -184,6 +184,75 @@ inline void InsertIntoSubmap(const sensor::RangeData& range_data_in_local, const
                           HG_HOST, nullptr), "hg_pyramid_insert");
 }
 
+// Submap3D + ActiveSubmaps3D for TSDF grids (submap_3d.h:58-141, submap_3d.cc:427-514): every range
+// data goes into all live submaps (at most two); a new submap starts when the newest one holds
+// num_range_data insertions and the oldest is finished — and dropped from the active set — at twice
+// that number. The yaw histogram of the rotational scan matcher is outside the TSDF path.
+class Submap3D {
+ public:
+  Submap3D(Context* ctx, float high_resolution, float low_resolution, const Pose& local_pose,
+           float relative_truncation_distance, float maximum_weight, uint32_t max_blocks)
+      : local_pose_(local_pose),
+        high_(new HybridGridTSDF(ctx, high_resolution, relative_truncation_distance, maximum_weight, max_blocks)),
+        low_(new HybridGridTSDF(ctx, low_resolution, relative_truncation_distance, maximum_weight, max_blocks)) {}
+  const Pose& local_pose() const { return local_pose_; }
+  int num_range_data() const { return num_range_data_; }
+  bool insertion_finished() const { return finished_; }
+  HybridGridTSDF& high_resolution_hybrid_grid() { return *high_; }
+  HybridGridTSDF& low_resolution_hybrid_grid() { return *low_; }
+  void InsertData(const sensor::RangeData& range_data_in_local, const TSDFRangeDataInserter3D& high,
+                  const TSDFRangeDataInserter3D& low) {
+    if (finished_) throw Error("Submap3D::InsertData after Finish", HG_ERR_INVALID);  // CHECK(!insertion_finished())
+    InsertIntoSubmap(range_data_in_local, local_pose_, high, low, high_.get(), low_.get());
+    ++num_range_data_;
+  }
+  void Finish() { finished_ = true; }
+
+ private:
+  Pose local_pose_;
+  std::unique_ptr<HybridGridTSDF> high_, low_;
+  int num_range_data_ = 0;
+  bool finished_ = false;
+};
+
+class ActiveSubmaps3D {
+ public:
+  struct Options {  // proto::SubmapsOptions3D (trajectory_builder_3d.lua:64-117)
+    float high_resolution = 0.10f, low_resolution = 0.45f;
+    int num_range_data = 160;
+    float relative_truncation_distance = 2.5f, maximum_weight = 1000.f;
+    uint32_t max_blocks = 1u << 16;
+    hg_insert_opts high_resolution_inserter = DefaultTSDFInserterOptions();
+    hg_insert_opts low_resolution_inserter = DefaultTSDFInserterOptions();
+  };
+  ActiveSubmaps3D(Context* ctx, const Options& options)
+      : ctx_(ctx), options_(options), high_inserter_(options.high_resolution_inserter),
+        low_inserter_(options.low_resolution_inserter) {}
+  const std::vector<std::shared_ptr<Submap3D>>& submaps() const { return submaps_; }
+  // range_data in the local frame; a new submap is placed at the sensor origin with
+  // `local_from_gravity_aligned` as its orientation (submap_3d.cc:496-501)
+  const std::vector<std::shared_ptr<Submap3D>>& InsertData(const sensor::RangeData& range_data,
+                                                            const std::array<double, 4>& local_from_gravity_aligned) {
+    if (submaps_.empty() || submaps_.back()->num_range_data() == options_.num_range_data) {
+      if (submaps_.size() > 1) submaps_.erase(submaps_.begin());  // AddSubmap: the finished one leaves (:555-559)
+      const Pose origin{{range_data.origin[0], range_data.origin[1], range_data.origin[2], local_from_gravity_aligned[0],
+                         local_from_gravity_aligned[1], local_from_gravity_aligned[2], local_from_gravity_aligned[3]}};
+      submaps_.push_back(std::make_shared<Submap3D>(ctx_, options_.high_resolution, options_.low_resolution, origin,
+                                                    options_.relative_truncation_distance, options_.maximum_weight,
+                                                    options_.max_blocks));
+    }
+    for (auto& submap : submaps_) submap->InsertData(range_data, high_inserter_, low_inserter_);
+    if (submaps_.front()->num_range_data() == 2 * options_.num_range_data) submaps_.front()->Finish();
+    return submaps_;
+  }
+
+ private:
+  Context* ctx_;
+  Options options_;
+  TSDFRangeDataInserter3D high_inserter_, low_inserter_;
+  std::vector<std::shared_ptr<Submap3D>> submaps_;
+};
+
 namespace scan_matching {
 
 struct PointCloudAndGrid {

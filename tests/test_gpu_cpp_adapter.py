@@ -35,3 +35,7 @@ def test_cpp_local_trajectory_builder_example():
     for k, (x, y, z) in enumerate(wposes):
         assert abs(x - 0.05 * k) < 0.021 and abs(y) < 0.02 and abs(z) < 0.02
     assert "(window 3)" in out.stdout
+    # ActiveSubmaps3D bookkeeping (submap_3d.cc:492-514, 548-559) with num_range_data = 3
+    lines = re.findall(r"^submaps after insert (\d+):(.*)$", out.stdout, re.M)
+    assert [l[1].split() for l in lines] == [["1"], ["2"], ["3"], ["4", "1"], ["5", "2"],
+                                             ["6(finished)", "3"], ["4", "1"]]
