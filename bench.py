@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--cpu-scans", type=int, default=3)
     ap.add_argument("--max-blocks", type=int, default=1 << 18)
     ap.add_argument("--window", type=int, default=10, help="control points of --workload window")
-    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window"],
+    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "register_filtered"],
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
@@ -167,6 +167,37 @@ def run_insert_stream(args):
     step(True)
     U = sum(s_.num_updates for s_ in st)
     N_in = sum(s_.num_hits for s_ in st)
+    base = None
+    if not args.no_cpu_baseline:
+        # (i) 1 thread = the reference's single-threaded inserter; (ii) all cores, one
+        # independent submap per thread (ctypes drops the GIL inside the oracle calls)
+        import threading
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        sample = scans[:args.cpu_scans]
+
+        def cpu_insert():
+            og = [po.Grid(r) for r in RESOLUTIONS]
+            for pose, pts in sample:
+                loc = synth.transform_points(pose, pts)
+                for g in og:
+                    g.insert(pose[:3], loc)
+
+        t1 = time.perf_counter()
+        cpu_insert()
+        one = len(sample) / (time.perf_counter() - t1)
+        cores = os.cpu_count() or 1
+        threads = [threading.Thread(target=cpu_insert) for _ in range(cores)]
+        t1 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        allc = cores * len(sample) / (time.perf_counter() - t1)
+        base = {"value": one, "unit": "scans/s", "cores": 1, "kind": "port",
+                "sample": "%d scans x 3 levels into fresh grids, oracle -O3 1 thread" % len(sample),
+                "all_cores": {"value": allc, "cores": cores,
+                              "sample": "one independent submap per thread, %d scans each" % len(sample)}}
     t_fam = sum(prof[k][1] for k in ("ray_count", "scan", "ray_expand", "sort", "alloc", "apply"))
     avg_ms = t_fam / max(1, prof["apply"][0])
     bytes_per = 12.0 * N_in + 8.0 * U
@@ -185,6 +216,8 @@ def run_insert_stream(args):
                      "avg_launch_ms": avg_ms, "algorithmic_bytes_per_step": bytes_per,
                      "per_kernel_ms_total": {k: round(v[1], 3) for k, v in prof.items()},
                      "per_kernel_launches": {k: v[0] for k, v in prof.items()}},
+        "cpu_baseline": base,
+        "gpu_over_cpu": (args.steps * B / elapsed) / base["value"] if base else None,
     }
 
 
@@ -282,9 +315,96 @@ def run_window(args):
     }
 
 
+def run_register_filtered(args):
+    """Context run: the registration step with the reference's Lua-default matching
+    set -- the adaptive voxel filter (max_length 2 m, >= 150 points, max_range 15 m,
+    trajectory_builder_3d.lua:23-27) picks the points the matcher sees; ALL points are inserted at the
+    solved pose. Extra workload, not the headline metric."""
+    import torch
+    from hectorgrapher_amd import api, synth
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0)
+    n_pts = args.rings * args.cols
+    map_scans = make_scans(args.rings, args.cols, 0, args.map_scans, 0)
+    query = make_scans(args.rings, args.cols, args.map_scans, args.warmup + args.steps, 0)
+    grids = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+    inserters = [api.TSDFRangeDataInserter3D() for _ in grids]
+    for pose, pts in map_scans:
+        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                           pose_tq=pose.astype(np.float32))
+    d_scans = [torch.from_numpy(pts).to(dev) for _, pts in query]
+    guesses = [synth.pose_mul(pose, synth.perturbation()) for pose, _ in query]
+    avf = api.AdaptiveVoxelFilter(ctx, 2.0, 150, 15.0)
+    problem = api.Problem(ctx)
+    errs, kept = [], []
+    torch.cuda.synchronize()
+
+    def step(i):
+        idx = avf.Filter(d_scans[i])
+        sel = d_scans[i][torch.from_numpy(idx.astype(np.int64)).to(dev)].contiguous()
+        problem.reset()
+        pi = problem.add_pose(guesses[i])
+        problem.add_block(sel, grids, 1.0 / np.sqrt(float(len(idx))), pi, multi_res=True)
+        est, _ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i]), grids)
+        errs.append(float(np.linalg.norm(est[:3] - query[i][0][:3])))
+        kept.append(len(idx))
+
+    for i in range(args.warmup):
+        step(i)
+    errs.clear()
+    kept.clear()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    base = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        og = [po.Grid(r) for r in RESOLUTIONS]
+        for pose, pts in map_scans:
+            loc = synth.transform_points(pose, pts)
+            for g in og:
+                g.insert(pose[:3], loc)
+        t_cpu, n_cpu = 0.0, 0
+        for pose, pts in query[args.warmup:args.warmup + args.cpu_scans]:
+            guess = synth.pose_mul(pose, synth.perturbation())
+            t1 = time.perf_counter()
+            sel = pts[po.adaptive_voxel_filter(2.0, 150, 15.0, pts)]
+            pr = po.Problem()
+            i = pr.add_pose(guess)
+            pr.add_block(sel, og, 1.0 / np.sqrt(len(sel)), i, multi_res=True)
+            pr.solve()
+            est = pr.get_pose(i)
+            loc = synth.transform_points(est, pts)
+            for g in og:
+                g.insert(est[:3].astype(np.float32), loc)
+            t_cpu += time.perf_counter() - t1
+            n_cpu += 1
+        base = {"value": n_cpu / t_cpu, "unit": "scans/s", "cores": 1, "kind": "port",
+                "sample": "%d scans of the same workload (filter + match + 3-level insert), oracle -O3 1 thread" % n_cpu}
+    return {
+        "metric": "scans/s (100k-pt scan, adaptive-voxel-filtered match + full 3-res TSDF insert)",
+        "value": args.steps / elapsed, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "register_filtered: AdaptiveVoxelFilter(2 m, >=150 pts, 15 m) matching set, "
+                               "multi-res LM match, exact insert of all %d points x3" % n_pts,
+                   "mean_matched_points": float(np.mean(kept)), "mean_pose_error_m": float(np.mean(errs))},
+        "roofline": None, "cpu_baseline": base,
+        "gpu_over_cpu": (args.steps / elapsed) / base["value"] if base else None,
+    }
+
+
 def run(args):
     if args.workload == "insert_stream":
         return run_insert_stream(args)
+    if args.workload == "register_filtered":
+        return run_register_filtered(args)
     if args.workload == "window":
         return run_window(args)
     rank = int(os.environ.get("RANK", "0"))

@@ -57,3 +57,19 @@ def test_device_input_and_gathered_output(po, hg, ctx):
     from hectorgrapher_amd.distributed import _DevArray
     got = torch.as_tensor(_DevArray(xyz.value, (n.value, 3), "<f4"), device="cuda:0").cpu().numpy()
     assert np.array_equal(got, pts[keep])
+
+
+def test_adaptive_voxel_filter_random_sweep(po, hg, ctx):
+    """The device replays the reference's search chain from the pass counts (no host round trips):
+    sweep lengths / thresholds so every exit of the chain is taken (pass-through, max_length enough,
+    bisection after each halving, no length enough)."""
+    rng = np.random.default_rng(11)
+    for case in range(40):
+        n = int(rng.integers(1, 30000))
+        spread = float(rng.choice([0.2, 1.0, 5.0, 20.0]))
+        pts = (rng.standard_normal((n, 3)) * spread).astype(np.float32)
+        opts = (float(rng.choice([0.3, 1.0, 2.0, 4.0])), float(rng.choice([1, 50, 150, 1000, 20000, 1e7])),
+                float(rng.choice([0.5, 5.0, 15.0, 60.0])))
+        a = po.adaptive_voxel_filter(*opts, pts)
+        b = hg.AdaptiveVoxelFilter(ctx, *opts).Filter(pts)
+        assert np.array_equal(a, b), (case, n, spread, opts, len(a), len(b))
