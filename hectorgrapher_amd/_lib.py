@@ -23,7 +23,7 @@ SYMBOLS = [
     "hg_ctx_create", "hg_ctx_destroy", "hg_ctx_synchronize", "hg_ctx_stream", "hg_last_error",
     "hg_version", "hg_prof_enable", "hg_prof_reset", "hg_prof_read", "hg_grid_create", "hg_grid_destroy", "hg_grid_clear", "hg_grid_resolution",
     "hg_grid_set_cells", "hg_grid_read_cells", "hg_grid_count", "hg_grid_export",
-    "hg_grid_num_blocks", "hg_grid_to_proto", "hg_grid_from_proto", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
+    "hg_grid_num_blocks", "hg_grid_to_proto", "hg_grid_from_proto", "hg_grid_xray", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
     "hg_grid_insert_batch", "hg_pyramid_insert", "hg_pyramid_insert_batch", "hg_grid_status",
     "hg_voxel_filter", "hg_adaptive_voxel_filter", "hg_filter_last_device",
     "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
@@ -143,6 +143,7 @@ def load():
     L.hg_grid_num_blocks.argtypes = [vp, P(u32)]
     L.hg_grid_to_proto.argtypes = [vp, vp, sz, P(sz)]
     L.hg_grid_from_proto.argtypes = [vp, vp, sz, u32, P(vp)]
+    L.hg_grid_xray.argtypes = [vp, vp, vp, sz, P(i32), P(i32), vp, P(sz)]
     L.hg_grid_block_arrays.argtypes = [vp, P(vp), P(vp), P(u32)]
     L.hg_grid_import_blocks.argtypes = [vp, vp, vp, u32, i32]
     L.hg_grid_insert.argtypes = [vp, P(InsertOpts), vp, vp, sz, sz, vp, i32, i32, P(InsertStats)]

@@ -209,6 +209,21 @@ class HybridGridTSDF:
         check(self._L.hg_grid_to_proto(self._h, buf, n.value, C.byref(n)), "hg_grid_to_proto")
         return bytes(buf[:n.value])
 
+    def xray(self, global_submap_pose):
+        """AddToTextureProto(HybridGridTSDF) (submap_3d.cc:245-276) without the gzip: returns
+        (cells uint8 [height, width, 2] = value, alpha; max_index xy int32[2])."""
+        pose = np.ascontiguousarray(global_submap_pose, np.float64)
+        assert pose.shape == (7,)
+        w, h, n = C.c_int32(), C.c_int32(), C.c_size_t()
+        mx = np.zeros(2, np.int32)
+        check(self._L.hg_grid_xray(self._h, _p(pose), None, 0, C.byref(w), C.byref(h), _p(mx), C.byref(n)),
+              "hg_grid_xray")
+        cells = np.zeros(n.value, np.uint8)
+        if n.value:
+            check(self._L.hg_grid_xray(self._h, _p(pose), _p(cells), n.value, C.byref(w), C.byref(h), _p(mx),
+                                       C.byref(n)), "hg_grid_xray")
+        return cells.reshape(h.value, w.value, 2), mx
+
     @classmethod
     def FromProto(cls, ctx, data, max_blocks=1 << 16):
         """HybridGridTSDF(const proto::HybridGridTSDF&)."""

@@ -73,12 +73,22 @@ int main() {
       rd.origin = Point{{0.05f * k, 0.f, 0.f}};
       for (int c = 0; c < 360; ++c) {
         const float az = 6.2831853f * c / 360.f;
-        rd.returns.push_back(Point{{0.05f * k + 3.f * std::cos(az), 3.f * std::sin(az), 0.1f}});
+        for (int ring = -3; ring <= 3; ++ring)
+          rd.returns.push_back(Point{{0.05f * k + 3.f * std::cos(az), 3.f * std::sin(az), 0.1f * ring}});
       }
       const auto& live = active.InsertData(rd, {{1.0, 0.0, 0.0, 0.0}});
       std::printf("submaps after insert %d:", k);
       for (const auto& sm : live) std::printf(" %d%s", sm->num_range_data(), sm->insertion_finished() ? "(finished)" : "");
       std::printf("\n");
+    }
+    // X-ray texture of the finished submap (Submap3D::ToResponseProto -> AddToTextureProto)
+    {
+      auto finished = active.submaps().front();
+      const mapping::SubmapTexture tex = mapping::AddToTexture(finished->high_resolution_hybrid_grid(), finished->local_pose());
+      size_t solid = 0;
+      for (size_t i = 1; i < tex.cells.size(); i += 2) solid += tex.cells[i] != 0;
+      std::printf("texture %d x %d, %zu pixels with alpha, slice pose %.3f %.3f %.3f\n", tex.width, tex.height, solid,
+                  tex.slice_pose[0], tex.slice_pose[1], tex.slice_pose[2]);
     }
   } catch (const Error& e) {
     std::fprintf(stderr, "error %d: %s\n", e.code, e.what());

@@ -144,6 +144,37 @@ class HybridGridTSDF {
   hg_grid* grid_ = nullptr;
 };
 
+// proto::SubmapQuery::Response::SubmapTexture as AddToTextureProto(const HybridGridTSDF&, ...) fills
+// it (submap_3d.cc:245-276); `cells` is the uncompressed cell string, to be passed through
+// common::FastGzipString by the caller.
+struct SubmapTexture {
+  std::string cells;
+  int width = 0, height = 0;
+  double resolution = 0.;
+  Pose slice_pose{{0, 0, 0, 1, 0, 0, 0}};
+};
+
+inline SubmapTexture AddToTexture(const HybridGridTSDF& grid, const Pose& global_submap_pose) {
+  SubmapTexture texture;
+  texture.resolution = grid.resolution();
+  int32_t width = 0, height = 0, max_index[2] = {0, 0};
+  size_t bytes = 0;
+  Check(hg_grid_xray(grid.get(), global_submap_pose.data(), nullptr, 0, &width, &height, max_index, &bytes),
+        "hg_grid_xray");
+  texture.cells.resize(bytes);
+  if (bytes)
+    Check(hg_grid_xray(grid.get(), global_submap_pose.data(), reinterpret_cast<uint8_t*>(&texture.cells[0]), bytes,
+                       &width, &height, max_index, &bytes), "hg_grid_xray");
+  texture.width = width;
+  texture.height = height;
+  const float resolution = grid.resolution();
+  // global_submap_pose.inverse() * Translation(max_index.x * resolution, max_index.y * resolution, global z)
+  const Pose translation{{static_cast<double>(max_index[0] * resolution), static_cast<double>(max_index[1] * resolution),
+                          global_submap_pose[2], 1, 0, 0, 0}};
+  texture.slice_pose = transform::Multiply(transform::Inverse(global_submap_pose), translation);
+  return texture;
+}
+
 // proto::TSDFRangeDataInserterOptions3D defaults of configuration_files/trajectory_builder_3d.lua:78-93
 inline hg_insert_opts DefaultTSDFInserterOptions() {
   hg_insert_opts o{};

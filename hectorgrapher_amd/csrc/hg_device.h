@@ -81,6 +81,17 @@ __device__ inline float value_to_weight(const GridView& g, uint32_t code) {
 }
 
 // ---- indexing (ref mapping/3d/hybrid_grid_base.h:40-43,428-446) ----
+// Eigen Quaternion<float>::_transformVector followed by + translation
+// (transform/rigid_transform.h:193-197, sensor/range_data.cc:25-39).
+__device__ inline void transform_point(const float* pose, float& x, float& y, float& z) {
+  const float qw = pose[3], qx = pose[4], qy = pose[5], qz = pose[6];
+  float ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const float cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+  const float rx = x + qw * ux + cx, ry = y + qw * uy + cy, rz = z + qw * uz + cz;
+  x = rx + pose[0]; y = ry + pose[1]; z = rz + pose[2];
+}
+
 __device__ inline int cell_index_1d(float p, float resolution) { return round_to_int(p / resolution); }
 
 // Block key of a cell index: 11 bits per axis of (index + 8192) >> 3.

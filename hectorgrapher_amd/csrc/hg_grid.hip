@@ -354,15 +354,6 @@ int hg_grid_read_cells(hg_grid* g, const int32_t* ijk, size_t m, uint16_t* tsd, 
   return HG_OK;
 }
 
-// Export order key of a block (ref hybrid_grid_base.h:304-372: meta cells of 64^3 voxels z-major,
-// then 8^3 leaves z-major). The DynamicGrid's centring shift is a multiple of 64 cells, so the
-// order is independent of how far the reference tree has grown.
-static uint64_t export_order_key(unsigned long long key) {
-  const uint64_t bx = key & 2047u, by = (key >> 11) & 2047u, bz = (key >> 22) & 2047u;
-  const uint64_t mx = bx >> 3, my = by >> 3, mz = bz >> 3;
-  const uint64_t lx = bx & 7u, ly = by & 7u, lz = bz & 7u;
-  return (((((mz << 8 | my) << 8 | mx) << 3 | lz) << 3 | ly) << 3) | lx;
-}
 
 static int export_impl(hg_grid* g, int32_t* ijk, uint16_t* tsd, uint16_t* weight, size_t cap,
                        size_t* count) {

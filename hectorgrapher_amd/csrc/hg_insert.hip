@@ -63,17 +63,6 @@ __device__ inline float norm3(float x, float y, float z) {
   return sqrtf(x * x + (y * y + z * z));
 }
 
-// Eigen Quaternion<float>::_transformVector followed by + translation
-// (transform/rigid_transform.h:193-197, sensor/range_data.cc:25-39).
-__device__ inline void transform_point(const float* pose, float& x, float& y, float& z) {
-  const float qw = pose[3], qx = pose[4], qy = pose[5], qz = pose[6];
-  float ux = qy * z - qz * y, uy = qz * x - qx * z, uz = qx * y - qy * x;
-  ux = ux + ux; uy = uy + uy; uz = uz + uz;
-  const float cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
-  const float rx = x + qw * ux + cx, ry = y + qw * uy + cy, rz = z + qw * uz + cz;
-  x = rx + pose[0]; y = ry + pose[1]; z = rz + pose[2];
-}
-
 __device__ inline uint32_t find_scan(const ScanTable* scans, uint32_t n_scans, unsigned long long i) {
   uint32_t lo = 0, hi = n_scans;  // last scan with begin <= i
   while (hi - lo > 1) {

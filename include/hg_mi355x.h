@@ -158,6 +158,19 @@ int hg_grid_to_proto(hg_grid* grid, uint8_t* buf, size_t cap, size_t* len);
 int hg_grid_from_proto(hg_ctx* ctx, const uint8_t* buf, size_t len, uint32_t max_blocks,
                        hg_grid** out);
 
+/* X-ray texture of the grid, the view Submap3D::ToResponseProto serves: replaces
+ * AddToTextureProto(const HybridGridTSDF&, ...) (mapping/3d/submap_3d.cc:245-276) with its helpers
+ * ExtractVoxelData (:142-177), AccumulatePixelData (:80-105) and ComputePixelValues (:179-214).
+ * global_submap_pose: double[7] (t xyz, q wxyz). cells receives the UNcompressed cell string
+ * (value, alpha per pixel; pixel (x, y) at x * width + y, width = y extent, height = x extent);
+ * the caller gzips it (common::FastGzipString) and forms slice_pose = global_submap_pose^-1 *
+ * Translation(max_index_xy[0] * resolution, max_index_xy[1] * resolution, global z) (:271-275).
+ * cells == NULL: only the sizes are computed. cap < *bytes: HG_ERR_CAPACITY with the sizes set.
+ * A grid without a voxel above the obstruction limit gives width = height = 0 (the reference's
+ * bounding box is undefined there). */
+int hg_grid_xray(hg_grid* grid, const double* global_submap_pose, uint8_t* cells, size_t cap,
+                 int32_t* width, int32_t* height, int32_t* max_index_xy, size_t* bytes);
+
 /* ---- insertion: TSDFRangeDataInserter3D::Insert ----------------------------------------- */
 /* xyz: n x 3 floats in the grid (submap) frame, or — when pose_tq != NULL — in the frame that
  * pose_tq (float[7], = local_pose().inverse().cast<float>()) maps into the grid frame; the origin

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <array>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -1527,6 +1528,124 @@ inline SolverSummary Problem::Solve(const SolverOptions& opt) {
       reuse_diagonal = true;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// X-ray texture of a TSDF submap (the view Submap3D::ToResponseProto serves).
+// ref: mapping/3d/submap_3d.cc:31-37 (PixelData), :80-105 (AccumulatePixelData), :142-177
+// (ExtractVoxelData, TSDF overload), :179-214 (ComputePixelValues), :245-276 (AddToTextureProto,
+// TSDF overload; the gzip of the cell string and the slice pose stay with the caller);
+// mapping/probability_values.h:32-44,66-69,92-105 and .cc:30-62; mapping/submaps.h:36-52.
+// ---------------------------------------------------------------------------
+struct XrayTexture {
+  int width = 0, height = 0;  // width = y extent, height = x extent (submap_3d.cc:261-262)
+  int max_x = 0, max_y = 0;   // max_index, the caller needs it for slice_pose (:271-275)
+  std::vector<uint8_t> cells;  // interleaved value, alpha; pixel (x, y) at x * width + y
+};
+
+constexpr float kMinProbability = 0.1f;
+constexpr float kMaxProbability = 1.f - kMinProbability;
+
+inline uint16 ProbabilityToValue(const float probability) {
+  const int value = RoundToInt((Clamp(probability, kMinProbability, kMaxProbability) - kMinProbability) *
+                               (32766.f / (kMaxProbability - kMinProbability))) +
+                    1;
+  return static_cast<uint16>(value);
+}
+
+// kValueToProbability (probability_values.cc:30-62), entries [0, 32767]
+inline float ValueToProbability(const int value) {
+  if (value == 0) return kMinProbability;
+  const float kScale = (kMaxProbability - kMinProbability) / (32768 - 2.f);
+  return value * kScale + (kMinProbability - kScale);
+}
+
+inline float Logit(float probability) { return std::log(probability / (1.f - probability)); }
+
+inline uint8_t ProbabilityToLogOddsInteger(const float probability) {
+  const float kMaxLogOdds = Logit(kMaxProbability);
+  const float kMinLogOdds = Logit(kMinProbability);
+  const int value = RoundToInt((Logit(probability) - kMinLogOdds) * 254.f / (kMaxLogOdds - kMinLogOdds)) + 1;
+  return static_cast<uint8_t>(value);
+}
+
+inline XrayTexture XrayTextureTSDF(const HybridGridTSDF& grid, const Rigid3<double>& global_submap_pose) {
+  XrayTexture out;
+  const Rigid3<float> transform{{static_cast<float>(global_submap_pose.t.x),
+                                 static_cast<float>(global_submap_pose.t.y),
+                                 static_cast<float>(global_submap_pose.t.z)},
+                                {static_cast<float>(global_submap_pose.q.w),
+                                 static_cast<float>(global_submap_pose.q.x),
+                                 static_cast<float>(global_submap_pose.q.y),
+                                 static_cast<float>(global_submap_pose.q.z)}};
+  // ExtractVoxelData
+  struct Entry { int x, y, z, value; };
+  std::vector<Entry> entries;
+  const float resolution_inverse = 1.f / grid.resolution();
+  constexpr float kXrayObstructedCellProbabilityLimit = 0.501f;
+  int min_x = INT_MAX, min_y = INT_MAX, max_x = INT_MIN, max_y = INT_MIN;
+  grid.grid().ForEach([&](const Vec3i& index, const TSDFVoxel& voxel) {
+    const float tsd = grid.ValueConverter().ValueToTSD(voxel.discrete_tsd);
+    const float probability = 1.f - std::abs(tsd) / grid.ValueConverter().getMaxTSD();
+    const float probability_value = ProbabilityToValue(probability);
+    if (probability < kXrayObstructedCellProbabilityLimit) return;
+    const Vec3f cell_center_global = transform * grid.GetCenterOfCell(index);
+    const Entry e{RoundToInt(cell_center_global.x * resolution_inverse),
+                  RoundToInt(cell_center_global.y * resolution_inverse),
+                  RoundToInt(cell_center_global.z * resolution_inverse),
+                  static_cast<int>(probability_value)};
+    entries.push_back(e);
+    min_x = std::min(min_x, e.x);
+    min_y = std::min(min_y, e.y);
+    max_x = std::max(max_x, e.x);
+    max_y = std::max(max_y, e.y);
+  });
+  if (entries.empty()) return out;  // the reference computes INT_MIN - INT_MAX + 1 here (UB)
+  out.width = max_y - min_y + 1;
+  out.height = max_x - min_x + 1;
+  out.max_x = max_x;
+  out.max_y = max_y;
+  // AccumulatePixelData
+  struct PixelData {
+    int min_z = INT_MAX, max_z = INT_MIN, count = 0;
+    float probability_sum = 0.f, max_probability = 0.5f;
+  };
+  std::vector<PixelData> pixels(static_cast<size_t>(out.width) * out.height);
+  for (const Entry& e : entries) {
+    const int x = max_x - e.x, y = max_y - e.y;
+    PixelData& pixel = pixels[static_cast<size_t>(x) * out.width + y];
+    ++pixel.count;
+    pixel.min_z = std::min(pixel.min_z, e.z);
+    pixel.max_z = std::max(pixel.max_z, e.z);
+    const float probability = ValueToProbability(e.value);
+    pixel.probability_sum += probability;
+    pixel.max_probability = std::max(pixel.max_probability, probability);
+  }
+  // ComputePixelValues
+  out.cells.reserve(2 * pixels.size());
+  constexpr float kMinZDifference = 3.f;
+  constexpr float kFreeSpaceWeight = 0.15f;
+  for (const PixelData& pixel : pixels) {
+    const float z_difference = pixel.count > 0 ? pixel.max_z - pixel.min_z : 0;
+    if (z_difference < kMinZDifference) {
+      out.cells.push_back(0);
+      out.cells.push_back(0);
+      continue;
+    }
+    const float free_space = std::max(z_difference - pixel.count, 0.f);
+    const float free_space_weight = kFreeSpaceWeight * free_space;
+    const float total_weight = pixel.count + free_space_weight;
+    const float free_space_probability = 1.f - pixel.max_probability;
+    const float average_probability =
+        Clamp((pixel.probability_sum + free_space_probability * free_space_weight) / total_weight,
+              kMinProbability, kMaxProbability);
+    const int delta = 128 - ProbabilityToLogOddsInteger(average_probability);
+    const uint8_t alpha = delta > 0 ? 0 : -delta;
+    const uint8_t value = delta > 0 ? delta : 0;
+    out.cells.push_back(value);
+    out.cells.push_back((value || alpha) ? alpha : 1);
+  }
+  return out;
 }
 
 }  // namespace hgo

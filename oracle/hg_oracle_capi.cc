@@ -150,6 +150,20 @@ size_t hgo_grid_export(void* g, int32_t* ijk, uint16_t* tsd, uint16_t* weight, s
   return n;
 }
 
+// X-ray texture (submap_3d.cc:245-276). pose_tq: double[7] global submap pose (t xyz, q wxyz).
+// Returns the bytes of the cell string; writes min(cap, bytes) of them.
+size_t hgo_grid_xray(void* g, const double* pose_tq, uint8_t* cells, size_t cap, int32_t* width,
+                     int32_t* height, int32_t* max_index_xy) {
+  const Rigid3<double> T{{pose_tq[0], pose_tq[1], pose_tq[2]}, {pose_tq[3], pose_tq[4], pose_tq[5], pose_tq[6]}};
+  const XrayTexture t = XrayTextureTSDF(*static_cast<HybridGridTSDF*>(g), T);
+  *width = t.width;
+  *height = t.height;
+  max_index_xy[0] = t.max_x;
+  max_index_xy[1] = t.max_y;
+  if (cells && cap) std::memcpy(cells, t.cells.data(), std::min(cap, t.cells.size()));
+  return t.cells.size();
+}
+
 // ---- inserter -------------------------------------------------------------
 // pose_tq: optional float[7] (t xyz, q wxyz) = local_pose().inverse().cast<float>()
 // applied to origin and returns first (Submap3D::InsertData, submap_3d.cc:436-437).

@@ -113,6 +113,8 @@ def lib():
     L.hgo_grid_get_float.argtypes = [vp, vp, sz, vp, vp, vp]
     L.hgo_grid_count.restype = sz
     L.hgo_grid_count.argtypes = [vp]
+    L.hgo_grid_xray.restype = sz
+    L.hgo_grid_xray.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     L.hgo_grid_export.restype = sz
     L.hgo_grid_export.argtypes = [vp, vp, vp, vp, sz]
     L.hgo_grid_insert.restype = C.c_int
@@ -238,6 +240,16 @@ class Grid:
         w = np.empty(n, np.uint16)
         lib().hgo_grid_export(self._h, _ptr(ijk), _ptr(t), _ptr(w), n)
         return ijk, t, w
+
+    def xray(self, global_submap_pose):
+        """X-ray texture (submap_3d.cc:245-276): (cells uint8 [height, width, 2], max_index xy)."""
+        pose = np.ascontiguousarray(global_submap_pose, np.float64)
+        w, h = C.c_int32(), C.c_int32()
+        mx = np.zeros(2, np.int32)
+        n = lib().hgo_grid_xray(self._h, _ptr(pose), None, 0, C.byref(w), C.byref(h), _ptr(mx))
+        cells = np.empty(n, np.uint8)
+        lib().hgo_grid_xray(self._h, _ptr(pose), _ptr(cells), n, C.byref(w), C.byref(h), _ptr(mx))
+        return cells.reshape(h.value, w.value, 2), mx
 
     def insert(self, origin, xyz, opts=None, width=0, pose_tq=None):
         """TSDFRangeDataInserter3D::Insert. Returns (N_in, U)."""

@@ -39,3 +39,7 @@ def test_cpp_local_trajectory_builder_example():
     lines = re.findall(r"^submaps after insert (\d+):(.*)$", out.stdout, re.M)
     assert [l[1].split() for l in lines] == [["1"], ["2"], ["3"], ["4", "1"], ["5", "2"],
                                              ["6(finished)", "3"], ["4", "1"]]
+    # AddToTexture: the x-ray view of the first submap (ring of radius 3 m at 0.10 m: ~60 x 60 pixels)
+    tex = re.search(r"^texture (\d+) x (\d+), (\d+) pixels with alpha", out.stdout, re.M)
+    assert tex, out.stdout
+    assert 55 <= int(tex.group(1)) <= 70 and 55 <= int(tex.group(2)) <= 70 and int(tex.group(3)) > 100

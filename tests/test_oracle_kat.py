@@ -262,3 +262,38 @@ def test_odometry_and_imu_blocks_jacobian_and_minimum(po):
     assert s.termination_type == 0 and s.final_cost < 1e-12
     np.testing.assert_allclose(pr.get_pose(1), synth.pose_k(4), atol=1e-6)
     np.testing.assert_allclose(pr.get_velocity(1), [0.5, 0.2, 0.0], atol=1e-6)
+
+
+def test_xray_texture_known_answers(po):
+    """submap_3d.cc:80-105,142-214 on hand-built columns (identity pose, r = 0.1 m, tau = 0.25 m).
+    tsd = 0 -> probability 1 - 0/tau = 1, stored as ProbabilityToValue(clamp 0.9) = 32767, read back
+    as 0.9. Expected bytes derived by hand:
+      full column z = 0..4:  count 5, z_difference 4, no free space, mean 0.9 -> log-odds integer
+                             255 -> delta -127 -> (value 0, alpha 127)
+      gapped column z = 0,4: count 2, free space 2 * 0.15, mean (1.8 + 0.1 * 0.3) / 2.3 = 0.79565
+                             -> RoundToInt((1.35949 + 2.19722) * 254 / 4.39445) + 1 = 207 -> (0, 79)
+      short column z = 0..2: z_difference 2 < 3 -> (0, 0)
+      far voxel |tsd| = 0.2: probability 0.2 < 0.501, ignored (would otherwise widen the box)"""
+    g = po.Grid(0.1)
+    for z in range(5):
+        g.set_cell([0, 0, z], 0.0, 1.0)
+    for z in (0, 4):
+        g.set_cell([2, 1, z], 0.0, 1.0)
+    for z in range(3):
+        g.set_cell([1, 3, z], 0.0, 1.0)
+    g.set_cell([9, 9, 0], 0.2, 1.0)
+    cells, mx = g.xray(np.array([0, 0, 0, 1, 0, 0, 0.0]))
+    assert mx.tolist() == [2, 3]
+    assert cells.shape == (3, 4, 2)                 # height = x extent 0..2, width = y extent 0..3
+    want = np.zeros((3, 4, 2), np.uint8)
+    want[2 - 0, 3 - 0] = (0, 127)                   # pixel (max_x - x, max_y - y)
+    want[2 - 2, 3 - 1] = (0, 79)
+    assert np.array_equal(cells, want)
+    # a free-space-dominated column turns into "value": two voxels at probability 0.52 spanning z 0..30
+    g2 = po.Grid(0.1)
+    for z in (0, 30):
+        g2.set_cell([0, 0, z], 0.12, 1.0)           # probability 1 - 0.12 / 0.25 = 0.52
+    cells2, _ = g2.xray(np.array([0, 0, 0, 1, 0, 0, 0.0]))
+    # count 2, free space 28 * 0.15 = 4.2, max_probability 0.52 -> mean (1.04 + 0.48 * 4.2) / 6.2 = 0.4929
+    # -> logit -0.0284 -> RoundToInt(2.16883 * 57.8002) + 1 = 126 -> delta 2 -> (value 2, alpha 0)
+    assert cells2.shape == (1, 1, 2) and cells2[0, 0].tolist() == [2, 0]
