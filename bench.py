@@ -42,6 +42,10 @@ def parse_args():
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
+    ap.add_argument("--submaps", type=int, default=1,
+                    help="--workload register: independent submaps mapped concurrently on ONE GPU, one process "
+                         "each (BASELINE configs[3] at G = 1 puts all submaps on one GPU); 1 = the headline case")
+    ap.add_argument("--submap-index", type=int, default=-1, help=argparse.SUPPRESS)  # child of --submaps
     ap.add_argument("--prof-every", type=int, default=4,
                     help="HIP-event kernel timing on every N-th timed step (each event pair costs "
                          "~8 us of stream serialisation; 0 disables)")
@@ -114,13 +118,68 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        result = run(args)
+        if args.submaps > 1 and args.workload == "register" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+            result = run_submap_processes(args, saved_stdout)
+        else:
+            result = run(args, saved_stdout)
     finally:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     if result is not None:
         print(json.dumps(result), flush=True)
+
+
+def run_submap_processes(args, out_fd):
+    """S independent submaps on one GPU, one child process each (own HIP context and stream). The
+    children warm up, report READY, start their timed steps together on GO and return their own JSON
+    line with wall-clock start / end stamps; the whole-job rate is all their scans over the span from
+    the first start to the last end. This process never touches the GPU."""
+    import subprocess
+    S = args.submaps
+    base_cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps),
+                "--warmup", str(args.warmup), "--rings", str(args.rings), "--cols", str(args.cols),
+                "--map-scans", str(args.map_scans), "--max-blocks", str(args.max_blocks),
+                "--cpu-scans", str(args.cpu_scans), "--prof-every", str(args.prof_every)]
+    children = []
+    for j in range(S):
+        cmd = base_cmd + ["--submap-index", str(j)]
+        if j > 0 or args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        children.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+    for c in children:
+        line = c.stdout.readline()
+        if line.strip() != "READY":
+            for k in children:
+                k.kill()
+            raise RuntimeError("submap child failed before its timed region: %r" % line)
+    for c in children:
+        c.stdin.write("GO\n")
+        c.stdin.flush()
+    results = []
+    for c in children:
+        out, _ = c.communicate()
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        if c.returncode != 0 or not lines:
+            raise RuntimeError("submap child failed (rc %s)" % c.returncode)
+        results.append(json.loads(lines[-1]))
+    t_start = min(r["t_start"] for r in results)
+    t_end = max(r["t_end"] for r in results)
+    elapsed = t_end - t_start
+    out = dict(results[0])
+    for k in ("t_start", "t_end"):
+        out.pop(k, None)
+    out["value"] = args.steps * S / elapsed
+    out["ms_per_step"] = elapsed / args.steps * 1e3
+    out["config"] = dict(out["config"])
+    out["config"]["workload"] += "; a step registers one scan into each of %d concurrent submaps (one process each)" % S
+    out["config"]["parallelism"] = "%d independent submaps on one GPU, one process each" % S
+    out["config"]["submaps_per_gpu"] = S
+    out["config"]["per_submap_scans_per_s"] = [r["value"] for r in results]
+    out["config"]["mean_pose_error_m"] = float(np.mean([r["config"]["mean_pose_error_m"] for r in results]))
+    if "cpu_baseline" in out:
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
 
 
 def run_insert_stream(args):
@@ -400,7 +459,7 @@ def run_register_filtered(args):
     }
 
 
-def run(args):
+def run(args, out_fd=None):
     if args.workload == "insert_stream":
         return run_insert_stream(args)
     if args.workload == "register_filtered":
@@ -428,7 +487,7 @@ def run(args):
     n_pts = args.rings * args.cols
 
     # independent submap per rank: rank r uses PRNG streams offset by 1000*r
-    sb = 1000 * rank
+    sb = 1000 * rank + (100000 * (args.submap_index + 1) if args.submap_index >= 0 else 0)
     map_scans = make_scans(args.rings, args.cols, 0, args.map_scans, sb)
     query = make_scans(args.rings, args.cols, args.map_scans, args.warmup + args.steps, sb)
 
@@ -471,6 +530,10 @@ def run(args):
     errs.clear()
     ctx.prof_reset()
     barrier()
+    if args.submap_index >= 0:  # child of --submaps: all submaps start their timed steps together
+        os.write(out_fd, b"READY\n")
+        sys.stdin.readline()
+    t_start = time.time()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         # kernel durations are sampled with HIP events on every prof_every-th step of the timed region
@@ -479,6 +542,7 @@ def run(args):
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    t_end = time.time()
     prof = ctx.prof_read()
     ctx.prof_enable(False)
     # accounting pass (untimed): N_in and U of one more scan of the same workload
@@ -580,6 +644,8 @@ def run(args):
         out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
         out["cpu_baseline"]["cores_available"] = os.cpu_count()
         out["gpu_over_cpu"] = value / world / base["value"]
+    if args.submap_index >= 0:
+        out["t_start"], out["t_end"] = t_start, t_end
     if dist is not None:
         dist.destroy_process_group()
     return out
