@@ -42,6 +42,9 @@ def parse_args():
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
+    ap.add_argument("--insert-mode", default="exact", choices=["exact", "fast"],
+                    help="--workload insert_stream: exact = bit-identical to the reference (headline), "
+                         "fast = HG_INSERT_FAST tolerance mode (order-free sums, one quantisation per call)")
     ap.add_argument("--submaps", type=int, default=1,
                     help="--workload register: independent submaps mapped concurrently on ONE GPU, one process "
                          "each (BASELINE configs[3] at G = 1 puts all submaps on one GPU); 1 = the headline case")
@@ -204,11 +207,12 @@ def run_insert_stream(args):
     garr = (C.c_void_p * 3)(*[g._h for g in grids])
     opts = (api.InsertOpts * 3)(*[api.InsertOpts() for _ in grids])
     st = (api.InsertStats * 3)()
+    mode = api._lib.HG_INSERT_FAST if args.insert_mode == "fast" else api._lib.HG_INSERT_EXACT
 
     def step(stats):
         api.check(L.hg_pyramid_insert_batch(garr, opts, 3, origins.ctypes.data_as(C.c_void_p), xyz.data_ptr(),
                                             offs.ctypes.data_as(C.c_void_p), B, 0,
-                                            poses.ctypes.data_as(C.c_void_p), 0, 1, st if stats else None),
+                                            poses.ctypes.data_as(C.c_void_p), mode, 1, st if stats else None),
                   "hg_pyramid_insert_batch")
 
     for _ in range(args.warmup):
@@ -263,12 +267,13 @@ def run_insert_stream(args):
     launches = max(1, prof["apply"][0])
     achieved = bytes_per * (args.steps / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     return {
-        "metric": "scans/s (100k-pt scan stream, exact TSDF insert into 3 hashed-block grids)",
+        "metric": "scans/s (100k-pt scan stream, %s TSDF insert into 3 hashed-block grids)" % args.insert_mode,
         "value": args.steps * B / elapsed, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32/u16", "data": "synthetic",
-        "config": {"workload": "insert_stream: %d scans x %d pts per batched call, 3-res TSDF, exact mode"
-                               % (B, n_pts), "updates_per_step": U, "hits_per_step": N_in},
+        "config": {"workload": "insert_stream: %d scans x %d pts per batched call, 3-res TSDF, %s mode"
+                               % (B, n_pts, args.insert_mode), "updates_per_step": U, "hits_per_step": N_in,
+                   "insert_mode": args.insert_mode},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "insert family (expand+sort+alloc+apply) per chunk launch",

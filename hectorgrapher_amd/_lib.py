@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libhg_mi355x.so")
 HG_OK = 0
 HG_HOST, HG_DEVICE = 0, 1
 HG_INSERT_EXACT = 0
+HG_INSERT_FAST = 1
 KERNELS = {"ray_count": 0, "ray_expand": 1, "sort": 2, "alloc": 3, "apply": 4, "residuals": 5,
            "lm": 6, "scan": 7}
 

@@ -29,6 +29,7 @@ struct GridView {
   uint32_t* touched;          // slots touched by the current insert call
   unsigned long long* work;   // apply work items: slot | lo << 24 | hi << 34 | n << 44
   uint32_t work_capacity;
+  unsigned long long* accum;  // HG_INSERT_FAST: per voxel count << 44 | fixed-point tsd sum (or null)
   float resolution;
   float max_tsd, min_tsd, max_weight;
   float tsd_resolution, weight_resolution;  // encode scales (tsd_value_converter.cc:27-28)

@@ -274,6 +274,7 @@ int hg_grid_destroy(hg_grid* g) {
   if (g->view.block_keys) (void)hipFree(g->view.block_keys);
   if (g->view.counters) (void)hipFree(g->view.counters);
   if (g->view.bin_count) (void)hipFree(g->view.bin_count);
+  if (g->view.accum) (void)hipFree(g->view.accum);
   delete g;
   return HG_OK;
 }

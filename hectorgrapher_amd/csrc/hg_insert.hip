@@ -864,6 +864,244 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
   if (threadIdx.x == 0) wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
 }
 
+// ==========================================================================================
+// Tolerance path (HG_INSERT_FAST, unit update weight): the updates a voxel receives in one call
+// are SUMMED (order-free integer sums) and applied once, instead of the reference's chain of
+// re-quantised updates. No per-voxel chain, no records, no sort:
+//   k_fast_accumulate  per (return, level): walks the ray, finds / inserts its blocks, and adds
+//                      every sample to the voxel's accumulator with ONE 64-bit atomic:
+//                      count << 44 | sum of (tsd + tau) in units of 2 tau / (2^23 - 1)
+//   k_fast_apply       one workgroup per touched block, one thread per voxel: closed form of the
+//                      m updates (running mean while the weight grows, the clamp's moving average
+//                      after it saturates), ONE quantisation, accumulator cleared.
+// Results differ from the exact mode by the re-quantisation noise the reference accumulates per
+// update (tests/test_gpu_insert.py states the tolerance); they do not depend on arrival order, so
+// the mode is deterministic.
+// ==========================================================================================
+constexpr unsigned kFastCountShift = 44;
+constexpr unsigned kFastUnits = (1u << 23) - 1u;
+
+__global__ __launch_bounds__(256) void k_fast_accumulate(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
+                                                         const float* xyz, unsigned n, unsigned* wg_hits) {
+  const int level = blockIdx.y;
+  const LevelIns& L = P.lv[level];
+  const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  __shared__ unsigned s_hits;
+  if (threadIdx.x == 0) s_hits = 0;
+  __syncthreads();
+  bool hit = false;
+  unsigned long long run_key[kMaxRuns];
+  int run_begin[kMaxRuns], run_len[kMaxRuns];
+  int nr = 0;
+  Ray r;
+  r.valid = false;
+  if (i < n) {
+    const ScanTable sc = scans ? scans[find_scan(scans, n_scans, i)] : scan_of(P);
+    r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
+    hit = r.valid && r.n + 1 <= kSlots;
+    if (r.valid && !hit) atomicOr(&L.g.counters[1], kFlagStride);
+    if (hit) {
+      bool range_err = false;
+      nr = ray_block_runs(r, run_key, run_begin, run_len, &range_err);
+      if (range_err) atomicOr(&L.g.counters[1], kFlagRange);
+    }
+  }
+  unsigned long long entry[kMaxRuns];
+  uint32_t slot[kMaxRuns];
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k)
+    entry[k] = (k < nr) ? L.g.table[hash_key(run_key[k]) & L.g.table_mask] : 0ull;
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) {
+    slot[k] = 0xFFFFFFFFu;
+    if (k < nr) {
+      if ((entry[k] >> 24) == run_key[k] + 1ull && (entry[k] & 0xFFFFFFu) != kSlotPending)
+        slot[k] = static_cast<uint32_t>(entry[k] & 0xFFFFFFu);
+      else
+        slot[k] = insert_block_shared(L.g, run_key[k]);
+    }
+  }
+  // touched list: bin_count is only a flag on this path; whoever flips it 0 -> 1 enlists the block.
+  // One exchange per (wavefront, block): the returns of a wavefront share their blocks, and a hot
+  // block would otherwise take thousands of same-address atomics.
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) {
+    const bool want = k < nr && slot[k] < L.g.max_blocks;
+    unsigned long long todo = __ballot(want);
+    bool leader = false;
+    while (todo) {
+      const int l = __builtin_ctzll(todo);
+      const uint32_t ls = __builtin_amdgcn_readlane(slot[k], l);
+      leader = leader || lane == l;
+      todo &= ~__ballot(want && slot[k] == ls);
+    }
+    if (leader && atomicExch(&L.g.bin_count[slot[k]], 1u) == 0u)
+      L.g.touched[atomicAdd(&L.g.counters[6], 1u)] = slot[k];
+  }
+  const float tau = L.p.truncation_distance;
+  const float to_units = static_cast<float>(kFastUnits) / (tau + tau);
+  // Sample `pos` of all lanes together: consecutive returns of a scan hit the same voxels, so runs
+  // of neighbouring lanes with the same (block, voxel) are summed in registers (segmented prefix
+  // sum) and only the last lane of a run issues the atomic — the hot voxels next to the sensor
+  // would otherwise serialise thousands of same-address atomics.
+  for (int pos = 0; pos < kSlots; ++pos) {
+    bool valid = hit && pos <= r.n;
+    uint32_t key = 0xFFFFFFFFu;
+    unsigned units = 0;
+    if (valid) {
+      int cx, cy, cz;
+      float tsd, w;
+      ray_sample(L.g, L.p, r, pos, cx, cy, cz, tsd, w);
+      valid = cell_in_range(cx, cy, cz);
+      if (valid) {
+        const unsigned long long bk = block_key(cx, cy, cz);
+        uint32_t sl = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < kMaxRuns; ++k)
+          if (k < nr && run_key[k] == bk) sl = slot[k];
+        valid = sl < L.g.max_blocks;
+        key = (sl << 9) | voxel_in_block(cx, cy, cz);
+        units = static_cast<unsigned>(__float2int_rn((tsd + tau) * to_units));
+      }
+    }
+    if (__ballot(valid) == 0ull) continue;
+    const uint32_t prev = __shfl_up(key, 1);
+    const uint32_t next = __shfl_down(key, 1);
+    const bool head = lane == 0 || !valid || key != prev;
+    const bool tail = lane == kWave - 1 || !valid || key != next;
+    unsigned incl = valid ? units : 0u;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    const unsigned long long heads = __ballot(head);
+    const int start = 63 - __clzll(static_cast<long long>(heads & ((2ull << lane) - 1ull)));
+    const unsigned before = __shfl(incl, max(start - 1, 0));
+    if (valid && tail) {
+      const unsigned sum = incl - (start > 0 ? before : 0u);
+      const unsigned long long cnt = static_cast<unsigned long long>(lane - start + 1);
+      atomicAdd(&L.g.accum[static_cast<size_t>(key >> 9) * kVoxelsPerBlock + (key & 511u)],
+                (cnt << kFastCountShift) | sum);
+    }
+  }
+  const unsigned long long m = __ballot(hit);
+  if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
+  __syncthreads();
+  if (threadIdx.x == 0) wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
+}
+
+// Product over the m updates of w_{k-1} / (w_{k-1} + 1): the share of the voxel's previous tsd
+// that survives (UpdateCell :725-737). The reference re-quantises the weight after every update,
+// so its weight CODE grows by round(weight_resolution) per update (33 for max weight 1000, i.e.
+// 1.0071 instead of 1) until the clamp pins it at 32767; with that sequence the product is a
+// ratio of Gamma functions. `code` is the weight code before the call (0 = unknown = weight 0).
+__device__ inline double fast_survival(const GridView& g, float maxw, uint32_t code, double m, uint32_t* code_out) {
+  const int step = static_cast<int>(roundf(g.weight_resolution));
+  const double kw = static_cast<double>(g.weight_scale);
+  const int c0 = static_cast<int>(code & 0x7FFFu) == 0 ? 1 : static_cast<int>(code & 0x7FFFu);
+  // updates applied while the code still grows, then updates at the pinned maximum
+  const double grow_all = ceil(static_cast<double>(32767 - c0) / static_cast<double>(step));
+  const double n = fmin(m, fmax(0.0, grow_all));
+  const double c_end = fmin(static_cast<double>(c0) + static_cast<double>(step) * m, 32767.0);
+  *code_out = static_cast<uint32_t>(c_end);
+  double A = 1.0;
+  if (n > 0.0) {
+    if (c0 == 1) {
+      A = 0.0;  // weight 0: the first update replaces the value
+    } else if (n <= 32.0) {
+      for (int j = 0; j < static_cast<int>(n); ++j) {
+        const double w = static_cast<double>(static_cast<float>(c0 - 1 + step * j) * g.weight_scale);
+        A *= w / (w + 1.0);
+      }
+    } else {
+      const double alpha = static_cast<double>(c0 - 1) / static_cast<double>(step);
+      const double beta = alpha + 1.0 / (kw * static_cast<double>(step));
+      A = exp(lgamma(n + alpha) - lgamma(alpha) - lgamma(n + beta) + lgamma(beta));
+    }
+  }
+  if (m > n) {
+    const double wmax = static_cast<double>(32766.f * g.weight_scale);
+    A *= pow(wmax / (wmax + 1.0), m - n);
+  }
+  (void)maxw;
+  return A;
+}
+
+// Same quantities by walking the weight sequence update by update: for weight resolutions whose
+// fraction is too close to one half for the closed form above (not the case for the defaults).
+__device__ inline double fast_survival_walk(const GridView& g, float maxw, uint32_t code, double m, uint32_t* code_out) {
+  float w = value_to_weight(g, code);
+  double A = 1.0;
+  uint32_t c = code & 0x7FFFu;
+  for (double k = 0; k < m; k += 1.0) {
+    const float W = w + 1.0f;
+    A *= static_cast<double>(w) / static_cast<double>(W);
+    c = weight_to_value(g, fminf(W, maxw));
+    w = value_to_weight(g, c);
+  }
+  *code_out = c;
+  return A;
+}
+
+// grid (G, levels), 512 threads = the voxels of a block.
+__global__ __launch_bounds__(kBinThreads) void k_fast_apply(PyramidIns P) {
+  const LevelIns& L = P.lv[blockIdx.y];
+  const GridView& g = L.g;
+  const unsigned nt = min(g.counters[6], g.max_blocks);
+  const unsigned v = threadIdx.x;
+  const double tau = static_cast<double>(L.p.truncation_distance);
+  const double unit = (tau + tau) / static_cast<double>(kFastUnits);
+  const float maxw = L.p.maximum_weight;
+  const float frac = g.weight_resolution - floorf(g.weight_resolution);
+  const bool closed_form = fabsf(frac - 0.5f) > 0.05f && g.weight_resolution >= 1.0f && maxw == g.max_weight;
+  unsigned long long updates = 0;
+  for (unsigned t = blockIdx.x; t < nt; t += gridDim.x) {
+    const uint32_t slot = g.touched[t];
+    unsigned long long* acc = g.accum + static_cast<size_t>(slot) * kVoxelsPerBlock + v;
+    const unsigned long long a = *acc;
+    if (a) {
+      *acc = 0ull;
+      const double m = static_cast<double>(a >> kFastCountShift);
+      const double sum = static_cast<double>(a & ((1ull << kFastCountShift) - 1ull)) * unit - m * tau;
+      const double mean = sum / m;
+      uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + v;
+      const uint32_t code = *cell;
+      const double d0 = static_cast<double>(value_to_tsd(g, code & 0xFFFFu));
+      uint32_t wcode;
+      const double A = closed_form ? fast_survival(g, maxw, code >> 16, m, &wcode)
+                                   : fast_survival_walk(g, maxw, code >> 16, m, &wcode);
+      // every update is a convex combination, so the m updates carry the weight 1 - A together;
+      // they enter at their mean (their individual shares depend on the arrival order)
+      const double d = d0 * A + mean * (1.0 - A);
+      *cell = (tsd_to_value(g, static_cast<float>(d)) | kUpdateMarker) | (wcode << 16);
+      updates += static_cast<unsigned long long>(a >> kFastCountShift);
+    }
+    if (v == 0) g.bin_count[slot] = 0;  // ready for the next call
+  }
+  for (int off = 32; off > 0; off >>= 1) updates += __shfl_xor(updates, off);
+  __shared__ unsigned long long s_upd[kBinThreads / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) s_upd[threadIdx.x / kWave] = updates;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long u = 0;
+    for (int w = 0; w < kBinThreads / kWave; ++w) u += s_upd[w];
+    if (u) atomicAdd(reinterpret_cast<unsigned long long*>(&g.counters[4]), u);
+  }
+}
+
+// <<<1, levels>>> before / after the two kernels above: per-call counters.
+__global__ void k_fast_begin(PyramidIns P) {
+  const GridView& g = P.lv[threadIdx.x].g;
+  if (!P.accumulate) { g.counters[4] = 0; g.counters[5] = 0; }
+}
+__global__ void k_fast_end(PyramidIns P) {
+  const GridView& g = P.lv[threadIdx.x].g;
+  if (g.counters[6] > g.max_blocks) atomicOr(&g.counters[1], kFlagCapacity);
+  g.counters[6] = 0;
+}
+
 // Lanes of the wavefront (among `valid` ones) that hold the same 9-bit value as this lane.
 __device__ inline unsigned long long match_voxel(unsigned v, bool valid) {
   unsigned long long m = __ballot(valid);
@@ -1570,6 +1808,49 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P, const float* d_xyz, unsi
   return HG_OK;
 }
 
+// The accumulators of the tolerance path (8 B per voxel) are allocated on a grid's first
+// HG_INSERT_FAST call and are all-zero between calls.
+int ensure_accumulators(hg_grid* grid) {
+  if (grid->view.accum) return HG_OK;
+  const size_t bytes = sizeof(unsigned long long) * kVoxelsPerBlock * static_cast<size_t>(grid->view.max_blocks);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&grid->view.accum), bytes);
+  if (e != hipSuccess) {
+    grid->view.accum = nullptr;
+    set_last_error(std::string("hipMalloc accumulators: ") + hipGetErrorString(e));
+    return HG_ERR_HIP;
+  }
+  HG_HIP_CHECK(hipMemsetAsync(grid->view.accum, 0, bytes, grid->ctx->stream));
+  return HG_OK;
+}
+
+// ---- tolerance path (HG_INSERT_FAST, unit weight) -------------------------------------------
+int insert_chunk_fast(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans, uint32_t n_scans,
+                      const float* d_xyz, unsigned long long n, bool want_stats) {
+  hipStream_t s = c->stream;
+  int rc;
+  const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
+  if ((rc = c->ws_counts.reserve(sizeof(unsigned) * static_cast<size_t>(nwg_e) * kMaxInsLevels)) != HG_OK) return rc;
+  unsigned* wg_hits = c->ws_counts.as<unsigned>();
+  hipLaunchKernelGGL(k_fast_begin, dim3(1), dim3(P.levels), 0, s, P);
+  {
+    ProfScope ps(c, HG_K_RAY_EXPAND, n * P.levels);
+    hipLaunchKernelGGL(k_fast_accumulate, dim3(nwg_e, P.levels), dim3(256), 0, s, P, d_scans, n_scans, d_xyz,
+                       static_cast<unsigned>(n), wg_hits);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  {
+    ProfScope ps(c, HG_K_APPLY, n * P.levels);
+    hipLaunchKernelGGL(k_fast_apply, dim3(2048, P.levels), dim3(kBinThreads), 0, s, P);
+  }
+  hipLaunchKernelGGL(k_fast_end, dim3(1), dim3(P.levels), 0, s, P);
+  HG_HIP_CHECK(hipGetLastError());
+  if (want_stats) {
+    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, nullptr, 0u);
+    HG_HIP_CHECK(hipGetLastError());
+  }
+  return HG_OK;
+}
+
 int read_stats(hg_grid* grid, hg_insert_stats* out) {
   uint32_t cnt[8];
   hipStream_t s = grid->ctx->stream;
@@ -1639,7 +1920,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   if (d_pose_tq && (n_scans != 1 || !poses_tq)) return HG_ERR_INVALID;
   if (!grids || !opts || levels < 1 || levels > kMaxInsLevels || !origins || !scan_offsets || n_scans == 0)
     return HG_ERR_INVALID;
-  if (mode != HG_INSERT_EXACT) return HG_ERR_UNSUPPORTED;
+  if (mode != HG_INSERT_EXACT && mode != HG_INSERT_FAST) return HG_ERR_INVALID;
   hg_ctx* c = grids[0] ? grids[0]->ctx : nullptr;
   if (!c) return HG_ERR_INVALID;
   for (int l = 0; l < levels; ++l) {
@@ -1701,6 +1982,17 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     if (opts[l].num_free_space_voxels > 0 || !(opts[l].relative_truncation_distance <= 3.0)) fixed_ok = false;
     if (!(static_cast<float>(opts[l].weight_function_epsilon) >= 1.0f)) unit_weight = false;
   }
+  if (mode == HG_INSERT_FAST) {
+    if (!fixed_ok || !unit_weight || d_pose_tq) {
+      set_last_error("HG_INSERT_FAST needs unit update weights (weight_function_epsilon >= 1), no free-space "
+                     "voxels and relative_truncation_distance <= 3");
+      return HG_ERR_UNSUPPORTED;
+    }
+    for (int l = 0; l < levels; ++l) {
+      const int rc = ensure_accumulators(grids[l]);
+      if (rc != HG_OK) return rc;
+    }
+  }
   if (!fixed_ok && levels > 1) {
     // general options: fall back to one compaction pass per level
     int rc = HG_OK;
@@ -1746,7 +2038,9 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   // is its own chunk (same per-voxel chain length as one sorted batch, without the global sort)
   const char* force_sort = getenv("HG_INSERT_SORT");
   const bool binned_ok = fixed_ok && unit_weight && !(force_sort && force_sort[0] == '1');
-  const unsigned long long kMaxChunkPoints = 4ull << 20;
+  // a voxel receives at most one update per return: FAST chunks stay below the 20-bit update count
+  const unsigned long long kMaxChunkPoints = mode == HG_INSERT_FAST ? (1ull << 20) - 1ull : 4ull << 20;
+  const bool fast = mode == HG_INSERT_FAST;
   std::vector<ScanTable> table;
   size_t s0 = 0;
   int rc = HG_OK;
@@ -1754,7 +2048,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     size_t s1 = s0;
     unsigned long long pts = 0;
     table.clear();
-    while (s1 < n_scans && (s1 == s0 || (!(binned_ok && pts < (1ull << 20)) &&
+    while (s1 < n_scans && (s1 == s0 || (!(binned_ok && !fast && pts < (1ull << 20)) &&
                                          pts + (scan_offsets[s1 + 1] - scan_offsets[s1]) <= kMaxChunkPoints))) {
       ScanTable t;
       t.begin = scan_offsets[s1] - scan_offsets[s0];
@@ -1781,7 +2075,14 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
       Pc.accumulate = s0 > 0 ? 1 : 0;
       for (int l = 0; l < levels; ++l)
         if (Pc.lv[l].gate) Pc.lv[l].gate += first;
-      if (binned_ok && table.size() == 1 && pts < (1ull << 20)) {
+      if (fast) {
+        if (pts > kMaxChunkPoints) {
+          set_last_error("HG_INSERT_FAST: a single scan is limited to 2^20 - 1 returns");
+          return HG_ERR_UNSUPPORTED;
+        }
+        rc = insert_chunk_fast(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts,
+                               stats != nullptr);
+      } else if (binned_ok && table.size() == 1 && pts < (1ull << 20)) {
         rc = insert_chunk_binned(c, Pc, d_xyz + 3 * first, pts, stats != nullptr);
       } else if (fixed_ok) {
         const bool ws = stats != nullptr;
