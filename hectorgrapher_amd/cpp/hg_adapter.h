@@ -187,18 +187,21 @@ inline hg_insert_opts DefaultTSDFInserterOptions() {
 
 class TSDFRangeDataInserter3D {
  public:
-  explicit TSDFRangeDataInserter3D(const hg_insert_opts& options) : options_(options) {}
+  // mode: HG_INSERT_EXACT (the reference's codes, bit for bit) or HG_INSERT_FAST (order-free tolerance mode)
+  explicit TSDFRangeDataInserter3D(const hg_insert_opts& options, int mode = HG_INSERT_EXACT)
+      : options_(options), mode_(mode) {}
   // RangeDataInserterInterface::Insert
   void Insert(const sensor::RangeData& range_data, HybridGridTSDF* grid) const {
     Check(hg_grid_insert(grid->get(), &options_, range_data.origin.data(),
                          range_data.returns.empty() ? nullptr : range_data.returns[0].data(),
-                         range_data.returns.size(), range_data.width, nullptr, HG_INSERT_EXACT, HG_HOST, nullptr),
+                         range_data.returns.size(), range_data.width, nullptr, mode_, HG_HOST, nullptr),
           "hg_grid_insert");
   }
   bool RequiresStructuredData() const { return options_.project_sdf_distance_to_scan_normal != 0; }
   const hg_insert_opts& options() const { return options_; }
  private:
   hg_insert_opts options_;
+  int mode_;
 };
 
 // Submap3D::InsertData for the TSDF grids of one submap (submap_3d.cc:427-452): frame change by
