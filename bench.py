@@ -127,6 +127,11 @@ def main():
             result = run(args, saved_stdout)
     finally:
         sys.stdout.flush()
+        try:  # banners buffered in C stdio (RCCL prints through printf) must not land after the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     if result is not None:
