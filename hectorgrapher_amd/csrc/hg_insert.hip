@@ -870,7 +870,9 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
 // re-quantised updates. No per-voxel chain, no records, no sort:
 //   k_fast_accumulate  per (return, level): walks the ray, finds / inserts its blocks, and adds
 //                      every sample to the voxel's accumulator with ONE 64-bit atomic:
-//                      count << 44 | sum of (tsd + tau) in units of 2 tau / (2^23 - 1)
+//                      count << 44 | sum of (tsd + tau) in units of 2 tau / (2^23 - 1);
+//                      samples are first combined in registers (runs of neighbouring lanes) and in
+//                      an LDS table per workgroup, so one atomic leaves per distinct voxel
 //   k_fast_apply       one workgroup per touched block, one thread per voxel: closed form of the
 //                      m updates (running mean while the weight grows, the clamp's moving average
 //                      after it saturates), ONE quantisation, accumulator cleared.
@@ -880,14 +882,19 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
 // ==========================================================================================
 constexpr unsigned kFastCountShift = 44;
 constexpr unsigned kFastUnits = (1u << 23) - 1u;
+constexpr unsigned kFastThreads = 512;   // returns per workgroup: the wider the window, the more voxels are shared
+constexpr unsigned kFastTableBits = 12;
+constexpr unsigned kFastTable = 1u << kFastTableBits;  // LDS slots per workgroup (about 5 samples per return)
 
-__global__ __launch_bounds__(256) void k_fast_accumulate(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
+__global__ __launch_bounds__(kFastThreads) void k_fast_accumulate(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
                                                          const float* xyz, unsigned n, unsigned* wg_hits) {
   const int level = blockIdx.y;
   const LevelIns& L = P.lv[level];
-  const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+  const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * kFastThreads + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   __shared__ unsigned s_hits;
+  __shared__ uint32_t s_key[kFastTable];
+  __shared__ unsigned long long s_val[kFastTable];
   if (threadIdx.x == 0) s_hits = 0;
   __syncthreads();
   bool hit = false;
@@ -941,6 +948,11 @@ __global__ __launch_bounds__(256) void k_fast_accumulate(PyramidIns P, const Sca
   }
   const float tau = L.p.truncation_distance;
   const float to_units = static_cast<float>(kFastUnits) / (tau + tau);
+  for (unsigned e = threadIdx.x; e < kFastTable; e += kFastThreads) {
+    s_key[e] = 0xFFFFFFFFu;
+    s_val[e] = 0ull;
+  }
+  __syncthreads();
   // Sample `pos` of all lanes together: consecutive returns of a scan hit the same voxels, so runs
   // of neighbouring lanes with the same (block, voxel) are summed in registers (segmented prefix
   // sum) and only the last lane of a run issues the atomic — the hot voxels next to the sensor
@@ -982,13 +994,33 @@ __global__ __launch_bounds__(256) void k_fast_accumulate(PyramidIns P, const Sca
     if (valid && tail) {
       const unsigned sum = incl - (start > 0 ? before : 0u);
       const unsigned long long cnt = static_cast<unsigned long long>(lane - start + 1);
-      atomicAdd(&L.g.accum[static_cast<size_t>(key >> 9) * kVoxelsPerBlock + (key & 511u)],
-                (cnt << kFastCountShift) | sum);
+      // second stage: the workgroup's LDS table (returns a few columns apart share voxels too)
+      const unsigned long long add = (cnt << kFastCountShift) | sum;
+      uint32_t h = (key * 2654435761u) >> (32 - kFastTableBits);
+      bool placed = false;
+#pragma unroll 1
+      for (int probe = 0; probe < 8 && !placed; ++probe) {
+        const uint32_t seen = atomicCAS(&s_key[h], 0xFFFFFFFFu, key);
+        if (seen == 0xFFFFFFFFu || seen == key) {
+          atomicAdd(&s_val[h], add);
+          placed = true;
+        }
+        h = (h + 1u) & (kFastTable - 1u);
+      }
+      if (!placed)
+        atomicAdd(&L.g.accum[static_cast<size_t>(key >> 9) * kVoxelsPerBlock + (key & 511u)], add);
     }
   }
   const unsigned long long m = __ballot(hit);
   if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
   __syncthreads();
+  // one device-scope atomic per distinct voxel of the workgroup (they execute at the memory side on
+  // a multi-XCD part and are what this kernel is bound by)
+  for (unsigned e = threadIdx.x; e < kFastTable; e += kFastThreads) {
+    const uint32_t key = s_key[e];
+    if (key != 0xFFFFFFFFu)
+      atomicAdd(&L.g.accum[static_cast<size_t>(key >> 9) * kVoxelsPerBlock + (key & 511u)], s_val[e]);
+  }
   if (threadIdx.x == 0) wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
 }
 
@@ -1828,13 +1860,13 @@ int insert_chunk_fast(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans, 
                       const float* d_xyz, unsigned long long n, bool want_stats) {
   hipStream_t s = c->stream;
   int rc;
-  const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
+  const unsigned nwg_e = static_cast<unsigned>((n + kFastThreads - 1) / kFastThreads);
   if ((rc = c->ws_counts.reserve(sizeof(unsigned) * static_cast<size_t>(nwg_e) * kMaxInsLevels)) != HG_OK) return rc;
   unsigned* wg_hits = c->ws_counts.as<unsigned>();
   hipLaunchKernelGGL(k_fast_begin, dim3(1), dim3(P.levels), 0, s, P);
   {
     ProfScope ps(c, HG_K_RAY_EXPAND, n * P.levels);
-    hipLaunchKernelGGL(k_fast_accumulate, dim3(nwg_e, P.levels), dim3(256), 0, s, P, d_scans, n_scans, d_xyz,
+    hipLaunchKernelGGL(k_fast_accumulate, dim3(nwg_e, P.levels), dim3(kFastThreads), 0, s, P, d_scans, n_scans, d_xyz,
                        static_cast<unsigned>(n), wg_hits);
   }
   HG_HIP_CHECK(hipGetLastError());
