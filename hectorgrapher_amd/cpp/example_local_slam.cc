@@ -81,6 +81,18 @@ int main() {
       for (const auto& sm : live) std::printf(" %d%s", sm->num_range_data(), sm->insertion_finished() ? "(finished)" : "");
       std::printf("\n");
     }
+    // the filters in front of the matcher (trajectory_builder_3d.lua:21-27 defaults)
+    {
+      std::vector<Point> cloud;
+      for (int c = 0; c < 3600; ++c) {
+        const float az = 6.2831853f * c / 3600.f;
+        for (int ring = -8; ring <= 8; ++ring)
+          cloud.push_back(Point{{4.f * std::cos(az), 4.f * std::sin(az), 0.05f * ring}});
+      }
+      const std::vector<Point> coarse = sensor::VoxelFilter(&ctx, 0.15f).Filter(cloud);
+      const std::vector<Point> matched = sensor::AdaptiveVoxelFilter(&ctx, 2.f, 150.f, 15.f).Filter(coarse);
+      std::printf("filters: %zu -> %zu -> %zu points\n", cloud.size(), coarse.size(), matched.size());
+    }
     // X-ray texture of the finished submap (Submap3D::ToResponseProto -> AddToTextureProto)
     {
       auto finished = active.submaps().front();

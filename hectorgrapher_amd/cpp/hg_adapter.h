@@ -101,6 +101,47 @@ class Context {
   hg_ctx* ctx_ = nullptr;
 };
 
+namespace sensor {
+// sensor::VoxelFilter (sensor/internal/voxel_filter.h:30-47): the first point of every voxel, order kept.
+class VoxelFilter {
+ public:
+  VoxelFilter(Context* ctx, float size) : ctx_(ctx), size_(size) {}
+  std::vector<Point> Filter(const std::vector<Point>& point_cloud) const {
+    std::vector<uint32_t> keep(point_cloud.size());
+    size_t n = 0;
+    Check(hg_voxel_filter(ctx_->get(), size_, point_cloud.empty() ? nullptr : point_cloud[0].data(), point_cloud.size(),
+                          3, HG_HOST, keep.data(), &n), "hg_voxel_filter");
+    std::vector<Point> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = point_cloud[keep[i]];
+    return out;
+  }
+ private:
+  Context* ctx_;
+  float size_;
+};
+
+// sensor::AdaptiveVoxelFilter (sensor/internal/adaptive_voxel_filter.h:88-110) with the fields of
+// proto::AdaptiveVoxelFilterOptions (max_length, min_num_points, max_range).
+class AdaptiveVoxelFilter {
+ public:
+  AdaptiveVoxelFilter(Context* ctx, float max_length, float min_num_points, float max_range)
+      : ctx_(ctx), max_length_(max_length), min_num_points_(min_num_points), max_range_(max_range) {}
+  std::vector<Point> Filter(const std::vector<Point>& point_cloud) const {
+    std::vector<uint32_t> keep(point_cloud.size());
+    size_t n = 0;
+    Check(hg_adaptive_voxel_filter(ctx_->get(), max_length_, min_num_points_, max_range_,
+                                   point_cloud.empty() ? nullptr : point_cloud[0].data(), point_cloud.size(), 3, HG_HOST,
+                                   keep.data(), &n), "hg_adaptive_voxel_filter");
+    std::vector<Point> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = point_cloud[keep[i]];
+    return out;
+  }
+ private:
+  Context* ctx_;
+  float max_length_, min_num_points_, max_range_;
+};
+}  // namespace sensor
+
 namespace mapping {
 
 class HybridGridTSDF {

@@ -43,3 +43,8 @@ def test_cpp_local_trajectory_builder_example():
     tex = re.search(r"^texture (\d+) x (\d+), (\d+) pixels with alpha", out.stdout, re.M)
     assert tex, out.stdout
     assert 55 <= int(tex.group(1)) <= 70 and 55 <= int(tex.group(2)) <= 70 and int(tex.group(3)) > 100
+    # sensor::VoxelFilter / AdaptiveVoxelFilter wrappers: 61200 points -> 0.15 m voxels -> >= 150 points
+    flt = re.search(r"^filters: (\d+) -> (\d+) -> (\d+) points", out.stdout, re.M)
+    assert flt, out.stdout
+    n0, n1, n2 = (int(flt.group(i)) for i in (1, 2, 3))
+    assert n0 == 61200 and 300 < n1 < 2000 and 150 <= n2 <= n1
