@@ -38,10 +38,11 @@ def parse_args():
     ap.add_argument("--cpu-scans", type=int, default=3)
     ap.add_argument("--max-blocks", type=int, default=1 << 18)
     ap.add_argument("--window", type=int, default=10, help="control points of --workload window")
-    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "register_filtered"],
+    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "register_filtered", "match_batch"],
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=8, help="--workload match_batch: independent matches per call")
     ap.add_argument("--insert-mode", default="exact", choices=["exact", "fast"],
                     help="--workload insert_stream: exact = bit-identical to the reference (headline), "
                          "fast = HG_INSERT_FAST tolerance mode (order-free sums, one quantisation per call)")
@@ -469,7 +470,111 @@ def run_register_filtered(args):
     }
 
 
+def run_match_batch(args):
+    """Independent scan-to-submap matches solved together (hg_problem_solve_batch): the shape of a
+    constraint search, which hands one finished submap and many scans to CeresScanMatcher3D::Match. One
+    step = --batch matches of different 100k-point scans against the same 3-resolution TSDF, no
+    insertion. Extra workload, not the headline metric."""
+    import torch
+    from hectorgrapher_amd import api, synth
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0)
+    n_pts = args.rings * args.cols
+    B = args.batch
+    map_scans = make_scans(args.rings, args.cols, 0, args.map_scans, 0)
+    grids = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+    inserters = [api.TSDFRangeDataInserter3D() for _ in grids]
+    for pose, pts in map_scans:
+        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                           pose_tq=pose.astype(np.float32))
+    # queries around the mapped stretch of the trajectory
+    queries = []
+    for j in range(B):
+        k = j % args.map_scans
+        pose = synth.pose_k(k)
+        pts = synth.generate_scan(pose, args.rings, args.cols, stream=5000 + j)
+        queries.append((pose, pts, torch.from_numpy(pts).to(dev), synth.pose_mul(pose, synth.perturbation())))
+    torch.cuda.synchronize()
+    scale = 1.0 / np.sqrt(float(n_pts))
+    problems = [api.Problem(ctx) for _ in range(B)]
+    stats = {"its": [], "evals": 0}
+
+    def step(sample):
+        for p, (_, _, d, guess) in zip(problems, queries):
+            p.reset()
+            i = p.add_pose(guess)
+            p.add_block(d, grids, scale, i, multi_res=True)
+        summ = api.solve_batch(problems)
+        stats["its"].append(np.mean([s_.num_iterations for s_ in summ]))
+        if sample:
+            stats["evals"] += sum(s_.num_cost_evaluations for s_ in summ)
+
+    for _ in range(args.warmup):
+        step(False)
+    stats = {"its": [], "evals": 0}
+    ctx.prof_reset()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sampling = args.prof_every > 0 and i % args.prof_every == 0
+        ctx.prof_enable(sampling)
+        step(sampling)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    errs = [float(np.linalg.norm(p.get_pose(0)[:3] - q[0][:3])) for p, q in zip(problems, queries)]
+    base = None
+    lbar = 4.0 / 3.0
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        og = [po.Grid(r) for r in RESOLUTIONS]
+        for pose, pts in map_scans:
+            loc = synth.transform_points(pose, pts)
+            for g in og:
+                g.insert(pose[:3], loc)
+        t1 = time.perf_counter()
+        n_cpu = min(B, args.cpu_scans)
+        lk = pb = 0
+        for pose, pts, _, guess in queries[:n_cpu]:
+            pr = po.Problem()
+            i = pr.add_pose(guess)
+            pr.add_block(pts, og, scale, i, multi_res=True)
+            pr.solve()
+            a, b = pr.lookup_stats()
+            lk += a
+            pb += b
+        lbar = pb / max(1, lk)
+        base = {"value": n_cpu / (time.perf_counter() - t1), "unit": "matches/s", "cores": 1, "kind": "port",
+                "sample": "%d matches of the same workload, oracle -O3 1 thread" % n_cpu}
+    n_launch = max(1, prof["residuals"][0])
+    avg_ms = prof["residuals"][1] / n_launch
+    # launches after a problem's termination move no data for it: scale by the share that evaluated
+    sampled_steps = max(1, len([i for i in range(args.steps) if args.prof_every > 0 and i % args.prof_every == 0]))
+    evals_per_launch = stats["evals"] / max(1, n_launch)
+    bytes_per_launch = n_pts * (12.0 + 32.0 * lbar) * evals_per_launch
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {
+        "metric": "matches/s (batch of %d independent 100k-pt scan-to-submap matches, 3-res TSDF)" % B,
+        "value": args.steps * B / elapsed, "unit": "matches/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "match_batch: %d independent single-pose multi-res LM matches per call "
+                               "(hg_problem_solve_batch), %d-pt scans, no insertion" % (B, n_pts),
+                   "mean_lm_iterations": float(np.mean(stats["its"])), "mean_pose_error_m": float(np.mean(errs))},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_tsdf_residuals_single_batch",
+                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "problems_evaluating_per_launch": evals_per_launch, "sampled_steps": sampled_steps},
+        "cpu_baseline": base,
+        "gpu_over_cpu": (args.steps * B / elapsed) / base["value"] if base else None,
+    }
+
+
 def run(args, out_fd=None):
+    if args.workload == "match_batch":
+        return run_match_batch(args)
     if args.workload == "insert_stream":
         return run_insert_stream(args)
     if args.workload == "register_filtered":

@@ -498,6 +498,21 @@ class Problem:
         return s
 
 
+def solve_batch(problems, **kw):
+    """hg_problem_solve_batch: independent problems of one context solved with shared kernel launches
+    (the many scan-to-submap matches of a constraint search). Returns the list of summaries."""
+    L = _lib.load()
+    o = SolverOpts()
+    L.hg_solver_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    n = len(problems)
+    arr = (C.c_void_p * n)(*[p._h for p in problems])
+    summ = (SolverSummary * n)()
+    check(L.hg_problem_solve_batch(arr, n, C.byref(o), summ), "hg_problem_solve_batch")
+    return list(summ)
+
+
 def register_scan(problem, pose_index, inserters, range_data, grids, **solver_kw):
     """One registration step on the device (hg_register_scan): solve `problem`, then insert
     `range_data` (tracking frame) into `grids` at the solved pose. Returns (pose, summary)."""

@@ -2123,9 +2123,10 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
 // the X tiles (36 KB) instead of the general solver's working set (139 KB). (256-thread workgroups
 // — 391 of them, on all 256 CUs — were measured slower: twice the partials for the tail to sum.)
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
-    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
-    const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket) {
+__device__ __forceinline__ void single_eval(const PyramidView& pv, const float* __restrict__ xyz, unsigned n,
+                                            double scaling, const BlockXform* __restrict__ xf,
+                                            double* __restrict__ partials, LmState* G, unsigned* ticket,
+                                            unsigned wg_index, unsigned num_wg) {
   if (G->h.done) return;
 #ifdef HG_EVAL_STAMPS
   const int eval_it = G->h.iteration;
@@ -2138,7 +2139,7 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
   tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, partials, nullptr,
                                reinterpret_cast<double (*)[kWave][8]>(smem),
                                reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
-                               xcd_chunk(blockIdx.x, gridDim.x));
+                               xcd_chunk(wg_index, num_wg));
   EVAL_STAMP(1);
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
@@ -2147,7 +2148,7 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = atomicAdd(ticket, 1u);
-    s_last = (t == gridDim.x - 1u) ? 1 : 0;
+    s_last = (t == num_wg - 1u) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;
@@ -2158,8 +2159,39 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
   }
   __syncthreads();
   EVAL_STAMP(2);
-  lm_step_single(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), partials, gridDim.x);
+  lm_step_single(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), partials, num_wg);
   EVAL_STAMP(3);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
+    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
+    const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket) {
+  single_eval<THREADS>(pv, xyz, n, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x);
+}
+
+// Several INDEPENDENT single-pose problems per launch (blockIdx.y = problem): each keeps its own
+// state, partials, ticket and mailbox and runs exactly the arithmetic of k_tsdf_residuals_single,
+// so results are identical to solving them one after the other; a problem that has terminated, or
+// whose scan needs fewer workgroups than the widest of the batch, leaves at once. One registration
+// chain is latency-bound and fills a fraction of the chip; a batch shares the launches.
+struct SingleJob {
+  PyramidView pv;
+  const float* xyz;
+  const BlockXform* xf;
+  double* partials;
+  LmState* G;
+  unsigned* ticket;
+  double scaling;
+  unsigned n;
+  unsigned num_wg;
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
+  const SingleJob& J = jobs[blockIdx.y];
+  if (blockIdx.x >= J.num_wg) return;
+  single_eval<THREADS>(J.pv, J.xyz, J.n, J.scaling, J.xf, J.partials, J.G, J.ticket, blockIdx.x, J.num_wg);
 }
 
 // Same launch protocol for a block with per-return interpolation factors. The staging tiles of
@@ -2952,6 +2984,91 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
   int rc = hg_problem_solve_async(p, opts);
   if (rc != HG_OK) return rc;
   return hg_problem_fetch(p, summary);
+}
+
+int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solver_opts* opts,
+                           hg_solver_summary* summaries) {
+  if (!problems || count < 1) return HG_ERR_INVALID;
+  // the gather rate of the residual pass saturates at about 16 scans of 100k points in flight;
+  // larger lists go through in groups (measured: 32 in one launch is slower than 2 x 16)
+  constexpr int kGroup = 16;
+  if (count > kGroup) {
+    for (int i0 = 0; i0 < count; i0 += kGroup) {
+      const int rc = hg_problem_solve_batch(problems + i0, std::min(kGroup, count - i0), opts,
+                                            summaries ? summaries + i0 : nullptr);
+      if (rc != HG_OK) return rc;
+    }
+    return HG_OK;
+  }
+  for (int i = 0; i < count; ++i)
+    if (!problems[i] || problems[i]->ctx != problems[0]->ctx) return HG_ERR_INVALID;
+  hg_ctx* c = problems[0]->ctx;
+  hipStream_t s = c->stream;
+  HG_HIP_CHECK(hipSetDevice(c->device));
+  // the batched launch covers problems that take the register-resident single-pose step
+  bool batchable = count >= 2;
+  int rc = HG_OK;
+  for (int i = 0; i < count && rc == HG_OK; ++i) {
+    hg_problem* p = problems[i];
+    rc = upload_state(p, opts);
+    if (rc != HG_OK) break;
+    const LmHead& S = p->h_state.h;
+    if (!(p->single_threads && S.ncols == 6 && S.bw == 5 && S.num_blocks == 1 && S.num_small == 0 &&
+          S.blocks[0].active && S.opt.max_num_iterations == problems[0]->h_state.h.opt.max_num_iterations))
+      batchable = false;
+  }
+  if (rc != HG_OK) return rc;
+  if (!batchable) {
+    for (int i = 0; i < count; ++i) {
+      rc = hg_problem_solve(problems[i], opts, summaries ? summaries + i : nullptr);
+      if (rc != HG_OK) return rc;
+    }
+    return HG_OK;
+  }
+  std::vector<SingleJob> jobs(count);
+  unsigned max_wg = 0;
+  unsigned long long units = 0;
+  for (int i = 0; i < count; ++i) {
+    hg_problem* p = problems[i];
+    const LmHead& S = p->h_state.h;
+    const BlockInfo& bi = S.blocks[0];
+    const hg_problem::Block& hb = p->blocks[0];
+    SingleJob& J = jobs[i];
+    std::memset(&J, 0, sizeof(J));
+    J.pv.levels = static_cast<int>(hb.pyramid.size());
+    J.pv.multi_res = hb.multi_res;
+    for (int l = 0; l < J.pv.levels; ++l) J.pv.level[l] = hb.pyramid[l]->view;
+    J.xyz = hb.d_xyz;
+    J.xf = p->d_xf;
+    J.partials = p->partials.as<double>();
+    J.G = p->d_state;
+    J.ticket = p->d_ticket;
+    J.scaling = bi.scaling;
+    J.n = bi.n;
+    J.num_wg = bi.num_wg;
+    max_wg = std::max(max_wg, bi.num_wg);
+    units += bi.n;
+    p->solve_pending = true;
+    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small,
+                       MODE_PREPARE, p->d_box, p->up_words);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  if ((rc = c->ws_misc.reserve(sizeof(SingleJob) * jobs.size())) != HG_OK) return rc;
+  HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs.data(), sizeof(SingleJob) * jobs.size(), hipMemcpyHostToDevice, s));
+  HG_HIP_CHECK(hipStreamSynchronize(s));  // `jobs` leaves scope below; the copy is from pageable memory
+  const int max_it = problems[0]->h_state.h.opt.max_num_iterations;
+  {
+    ProfScope group(c, HG_K_RESIDUALS, units * (max_it + 1), static_cast<unsigned>(max_it + 1), true);
+    for (int it = 0; it <= max_it; ++it)
+      hipLaunchKernelGGL(k_tsdf_residuals_single_batch<kEvalThreads>, dim3(max_wg, count), dim3(kEvalThreads), 0, s,
+                         static_cast<const SingleJob*>(c->ws_misc.ptr));
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  for (int i = 0; i < count; ++i) {
+    const int r2 = hg_problem_fetch(problems[i], summaries ? summaries + i : nullptr);
+    if (r2 != HG_OK) rc = r2;
+  }
+  return rc;
 }
 
 int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,

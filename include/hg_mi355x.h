@@ -279,6 +279,15 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
 int hg_solver_default_opts(hg_solver_opts* opts);
 /* ceres::Solve: Levenberg-Marquardt trust region on the device; poses are updated in place. */
 int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summary* summary);
+/* Solves `count` INDEPENDENT problems of one context, e.g. the scan-to-submap matches a constraint
+ * search hands to CeresScanMatcher3D::Match one by one (mapping/internal/3d/scan_matching/
+ * ceres_scan_matcher_3d.cc:72-118). Problems of the single-pose shape (one free pose, one TSDF
+ * block, no odometry / IMU blocks) share their kernel launches (one grid row per problem); every
+ * problem keeps its own solver state, so poses, costs and iteration counts are exactly those of
+ * hg_problem_solve on each. Other shapes are solved one after the other. summaries: count entries
+ * or NULL. */
+int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solver_opts* opts,
+                           hg_solver_summary* summaries);
 
 /* Enqueue-only solve and the matching read-back (hg_problem_solve = both). Between the two the
  * solved poses live in device memory only. */

@@ -417,3 +417,62 @@ def test_free_velocity_without_imu_block(po, hg, ctx, maps):
     assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
     a, b = op.get_pose(1), gp.get_pose(1)
     assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M and rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+
+
+def test_solve_batch_equals_individual_solves(po, hg, ctx):
+    """hg_problem_solve_batch: independent single-pose problems share their launches; every problem
+    keeps its own solver state, so poses and summaries are those of solving them one by one (and of
+    the oracle). Scans of different sizes and different pyramids in one batch; a problem of another
+    shape in the list makes the call fall back to sequential solves."""
+    import torch
+    dev = torch.device("cuda", 0)
+    grids_a = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in (0.05, 0.10, 0.20)]
+    grids_b = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in (0.10, 0.20)]
+    ogrids_a = [po.Grid(r) for r in (0.05, 0.10, 0.20)]
+    for k in range(4):
+        pose = synth.pose_k(k)
+        loc = synth.transform_points(pose, synth.generate_scan(pose, 32, 900, stream=k))
+        for g in grids_a + grids_b:
+            hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(pose[:3], loc), g)
+        for g in ogrids_a:
+            g.insert(pose[:3], loc)
+    cases = []
+    for j, (rings, cols) in enumerate([(32, 900), (16, 625), (50, 1200), (8, 100), (32, 901), (20, 333)]):
+        pose = synth.pose_k(4 + j % 3)
+        pts = synth.generate_scan(pose, rings, cols, stream=40 + j)
+        guess = synth.pose_mul(pose, synth.perturbation())
+        cases.append((pts, guess, grids_a if j % 2 == 0 else grids_b))
+
+    def build():
+        ps = []
+        for pts, guess, gl in cases:
+            p = hg.Problem(ctx)
+            i = p.add_pose(guess)
+            p.add_block(torch.from_numpy(pts).to(dev), gl, 1.0 / np.sqrt(len(pts)), i, multi_res=True)
+            ps.append(p)
+        return ps
+
+    single = build()
+    s_single = [p.solve() for p in single]
+    batch = build()
+    s_batch = hg.solve_batch(batch)
+    for a, b, sa, sb in zip(single, batch, s_single, s_batch):
+        assert np.array_equal(a.get_pose(0), b.get_pose(0))
+        assert (sa.num_iterations, sa.termination_type, sa.termination_reason, sa.final_cost, sa.initial_cost) == \
+               (sb.num_iterations, sb.termination_type, sb.termination_reason, sb.final_cost, sb.initial_cost)
+    # against the oracle for the first case
+    pr = po.Problem()
+    i = pr.add_pose(cases[0][1])
+    pr.add_block(cases[0][0], ogrids_a, 1.0 / np.sqrt(len(cases[0][0])), i, multi_res=True)
+    so = pr.solve()
+    assert so.num_iterations == s_batch[0].num_iterations
+    assert np.abs(pr.get_pose(i) - batch[0].get_pose(0)).max() < 1e-9
+    # mixed shapes: a two-pose problem in the list -> sequential fallback, same results
+    mixed = build()[:2]
+    p2 = hg.Problem(ctx)
+    a_ = p2.add_pose(cases[0][1], True)
+    b_ = p2.add_pose(cases[1][1])
+    p2.add_block(torch.from_numpy(cases[0][0]).to(dev), grids_a, 1e-2, a_, b_, 0.4, multi_res=True)
+    s_mixed = hg.solve_batch(mixed + [p2])
+    assert np.array_equal(mixed[0].get_pose(0), single[0].get_pose(0))
+    assert s_mixed[2].num_iterations >= 1
