@@ -241,8 +241,17 @@ __device__ inline void fetch_setup(const GridView& g, double x, double y, double
   }
 }
 __device__ inline void fetch_probe(const GridView& g, LevelFetch& f) {
+  // the 8 corners lie in one block unless an axis crosses a block face (1/8 per axis): only the
+  // corners whose block differs from corner 0's take their own probe (2.4 instead of 8 lane-loads
+  // per return and level; the residual pass is bound by the rate of divergent gathers)
+  const unsigned long long e0 = g.table[f.hash[0] & g.table_mask];
+  f.entry[0] = e0;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) f.entry[c] = g.table[f.hash[c] & g.table_mask];
+  for (int c = 1; c < 8; ++c) {
+    unsigned long long e = e0;
+    if (f.key[c] != f.key[0]) e = g.table[f.hash[c] & g.table_mask];
+    f.entry[c] = e;
+  }
 }
 __device__ inline void fetch_voxels(const GridView& g, LevelFetch& f) {
 #pragma unroll
@@ -350,8 +359,36 @@ __device__ inline D3 pyramid_tsd_n(const PyramidView& pv, double x, double y, do
   return r;
 }
 
+// Throughput form of the multi-resolution lookup (batched matching): the levels are visited one
+// after the other and only by the lanes that have not found a fully valid level yet — fewer
+// gathers and registers (two workgroups per CU) for more dependent round trips. Same selection,
+// same arithmetic, same result as pyramid_tsd_n.
+__device__ inline D3 pyramid_tsd_seq(const PyramidView& pv, double x, double y, double z) {
+  LevelSel s;
+  bool found = false;
+  for (int l = 0; l < pv.levels; ++l) {
+    if (__ballot(!found) == 0ull) break;
+    if (!found) {
+      LevelFetch f;
+      fetch_setup(pv.level[l], x, y, z, f);
+      fetch_probe(pv.level[l], f);
+      fetch_voxels(pv.level[l], f);
+      bool valid = true;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) valid = valid && ((f.code[c] >> 16) & 0x7FFFu) > 1u;
+      if (valid || l == 0) select_level(pv.level[l], f, s);  // level 0 stands in until a level is found
+      found = valid;
+    }
+  }
+  const D3 r = interp_selected(s, static_cast<double>(s.min_tsd), x, y, z);
+  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
+  return r;
+}
+
+template <bool SEQ = false>
 __device__ inline D3 pyramid_tsd(const PyramidView& pv, double x, double y, double z) {
   const int levels = pv.multi_res ? pv.levels : 1;
+  if (SEQ && pv.multi_res && levels > 1) return pyramid_tsd_seq(pv, x, y, z);
   switch (levels) {  // wave-uniform
     case 1: return pyramid_tsd_n<1>(pv, x, y, z);
     case 2: return pyramid_tsd_n<2>(pv, x, y, z);
@@ -368,6 +405,7 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
 
 // One return at transform (t, q): row8 = [d r / d(t, q) (7) | r]. The world point follows Eigen's
 // QuaternionBase::_transformVector, then + translation (rigid_transform.h:193-197).
+template <bool SEQ = false>
 __device__ __forceinline__ void return_row(const PyramidView& pv, const double* t, const double* q,
                                            const double* v, double scaling, double* row8) {
   const double qw = q[0];
@@ -379,7 +417,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const double* 
   const double wx = (v[0] + qw * uv[0] + c2[0]) + t[0];
   const double wy = (v[1] + qw * uv[1] + c2[1]) + t[1];
   const double wz = (v[2] + qw * uv[2] + c2[2]) + t[2];
-  const D3 tsd = pyramid_tsd(pv, wx, wy, wz);
+  const D3 tsd = pyramid_tsd<SEQ>(pv, wx, wy, wz);
   const double r = scaling * tsd.a;
   const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
   // d world / d q = [uv | w*duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v)
@@ -401,7 +439,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const double* 
 }
 
 // residuals of one block at its current transform + 36 partial sums per workgroup
-template <int THREADS = kEvalThreads>
+template <int THREADS = kEvalThreads, bool SEQ = false>
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
@@ -412,7 +450,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
   if (i < n) {
     const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
                          static_cast<double>(xyz[3 * i + 2])};
-    return_row(pv, xf->t, xf->q, v, scaling, row8);
+    return_row<SEQ>(pv, xf->t, xf->q, v, scaling, row8);
     if (residuals) residuals[i] = row8[7];
   }
   BODY_STAMP(4);
@@ -2122,7 +2160,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
 // the register-resident LM step in the tail, in a kernel of its own so that its LDS footprint is
 // the X tiles (36 KB) instead of the general solver's working set (139 KB). (256-thread workgroups
 // — 391 of them, on all 256 CUs — were measured slower: twice the partials for the tail to sum.)
-template <int THREADS>
+template <int THREADS, bool SEQ = false>
 __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* __restrict__ xyz, unsigned n,
                                             double scaling, const BlockXform* __restrict__ xf,
                                             double* __restrict__ partials, LmState* G, unsigned* ticket,
@@ -2136,7 +2174,7 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
   constexpr size_t kTiles = (THREADS / kWave) * (kWave * 8 + 64) * sizeof(double);
   constexpr size_t kTail = ((THREADS / kAcc) + 1) * kAcc * sizeof(double) + sizeof(LmHead) + 36 * sizeof(double);
   __shared__ __align__(16) unsigned char smem[kTiles > kTail ? kTiles : kTail];
-  tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, partials, nullptr,
+  tsdf_residuals_body<THREADS, SEQ>(pv, xyz, n, scaling, xf, partials, nullptr,
                                reinterpret_cast<double (*)[kWave][8]>(smem),
                                reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
                                xcd_chunk(wg_index, num_wg));
@@ -2188,10 +2226,10 @@ struct SingleJob {
 };
 
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
+__global__ __launch_bounds__(THREADS, 4) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
   const SingleJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.num_wg) return;
-  single_eval<THREADS>(J.pv, J.xyz, J.n, J.scaling, J.xf, J.partials, J.G, J.ticket, blockIdx.x, J.num_wg);
+  single_eval<THREADS, true>(J.pv, J.xyz, J.n, J.scaling, J.xf, J.partials, J.G, J.ticket, blockIdx.x, J.num_wg);
 }
 
 // Same launch protocol for a block with per-return interpolation factors. The staging tiles of
