@@ -203,15 +203,18 @@ struct LevelFetch {
 __device__ inline void fetch_setup(const GridView& g, double x, double y, double z, LevelFetch& f) {
   const float res = g.resolution;
   // CenterOfLowerVoxel (interpolated_tsdf.h:176-192): float centre, compared against the double
-  float cx = static_cast<float>(cell_index_1d(static_cast<float>(x), res)) * res;
-  float cy = static_cast<float>(cell_index_1d(static_cast<float>(y), res)) * res;
-  float cz = static_cast<float>(cell_index_1d(static_cast<float>(z), res)) * res;
-  if (static_cast<double>(cx) > x) cx -= res;
-  if (static_cast<double>(cy) > y) cy -= res;
-  if (static_cast<double>(cz) > z) cz -= res;
+  int i0[3] = {cell_index_1d(static_cast<float>(x), res), cell_index_1d(static_cast<float>(y), res),
+               cell_index_1d(static_cast<float>(z), res)};
+  float cx = static_cast<float>(i0[0]) * res;
+  float cy = static_cast<float>(i0[1]) * res;
+  float cz = static_cast<float>(i0[2]) * res;
+  // GetCellIndex of the lowered centre (:99-101 via GetWeight/GetTSD) is the index minus one:
+  // (i * res -+ res) / res is within 1e-2 of an integer for |i| <= 8192, far from a rounding tie
+  if (static_cast<double>(cx) > x) { cx -= res; i0[0] -= 1; }
+  if (static_cast<double>(cy) > y) { cy -= res; i0[1] -= 1; }
+  if (static_cast<double>(cz) > z) { cz -= res; i0[2] -= 1; }
   f.x1 = cx; f.y1 = cy; f.z1 = cz;
   f.x2 = cx + res; f.y2 = cy + res; f.z2 = cz + res;
-  const int i0[3] = {cell_index_1d(cx, res), cell_index_1d(cy, res), cell_index_1d(cz, res)};
   // per-axis pieces of key / hash / voxel index for index i and i + 1
   uint32_t kb[3][2], hs[3][2], vx[3][2];
   bool ok[3][2];
