@@ -52,3 +52,21 @@ def test_structs_match_header_layout():
     assert ctypes.sizeof(_lib.InsertStats) == 32
     assert ctypes.sizeof(_lib.SolverOpts) == 80
     assert ctypes.sizeof(_lib.SolverSummary) == 56
+
+
+def test_null_arguments_are_refused_before_any_device_work():
+    """Every entry point validates its pointers first and returns HG_ERR_INVALID (-1): callable
+    without a GPU, and it never aborts like the reference's CHECKs."""
+    import ctypes as C
+    from hectorgrapher_amd import _lib
+    L = _lib.load()
+    n = C.c_size_t()
+    w = C.c_int32()
+    assert L.hg_grid_xray(None, None, None, 0, C.byref(w), C.byref(w), None, C.byref(n)) == -1
+    assert L.hg_problem_solve_batch(None, 0, None, None) == -1
+    assert L.hg_problem_solve(None, None, None) == -1
+    assert L.hg_grid_insert(None, None, None, None, 0, 0, None, 0, 0, None) == -1
+    assert L.hg_grid_export(None, None, None, None, 0, C.byref(n)) == -1
+    assert L.hg_grid_to_proto(None, None, 0, C.byref(n)) == -1
+    assert L.hg_voxel_filter(None, 0.1, None, 0, 3, 0, None, C.byref(n)) == -1
+    assert L.hg_adaptive_voxel_filter(None, 2.0, 150.0, 15.0, None, 0, 3, 0, None, C.byref(n)) == -1
