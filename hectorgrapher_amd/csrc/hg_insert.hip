@@ -748,12 +748,11 @@ __device__ inline int ray_block_runs(const Ray& r, unsigned long long* run_key, 
 }
 
 // Per-thread result of k_bin_count, consumed by k_bin_scatter: for each of <= 4 runs the block
-// slot and the run's first record position inside the block's bin. begin/len: 4 bits each.
+// slot and the run's first record position inside the block's bin. 32 bytes (two 16-byte stores):
+// the run's begin / len (4 bits each) ride in the top byte of its slot word (slots have 24 bits).
 struct RunInfo {
-  uint32_t slot[kMaxRuns];
+  uint32_t slot[kMaxRuns];  // run k: slot | begin << 24 | len << 28; len 0 = no run
   uint32_t off[kMaxRuns];
-  uint32_t packed;  // run k: begin = (packed >> 8k) & 15, len = (packed >> (8k + 4)) & 15
-  uint32_t pad[3];
 };
 
 // Groups the lanes of a wavefront by `slot` (lanes with want == false stay out): returns the
@@ -846,17 +845,16 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
     if (want[k] && lane == leader[k]) base[k] = atomicAdd(&L.g.bin_count[slot[k]], total[k]);
   }
   RunInfo info;
-  info.packed = 0;
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
     const unsigned b = __shfl(base[k], leader[k]);
     if (want[k] && lane == leader[k] && b == 0u)  // first records of this bin in this call
       L.g.touched[atomicAdd(&L.g.counters[6], 1u)] = slot[k];
-    info.slot[k] = want[k] ? slot[k] : 0xFFFFFFFFu;
+    info.slot[k] = want[k] ? (slot[k] | (static_cast<uint32_t>(run_begin[k]) << 24) |
+                              (static_cast<uint32_t>(run_len[k]) << 28))
+                           : 0u;
     info.off[k] = b + prefix[k];
-    if (k < nr) info.packed |= (static_cast<uint32_t>(run_begin[k]) | (static_cast<uint32_t>(run_len[k]) << 4)) << (8 * k);
   }
-  info.pad[0] = info.pad[1] = info.pad[2] = 0;
   if (i < n) runs[static_cast<size_t>(level) * n + i] = info;
   const unsigned long long m = __ballot(hit);
   if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
@@ -1283,15 +1281,15 @@ __global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const float* 
   const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
   if (i >= n) return;
   const RunInfo info = runs[static_cast<size_t>(level) * n + i];
-  if (info.packed == 0u) return;
+  if ((info.slot[0] | info.slot[1] | info.slot[2] | info.slot[3]) == 0u) return;
   const ScanTable sc = scan_of(P);
   const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
-    const int len = (info.packed >> (8 * k + 4)) & 15;
-    if (len == 0 || info.slot[k] == 0xFFFFFFFFu) continue;
-    const int begin = (info.packed >> (8 * k)) & 15;
-    const unsigned dst = L.g.bin_offset[info.slot[k]] + info.off[k];
+    const int len = static_cast<int>(info.slot[k] >> 28);
+    if (len == 0) continue;
+    const int begin = static_cast<int>((info.slot[k] >> 24) & 15u);
+    const unsigned dst = L.g.bin_offset[info.slot[k] & 0xFFFFFFu] + info.off[k];
     int q = 0;
     for (int pos = begin; q < len; ++pos) {
       int cx, cy, cz;
