@@ -795,8 +795,8 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
   const LevelIns& L = P.lv[level];
   const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;  // see hg_device.h
   const int lane = threadIdx.x & (kWave - 1);
-  __shared__ unsigned s_hits;
-  if (threadIdx.x == 0) s_hits = 0;
+  __shared__ unsigned s_hits, s_first, s_first_base;
+  if (threadIdx.x == 0) { s_hits = 0; s_first = 0; }
   __syncthreads();
   bool hit = false;
   unsigned long long run_key[kMaxRuns];
@@ -845,11 +845,15 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
     if (want[k] && lane == leader[k]) base[k] = atomicAdd(&L.g.bin_count[slot[k]], total[k]);
   }
   RunInfo info;
+  // blocks that receive their first records of this call are enlisted in `touched`. The list's
+  // cursor is ONE device-wide word: the workgroup reserves its entries with a single atomic (one
+  // per first-touch would put ~10^4 same-address atomics per level on the kernel's critical path)
+  unsigned first_pos[kMaxRuns];
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
     const unsigned b = __shfl(base[k], leader[k]);
-    if (want[k] && lane == leader[k] && b == 0u)  // first records of this bin in this call
-      L.g.touched[atomicAdd(&L.g.counters[6], 1u)] = slot[k];
+    first_pos[k] = 0xFFFFFFFFu;
+    if (want[k] && lane == leader[k] && b == 0u) first_pos[k] = atomicAdd(&s_first, 1u);
     info.slot[k] = want[k] ? (slot[k] | (static_cast<uint32_t>(run_begin[k]) << 24) |
                               (static_cast<uint32_t>(run_len[k]) << 28))
                            : 0u;
@@ -859,7 +863,14 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
   const unsigned long long m = __ballot(hit);
   if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
   __syncthreads();
-  if (threadIdx.x == 0) wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
+  if (threadIdx.x == 0) {
+    wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
+    s_first_base = s_first ? atomicAdd(&L.g.counters[6], s_first) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k)
+    if (first_pos[k] != 0xFFFFFFFFu) L.g.touched[s_first_base + first_pos[k]] = slot[k];
 }
 
 // ==========================================================================================
