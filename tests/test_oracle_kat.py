@@ -3,6 +3,7 @@
 Each test names the reference test it restates (paths relative to /root/reference/cartographer/).
 """
 import numpy as np
+import pytest
 
 
 def test_tsd_value_converter_defaults_and_roundtrips(po):
@@ -297,3 +298,52 @@ def test_xray_texture_known_answers(po):
     # count 2, free space 28 * 0.15 = 4.2, max_probability 0.52 -> mean (1.04 + 0.48 * 4.2) / 6.2 = 0.4929
     # -> logit -0.0284 -> RoundToInt(2.16883 * 57.8002) + 1 = 126 -> delta 2 -> (value 2, alpha 0)
     assert cells2.shape == (1, 1, 2) and cells2[0, 0].tolist() == [2, 0]
+
+
+def test_lm_reaches_the_minimum_an_independent_solver_finds(po):
+    """The restated Ceres loop against scipy.optimize.least_squares (trust-region reflective, its own
+    finite-difference Jacobian, no shared code with the oracle's solver): same local minimum of the
+    same residual function from the same start."""
+    scipy_opt = pytest.importorskip("scipy.optimize")
+    from hectorgrapher_amd import synth
+    g = po.Grid(0.1)
+    for k in range(4):
+        pose = synth.pose_k(k)
+        g.insert(pose[:3], synth.transform_points(pose, synth.generate_scan(pose, 16, 400, stream=k)))
+    pose = synth.pose_k(4)
+    pts = synth.generate_scan(pose, 16, 400, stream=4)
+    start = synth.pose_mul(pose, synth.perturbation())
+    pr = po.Problem()
+    pr.add_pose(start)
+    pr.add_block(pts, [g], 1.0 / np.sqrt(len(pts)), 0)
+    summ = pr.solve(max_num_iterations=50, function_tolerance=1e-12, gradient_tolerance=1e-14,
+                    parameter_tolerance=1e-12)
+    solved = pr.get_pose(0)
+
+    ev = po.Problem()
+    ev.add_pose(start)
+    ev.add_block(pts, [g], 1.0 / np.sqrt(len(pts)), 0)
+
+    def residuals(x):  # x: translation + rotation-vector increment on the start pose
+        tq = start.copy()
+        tq[:3] = start[:3] + x[:3]
+        tq[3:] = po.quaternion_plus(start[3:], x[3:])
+        ev.set_pose(0, tq)
+        return ev.evaluate(False)[1].copy()
+
+    ref = scipy_opt.least_squares(residuals, np.zeros(6), method="trf", xtol=1e-12, ftol=1e-12, gtol=1e-12,
+                                  diff_step=1e-6)
+    assert ref.cost <= summ.initial_cost
+    # the cost is piecewise smooth (validity branches of the interpolation flip between voxels), so two
+    # optimisers stop a few branch cells apart: both remove the same share of the cost, within 1 % of
+    # the initial cost, at poses within 3 mm / 3 mrad
+    tq = start.copy()
+    tq[:3] = start[:3] + ref.x[:3]
+    tq[3:] = po.quaternion_plus(start[3:], ref.x[3:])
+    print("cost oracle %.6e scipy %.6e initial %.6e; dt %.2e dq %.2e" % (
+        summ.final_cost, ref.cost, summ.initial_cost, np.abs(tq[:3] - solved[:3]).max(),
+        min(np.abs(tq[3:] - solved[3:]).max(), np.abs(tq[3:] + solved[3:]).max())))
+    assert summ.final_cost < 0.7 * summ.initial_cost
+    assert abs(summ.final_cost - ref.cost) <= 1e-2 * summ.initial_cost
+    assert np.abs(tq[:3] - solved[:3]).max() < 3e-3
+    assert min(np.abs(tq[3:] - solved[3:]).max(), np.abs(tq[3:] + solved[3:]).max()) < 3e-3
