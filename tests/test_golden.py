@@ -48,3 +48,29 @@ def test_hip_reproduces_golden(hg, ctx):
         assert np.linalg.norm(pose[:3] - G[name + "_pose"][:3]) < 1e-4       # north_star tolerance
         assert 2 * np.arccos(min(1.0, abs(float(pose[3:] @ G[name + "_pose"][3:])))) < 1e-4
         assert [s.num_iterations, s.num_successful_steps, s.termination_type, s.termination_reason] == G[name + "_summary"].tolist()
+
+
+N = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "next_rows.npz"))
+
+
+def test_oracle_reproduces_golden_filters_and_xray(po):
+    grid = po.Grid(float(G["resolutions"][0]))
+    for o, s in zip(G["origins"], G["scans"]):
+        grid.insert(o, s)
+    cells, mx = grid.xray(N["xray_pose"])
+    assert np.array_equal(cells, N["xray_cells"]) and np.array_equal(mx, N["xray_max_index"])
+    assert np.array_equal(po.voxel_filter(0.15, N["cloud"]), N["voxel_filter_015"])
+    assert np.array_equal(po.adaptive_voxel_filter(2.0, 150, 15.0, N["cloud"]), N["adaptive_high"])
+    assert np.array_equal(po.adaptive_voxel_filter(4.0, 200, 60.0, N["cloud"]), N["adaptive_low"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_filters_and_xray(hg, ctx):
+    grid = hg.HybridGridTSDF(ctx, float(G["resolutions"][0]), max_blocks=1 << 13)
+    for o, s in zip(G["origins"], G["scans"]):
+        hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(o, s), grid)
+    cells, mx = grid.xray(N["xray_pose"])
+    assert np.array_equal(cells, N["xray_cells"]) and np.array_equal(mx, N["xray_max_index"])
+    assert np.array_equal(hg.VoxelFilter(ctx, 0.15).Filter(N["cloud"]), N["voxel_filter_015"])
+    assert np.array_equal(hg.AdaptiveVoxelFilter(ctx, 2.0, 150, 15.0).Filter(N["cloud"]), N["adaptive_high"])
+    assert np.array_equal(hg.AdaptiveVoxelFilter(ctx, 4.0, 200, 60.0).Filter(N["cloud"]), N["adaptive_low"])
