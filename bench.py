@@ -732,11 +732,17 @@ def run(args, out_fd=None):
     except Exception:
         traffic = None
     achieved = bytes_per / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    families = {}
+    for name, (ms, nbytes, _) in fam.items():
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        families[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved": gbs,
+                          "frac": gbs / HBM_PEAK_GBS}
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per,
                 "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
                 "per_kernel_launches": {k: v[0] for k, v in prof.items()},
+                "families": families,
                 "hip_event_sampling": "every %d-th of the %d timed steps" % (max(1, args.prof_every), args.steps),
                 "residual_launches_evaluating": active_share}
 
