@@ -514,8 +514,9 @@ def solve_batch(problems, **kw):
 
 
 def register_scan(problem, pose_index, inserters, range_data, grids, **solver_kw):
-    """One registration step on the device (hg_register_scan): solve `problem`, then insert
-    `range_data` (tracking frame) into `grids` at the solved pose. Returns (pose, summary)."""
+    """One registration step on the device (hg_register_scan_mode): solve `problem`, then insert
+    `range_data` (tracking frame) into `grids` at the solved pose, in the mode of inserters[0]
+    (HG_INSERT_EXACT unless chosen otherwise). Returns (pose, summary)."""
     L = _lib.load()
     o = SolverOpts()
     L.hg_solver_default_opts(C.byref(o))
@@ -532,9 +533,9 @@ def register_scan(problem, pose_index, inserters, range_data, grids, **solver_kw
         n, ptr, space = len(r), _p(r), _lib.HG_HOST
     pose = np.empty(7, np.float64)
     s = SolverSummary()
-    check(L.hg_register_scan(problem._h, C.byref(o), pose_index, garr, opts, n_l,
-                             _p(range_data.origin), ptr, n, range_data.width, space, _p(pose),
-                             C.byref(s)), "hg_register_scan")
+    check(L.hg_register_scan_mode(problem._h, C.byref(o), pose_index, garr, opts, n_l,
+                                  _p(range_data.origin), ptr, n, range_data.width, space, int(inserters[0].mode),
+                                  _p(pose), C.byref(s)), "hg_register_scan")
     return pose, s
 
 

@@ -2024,7 +2024,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     if (!(static_cast<float>(opts[l].weight_function_epsilon) >= 1.0f)) unit_weight = false;
   }
   if (mode == HG_INSERT_FAST) {
-    if (!fixed_ok || !unit_weight || d_pose_tq) {
+    if (!fixed_ok || !unit_weight) {
       set_last_error("HG_INSERT_FAST needs unit update weights (weight_function_epsilon >= 1), no free-space "
                      "voxels and relative_truncation_distance <= 3");
       return HG_ERR_UNSUPPORTED;

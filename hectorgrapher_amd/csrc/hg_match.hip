@@ -3116,6 +3116,14 @@ int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
                      hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
                      const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
                      double pose_out[7], hg_solver_summary* summary) {
+  return hg_register_scan_mode(p, sopts, pose_index, grids, iopts, levels, origin, xyz, n, width, memspace,
+                               HG_INSERT_EXACT, pose_out, summary);
+}
+
+int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
+                          hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
+                          const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
+                          int insert_mode, double pose_out[7], hg_solver_summary* summary) {
   if (!p || !grids || !iopts || !origin || pose_index < 0 ||
       pose_index >= static_cast<int>(p->poses.size()))
     return HG_ERR_INVALID;
@@ -3137,7 +3145,7 @@ int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
   const double* d_pose = (p->h_state.h.ncols == 0) ? nullptr : &p->d_state->h.x[pose_index][0];
   const uint64_t offsets[2] = {0, n};
   rc = pyramid_insert_impl(grids, iopts, levels, origin, xyz, offsets, 1, width, approx, d_pose,
-                           HG_INSERT_EXACT, memspace, nullptr);
+                           insert_mode, memspace, nullptr);
 #ifdef HG_HOST_STAMPS
   const auto h2 = std::chrono::steady_clock::now();
 #endif

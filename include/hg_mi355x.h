@@ -302,6 +302,13 @@ int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
                      hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
                      const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
                      double pose_out[7], hg_solver_summary* summary);
+/* The same step with the insert mode chosen: HG_INSERT_EXACT (what hg_register_scan does) or
+ * HG_INSERT_FAST — the match is unchanged, the insertion costs the same wherever the sensor stands
+ * (no per-voxel chain), the map differs from the reference's within the tolerance of that mode. */
+int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
+                          hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
+                          const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
+                          int insert_mode, double pose_out[7], hg_solver_summary* summary);
 
 /* ---- one-block convenience (CeresScanMatcher3D::{Evaluate,Match} shape) ----------------- */
 int hg_match_evaluate(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_res,

@@ -140,3 +140,40 @@ def test_fast_refuses_options_it_cannot_honour(hg, ctx):
     pts = np.array([[3.0, 0.1, 0.2]], np.float32)
     with pytest.raises(hg.HgError):
         hg.TSDFRangeDataInserter3D(o, mode=hg._lib.HG_INSERT_FAST).Insert(hg.RangeData([0, 0, 0], pts), g)
+
+
+def test_register_scan_with_fast_insert(po, hg, ctx):
+    """hg_register_scan_mode(HG_INSERT_FAST): the match is the one of the exact step (same map, same
+    solver), the scan is inserted at the solved pose taken from device memory, in tolerance mode."""
+    import torch
+    dev = torch.device("cuda", 0)
+    exact = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in RES]
+    fast = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in RES]
+    ins_e = [hg.TSDFRangeDataInserter3D() for _ in RES]
+    ins_f = [hg.TSDFRangeDataInserter3D(mode=hg._lib.HG_INSERT_FAST) for _ in RES]
+    for k in range(4):                                        # identical maps to start from
+        pose = synth.pose_k(k)
+        pts = synth.generate_scan(pose, 32, 900, stream=k)
+        for grids in (exact, fast):
+            hg.insert_pyramid(ins_e, hg.RangeData([0, 0, 0], pts), grids, pose_tq=pose.astype(np.float32))
+    pose = synth.pose_k(4)
+    pts = synth.generate_scan(pose, 32, 900, stream=4)
+    d = torch.from_numpy(pts).to(dev)
+    guess = synth.pose_mul(pose, synth.perturbation())
+    out = []
+    for grids, ins in ((exact, ins_e), (fast, ins_f)):
+        p = hg.Problem(ctx)
+        i = p.add_pose(guess)
+        p.add_block(d, grids, 1.0 / np.sqrt(len(pts)), i, multi_res=True)
+        est, summ = hg.register_scan(p, i, ins, hg.RangeData([0, 0, 0], d), grids)
+        out.append((est, summ.num_iterations))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    for ge, gf, r in zip(exact, fast, RES):
+        tau = float(np.float32(2.5 * r))
+        a = sorted_cells(*ge.export())
+        b = sorted_cells(*gf.export())
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])   # cells and weight codes
+        ta, _ = decode(*a, tau, 1000.0)
+        tb, _ = decode(*b, tau, 1000.0)
+        assert np.abs(ta - tb).max() <= 5e-3 * tau
+        assert (ta != tb).any()                                            # it really took the other path
