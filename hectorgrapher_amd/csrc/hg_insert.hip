@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_accumulate(PyramidIns P, 
 // so its weight CODE grows by round(weight_resolution) per update (33 for max weight 1000, i.e.
 // 1.0071 instead of 1) until the clamp pins it at 32767; with that sequence the product is a
 // ratio of Gamma functions. `code` is the weight code before the call (0 = unknown = weight 0).
-__device__ inline double fast_survival(const GridView& g, float maxw, uint32_t code, double m, uint32_t* code_out) {
+__device__ inline double fast_survival(const GridView& g, uint32_t code, double m, uint32_t* code_out) {
   const int step = static_cast<int>(roundf(g.weight_resolution));
   const double kw = static_cast<double>(g.weight_scale);
   const int c0 = static_cast<int>(code & 0x7FFFu) == 0 ? 1 : static_cast<int>(code & 0x7FFFu);
@@ -1066,7 +1066,6 @@ __device__ inline double fast_survival(const GridView& g, float maxw, uint32_t c
     const double wmax = static_cast<double>(32766.f * g.weight_scale);
     A *= pow(wmax / (wmax + 1.0), m - n);
   }
-  (void)maxw;
   return A;
 }
 
@@ -1111,7 +1110,7 @@ __global__ __launch_bounds__(kBinThreads) void k_fast_apply(PyramidIns P) {
       const uint32_t code = *cell;
       const double d0 = static_cast<double>(value_to_tsd(g, code & 0xFFFFu));
       uint32_t wcode;
-      const double A = closed_form ? fast_survival(g, maxw, code >> 16, m, &wcode)
+      const double A = closed_form ? fast_survival(g, code >> 16, m, &wcode)
                                    : fast_survival_walk(g, maxw, code >> 16, m, &wcode);
       // every update is a convex combination, so the m updates carry the weight 1 - A together;
       // they enter at their mean (their individual shares depend on the arrival order)
