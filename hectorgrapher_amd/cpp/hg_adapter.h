@@ -444,6 +444,7 @@ class LocalTrajectoryBuilder3D {
     double high_resolution_grid_weight = 1.0;
     int max_num_iterations = 12;
     float min_range = 1.f, max_range = 60.f;  // trajectory_builder_3d.lua:18-19
+    int insert_mode = HG_INSERT_EXACT;        // HG_INSERT_FAST: tolerance insert (see hg_mi355x.h)
   };
 
   LocalTrajectoryBuilder3D(Context* ctx, const Options& options) : ctx_(ctx), options_(options) {
@@ -509,7 +510,7 @@ class LocalTrajectoryBuilder3D {
       for (auto& g : grids_) pyr.push_back(g->get());
       const std::array<float, 7> pf = transform::ToFloat(estimate);
       Check(hg_pyramid_insert(pyr.data(), opts.data(), static_cast<int>(pyr.size()), data.origin.data(), cloud[0].data(),
-                              cloud.size(), 0, pf.data(), HG_INSERT_EXACT, HG_HOST, nullptr), "hg_pyramid_insert");
+                              cloud.size(), 0, pf.data(), options_.insert_mode, HG_HOST, nullptr), "hg_pyramid_insert");
       std::unique_ptr<InsertionResult> ins(new InsertionResult);
       for (auto& g : grids_) ins->insertion_grids.push_back(g.get());
       result->insertion_result = std::move(ins);
@@ -618,7 +619,7 @@ class OptimizingLocalTrajectoryBuilder {
         std::vector<hg_insert_opts> opts(grids_.size(), options_.inserter);
         const std::array<float, 7> pf = transform::ToFloat(out.pose);
         Check(hg_pyramid_insert(pyr.data(), opts.data(), static_cast<int>(pyr.size()), out.origin.data(),
-                                out.cloud[0].data(), out.cloud.size(), 0, pf.data(), HG_INSERT_EXACT, HG_HOST, nullptr),
+                                out.cloud[0].data(), out.cloud.size(), 0, pf.data(), options_.insert_mode, HG_HOST, nullptr),
               "hg_pyramid_insert");
         out.inserted = true;
         std::unique_ptr<InsertionResult> ins(new InsertionResult);
