@@ -1223,6 +1223,11 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
         while (slices < 64 && cnt > slices * 1024u) slices <<= 1;
+        // a block next to the sensor (tens of thousands of records) holds several voxels with
+        // ~10^3 updates each, usually neighbours: one voxel per workgroup, or their chains and
+        // sorts queue up behind each other in one slice
+        if (cnt > 32768u) slices = 512;
+        else if (cnt > 16384u) slices = min(512u, slices * 4u);
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -1256,6 +1261,11 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
         while (slices < 64 && cnt > slices * 1024u) slices <<= 1;
+        // a block next to the sensor (tens of thousands of records) holds several voxels with
+        // ~10^3 updates each, usually neighbours: one voxel per workgroup, or their chains and
+        // sorts queue up behind each other in one slice
+        if (cnt > 32768u) slices = 512;
+        else if (cnt > 16384u) slices = min(512u, slices * 4u);
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
