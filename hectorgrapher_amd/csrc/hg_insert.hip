@@ -1180,7 +1180,8 @@ __device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* s_wave /*[
 
 // grid (levels), 1024 threads: bin offsets by an exclusive scan over the touched list, and the
 // apply work list: a bin larger than one LDS pass is split into voxel slices handled by
-// different workgroups (voxels are independent of each other).
+// different workgroups (voxels are independent of each other); slice k takes the voxels
+// v with v mod slices == k (see k_bin_apply).
 __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned records_per_level) {
   const LevelIns& L = P.lv[blockIdx.x];
   __shared__ unsigned s_scan[16];
@@ -1223,11 +1224,6 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
         while (slices < 64 && cnt > slices * 1024u) slices <<= 1;
-        // a block next to the sensor (tens of thousands of records) holds several voxels with
-        // ~10^3 updates each, usually neighbours: one voxel per workgroup, or their chains and
-        // sorts queue up behind each other in one slice
-        if (cnt > 32768u) slices = 512;
-        else if (cnt > 16384u) slices = min(512u, slices * 4u);
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -1261,11 +1257,6 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
         while (slices < 64 && cnt > slices * 1024u) slices <<= 1;
-        // a block next to the sensor (tens of thousands of records) holds several voxels with
-        // ~10^3 updates each, usually neighbours: one voxel per workgroup, or their chains and
-        // sorts queue up behind each other in one slice
-        if (cnt > 32768u) slices = 512;
-        else if (cnt > 16384u) slices = min(512u, slices * 4u);
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -1378,6 +1369,16 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
     const unsigned v_lo = static_cast<unsigned>(item >> 24) & 1023u;
     const unsigned v_hi = static_cast<unsigned>(item >> 34) & 1023u;
     const unsigned n = static_cast<unsigned>(item >> 44);
+    // The slices of a bin interleave its voxels (voxel v belongs to slice v mod S): the heavy voxels
+    // of a block are spatial neighbours, contiguous slices would queue their chains in one workgroup.
+    // Inside the kernel a voxel is addressed by pv = (v mod S) * (512 / S) + v / S, which makes every
+    // slice a contiguous range [v_lo, v_hi) of pv.
+    const unsigned per_slice = v_hi - v_lo;                 // 512 / S, a power of two
+    const unsigned s_bits = 9u - (31u - __builtin_clz(per_slice));  // log2(S)
+    const unsigned s_mask = (1u << s_bits) - 1u;
+    auto to_pv = [&](unsigned v) { return (v & s_mask) * per_slice + (v >> s_bits); };
+    auto from_pv = [&](unsigned pv) { return ((pv & (per_slice - 1u)) << s_bits) | (pv / per_slice); };
+    const uint32_t seq_mask_all = (1u << kSeqBits) - 1u;
     const uint32_t* bk = rec_keys + g.bin_offset[slot];
     const uint32_t* bv = rec_vals + g.bin_offset[slot];
     BIN_STAMP(0);
@@ -1399,7 +1400,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (single) rk4[u] = k4[u];
-        const unsigned v = k4[u] >> kSeqBits;
+        const unsigned v = to_pv(k4[u] >> kSeqBits);
         if (k4[u] != 0xFFFFFFFFu && v >= v_lo && v < v_hi) atomicAdd(&hist[v], 1u);
       }
     }
@@ -1436,7 +1437,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
         const unsigned total_v = hist[lo];
         unsigned done_v = 0;
         const uint32_t seq_mask = (1u << kSeqBits) - 1u;
-        uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + lo;
+        uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + from_pv(lo);
+        const unsigned lo_v = from_pv(lo);  // the voxel id as the records carry it
         UnitChain chain;
         if (tid == 0) chain.begin(g, *cell);
         uint32_t cur_lo = 0;  // records with seq < cur_lo are applied
@@ -1455,7 +1457,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
             for (unsigned i = tid; i < n; i += kBinThreads) {
               const uint32_t k = bk[i];
               const uint32_t sq = k & seq_mask;
-              if ((k >> kSeqBits) == lo && sq >= cur_lo && sq < range_hi) atomicAdd(&bucket[(sq - cur_lo) >> S], 1u);
+              if ((k >> kSeqBits) == lo_v && sq >= cur_lo && sq < range_hi) atomicAdd(&bucket[(sq - cur_lo) >> S], 1u);
             }
             __syncthreads();
             {
@@ -1484,7 +1486,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
           for (unsigned i = tid; i < n; i += kBinThreads) {
             const uint32_t k = bk[i];
             const uint32_t sq = k & seq_mask;
-            if ((k >> kSeqBits) == lo && sq >= cur_lo && sq < T) {
+            if ((k >> kSeqBits) == lo_v && sq >= cur_lo && sq < T) {
               const unsigned p = atomicAdd(&s_hi, 1u);
               if (p < static_cast<unsigned>(kBinCap)) { gk[p] = k; gv[p] = bv[i]; }
             }
@@ -1526,10 +1528,10 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const unsigned v = k4[u] >> kSeqBits;
+            const unsigned v = to_pv(k4[u] >> kSeqBits);
             if (k4[u] != 0xFFFFFFFFu && v >= lo && v < hi) {
               const unsigned p = base[v] - b_lo + atomicAdd(&cursor[v], 1u);
-              gk[p] = k4[u];
+              gk[p] = (v << kSeqBits) | (k4[u] & seq_mask_all);  // keyed by pv from here on
               gv[p] = v4[u];
             }
           }
@@ -1572,7 +1574,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
           if (__ballot(mine > 48u)) __builtin_amdgcn_s_setprio(3);
         }
         if (tid >= lo && tid < hi && hist[tid]) {
-          uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + tid;
+          uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + from_pv(tid);
           uint32_t code = *cell;
           const unsigned b0 = base[tid] - b_lo, b1 = b0 + hist[tid];
           code = update_chain_unit(g, L.p.maximum_weight, code, sv + b0, b1 - b0);
