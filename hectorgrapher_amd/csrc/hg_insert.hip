@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
       const bool large = cnt > 512u;
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
-        while (slices < 64 && cnt > slices * 1024u) slices <<= 1;
+        while (slices < 128 && cnt > slices * 512u) slices <<= 1;
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
       const bool large = cnt > 512u;
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
-        while (slices < 64 && cnt > slices * 1024u) slices <<= 1;
+        while (slices < 128 && cnt > slices * 512u) slices <<= 1;
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
