@@ -123,7 +123,12 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        if args.submaps > 1 and args.workload == "register" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            # no external launcher: this process starts the N ranks itself and never touches a GPU
+            result = run_rank_processes(args)
+        elif "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]))
+        elif args.submaps > 1 and args.workload == "register" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
             result = run_submap_processes(args, saved_stdout)
         else:
             result = run(args, saved_stdout)
@@ -138,6 +143,43 @@ def main():
         os.close(saved_stdout)
     if result is not None:
         print(json.dumps(result), flush=True)
+
+
+def run_rank_processes(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, the
+    environment torch.distributed.run would give them) BEFORE anything initialises a GPU in this
+    process, wait for them and hand rank 0's JSON line through. Fails loudly when the box has fewer
+    than N GPUs -- a silent 1-rank run would be reported as an N-GPU number."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()  # counts devices without creating a HIP context
+    if have < args.gpus:
+        raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (args.gpus, have))
+    if args.workload != "register":
+        raise SystemExit("bench.py: --gpus N > 1 runs the register workload (independent submap per rank)")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        raise SystemExit("bench.py: rank processes failed, exit codes %r" % (rcs,))
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if not lines:
+        raise SystemExit("bench.py: rank 0 printed no result line")
+    result = json.loads(lines[-1])
+    if result.get("n_gpus") != args.gpus:
+        raise SystemExit("bench.py: rank 0 reported n_gpus=%r, expected %d" % (result.get("n_gpus"), args.gpus))
+    return result
 
 
 def run_submap_processes(args, out_fd):
@@ -677,6 +719,7 @@ def run(args, out_fd=None):
 
     # one-shot exchange at the end of mapping: gather finished TSDF blocks to rank 0
     gather_ms = None
+    gather_check = None
     if dist is not None:
         try:
             barrier()
@@ -684,6 +727,8 @@ def run(args, out_fd=None):
             gathered = hgd.gather_grids(grids, dist, rank, world, dev)
             barrier()
             gather_ms = (time.perf_counter() - tg) * 1e3
+            # rank 0 imports every peer's blocks into fresh grids; their export must equal the peer's own
+            gather_check = hgd.verify_gather(api, ctx, grids, gathered, dist, rank, world)
             del gathered
         except Exception as e:  # the exchange is reported separately; never lose the timed result
             sys.stderr.write("gather of TSDF blocks failed: %r\n" % (e,))
@@ -762,7 +807,7 @@ def run(args, out_fd=None):
                    "points_per_scan": n_pts, "map_scans": args.map_scans,
                    "parallelism": "independent submap per GPU x%d" % world,
                    "insert_mode": args.insert_mode, "mean_pose_error_m": float(np.mean(errs)),
-                   "gather_ms": gather_ms},
+                   "gather_ms": gather_ms, "gather_check": gather_check},
         "roofline": roofline,
     }
     if base:

@@ -108,6 +108,7 @@ class HybridGridTSDF:
         self.min_tsd = -self.max_tsd
         self.max_weight = f(max_weight)
         self.max_blocks = int(max_blocks)
+        self.relative_truncation_distance = float(relative_truncation_distance)
 
     def resolution(self):
         return self._resolution

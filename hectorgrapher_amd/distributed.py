@@ -68,11 +68,67 @@ def gather_block_arrays(keys, vox, dist, rank, world, dst=0):
     return None
 
 
-def gather_grids(grids, dist, rank, world, dev, dst=0):
-    """Gathers every pyramid level's blocks to `dst`. Returns [level][src_rank] -> (keys, vox)."""
+def gather_grids(grids, dist, rank, world, dev, dst=0, host=False):
+    """Gathers every pyramid level's blocks to `dst`. Returns [level][src_rank] -> (keys, vox).
+    host=True stages the block arrays through host memory (gloo, or ranks that share one GPU)."""
     out = []
     for g in grids:
         g.ctx.synchronize()
         keys, vox = grid_block_tensors(g, dev)
+        if host:
+            keys, vox = keys.cpu(), vox.cpu()
         out.append(gather_block_arrays(keys, vox, dist, rank, world, dst))
     return out
+
+
+def export_digest(grid):
+    """(voxel count, sha1 of the grid's export in iterator order): what two grids must share to be
+    the same HybridGridTSDF (cells, order, tsd and weight codes)."""
+    import hashlib
+    import numpy as np
+    ijk, t, w = grid.export()
+    h = hashlib.sha1()
+    for a in (ijk, t, w):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return len(t), h.digest()
+
+
+def verify_gather(api, ctx, grids, gathered, dist, rank, world, dst=0):
+    """End-to-end check of the one exchange step: on `dst` every peer's gathered blocks are imported
+    into a fresh grid (hg_grid_import_blocks) whose export must equal the export the peer computed
+    from its own grid (digests travel by all_gather). Returns on dst
+    {"ok", "levels", "ranks", "blocks", "voxels"}; elsewhere None. Collective: every rank calls it."""
+    import numpy as np
+    dev = gathered[0][0][0].device if (rank == dst and gathered and gathered[0]) else None
+    mine = []
+    for g in grids:
+        n, d = export_digest(g)
+        mine.append(np.frombuffer(np.uint64(n).tobytes() + d, np.uint8))
+    mine = np.concatenate(mine) if mine else np.zeros(0, np.uint8)
+    t_dev = dev if dev is not None else (torch.device("cuda", torch.cuda.current_device())
+                                         if dist.get_backend() == "nccl" else torch.device("cpu"))
+    local = torch.from_numpy(mine.copy()).to(t_dev)
+    allv = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(allv, local)
+    if rank != dst:
+        return None
+    ok, blocks, voxels = True, 0, 0
+    for l, g in enumerate(grids):
+        for src in range(world):
+            keys, vox = gathered[l][src]
+            nb = int(keys.shape[0])
+            fresh = api.HybridGridTSDF(ctx, float(g.resolution()), g.relative_truncation_distance,
+                                       float(g.max_weight), max_blocks=max(64, nb))
+            if nb:
+                if keys.is_cuda:
+                    fresh.import_blocks(keys, vox, nb)
+                else:
+                    fresh.import_blocks(keys.numpy().view(np.uint64), vox.numpy().view(np.uint32).reshape(-1))
+            n, d = export_digest(fresh)
+            fresh.close()
+            want = allv[src].cpu().numpy()[28 * l:28 * (l + 1)]
+            want_n = int(np.frombuffer(want[:8].tobytes(), np.uint64)[0])
+            ok = ok and n == want_n and d == want[8:].tobytes()
+            blocks += nb
+            voxels += n
+    return {"ok": bool(ok), "levels": len(grids), "ranks": world, "blocks": blocks, "voxels": voxels}

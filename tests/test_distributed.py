@@ -46,6 +46,91 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+class _FakeGrid:
+    """Host stand-in with the HybridGridTSDF surface verify_gather uses (block dict; export in key
+    order): lets the collective protocol run on CPU, the device version is tests/test_gpu_distributed.py."""
+    relative_truncation_distance = 2.5
+    max_weight = 1000.0
+
+    def __init__(self, ctx=None, resolution=0.1, rtd=2.5, max_weight=1000.0, max_blocks=0):
+        self.blocks = {}
+        self._res = resolution
+
+    def resolution(self):
+        return self._res
+
+    def import_blocks(self, keys, voxels, num_blocks=None):
+        v = np.asarray(voxels).reshape(-1, 512)
+        for k, row in zip(np.asarray(keys).tolist(), v):
+            self.blocks[int(k)] = row.copy()
+
+    def export(self):
+        ijk, t, w = [], [], []
+        for k in sorted(self.blocks):
+            row = self.blocks[k]
+            nz = np.nonzero(row)[0]
+            ijk += [(k, int(i), 0) for i in nz]
+            t += [int(row[i]) & 0xFFFF for i in nz]
+            w += [int(row[i]) >> 16 for i in nz]
+        return (np.asarray(ijk, np.int32).reshape(-1, 3), np.asarray(t, np.uint16), np.asarray(w, np.uint16))
+
+    def close(self):
+        pass
+
+
+class _FakeApi:
+    HybridGridTSDF = _FakeGrid
+
+
+def _verify_worker(rank, world, port, out, corrupt):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from hectorgrapher_amd import distributed as hgd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7 + rank)
+    grids, gathered = [], []
+    for level in range(2):
+        g = _FakeGrid(resolution=0.05 * (level + 1))
+        nb = 4 + rank + level
+        keys = np.arange(nb, dtype=np.uint64) + 100 * rank
+        vox = rng.integers(0, 1 << 31, size=(nb, 512), dtype=np.uint32) * (rng.random((nb, 512)) < 0.3)
+        g.import_blocks(keys, vox.astype(np.uint32))
+        grids.append(g)
+        k = torch.from_numpy(keys.view(np.int64).copy())
+        v = torch.from_numpy(vox.astype(np.uint32).view(np.int32).copy())
+        if corrupt and rank == 1 and level == 1:
+            v = v.clone()
+            v[0, 5] += 1  # what travels differs from what the peer holds
+        gathered.append(hgd.gather_block_arrays(k, v, dist, rank, world, dst=0))
+    chk = hgd.verify_gather(_FakeApi, None, grids, gathered, dist, rank, world)
+    out.put((rank, chk))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_verify_gather_gloo_world2(corrupt):
+    """gather -> import into a fresh grid -> export equals the peer's own export (digest), and a
+    payload that differs from the peer's grid is caught."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, q, corrupt)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[1] is None
+    assert got[0]["ok"] == (not corrupt)
+    assert got[0]["ranks"] == 2 and got[0]["levels"] == 2 and got[0]["blocks"] == 4 + 5 + 5 + 6
+
+
 def test_gather_blocks_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -70,3 +155,26 @@ def test_shard_partitions():
         all_items = sorted(sum((hgd.shard(8, r, world) for r in range(world)), []))
         assert all_items == list(range(8))
         assert all(len(hgd.shard(8, r, world)) == 8 // world for r in range(world))
+
+
+def test_bench_gpus_flag_fails_loudly_without_enough_gpus():
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself; on a box with fewer
+    GPUs it must refuse instead of silently measuring one rank (this container has no GPU)."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2 requested but only" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

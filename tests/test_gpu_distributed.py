@@ -1,0 +1,81 @@
+"""The one exchange step of batch mapping, end to end on the device: two rank processes map two
+different submaps on the GPU, the finished TSDF blocks are gathered to rank 0 (gloo; both ranks
+share the one GPU of the test box, which RCCL refuses), rank 0 imports every peer's blocks into a
+fresh grid and its export must equal the export the peer made of its own grid
+(BASELINE.json configs[3]: "RCCL gather of final TSDF")."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from hectorgrapher_amd import api, synth
+    from hectorgrapher_amd import distributed as hgd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0)
+    res = [0.05, 0.10, 0.20]
+    grids = [api.HybridGridTSDF(ctx, r, max_blocks=1 << 14) for r in res]
+    ins = [api.TSDFRangeDataInserter3D() for _ in grids]
+    # rank r maps its own submap: different poses and noise streams
+    for k in range(3):
+        pose = synth.pose_k(10 * rank + k)
+        pts = synth.generate_scan(pose, 16, 400, stream=100 * rank + k)
+        api.insert_pyramid(ins, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                           pose_tq=pose.astype(np.float32))
+    nb = [g.num_blocks() for g in grids]
+    gathered = hgd.gather_grids(grids, dist, rank, world, dev, host=True)
+    chk = hgd.verify_gather(api, ctx, grids, gathered, dist, rank, world)
+    if rank == 0:
+        # device import of the gathered arrays as well (the N-GPU path hands device tensors over)
+        keys, vox = gathered[0][1]
+        fresh = api.HybridGridTSDF(ctx, res[0], max_blocks=max(64, int(keys.shape[0])))
+        fresh.import_blocks(keys.to(dev), vox.to(dev), int(keys.shape[0]))
+        n_dev, _ = hgd.export_digest(fresh)
+        out.put(("rank0", chk, nb, n_dev))
+    else:
+        assert chk is None
+        out.put(("peer", None, nb, hgd.export_digest(grids[0])[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def test_gather_import_export_two_ranks_one_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = {g[0]: g for g in got}
+    chk = got["rank0"][1]
+    assert chk["ok"], chk
+    assert chk["ranks"] == 2 and chk["levels"] == 3
+    assert chk["blocks"] == sum(got["rank0"][2]) + sum(got["peer"][2])
+    assert chk["voxels"] > 10000
+    assert got["rank0"][3] == got["peer"][3]  # device-memory import of rank 1's level 0
