@@ -71,8 +71,11 @@ def make_scans(rings, cols, first, count, stream_base):
     return out
 
 
-def cpu_baseline(args, map_scans, query_scans):
-    """Oracle (CPU restatement of the reference, 1 thread) on a bounded sample of the workload."""
+def cpu_baseline(args, map_scans, query_scans, gpu_steps):
+    """Oracle (CPU restatement of the reference, 1 thread) on a bounded sample of the workload: the
+    FIRST `--cpu-scans` registration steps of this very run (same map scans, same guesses, scans
+    inserted at the solved poses), so its poses are also the parity gate of the timed GPU steps:
+    gpu_steps[i] = (pose, num_iterations, termination_type, termination_reason) of GPU step i."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     from hectorgrapher_amd import synth
@@ -85,18 +88,28 @@ def cpu_baseline(args, map_scans, query_scans):
     n = 0
     probed = lookups = 0
     u_total = nin_total = 0
-    for pose, pts in query_scans[:args.cpu_scans]:
+    max_dt = max_dr = 0.0
+    same_flow = True
+    for k, (pose, pts) in enumerate(query_scans[:args.cpu_scans]):
         guess = synth.pose_mul(pose, synth.perturbation())
         t0 = time.perf_counter()
         pr = po.Problem()
         i = pr.add_pose(guess)
         pr.add_block(pts, grids, 1.0 / np.sqrt(len(pts)), i, multi_res=True)
-        pr.solve()
+        so = pr.solve()
         est = pr.get_pose(i)
         t1 = time.perf_counter()
-        loc = synth.transform_points(est, pts)
+        g_pose, g_it, g_tt, g_tr = gpu_steps[k]
+        max_dt = max(max_dt, float(np.linalg.norm(est[:3] - g_pose[:3])))
+        max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(np.dot(est[3:], g_pose[3:])))))))
+        same_flow = same_flow and (so.num_iterations, so.termination_type, so.termination_reason) == (g_it, g_tt, g_tr)
+        # the map the next step is matched against must be the GPU's: insert where the GPU inserted if
+        # the two float casts of the pose differ (they agree unless a component straddles a float tie)
+        at = est if np.array_equal(est.astype(np.float32), g_pose.astype(np.float32)) else g_pose
+        t1b = time.perf_counter()
+        loc = synth.transform_points(at, pts)
         for g in grids:
-            nin, u = g.insert(est[:3].astype(np.float32), loc)
+            nin, u = g.insert(at[:3].astype(np.float32), loc)
             u_total += u
             nin_total += nin
         t2 = time.perf_counter()
@@ -104,15 +117,17 @@ def cpu_baseline(args, map_scans, query_scans):
         lookups += lk
         probed += pb
         t_match += t1 - t0
-        t_insert += t2 - t1
+        t_insert += t2 - t1b
         n += 1
     total = t_match + t_insert
     return {
         "value": n / total, "unit": "scans/s", "cores": 1, "kind": "port",
-        "sample": "%d scans of the same workload (match + 3-level insert), oracle -O3 1 thread; "
+        "sample": "the first %d registration steps of this run (match + 3-level insert), oracle -O3 1 thread; "
                   "match %.3f s/scan, insert %.3f s/scan" % (n, t_match / n, t_insert / n),
         "mean_levels_probed": probed / max(1, lookups),
         "updates_per_scan": u_total / n, "hits_per_scan": nin_total / n,
+        "parity": {"max_dt_m": max_dt, "max_dr_rad": max_dr, "scans": n, "tolerance": 1e-4,
+                   "same_iterations_and_termination": bool(same_flow)},
     }
 
 
@@ -666,6 +681,7 @@ def run(args, out_fd=None):
     stats = {"U": 0, "N_in": 0, "evals": 0}
     errs = []
     sampling = [False]
+    gpu_steps = []  # (pose, iterations, termination) of every step from the first warmup step on
 
     def step(i):
         problem.reset()
@@ -673,6 +689,7 @@ def run(args, out_fd=None):
         problem.add_block(d_scans[i], grids, scale, pi, multi_res=True)
         est, summ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i]), grids)
         errs.append(float(np.linalg.norm(est[:3] - query[i][0][:3])))
+        gpu_steps.append((est, summ.num_iterations, summ.termination_type, summ.termination_reason))
         if sampling[0]:
             stats["evals"] += summ.num_cost_evaluations  # launches that evaluated (the rest exit early)
 
@@ -743,8 +760,13 @@ def run(args, out_fd=None):
     value = total_scans / elapsed
 
     base = None
+    parity = None
     if not args.no_cpu_baseline and world == 1:  # timed on rank 0 at N = 1 only
-        base = cpu_baseline(args, map_scans, query[args.warmup:])
+        base = cpu_baseline(args, map_scans, query, gpu_steps)
+        parity = base["parity"]
+        if args.insert_mode == "exact" and not (parity["max_dt_m"] <= 1e-4 and parity["max_dr_rad"] <= 1e-4):
+            # no timing counts unless the GPU poses are the CPU poses
+            raise SystemExit("bench.py: parity gate failed, GPU and oracle poses differ: %r" % (parity,))
 
     # ---- roofline of the dominant kernel family (HIP-event time on the ctx stream) ----
     insert_kernels = ["ray_count", "scan", "ray_expand", "sort", "alloc", "apply"]
@@ -811,6 +833,7 @@ def run(args, out_fd=None):
         "roofline": roofline,
     }
     if base:
+        out["parity"] = parity
         out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
         out["cpu_baseline"]["cores_available"] = os.cpu_count()
         out["gpu_over_cpu"] = value / world / base["value"]

@@ -22,7 +22,7 @@ ERRORS = {-1: "HG_ERR_INVALID", -2: "HG_ERR_NO_DEVICE", -3: "HG_ERR_HIP", -4: "H
 # Every symbol include/hg_mi355x.h declares.
 SYMBOLS = [
     "hg_ctx_create", "hg_ctx_destroy", "hg_ctx_synchronize", "hg_ctx_stream", "hg_last_error",
-    "hg_version", "hg_prof_enable", "hg_prof_reset", "hg_prof_read", "hg_grid_create", "hg_grid_destroy", "hg_grid_clear", "hg_grid_resolution",
+    "hg_version", "hg_prof_enable", "hg_prof_reset", "hg_prof_read", "hg_grid_create", "hg_grid_destroy", "hg_grid_clear", "hg_grid_resolution", "hg_grid_params",
     "hg_grid_set_cells", "hg_grid_read_cells", "hg_grid_count", "hg_grid_export",
     "hg_grid_num_blocks", "hg_grid_to_proto", "hg_grid_from_proto", "hg_grid_xray", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
     "hg_grid_insert_batch", "hg_pyramid_insert", "hg_pyramid_insert_batch", "hg_grid_status",
@@ -137,6 +137,7 @@ def load():
     L.hg_grid_clear.argtypes = [vp]
     L.hg_grid_resolution.restype = f32
     L.hg_grid_resolution.argtypes = [vp]
+    L.hg_grid_params.argtypes = [vp, P(f32), P(f32), P(f32), P(u32)]
     L.hg_grid_set_cells.argtypes = [vp, vp, sz, vp, vp]
     L.hg_grid_read_cells.argtypes = [vp, vp, sz, vp, vp]
     L.hg_grid_count.argtypes = [vp, P(sz)]

@@ -237,7 +237,14 @@ class HybridGridTSDF:
         ctx._children.add(g)
         g._resolution = np.float32(L.hg_grid_resolution(h))
         g.max_blocks = int(max_blocks)
-        g.max_tsd = g.min_tsd = g.max_weight = None  # set by the caller if float decoding is needed
+        # the proto constructor builds the grid from (resolution, field 8, field 9)
+        # (hybrid_grid_tsdf.h:69-83): read the converter constants back from the device grid
+        mt, mw = C.c_float(), C.c_float()
+        check(L.hg_grid_params(h, None, C.byref(mt), C.byref(mw), None), "hg_grid_params")
+        g.max_tsd = np.float32(mt.value)
+        g.min_tsd = -g.max_tsd
+        g.max_weight = np.float32(mw.value)
+        g.relative_truncation_distance = float(g.max_tsd / g._resolution) if g._resolution > 0 else 0.0
         return g
 
     def block_arrays(self):

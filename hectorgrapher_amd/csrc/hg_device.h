@@ -27,8 +27,8 @@ struct GridView {
   uint32_t* bin_count;        // per block slot: records of the current insert call
   uint32_t* bin_offset;       // per block slot: first record of its bin
   uint32_t* touched;          // slots touched by the current insert call
-  unsigned long long* work;   // apply work items: slot | lo << 24 | hi << 34 | n << 44
-  uint32_t work_capacity;
+  uint4* work;                // apply work items {slot, v_lo | v_hi << 16, records of the bin, 0}: per-call
+  uint32_t work_capacity;     // context workspace sized from the call's record count (set by the host per call)
   unsigned long long* accum;  // HG_INSERT_FAST: per voxel count << 44 | fixed-point tsd sum (or null)
   float resolution;
   float max_tsd, min_tsd, max_weight;

@@ -158,7 +158,13 @@ int hg_ctx_create(int device, void* stream, hg_ctx** out) {
     }
     c->own_stream = true;
   }
-  if (hipHostMalloc(&c->pinned, 4096) != hipSuccess) c->pinned = nullptr;
+  if (hipHostMalloc(&c->pinned, 4096, hipHostMallocMapped) != hipSuccess) c->pinned = nullptr;
+  if (c->pinned) {
+    std::memset(c->pinned, 0, 4096);
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, c->pinned, 0) == hipSuccess)
+      c->async_flags = reinterpret_cast<uint32_t*>(static_cast<char*>(dp) + 2048);
+  }
   *out = c;
   return HG_OK;
 }
@@ -182,7 +188,7 @@ int hg_ctx_destroy(hg_ctx* c) {
 int hg_ctx_synchronize(hg_ctx* c) {
   if (!c) return HG_ERR_INVALID;
   HG_HIP_CHECK(hipStreamSynchronize(c->stream));
-  return HG_OK;
+  return async_status(c);  // sticky errors of inserts that ran without a stats read-back
 }
 
 void* hg_ctx_stream(hg_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
@@ -248,13 +254,13 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
   if (e == hipSuccess)
     e = hipMalloc(reinterpret_cast<void**>(&v.block_keys), sizeof(unsigned long long) * max_blocks);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v.counters), 256);
-  // bin_count | bin_offset | touched (u32 each) | work (u64, 2 entries per block)
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v.bin_count), sizeof(uint32_t) * 8 * static_cast<size_t>(max_blocks));
+  // bin_count | bin_offset | touched (u32 each); the apply work list lives in the context workspace
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v.bin_count), sizeof(uint32_t) * 3 * static_cast<size_t>(max_blocks));
   if (e == hipSuccess) {
     v.bin_offset = v.bin_count + max_blocks;
     v.touched = v.bin_offset + max_blocks;
-    v.work = reinterpret_cast<unsigned long long*>(v.bin_count + 4 * static_cast<size_t>(max_blocks));
-    v.work_capacity = 2 * max_blocks;
+    v.work = nullptr;
+    v.work_capacity = 0;
   }
   if (e != hipSuccess) {
     set_last_error(std::string("hipMalloc grid: ") + hipGetErrorString(e));
@@ -286,11 +292,25 @@ int hg_grid_clear(hg_grid* g) {
   HG_HIP_CHECK(hipMemsetAsync(g->view.voxels, 0,
                               sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(g->view.max_blocks), s));
   HG_HIP_CHECK(hipMemsetAsync(g->view.counters, 0, 256, s));
-  HG_HIP_CHECK(hipMemsetAsync(g->view.bin_count, 0, sizeof(uint32_t) * 8 * static_cast<size_t>(g->view.max_blocks), s));
+  if (g->ctx->pinned) {  // a cleared grid starts without sticky errors
+    HG_HIP_CHECK(hipStreamSynchronize(s));
+    std::memset(static_cast<char*>(g->ctx->pinned) + 2048, 0, 16);
+  }
+  HG_HIP_CHECK(hipMemsetAsync(g->view.bin_count, 0, sizeof(uint32_t) * 3 * static_cast<size_t>(g->view.max_blocks), s));
   return HG_OK;
 }
 
 float hg_grid_resolution(const hg_grid* g) { return g ? g->view.resolution : 0.f; }
+
+int hg_grid_params(const hg_grid* g, float* resolution, float* max_tsd, float* max_weight,
+                   uint32_t* max_blocks) {
+  if (!g) return HG_ERR_INVALID;
+  if (resolution) *resolution = g->view.resolution;
+  if (max_tsd) *max_tsd = g->view.max_tsd;
+  if (max_weight) *max_weight = g->view.max_weight;
+  if (max_blocks) *max_blocks = g->view.max_blocks;
+  return HG_OK;
+}
 
 static int read_counters(hg_grid* g, uint32_t* out8) {
   HG_HIP_CHECK(hipMemcpyAsync(out8, g->view.counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost,

@@ -422,7 +422,19 @@ struct PyramidIns {
   const double* d_pose;  // optional: pose (t xyz, q wxyz, fp64) in device memory, e.g. the pose a
                          // solve left there; cast to float as Rigid3d::cast<float>() does
   int accumulate;        // not the first chunk of a call: hit / update counters add up
+  uint32_t* host_flags;  // mapped pinned words [kMaxInsLevels]: sticky error flags of calls that do not
+                         // read their stats back (written only when a flag is set)
 };
+
+// One thread per level: hands the level's sticky error flags to the host without a read-back.
+__device__ inline void publish_flags(const PyramidIns& P, int level) {
+  const uint32_t f = P.lv[level].g.counters[1];
+  if (f != 0u && P.host_flags) {
+    P.host_flags[level] = f;
+    __threadfence_system();
+  }
+}
+__global__ void k_publish_flags(PyramidIns P) { publish_flags(P, threadIdx.x); }
 
 enum : uint32_t { kFlagStride = 4u };
 
@@ -700,7 +712,7 @@ constexpr int kBinCap = 2048;       // records per LDS pass of k_bin_apply (4 pe
 constexpr int kBinThreads = 512;    // one thread per voxel of a block
 constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
 
-enum : uint32_t { kFlagBinOverflow = 8u };
+enum : uint32_t { kFlagBinOverflow = 8u, kFlagWorkOverflow = 16u };
 
 __device__ inline void ray_cell(const Ray& r, int pos, int& cx, int& cy, int& cz) {
   const float fp = static_cast<float>(pos), fn = static_cast<float>(r.n);
@@ -1140,6 +1152,7 @@ __global__ void k_fast_end(PyramidIns P) {
   const GridView& g = P.lv[threadIdx.x].g;
   if (g.counters[6] > g.max_blocks) atomicOr(&g.counters[1], kFlagCapacity);
   g.counters[6] = 0;
+  publish_flags(P, threadIdx.x);
 }
 
 // Lanes of the wavefront (among `valid` ones) that hold the same 9-bit value as this lane.
@@ -1228,12 +1241,9 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
           if (w0 + k < L.g.work_capacity)
-            L.g.work[w0 + k] = static_cast<unsigned long long>(slot) |
-                               (static_cast<unsigned long long>(k * step) << 24) |
-                               (static_cast<unsigned long long>((k + 1) * step) << 34) |
-                               (static_cast<unsigned long long>(cnt) << 44);
+            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 16), cnt, 0u);
           else
-            atomicOr(&L.g.counters[1], kFlagCapacity);
+            atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
       }
       if (round == 1 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
@@ -1261,12 +1271,9 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
           if (w0 + k < L.g.work_capacity)
-            L.g.work[w0 + k] = static_cast<unsigned long long>(slot) |
-                               (static_cast<unsigned long long>(k * step) << 24) |
-                               (static_cast<unsigned long long>((k + 1) * step) << 34) |
-                               (static_cast<unsigned long long>(cnt) << 44);
+            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 16), cnt, 0u);
           else
-            atomicOr(&L.g.counters[1], kFlagCapacity);
+            atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
       }
       if (round == 1 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
@@ -1281,6 +1288,7 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
     L.g.counters[6] = 0;                                // next call collects from scratch
     unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
     *upd = s_base + (P.accumulate ? *upd : 0ull);  // U of this call
+    publish_flags(P, blockIdx.x);
   }
 }
 
@@ -1364,11 +1372,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
   const unsigned nwork = g.counters[7];
   const unsigned tid = threadIdx.x;
   for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-    const unsigned long long item = g.work[wi];
-    const uint32_t slot = static_cast<uint32_t>(item & 0xFFFFFFu);
-    const unsigned v_lo = static_cast<unsigned>(item >> 24) & 1023u;
-    const unsigned v_hi = static_cast<unsigned>(item >> 34) & 1023u;
-    const unsigned n = static_cast<unsigned>(item >> 44);
+    const uint4 item = g.work[wi];
+    const uint32_t slot = item.x;
+    const unsigned v_lo = item.y & 0xFFFFu;
+    const unsigned v_hi = item.y >> 16;
+    const unsigned n = item.z;  // all 32 bits: a bin may hold every record of the scan
     // The slices of a bin interleave its voxels (voxel v belongs to slice v mod S): the heavy voxels
     // of a block are spatial neighbours, contiguous slices would queue their chains in one workgroup.
     // Inside the kernel a voxel is addressed by pv = (v mod S) * (512 / S) + v / S, which makes every
@@ -1751,17 +1759,36 @@ int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans,
   if (want_stats) {
     hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, wg_upd, nwg_a);
     HG_HIP_CHECK(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(P.levels), 0, s, P);
+    HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
 }
 
 // ---- binned path (single scan, unit weight) ------------------------------------------------
-int insert_chunk_binned(hg_ctx* c, const PyramidIns& P, const float* d_xyz, unsigned long long n,
+int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const float* d_xyz, unsigned long long n,
                         bool want_stats) {
   hipStream_t s = c->stream;
   const unsigned records_per_level = static_cast<unsigned>(n) * kSlots;
+  PyramidIns P = P_in;
   const size_t slots = static_cast<size_t>(records_per_level) * P.levels;
   int rc;
+  // Apply work list, per level: one item per touched bin (a return touches at most kMaxRuns blocks)
+  // plus the extra slices of large bins -- a bin of cnt > 512 records is cut into S <= cnt / 256
+  // slices, so all bins together add fewer than records / 256 items. Sized from the records of this
+  // call, not from the grid's block pool.
+  {
+    size_t max_pool = 0;
+    for (int l = 0; l < P.levels; ++l) max_pool = std::max<size_t>(max_pool, P.lv[l].g.max_blocks);
+    const size_t per_level = std::min<size_t>(static_cast<size_t>(n) * kMaxRuns, max_pool) +
+                             records_per_level / 256u + 64u;
+    if ((rc = c->ws_offsets.reserve(sizeof(uint4) * per_level * P.levels)) != HG_OK) return rc;
+    for (int l = 0; l < P.levels; ++l) {
+      P.lv[l].g.work = c->ws_offsets.as<uint4>() + per_level * l;
+      P.lv[l].g.work_capacity = static_cast<uint32_t>(per_level);
+    }
+  }
   if ((rc = c->ws_keys_a.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
   if ((rc = c->ws_vals_a.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
   const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
@@ -1903,6 +1930,33 @@ int insert_chunk_fast(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans, 
   return HG_OK;
 }
 
+}  // namespace
+// Sticky error flags of a grid -> status code + message.
+int hg::flags_to_status(uint32_t flags) {
+  if (flags & kFlagCapacity) {
+    set_last_error("block pool exhausted: raise max_blocks");
+    return HG_ERR_CAPACITY;
+  }
+  if (flags & kFlagRange) {
+    set_last_error("cell index outside +-8192 (or outside the 32-bit key window)");
+    return HG_ERR_RANGE;
+  }
+  if (flags & kFlagStride) {
+    set_last_error("ray produced more than 8 samples on the fixed-stride path");
+    return HG_ERR_UNSUPPORTED;
+  }
+  if (flags & kFlagBinOverflow) {
+    set_last_error("a voxel received more updates in one scan than the binned path supports");
+    return HG_ERR_UNSUPPORTED;
+  }
+  if (flags & kFlagWorkOverflow) {
+    set_last_error("apply work list overflow (internal sizing error)");
+    return HG_ERR_CAPACITY;
+  }
+  return HG_OK;
+}
+namespace {
+
 int read_stats(hg_grid* grid, hg_insert_stats* out) {
   uint32_t cnt[8];
   hipStream_t s = grid->ctx->stream;
@@ -1915,23 +1969,7 @@ int read_stats(hg_grid* grid, hg_insert_stats* out) {
   st.flags = cnt[1];
   grid->last_stats = st;
   if (out) *out = st;
-  if (cnt[1] & kFlagCapacity) {
-    set_last_error("block pool exhausted: raise max_blocks");
-    return HG_ERR_CAPACITY;
-  }
-  if (cnt[1] & kFlagRange) {
-    set_last_error("cell index outside +-8192 (or outside the 32-bit key window)");
-    return HG_ERR_RANGE;
-  }
-  if (cnt[1] & kFlagStride) {
-    set_last_error("ray produced more than 8 samples on the fixed-stride path");
-    return HG_ERR_UNSUPPORTED;
-  }
-  if (cnt[1] & kFlagBinOverflow) {
-    set_last_error("a voxel received more updates in one scan than the binned path supports");
-    return HG_ERR_UNSUPPORTED;
-  }
-  return HG_OK;
+  return flags_to_status(cnt[1]);
 }
 
 void host_transform(const float* pose, const float* in, float* out) {
@@ -1984,6 +2022,10 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   }
   hipStream_t s = c->stream;
   HG_HIP_CHECK(hipSetDevice(c->device));
+  if (!stats) {  // asynchronous call: report what earlier asynchronous calls have left behind
+    const int arc = async_status(c);
+    if (arc != HG_OK) return arc;
+  }
   const unsigned long long n_total = scan_offsets[n_scans] - scan_offsets[0];
   if (n_total && !xyz) return HG_ERR_INVALID;
   for (size_t i = 0; i < n_scans; ++i)
@@ -2066,6 +2108,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   std::memset(&P, 0, sizeof(P));
   P.levels = levels;
   P.d_pose = d_pose_tq;
+  P.host_flags = stats ? nullptr : c->async_flags;
   if (d_pose_tq && !fixed_ok) return HG_ERR_UNSUPPORTED;
   for (int l = 0; l < levels; ++l) {
     LevelIns& L = P.lv[l];
@@ -2096,6 +2139,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   std::vector<ScanTable> table;
   size_t s0 = 0;
   int rc = HG_OK;
+  bool chunk_launched = false;
   while (s0 < n_scans && rc == HG_OK) {
     size_t s1 = s0;
     unsigned long long pts = 0;
@@ -2124,7 +2168,8 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
       const unsigned long long first = scan_offsets[s0] - scan_offsets[0];
       PyramidIns Pc = P;
       Pc.scan0 = table[0];
-      Pc.accumulate = s0 > 0 ? 1 : 0;
+      Pc.accumulate = chunk_launched ? 1 : 0;  // counters restart with the first chunk that runs
+      chunk_launched = true;
       for (int l = 0; l < levels; ++l)
         if (Pc.lv[l].gate) Pc.lv[l].gate += first;
       if (fast) {
@@ -2148,7 +2193,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
           rc = insert_chunk_fixed<unsigned long long, unsigned long long>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
       } else {
         rc = insert_chunk_compact(grids[0], Pc.lv[0].p, d_scans, static_cast<uint32_t>(table.size()),
-                                  d_xyz + 3 * first, pts, Pc.lv[0].gate, s0 == 0);
+                                  d_xyz + 3 * first, pts, Pc.lv[0].gate, Pc.accumulate == 0);
       }
     }
     s0 = s1;

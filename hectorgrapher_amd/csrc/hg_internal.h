@@ -86,6 +86,10 @@ struct hg_ctx {
   const float* filter_xyz = nullptr;
   size_t filter_count = 0;
   void* pinned = nullptr;  // small pinned host staging (4 KiB)
+  // words [0, 4) of the second half of `pinned`: sticky error flags that insert calls without a
+  // stats read-back leave for the host (hg_register_scan, hg_pyramid_insert(stats = NULL)); checked
+  // by the next call of the context that can return a status
+  uint32_t* async_flags = nullptr;  // device address of those words
 };
 
 namespace hg {
@@ -125,6 +129,16 @@ struct ProfScope {
 }  // namespace hg
 
 namespace hg {
+int flags_to_status(uint32_t flags);
+// Status of the asynchronous insert calls issued so far on this context (HG_OK or the error of a
+// sticky flag that has arrived in the mailbox words).
+inline int async_status(const hg_ctx* c) {
+  if (!c->pinned) return HG_OK;
+  uint32_t f = 0;
+  const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(static_cast<const char*>(c->pinned) + 2048);
+  for (int l = 0; l < 4; ++l) f |= w[l];
+  return f ? flags_to_status(f) : HG_OK;
+}
 int pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                         const float* origins, const float* xyz, const uint64_t* scan_offsets,
                         size_t n_scans, size_t width, const float* poses_tq,

@@ -3133,7 +3133,11 @@ int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_i
   static std::chrono::steady_clock::time_point last_ret;
   const auto h0 = std::chrono::steady_clock::now();
 #endif
-  int rc = hg_problem_solve_async(p, sopts);
+  // an insertion of an earlier step that ran out of blocks (or left the index range) reports here:
+  // those steps return before their insertion has finished
+  int rc = async_status(p->ctx);
+  if (rc != HG_OK) return rc;
+  rc = hg_problem_solve_async(p, sopts);
   if (rc != HG_OK) return rc;
 #ifdef HG_HOST_STAMPS
   const auto h1 = std::chrono::steady_clock::now();

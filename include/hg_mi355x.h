@@ -115,6 +115,8 @@ typedef struct hg_solver_summary {
 /* `stream` is a hipStream_t to run on, or NULL to create a private stream. */
 int hg_ctx_create(int device, void* stream, hg_ctx** out);
 int hg_ctx_destroy(hg_ctx* ctx);
+/* Waits for the context's stream. Also returns the error (HG_ERR_CAPACITY, HG_ERR_RANGE, ...) an
+ * insertion that ran without a stats read-back has raised since the grids were last cleared. */
 int hg_ctx_synchronize(hg_ctx* ctx);
 void* hg_ctx_stream(hg_ctx* ctx);
 const char* hg_last_error(void);
@@ -139,6 +141,11 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
 int hg_grid_destroy(hg_grid* grid);
 int hg_grid_clear(hg_grid* grid);
 float hg_grid_resolution(const hg_grid* grid);
+/* Constants of the grid's TSDValueConverter (mapping/2d/tsd_value_converter.h:39-67): getMaxTSD()
+ * (= relative_truncation_distance * resolution in float; getMinTSD() = -getMaxTSD()), getMaxWeight(),
+ * and the capacity of the block pool. Any output may be NULL. */
+int hg_grid_params(const hg_grid* grid, float* resolution, float* max_tsd, float* max_weight,
+                   uint32_t* max_blocks);
 /* SetCell for m cells (host arrays): ijk[m*3], tsd[m], weight[m] floats are encoded by the codec. */
 int hg_grid_set_cells(hg_grid* grid, const int32_t* ijk, size_t m, const float* tsd,
                       const float* weight);
@@ -194,7 +201,9 @@ int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float*
 /* Pyramid form: the same range data inserted into `levels` grids (e.g. the high- and low-resolution
  * grids of Submap3D::InsertData, submap_3d.cc:441-444) with per-level options opts[levels], in one
  * fused device pass. stats: array[levels] or NULL. With stats == NULL the call does not synchronise;
- * errors (capacity, range) then surface at the next hg_grid_status / stats-returning call. */
+ * errors (capacity, range) raised on the device then surface as the return value of the next
+ * hg_pyramid_insert* (stats == NULL), hg_register_scan* or hg_ctx_synchronize call of the context
+ * (the kernels leave the sticky flags in a host-mapped mailbox), and of hg_grid_status. */
 int hg_pyramid_insert(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                       const float origin[3], const float* xyz, size_t n, size_t width,
                       const float* pose_tq, int mode, int memspace, hg_insert_stats* stats);
@@ -297,7 +306,10 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary);
  * optimizing_local_trajectory_builder.cc:1283 then :1437-1499): solve the prepared problem, then
  * insert `xyz` — given in the frame of pose `pose_index` (tracking frame), `origin` likewise —
  * into the pyramid at the SOLVED pose (cast to float as optimized_pose.cast<float>()), without a
- * host round trip in between; one synchronisation at the end returns pose and summary. */
+ * host round trip in between; one synchronisation at the end returns pose and summary. The call
+ * returns when the pose has arrived, while its insertion may still run: an insertion error (block
+ * pool exhausted, index out of range) is returned by the NEXT hg_register_scan* / hg_ctx_synchronize
+ * call of the context, never lost. */
 int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
                      hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
                      const float origin[3], const float* xyz, size_t n, size_t width, int memspace,

@@ -307,3 +307,77 @@ def test_giant_voxel_rounds_with_gaps_and_dense_runs(po, hg, ctx):
         st = hg.TSDFRangeDataInserter3D().Insert(hg.RangeData([0, 0, 0], pts), gg)
         assert (st.num_hits, st.num_updates) == a
         assert_grids_equal(og, gg)
+
+
+def test_small_block_pool_dense_scan(po, hg, ctx):
+    """The apply work list is sized from the records of the call, not from the block pool: a coarse
+    grid with a small pool takes a dense scan (about 10^5 returns -> 6 * 10^5 records, thousands of
+    work items) without losing an update."""
+    pose = synth.pose_k(4)
+    pts = synth.generate_scan(pose, 50, 2000, stream=4)
+    loc = synth.transform_points(pose, pts)
+    for res, pool in ((0.2, 1024), (0.45, 256)):
+        og = po.Grid(res)
+        gg = hg.HybridGridTSDF(ctx, res, max_blocks=pool)
+        a = og.insert(pose[:3], loc)
+        st = hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(pose[:3], loc), gg)
+        assert (st.num_hits, st.num_updates) == a
+        assert st.num_blocks <= pool
+        assert_grids_equal(og, gg)
+
+
+def test_more_than_2_pow_20_records_in_one_block(po, hg, ctx):
+    """190 000 returns whose whole truncation band lies inside ONE 8^3 block of a 0.2 m grid: the
+    block's bin holds more than 2^20 records (the record count of a work item is a full 32-bit
+    word); tens of thousands of updates per voxel run through the giant-voxel rounds."""
+    rng = np.random.default_rng(23)
+    # block [0, 1.6)^3 m holds cells 0..7; rays along +x end at x = 0.8 +- 0.5 m
+    hot = np.array([[0.8, 0.81, 0.79]], np.float32)
+    pts = hot + (rng.standard_normal((190000, 3)) * 4e-3).astype(np.float32)
+    origin = np.array([-3.0, 0.8, 0.8], np.float32)
+    og = po.Grid(0.2)
+    gg = hg.HybridGridTSDF(ctx, 0.2, max_blocks=64)
+    a = og.insert(origin, pts)
+    st = hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(origin, pts), gg)
+    assert a[1] > (1 << 20)
+    assert (st.num_hits, st.num_updates) == a
+    assert st.num_blocks == 1
+    assert_grids_equal(og, gg)
+
+
+def test_batch_with_empty_leading_scans_counts_only_this_call(po, hg, ctx):
+    """hg_insert_stats of a batch whose first scans are empty: the counters restart with the first
+    chunk that runs instead of adding onto the previous call's."""
+    res = 0.1
+    pose = synth.pose_k(1)
+    pts = synth.transform_points(pose, synth.generate_scan(pose, 8, 200, stream=1))
+    gg = hg.HybridGridTSDF(ctx, res, max_blocks=1 << 14)
+    ins = hg.TSDFRangeDataInserter3D()
+    first = ins.Insert(hg.RangeData(pose[:3], pts), gg)
+    og = po.Grid(res)
+    og.insert(pose[:3], pts)
+    n_in, u = og.insert(pose[:3], pts)
+    origins = np.array([pose[:3], pose[:3], pose[:3]], np.float32)
+    st = ins.InsertBatch(origins, pts, [0, 0, 0, len(pts)], gg)
+    assert (st.num_hits, st.num_updates) == (n_in, u)
+    assert (first.num_hits, first.num_updates) == (n_in, u)
+    assert_grids_equal(og, gg)
+
+
+def test_async_insert_errors_reach_the_next_call(hg, ctx):
+    """Inserts without a stats read-back (hg_pyramid_insert(stats = NULL), the insertion of
+    hg_register_scan) leave their sticky error flags in a host-mapped mailbox: the next such call and
+    hg_ctx_synchronize return the error instead of HG_OK."""
+    g = hg.HybridGridTSDF(ctx, 0.1, max_blocks=4)
+    ins = [hg.TSDFRangeDataInserter3D()]
+    pts = synth.generate_scan(synth.pose_k(0), 8, 128)
+    assert hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), [g], want_stats=False) is None
+    with pytest.raises(hg.HgError, match="HG_ERR_CAPACITY"):
+        ctx.synchronize()
+    with pytest.raises(hg.HgError, match="HG_ERR_CAPACITY"):
+        hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), [g], want_stats=False)
+    with pytest.raises(hg.HgError, match="HG_ERR_CAPACITY"):
+        g.status()
+    g.clear()        # a cleared grid starts without sticky errors
+    ctx.synchronize()
+    g.close()

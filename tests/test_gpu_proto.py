@@ -60,6 +60,16 @@ def test_to_proto_parses_and_round_trips(po, hg, ctx):
     g2 = hg.HybridGridTSDF.FromProto(ctx, data, max_blocks=1 << 14)
     a, b = g.export(), g2.export()
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # the loaded grid decodes with ITS converter: the proto constructor passes field 8 (getMaxTSD() of
+    # the writer, 0.025 m here) on as the relative truncation distance (hybrid_grid_tsdf.h:69-83)
+    f = np.float32
+    writer_max_tsd = f(2.5) * f(0.1)
+    assert g2.max_tsd == f(writer_max_tsd * f(0.1)) and g2.min_tsd == -g2.max_tsd
+    assert g2.max_weight == f(1000.0)
+    cells = a[0][:50]
+    tsd = g2.GetTSD(cells)
+    assert tsd.dtype == np.float32 and np.all(np.abs(tsd) <= g2.max_tsd + 1e-7)
+    assert np.all(g2.GetWeight(cells) > 0) and g2.IsKnown(cells).all()
     # and bytes written by the protobuf runtime load as well
     g3 = hg.HybridGridTSDF.FromProto(ctx, msg.SerializeToString(), max_blocks=1 << 14)
     assert all(np.array_equal(x, y) for x, y in zip(a, g3.export()))
