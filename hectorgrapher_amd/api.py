@@ -569,7 +569,9 @@ def per_point_subdivisions(point_times, cloud_time, control_times, num_points_pe
     step = int(num_points_per_subdivision)
     for start in range(0, n, step):
         end = min(start + step - 1, n - 1)
-        center = 0.5 * (float(point_times[start]) + float(point_times[end]))
+        # TimedRangefinderPoint::time is a float: the two times are added in float, then 0.5 (double)
+        # promotes the sum (oltb.cc:537-542)
+        center = 0.5 * float(np.float32(point_times[start]) + np.float32(point_times[end]))
         t = int(cloud_time) + from_seconds(center)
         if not (ct[0] < t < ct[-1]):
             continue

@@ -58,10 +58,28 @@ int main() {
       // room, where returns sit exactly on voxel boundaries and the interpolated TSDF cost jumps)
       odom.pose = Pose{{0.05 * k + ((k & 1) ? 0.01 : -0.01), 0.0013 * (k + 1), 0.0007 * (k + 1), 1.0, 0.0, 0.0, 0.0}};
       wbuilder.AddOdometryData(odom);
+      // a gyro at 100 Hz that reports no rotation (the trajectory is a straight line): the window's
+      // control points are tied by PredictionImuPreintegrationCostFunctor blocks with velocity states
+      for (int j = 0; j < 10; ++j) {
+        sensor::ImuData imu;
+        imu.time = scan.time - 0.1 + 0.01 * (j + 1);
+        imu.linear_acceleration = {{0.0, 0.0, 9.80665}};
+        imu.angular_velocity = {{0.0, 0.0, 0.0}};
+        wbuilder.AddImuData(imu);
+      }
       auto result = wbuilder.AddRangeData("lidar", scan);
       if (result)
-        std::printf("window scan %d pose %.4f %.4f %.4f (window %zu)\n", k, result->local_pose[0], result->local_pose[1],
-                    result->local_pose[2], wbuilder.window_size());
+        std::printf("window scan %d pose %.4f %.4f %.4f (window %zu, imu blocks %d, v %.3f %.3f %.3f)\n", k,
+                    result->local_pose[0], result->local_pose[1], result->local_pose[2], wbuilder.window_size(),
+                    wbuilder.num_imu_blocks_in_last_solve(), wbuilder.velocity(wbuilder.window_size() - 1)[0],
+                    wbuilder.velocity(wbuilder.window_size() - 1)[1], wbuilder.velocity(wbuilder.window_size() - 1)[2]);
+    }
+    // the pre-integration itself: 90 degrees about z in 1 s from a constant 100 Hz gyro
+    {
+      std::deque<sensor::ImuData> gyro;
+      for (int j = 0; j <= 100; ++j) gyro.push_back({0.01 * j, {{0.0, 0.0, 9.8}}, {{0.0, 0.0, 1.5707963267948966}}});
+      const std::array<double, 4> dq = mapping::IntegrateImuDeltaRotation(gyro, 0.0, 1.0);
+      std::printf("imu delta rotation %.6f %.6f %.6f %.6f\n", dq[0], dq[1], dq[2], dq[3]);
     }
     // ActiveSubmaps3D: two live submaps, a new one every 3 insertions, the old one finished at 6
     mapping::ActiveSubmaps3D::Options sopt;

@@ -11,6 +11,10 @@
 //   hg_amd::mapping::LocalTrajectoryBuilder3D  mapping/internal/3d/local_trajectory_builder_3d.h:46-79
 //                                              (AddImuData / AddRangeData / AddOdometryData /
 //                                              MatchingResult / InsertionResult)
+//   hg_amd::mapping::OptimizingLocalTrajectoryBuilder
+//                                              mapping/internal/3d/optimizing_local_trajectory_builder.cc
+//                                              (sliding window: TSDF blocks :323-511, IMU pre-integration
+//                                              blocks with velocity states :928-1000, odometry :1009-1074)
 // Header-only, C++11, no Eigen: poses are std::array<double, 7> (t xyz, q wxyz), points are
 // std::array<float, 3>. Errors throw hg_amd::Error (the reference CHECK-aborts instead).
 #ifndef HG_ADAPTER_H_
@@ -20,6 +24,8 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <deque>
+#include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -399,7 +405,8 @@ inline void AddPerPointMatchingResiduals(hg_problem* problem, const std::vector<
   std::vector<std::vector<double>> ratios(pairs);
   for (size_t start = 0; start < n; start += num_points_per_subdivision) {
     const size_t end = std::min(start + num_points_per_subdivision - 1, n - 1);
-    const double center = 0.5 * (static_cast<double>(point_times[start]) + static_cast<double>(point_times[end]));
+    // float + float, then promoted by the double 0.5 (oltb.cc:537-542)
+    const double center = 0.5 * (point_times[start] + point_times[end]);
     const int64_t t = cloud_time + FromSecondsTicks(center);
     if (!(t < control_times.back() && t > control_times.front())) continue;
     size_t next = 1;
@@ -531,6 +538,45 @@ class LocalTrajectoryBuilder3D {
   int num_scans_ = 0;
 };
 
+// Pre-integrated rotation between two control points, the only part of the pre-integration result
+// PredictionImuPreintegrationCostFunctor reads (prediction_imu_preintegration_cost_functor.h:81-84):
+// the rotation recurrence of IntegrateImuWithTranslationEuler (imu_integration.h:99-131) --
+// piecewise-constant angular velocity, delta_rotation *= AngleAxisVectorToRotationQuaternion(w * dt)
+// (transform/transform.h:121-135) -- with identity calibration. Host scalar code, as in the reference.
+// Returns (w, x, y, z). `imu` is ordered by time; samples before `start` other than the last one are
+// ignored, and without a sample at or before `start` the first sample is held.
+inline std::array<double, 4> IntegrateImuDeltaRotation(const std::deque<sensor::ImuData>& imu, double start,
+                                                       double end) {
+  std::array<double, 4> q{{1.0, 0.0, 0.0, 0.0}};
+  if (imu.empty() || !(start < end)) return q;
+  size_t it = 0;
+  while (it + 1 < imu.size() && imu[it + 1].time <= start) ++it;
+  double current = start;
+  while (current < end) {
+    const double next_imu = it + 1 < imu.size() ? imu[it + 1].time : std::numeric_limits<double>::infinity();
+    const double next = std::min(next_imu, end);
+    const double dt = next - current;
+    const double ax = imu[it].angular_velocity[0] * dt, ay = imu[it].angular_velocity[1] * dt,
+                 az = imu[it].angular_velocity[2] * dt;
+    double scale = 0.5, w = 1.0;
+    const double sq = ax * ax + ay * ay + az * az;
+    if (sq > 1e-8) {  // kCutoffAngle: linearised below
+      const double norm = std::sqrt(sq);
+      scale = std::sin(norm / 2.0) / norm;
+      w = std::cos(norm / 2.0);
+    }
+    const double x = scale * ax, y = scale * ay, z = scale * az;
+    const std::array<double, 4> r{{q[0] * w - q[1] * x - q[2] * y - q[3] * z,   // Eigen quaternion product q * d
+                                   q[0] * x + q[1] * w + q[2] * z - q[3] * y,
+                                   q[0] * y + q[2] * w + q[3] * x - q[1] * z,
+                                   q[0] * z + q[3] * w + q[1] * y - q[2] * x}};
+    q = r;
+    current = next;
+    if (current == next_imu) ++it;
+  }
+  return q;
+}
+
 // OptimizingLocalTrajectoryBuilder-shaped driver (mapping/internal/3d/optimizing_local_trajectory_builder.cc):
 // a sliding window of control points is re-optimised on every scan — AddRangeData (:188-264) queues the
 // cloud and adds a control point, MaybeOptimize (:1114-1413) builds one problem over the window (first
@@ -545,6 +591,10 @@ class OptimizingLocalTrajectoryBuilder {
   struct Options : LocalTrajectoryBuilder3D::Options {
     int window = 5;  // control points kept in the window (ct_window_horizon / ct_window_rate)
     double odometry_translation_weight = 1.0, odometry_rotation_weight = 1.0;  // trajectory_builder_3d.lua:126-127
+    // imu_cost_term = "PREINTEGRATION" with velocity_in_state (trajectory_builder_3d.lua:123-125,133,144):
+    // every neighbouring pair of control points gets a PredictionImuPreintegrationCostFunctor block once
+    // IMU data has arrived; all three weights zero switches the blocks off (oltb.cc:928-937)
+    double imu_translation_weight = 1.0, imu_velocity_weight = 1.0, imu_rotation_weight = 1.0;
   };
 
   OptimizingLocalTrajectoryBuilder(Context* ctx, const Options& options) : ctx_(ctx), options_(options) {
@@ -557,8 +607,15 @@ class OptimizingLocalTrajectoryBuilder {
   }
   ~OptimizingLocalTrajectoryBuilder() { if (problem_) hg_problem_destroy(problem_); }
 
-  void AddImuData(const sensor::ImuData&) {}  // pre-integration is host code: hg_problem_add_imu_block takes its result
+  // IMU samples are queued (oltb.cc:166-186); MaybeOptimize pre-integrates them between neighbouring
+  // control points on the host and hands the delta rotation to hg_problem_add_imu_block (:968-1000)
+  void AddImuData(const sensor::ImuData& imu) {
+    if (!imu_data_.empty() && imu.time < imu_data_.back().time) throw Error("AddImuData: samples must arrive in time order", HG_ERR_INVALID);
+    imu_data_.push_back(imu);
+  }
   void AddOdometryData(const sensor::OdometryData& odom) { last_odom_ = odom; have_odom_ = true; }
+  int num_imu_blocks_in_last_solve() const { return last_imu_blocks_; }
+  std::array<double, 3> velocity(size_t control_point) const { return window_[control_point].velocity; }
 
   std::unique_ptr<MatchingResult> AddRangeData(const std::string& /*sensor_id*/,
                                                const sensor::TimedPointCloudData& data) {
@@ -581,6 +638,10 @@ class OptimizingLocalTrajectoryBuilder {
       cp.pose = transform::Multiply(window_.back().pose,
                                     transform::Multiply(transform::Inverse(window_[window_.size() - 2].pose), window_.back().pose));
     else cp.pose = window_.back().pose;
+    // velocity of the new state: the translation of the predicted step over its duration (the
+    // constant-velocity form of PredictStateOdom, oltb.cc:1641); zero for the first control point
+    if (!window_.empty() && cp.time > window_.back().time)
+      for (int k = 0; k < 3; ++k) cp.velocity[k] = (cp.pose[k] - window_.back().pose[k]) / (cp.time - window_.back().time);
     window_.push_back(std::move(cp));
 
     std::vector<hg_grid*> pyr;
@@ -588,8 +649,25 @@ class OptimizingLocalTrajectoryBuilder {
     if (map_has_data_) {
       // MaybeOptimize: one problem over the window
       Check(hg_problem_reset(problem_), "hg_problem_reset");
-      for (size_t i = 0; i < window_.size(); ++i)
-        Check(hg_problem_add_pose(problem_, window_[i].pose.data(), i == 0 && window_.size() > 1), "hg_problem_add_pose");
+      const bool imu_blocks = !imu_data_.empty() && window_.size() > 1 &&
+                              (options_.imu_translation_weight != 0.0 || options_.imu_velocity_weight != 0.0 ||
+                               options_.imu_rotation_weight != 0.0);
+      last_imu_blocks_ = 0;
+      for (size_t i = 0; i < window_.size(); ++i) {
+        const bool first_constant = i == 0 && window_.size() > 1;  // :1268-1275 (velocity too)
+        Check(hg_problem_add_pose(problem_, window_[i].pose.data(), first_constant), "hg_problem_add_pose");
+        if (imu_blocks)
+          Check(hg_problem_set_velocity(problem_, static_cast<int>(i), window_[i].velocity.data(), first_constant),
+                "hg_problem_set_velocity");
+      }
+      for (size_t i = 1; imu_blocks && i < window_.size(); ++i) {
+        const std::array<double, 4> dq = IntegrateImuDeltaRotation(imu_data_, window_[i - 1].time, window_[i].time);
+        Check(hg_problem_add_imu_block(problem_, static_cast<int>(i) - 1, static_cast<int>(i),
+                                       options_.imu_translation_weight, options_.imu_velocity_weight,
+                                       options_.imu_rotation_weight, window_[i].time - window_[i - 1].time, dq.data()),
+              "hg_problem_add_imu_block");
+        ++last_imu_blocks_;
+      }
       for (size_t i = (window_.size() > 1 ? 1 : 0); i < window_.size(); ++i) {
         const std::vector<Point>& c = window_[i].cloud;
         Check(hg_problem_add_block(problem_, c[0].data(), c.size(), HG_HOST, pyr.data(), static_cast<int>(pyr.size()),
@@ -605,8 +683,13 @@ class OptimizingLocalTrajectoryBuilder {
       }
       hg_solver_summary summary;
       Check(hg_problem_solve(problem_, &solver_, &summary), "hg_problem_solve");
-      for (size_t i = 0; i < window_.size(); ++i)
+      for (size_t i = 0; i < window_.size(); ++i) {
         Check(hg_problem_get_pose(problem_, static_cast<int>(i), window_[i].pose.data()), "hg_problem_get_pose");
+        if (imu_blocks)
+          Check(hg_problem_get_velocity(problem_, static_cast<int>(i), window_[i].velocity.data()), "hg_problem_get_velocity");
+      }
+      // IMU samples older than the sample in force at the window's first control point are done with
+      while (imu_data_.size() > 1 && imu_data_[1].time <= window_.front().time) imu_data_.pop_front();
     }
     std::unique_ptr<MatchingResult> result(new MatchingResult);
     result->time = data.time;
@@ -641,6 +724,7 @@ class OptimizingLocalTrajectoryBuilder {
   struct ControlPoint {
     double time = 0;
     Pose pose, odom;
+    std::array<double, 3> velocity{{0.0, 0.0, 0.0}};
     bool has_odom = false, inserted = false;
     std::array<float, 3> origin;
     std::vector<Point> cloud;
@@ -651,6 +735,8 @@ class OptimizingLocalTrajectoryBuilder {
   hg_problem* problem_ = nullptr;
   hg_solver_opts solver_;
   std::vector<ControlPoint> window_;
+  std::deque<sensor::ImuData> imu_data_;
+  int last_imu_blocks_ = 0;
   sensor::OdometryData last_odom_{};
   bool have_odom_ = false, map_has_data_ = false;
 };

@@ -2,7 +2,8 @@
 // path: sensor/internal/voxel_filter.cc:26-69, sensor/internal/adaptive_voxel_filter.h:33-110).
 //
 // VoxelFilter keeps the FIRST point (input order) that falls into each voxel; cell = lround(p/res)
-// per axis. Device form: a hash table keyed by the packed cell (3 x 21 bits) holds the minimum
+// per axis. Device form: a hash table keyed by the packed cell (3 x 21 bits; a pass that meets a cell
+// outside that window is redone with the reference's 3 x 32-bit keys) holds the minimum
 // point index per voxel (atomicMin), a second pass flags the points that are their voxel's
 // minimum, and a stable stream compaction (rocPRIM select, library call) emits their indices in
 // input order — the same set and order as the reference's sequential hash-set loop.
@@ -34,6 +35,88 @@ __device__ inline uint32_t mix64(unsigned long long k) {
   k *= 0xff51afd7ed558ccdULL;
   k ^= k >> 29;
   return static_cast<uint32_t>(k) ^ static_cast<uint32_t>(k >> 32);
+}
+
+// ---- wide keys: 3 x 32-bit cell indices, the reference's key (voxel_filter.cc:64-69) ------------
+// Taken only when a cell leaves the 3 x 21-bit window of the fast path (coordinates beyond
+// 2^20 * resolution: voxel_filter_test.cc:40-48 has 1e5 m at 1 cm). A table slot is two 64-bit words,
+// A = x | y << 32 and B = z | state << 32 (state 0 empty, 1 being written, 2 ready); every access
+// during the insert pass is a 64-bit device-scope atomic, which is coherent across the XCDs' L2s.
+struct WideKey {
+  unsigned long long a;
+  uint32_t z;
+};
+__device__ inline WideKey cell_key96(const float* p, float res) {
+  // RoundToInt of a float beyond the int range is undefined in the reference too; coordinates below
+  // 2^31 * resolution are exact here
+  const int x = round_to_int(p[0] / res), y = round_to_int(p[1] / res), z = round_to_int(p[2] / res);
+  return {static_cast<unsigned long long>(static_cast<uint32_t>(x)) |
+              (static_cast<unsigned long long>(static_cast<uint32_t>(y)) << 32),
+          static_cast<uint32_t>(z)};
+}
+__device__ inline uint32_t mix96(const WideKey& k) { return mix64(k.a ^ (0x9E3779B97F4A7C15ull * (k.z + 1ull))); }
+
+__global__ void k_vf_insert_wide(const float* pts, unsigned n, int stride, float res, const uint8_t* mask,
+                                 unsigned long long* wa, unsigned long long* wb, uint32_t* min_idx,
+                                 uint32_t table_mask, uint32_t* err) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (mask && !mask[i])) return;
+  const WideKey key = cell_key96(pts + static_cast<size_t>(i) * stride, res);
+  const unsigned long long ready = static_cast<unsigned long long>(key.z) | (2ull << 32);
+  uint32_t h = mix96(key) & table_mask;
+  uint32_t probes = 0;
+  bool done = false;
+  while (!done) {
+    unsigned long long b = atomicAdd(&wb[h], 0ull);
+    if ((b >> 32) == 0ull) {
+      const unsigned long long prev = atomicCAS(&wb[h], 0ull, 1ull << 32);
+      if (prev == 0ull) {  // this lane owns the slot: publish the key inside the iteration it won in
+        atomicExch(&wa[h], key.a);
+        __threadfence();
+        atomicExch(&wb[h], ready);
+        b = ready;
+      } else {
+        b = prev;
+      }
+    }
+    if ((b >> 32) == 1ull) {
+      __builtin_amdgcn_s_sleep(1);  // the owner is publishing
+      continue;
+    }
+    if (b == ready && atomicAdd(&wa[h], 0ull) == key.a) {
+      atomicMin(&min_idx[h], i);
+      done = true;
+    } else {
+      h = (h + 1) & table_mask;
+      if (++probes > table_mask) {
+        atomicOr(err, kFlagCapacity);
+        done = true;
+      }
+    }
+  }
+}
+
+__global__ void k_vf_flags_wide(const float* pts, unsigned n, int stride, float res, const uint8_t* mask,
+                                const unsigned long long* wa, const unsigned long long* wb,
+                                const uint32_t* min_idx, uint32_t table_mask, uint8_t* flags) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t keep = 0;
+  if (!mask || mask[i]) {
+    const WideKey key = cell_key96(pts + static_cast<size_t>(i) * stride, res);
+    const unsigned long long ready = static_cast<unsigned long long>(key.z) | (2ull << 32);
+    uint32_t h = mix96(key) & table_mask;
+    for (uint32_t probe = 0; probe <= table_mask; ++probe) {
+      const unsigned long long b = wb[h];
+      if (b == 0ull) break;
+      if (b == ready && wa[h] == key.a) {
+        keep = (min_idx[h] == i) ? 1 : 0;
+        break;
+      }
+      h = (h + 1) & table_mask;
+    }
+  }
+  flags[i] = keep;
 }
 
 // True on the lowest active lane of every distinct key of the wavefront. Neighbouring returns of a
@@ -355,6 +438,27 @@ int voxel_filter_pass(FilterCall& f, float res, const uint8_t* select_mask_only,
     hipLaunchKernelGGL(k_vf_flags, dim3(nwg), dim3(wg), 0, s, f.d_pts, f.n, f.stride, res, f.d_mask,
                        f.d_keys, f.d_min, f.table_mask, f.d_flags);
     HG_HIP_CHECK(hipGetLastError());
+    {
+      // a cell outside the 3 x 21-bit window: redo the pass with the reference's 3 x 32-bit keys
+      uint32_t flags_now[2];
+      HG_HIP_CHECK(hipMemcpyAsync(flags_now, f.d_count, sizeof(flags_now), hipMemcpyDeviceToHost, s));
+      HG_HIP_CHECK(hipStreamSynchronize(s));
+      if (flags_now[1] & kFlagRange) {
+        int rc = f.c->ws_keys_b.reserve(cap * sizeof(unsigned long long));
+        if (rc != HG_OK) return rc;
+        unsigned long long* wb = f.c->ws_keys_b.as<unsigned long long>();
+        HG_HIP_CHECK(hipMemsetAsync(f.d_count + 1, 0, sizeof(uint32_t), s));
+        HG_HIP_CHECK(hipMemsetAsync(f.d_keys, 0, cap * sizeof(unsigned long long), s));
+        HG_HIP_CHECK(hipMemsetAsync(wb, 0, cap * sizeof(unsigned long long), s));
+        HG_HIP_CHECK(hipMemsetAsync(f.d_min, 0xFF, cap * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_vf_insert_wide, dim3(nwg), dim3(wg), 0, s, f.d_pts, f.n, f.stride, res, f.d_mask,
+                           f.d_keys, wb, f.d_min, f.table_mask, f.d_count + 1);
+        HG_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_vf_flags_wide, dim3(nwg), dim3(wg), 0, s, f.d_pts, f.n, f.stride, res, f.d_mask,
+                           f.d_keys, wb, f.d_min, f.table_mask, f.d_flags);
+        HG_HIP_CHECK(hipGetLastError());
+      }
+    }
     size_t tb = 0;
     HG_HIP_CHECK(rocprim::select(nullptr, tb, rocprim::counting_iterator<uint32_t>(0), f.d_flags,
                                  f.d_idx, f.d_count, f.n, s));

@@ -218,12 +218,14 @@ int hg_grid_status(hg_grid* grid, hg_insert_stats* stats);
 /* VoxelFilter(resolution).Filter (sensor/internal/voxel_filter.cc:26-37): keeps the first point
  * of every voxel, input order preserved. pts: n points of `stride` floats (3 = PointCloud, 4 =
  * TimedPointCloud, time ignored). indices_out (host, capacity n, may be NULL) receives the kept
- * indices; *count their number. Device key = 3 x 21-bit cell indices: |cell| >= 2^20 returns
- * HG_ERR_RANGE (the reference uses 3 x 32 bits). */
+ * indices; *count their number. Cells are keyed by 3 x 21 bits, or, when a cell index reaches
+ * +-2^20, by the reference's 3 x 32 bits (voxel_filter.cc:64-69; slower pass). */
 int hg_voxel_filter(hg_ctx* ctx, float resolution, const float* pts, size_t n, int stride,
                     int memspace, uint32_t* indices_out, size_t* count);
 /* AdaptiveVoxelFilter::Filter (sensor/internal/adaptive_voxel_filter.h:33-110): FilterByMaxRange,
- * then the binary search on the voxel edge length for >= min_num_points points. */
+ * then the binary search on the voxel edge length for >= min_num_points points. The trial lengths
+ * are >= max_length / 128 and the points lie within max_range, so cells stay inside 3 x 21 bits for
+ * max_range / max_length < 8192; beyond that HG_ERR_RANGE. */
 int hg_adaptive_voxel_filter(hg_ctx* ctx, float max_length, float min_num_points, float max_range,
                              const float* pts, size_t n, int stride, int memspace,
                              uint32_t* indices_out, size_t* count);

@@ -34,7 +34,18 @@ def test_cpp_local_trajectory_builder_example():
     assert len(wposes) == 8
     for k, (x, y, z) in enumerate(wposes):
         assert abs(x - 0.05 * k) < 0.021 and abs(y) < 0.02 and abs(z) < 0.02
-    assert "(window 3)" in out.stdout
+    assert "(window 3," in out.stdout
+    # the window carries IMU pre-integration blocks and velocity states (oltb.cc:928-1000): one block
+    # per neighbouring pair of control points, and the solved velocity follows the 0.5 m/s motion
+    blocks = [int(m.group(1)) for m in re.finditer(r"imu blocks (\d+)", out.stdout)]
+    assert blocks[0] == 0 and blocks[1] == 1 and max(blocks) == 3 and blocks[-1] == 3
+    vel = [tuple(float(v) for v in m.groups()) for m in re.finditer(r"v (\S+) (\S+) (\S+)\)", out.stdout)]
+    assert len(vel) == 8
+    for vx, vy, vz in vel[2:]:
+        assert abs(vx - 0.5) < 0.4 and abs(vy) < 0.3 and abs(vz) < 0.3
+    dq = re.search(r"^imu delta rotation (\S+) (\S+) (\S+) (\S+)", out.stdout, re.M)
+    w, x, y, z = (float(dq.group(i)) for i in range(1, 5))
+    assert abs(w - 0.70710678) < 1e-5 and abs(z - 0.70710678) < 1e-5 and abs(x) < 1e-12 and abs(y) < 1e-12
     # ActiveSubmaps3D bookkeeping (submap_3d.cc:492-514, 548-559) with num_range_data = 3
     lines = re.findall(r"^submaps after insert (\d+):(.*)$", out.stdout, re.M)
     assert [l[1].split() for l in lines] == [["1"], ["2"], ["3"], ["4", "1"], ["5", "2"],

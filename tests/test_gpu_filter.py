@@ -8,16 +8,32 @@ pytestmark = pytest.mark.gpu
 
 
 def test_reference_kats(hg, ctx):
-    """voxel_filter_test.cc:30-38,50-56; :40-48 (coordinates of 1e5 m at 1 cm) exceeds the device's
-    3 x 21-bit cell key and must be refused, not silently mis-filtered."""
+    """voxel_filter_test.cc:30-38 (first point of each voxel), :40-48 (coordinates of 1e5 m at 1 cm:
+    cell indices of 1e7 need the reference's 3 x 32-bit key), :50-56 (time ignored)."""
     pc = np.array([[0, 0, 0], [0.1, -0.1, 0.1], [0.3, -0.1, 0], [0, 0, 0.1]], np.float32)
     assert hg.VoxelFilter(ctx, 0.3).Filter(pc).tolist() == [0, 2]
     timed = np.array([[-100.0, 0.3, 0.4, float(i)] for i in range(100)], np.float32)
     assert hg.VoxelFilter(ctx, 0.3).Filter(timed).tolist() == [0]
-    far = np.array([[100000., 0, 0], [100000.001, -0.0001, 0.0001], [-200000., 0, 0]], np.float32)
-    with pytest.raises(hg.HgError):
-        hg.VoxelFilter(ctx, 0.01).Filter(far)
+    far = np.array([[100000., 0, 0], [100000.001, -0.0001, 0.0001], [100000.003, -0.0001, 0],
+                    [-200000., 0, 0]], np.float32)
+    assert hg.VoxelFilter(ctx, 0.01).Filter(far).tolist() == [0, 3]
     assert hg.VoxelFilter(ctx, 0.3).Filter(np.zeros((0, 3), np.float32)).tolist() == []
+
+
+def test_wide_keys_match_oracle(po, hg, ctx):
+    """Clouds that leave the 3 x 21-bit key window (|cell| >= 2^20) go through the 3 x 32-bit pass:
+    same index list as the oracle, including voxels that differ only in their high bits."""
+    rng = np.random.default_rng(9)
+    near = (rng.standard_normal((30000, 3)) * 2).astype(np.float32)
+    far = near[:8000] + np.array([[40000.0, -70000.0, 25000.0]], np.float32)
+    # aliases of `near` cells modulo 2^21 cells (what a truncated key would merge)
+    alias = near[:5000] + np.float32(0.02 * (1 << 21)) * np.array([[1, 0, 0]], np.float32)
+    pts = np.concatenate([near, far, alias, near[::-1]])[rng.permutation(30000 * 2 + 13000)]
+    for res in (0.02, 0.05):
+        a = po.voxel_filter(res, pts)
+        b = hg.VoxelFilter(ctx, res).Filter(pts)
+        assert np.array_equal(a, b)
+        assert len(a) < len(pts)
 
 
 @pytest.mark.parametrize("res", [0.05, 0.15, 0.5, 2.0])

@@ -25,7 +25,7 @@ def test_per_point_subdivisions_bracketing():
     expect = []
     for s in range(0, 36, 4):
         e = min(s + 3, 35)
-        t = cloud_time + api.from_seconds(0.5 * (float(times[s]) + float(times[e])))
+        t = cloud_time + api.from_seconds(0.5 * float(np.float32(times[s]) + np.float32(times[e])))  # float add
         if not (control[0] < t < control[-1]):
             continue
         nxt = next(i for i in range(1, 3) if control[i] > t)
@@ -39,3 +39,18 @@ def test_per_point_subdivisions_bracketing():
     # a ragged tail: the last subdivision is shorter
     subs7 = api.per_point_subdivisions(times[:10], cloud_time + api.from_seconds(0.08), control, 7)
     assert [(a, b) for a, b, *_ in subs7] == [(0, 7), (7, 10)]
+
+
+def test_subdivision_time_adds_the_two_point_times_in_float():
+    """oltb.cc:537-542: `0.5 * (a.time + b.time)` with float times is a FLOAT sum promoted by the
+    double 0.5. For these two times the float sum rounds, the double sum does not, and FromSeconds
+    lands one 100 ns tick apart: the float form is the reference's."""
+    a, b = np.float32(0.13493788), np.float32(0.11411292)
+    as_float = api.from_seconds(0.5 * float(np.float32(a + b)))
+    as_double = api.from_seconds(0.5 * (float(a) + float(b)))
+    assert as_float != as_double          # the case distinguishes the two forms
+    t0 = 1_000_000_000
+    control = [t0 - api.from_seconds(1.0), t0 + api.from_seconds(1.0)]
+    subs = api.per_point_subdivisions(np.array([a, b], np.float32), t0, control, 2)
+    want = api.to_seconds(t0 + as_float - control[0]) / api.to_seconds(control[1] - control[0])
+    assert subs == [(0, 2, 0, 1, want)]
