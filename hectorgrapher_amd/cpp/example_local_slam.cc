@@ -35,11 +35,17 @@ int main() {
     // shape): window of 3 control points, odometry with an alternating +-1 cm error
     mapping::OptimizingLocalTrajectoryBuilder::Options wopt;
     wopt.window = 3;
+    // the sensor rests for the first two scans (the window's first state is fixed, with zero
+    // velocity) and then moves at 0.5 m/s; the functor ties neighbouring velocities together (it reads
+    // only the pre-integrated rotation), so the step in velocity gets a small velocity weight
+    wopt.imu_translation_weight = 1.0;
+    wopt.imu_velocity_weight = 0.01;
+    wopt.imu_rotation_weight = 1.0;
     mapping::OptimizingLocalTrajectoryBuilder wbuilder(&ctx, wopt);
     for (int k = 0; k < 8; ++k) {
       sensor::TimedPointCloudData scan;
       scan.time = 0.1 * k;
-      const float sx = 0.05f * k;
+      const float sx = 0.05f * (k > 0 ? k - 1 : 0);
       for (int c = 0; c < 360; ++c)
         for (int r = 0; r < 16; ++r) {
           const float az = 6.2831853f * c / 360.f, el = (-15.f + 2.f * r) * 0.01745329f;
@@ -56,7 +62,7 @@ int main() {
       odom.time = scan.time;
       // (a small lateral offset keeps the predictions off the exact symmetry axis of this synthetic
       // room, where returns sit exactly on voxel boundaries and the interpolated TSDF cost jumps)
-      odom.pose = Pose{{0.05 * k + ((k & 1) ? 0.01 : -0.01), 0.0013 * (k + 1), 0.0007 * (k + 1), 1.0, 0.0, 0.0, 0.0}};
+      odom.pose = Pose{{0.05 * (k > 0 ? k - 1 : 0) + ((k & 1) ? 0.01 : -0.01), 0.0013 * (k + 1), 0.0007 * (k + 1), 1.0, 0.0, 0.0, 0.0}};
       wbuilder.AddOdometryData(odom);
       // a gyro at 100 Hz that reports no rotation (the trajectory is a straight line): the window's
       // control points are tied by PredictionImuPreintegrationCostFunctor blocks with velocity states
