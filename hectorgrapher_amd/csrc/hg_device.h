@@ -16,14 +16,28 @@ constexpr uint32_t kSlotPending = 0xFFFFFFu;
 constexpr uint16_t kUpdateMarker = 1u << 15;
 
 // Device view of one HybridGridTSDF. Passed to kernels by value.
+//
+// Block pool = dir_blocks "direct" slots followed by max_blocks overflow slots. A new block takes
+// the direct slot its coordinates map to (the low bits of each block coordinate: a toroidal window
+// of 2^dir_bits blocks per axis) when that slot is free, else the next overflow slot. While no block
+// has gone to the overflow area and the blocks' bounding box fits the window, the address of a voxel
+// is a function of its coordinates alone: lookups of the matcher then need no hash probe (one memory
+// round trip instead of two, see pool_is_direct / DirectWindow). The hash table always holds every
+// block and is what inserts, exports and the general lookup use.
 struct GridView {
   unsigned long long* table;  // open-addressing hash: 0 = empty, else ((key + 1) << 24) | slot
   uint32_t table_mask;        // capacity - 1 (power of two)
-  uint32_t max_blocks;
-  uint32_t* voxels;           // max_blocks * 512, voxel = tsd_code | weight_code << 16
-  unsigned long long* block_keys;  // key of slot s
+  uint32_t max_blocks;        // blocks the grid may hold (capacity of the overflow area)
+  uint32_t pool_blocks;       // dir_blocks + max_blocks slots
+  uint32_t dir_blocks;        // 1 << (dir_bits[0] + dir_bits[1] + dir_bits[2])
+  uint32_t dir_bits[3];       // window bits per axis (x, y, z)
+  uint32_t* voxels;           // pool_blocks * 512, voxel = tsd_code | weight_code << 16
+  unsigned long long* block_keys;  // per slot: key + 1 of the block it holds, 0 = free
+  uint32_t* block_list;       // slots in allocation order, [0, num_blocks)
   uint32_t* counters;         // [0] num_blocks, [1] error flags, [2] hits, [4..5] updates (u64),
-                              // [6] touched blocks being collected, [7] touched blocks to apply
+                              // [6] touched blocks being collected, [7] touched blocks to apply,
+                              // [8] blocks in the overflow area, [9..11] min / [12..14] max block
+                              // coordinate (x, y, z) over all blocks
   uint32_t* bin_count;        // per block slot: records of the current insert call
   uint32_t* bin_offset;       // per block slot: first record of its bin
   uint32_t* touched;          // slots touched by the current insert call
@@ -147,6 +161,41 @@ __device__ inline uint32_t find_block(const GridView& g, unsigned long long key)
   return 0xFFFFFFFFu;
 }
 
+// Direct slot of a block key: the low dir_bits of each block coordinate.
+__host__ __device__ inline uint32_t direct_slot(const GridView& g, unsigned long long key) {
+  const uint32_t bx = static_cast<uint32_t>(key) & 2047u, by = static_cast<uint32_t>(key >> 11) & 2047u,
+                 bz = static_cast<uint32_t>(key >> 22) & 2047u;
+  return ((bz & ((1u << g.dir_bits[2]) - 1u)) << (g.dir_bits[0] + g.dir_bits[1])) |
+         ((by & ((1u << g.dir_bits[1]) - 1u)) << g.dir_bits[0]) | (bx & ((1u << g.dir_bits[0]) - 1u));
+}
+
+// Pool slot for a new block (called by the one thread that won the block's hash entry): the direct
+// slot if it is free, else the next overflow slot. 0xFFFFFFFF (capacity flag set) when the grid
+// already holds max_blocks blocks.
+__device__ inline uint32_t alloc_slot(const GridView& g, unsigned long long key) {
+  const uint32_t n = atomicAdd(&g.counters[0], 1u);
+  if (n >= g.max_blocks) {
+    atomicSub(&g.counters[0], 1u);
+    atomicOr(&g.counters[1], kFlagCapacity);
+    return 0xFFFFFFFFu;
+  }
+  uint32_t slot = direct_slot(g, key);
+  if (atomicCAS(&g.block_keys[slot], 0ull, key + 1ull) != 0ull) {
+    slot = g.dir_blocks + atomicAdd(&g.counters[8], 1u);  // < pool_blocks: n < max_blocks
+    g.block_keys[slot] = key + 1ull;
+  }
+  g.block_list[n] = slot;
+  const uint32_t bx = static_cast<uint32_t>(key) & 2047u, by = static_cast<uint32_t>(key >> 11) & 2047u,
+                 bz = static_cast<uint32_t>(key >> 22) & 2047u;
+  if (bx < g.counters[9]) atomicMin(&g.counters[9], bx);
+  if (by < g.counters[10]) atomicMin(&g.counters[10], by);
+  if (bz < g.counters[11]) atomicMin(&g.counters[11], bz);
+  if (bx > g.counters[12]) atomicMax(&g.counters[12], bx);
+  if (by > g.counters[13]) atomicMax(&g.counters[13], by);
+  if (bz > g.counters[14]) atomicMax(&g.counters[14], bz);
+  return slot;
+}
+
 // Insert-or-get for kernels in which each distinct key is inserted by at most one thread.
 // Returns the slot, or 0xFFFFFFFF when the pool/table is full (flag set).
 __device__ inline uint32_t insert_block_unique(const GridView& g, unsigned long long key) {
@@ -158,14 +207,8 @@ __device__ inline uint32_t insert_block_unique(const GridView& g, unsigned long 
       const unsigned long long pending = (tag << 24) | kSlotPending;
       const unsigned long long prev = atomicCAS(&g.table[h], 0ull, pending);
       if (prev == 0ull) {
-        const uint32_t slot = atomicAdd(&g.counters[0], 1u);
-        if (slot >= g.max_blocks || slot >= kSlotPending) {
-          atomicSub(&g.counters[0], 1u);
-          atomicOr(&g.counters[1], kFlagCapacity);
-          // leave the entry pending: lookups treat a pending slot as missing
-          return 0xFFFFFFFFu;
-        }
-        g.block_keys[slot] = key;
+        const uint32_t slot = alloc_slot(g, key);
+        if (slot == 0xFFFFFFFFu) return slot;  // the entry stays pending: lookups treat it as missing
         atomicExch(&g.table[h], (tag << 24) | slot);
         return slot;
       }
@@ -196,15 +239,12 @@ __device__ inline uint32_t insert_block_shared(const GridView& g, unsigned long 
       const unsigned long long pending = (tag << 24) | kSlotPending;
       const unsigned long long prev = atomicCAS(&g.table[h], 0ull, pending);
       if (prev == 0ull) {
-        const uint32_t slot = atomicAdd(&g.counters[0], 1u);
-        if (slot >= g.max_blocks || slot >= kSlotPending) {
-          atomicSub(&g.counters[0], 1u);
-          atomicOr(&g.counters[1], kFlagCapacity);
+        const uint32_t slot = alloc_slot(g, key);
+        if (slot == 0xFFFFFFFFu) {
           // publish a poisoned entry so waiters stop: slot field stays pending but tag is cleared
           atomicExch(&g.table[h], (0x1FFFFFFFFFull << 24) | kSlotPending);
           done = true;
         } else {
-          g.block_keys[slot] = key;
           atomicExch(&g.table[h], (tag << 24) | slot);
           result = slot;
           done = true;
@@ -238,7 +278,7 @@ __device__ inline uint32_t insert_block_shared(const GridView& g, unsigned long 
 __device__ inline uint32_t load_voxel(const GridView& g, int x, int y, int z) {
   if (!cell_in_range(x, y, z)) return 0u;
   const uint32_t slot = find_block(g, block_key(x, y, z));
-  if (slot >= g.max_blocks) return 0u;
+  if (slot >= g.pool_blocks) return 0u;
   return g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + voxel_in_block(x, y, z)];
 }
 

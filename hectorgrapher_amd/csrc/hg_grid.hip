@@ -30,7 +30,7 @@ __global__ void k_set_cells(GridView g, const int* ijk, size_t m, const float* t
     return;
   }
   const uint32_t slot = insert_block_shared(g, block_key(x, y, z));
-  if (slot >= g.max_blocks) return;
+  if (slot >= g.pool_blocks) return;
   // SetCell: hybrid_grid_tsdf.h:87-92
   const uint32_t code = (tsd_to_value(g, tsd[i]) + kUpdateMarker) | (weight_to_value(g, weight[i]) << 16);
   g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + voxel_in_block(x, y, z)] = code;
@@ -66,7 +66,7 @@ __global__ void k_export_write(GridView g, const uint32_t* order, const uint64_t
   const uint32_t slot = order[b];
   const uint32_t* vox = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock;
   int ox, oy, oz;
-  key_to_block_origin(g.block_keys[slot], &ox, &oy, &oz);
+  key_to_block_origin(g.block_keys[slot] - 1ull, &ox, &oy, &oz);
   uint64_t base = offsets[b];
   for (int it = 0; it < 8; ++it) {
     const uint32_t idx = it * kWave + lane;
@@ -95,11 +95,30 @@ __global__ void k_import_blocks(GridView g, const unsigned long long* keys, cons
   uint32_t slot = 0;
   if (lane == 0) slot = insert_block_unique(g, keys[b]);
   slot = __shfl(slot, 0);
-  if (slot >= g.max_blocks) return;
+  if (slot >= g.pool_blocks) return;
   const uint4* src = reinterpret_cast<const uint4*>(voxels + static_cast<size_t>(b) * kVoxelsPerBlock);
   uint4* dst = reinterpret_cast<uint4*>(g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock);
   dst[lane] = src[lane];
   dst[lane + kWave] = src[lane + kWave];
+}
+
+// One wave per block of the block list: key and 2 KiB of voxels into contiguous arrays (the form the
+// multi-GPU gather ships and hg_grid_import_blocks takes).
+__global__ void k_pack_blocks(GridView g, uint32_t nblocks, unsigned long long* keys, uint32_t* voxels) {
+  const uint32_t b = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  const uint32_t lane = threadIdx.x % kWave;
+  if (b >= nblocks) return;
+  const uint32_t slot = g.block_list[b];
+  if (lane == 0) keys[b] = g.block_keys[slot] - 1ull;
+  const uint4* src = reinterpret_cast<const uint4*>(g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock);
+  uint4* dst = reinterpret_cast<uint4*>(voxels + static_cast<size_t>(b) * kVoxelsPerBlock);
+  dst[lane] = src[lane];
+  dst[lane + kWave] = src[lane + kWave];
+}
+
+__global__ void k_list_keys(GridView g, uint32_t nblocks, unsigned long long* keys) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nblocks) keys[b] = g.block_keys[g.block_list[b]] - 1ull;
 }
 
 static uint32_t next_pow2(uint32_t v) {
@@ -116,6 +135,37 @@ extern "C" {
 
 const char* hg_last_error(void) { return g_last_error.c_str(); }
 const char* hg_version(void) { return "hectorgrapher_amd 0.1 (gfx950)"; }
+
+}  // extern "C"
+
+// Slots of the grid's blocks in the reference's iterator order (hybrid_grid_base.h:304-372).
+int hg::grid_block_order(hg_grid* g, std::vector<uint32_t>* order) {
+  hipStream_t s = g->ctx->stream;
+  uint32_t nb = 0;
+  int rc = hg_grid_num_blocks(g, &nb);
+  if (rc != HG_OK) return rc;
+  order->clear();
+  if (nb == 0) return HG_OK;
+  DeviceBuffer& b = g->ctx->ws_misc;
+  if ((rc = b.reserve(nb * sizeof(unsigned long long))) != HG_OK) return rc;
+  hipLaunchKernelGGL(k_list_keys, dim3((nb + 255) / 256), dim3(256), 0, s, g->view, nb, b.as<unsigned long long>());
+  HG_HIP_CHECK(hipGetLastError());
+  std::vector<unsigned long long> keys(nb);
+  std::vector<uint32_t> slots(nb);
+  HG_HIP_CHECK(hipMemcpyAsync(keys.data(), b.ptr, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipMemcpyAsync(slots.data(), g->view.block_list, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HG_HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<uint32_t> idx(nb);
+  std::iota(idx.begin(), idx.end(), 0u);
+  std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) {
+    return export_order_key(keys[a]) < export_order_key(keys[c]);
+  });
+  order->resize(nb);
+  for (uint32_t i = 0; i < nb; ++i) (*order)[i] = slots[idx[i]];
+  return HG_OK;
+}
+
+extern "C" {
 
 static void prof_resolve(hg_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
@@ -224,7 +274,7 @@ int hg_prof_read(hg_ctx* c, int kernel, uint64_t* launches, double* total_ms, ui
 int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_distance,
                    float max_weight, uint32_t max_blocks, hg_grid** out) {
   if (!ctx || !out || !(resolution > 0.f) || !(max_weight > 0.f) ||
-      !(relative_truncation_distance > 0.f) || max_blocks == 0 || max_blocks >= kSlotPending)
+      !(relative_truncation_distance > 0.f) || max_blocks == 0 || max_blocks >= kSlotPending / 2)
     return HG_ERR_INVALID;
   *out = nullptr;
   HG_HIP_CHECK(hipSetDevice(ctx->device));
@@ -233,6 +283,22 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
   g->relative_truncation_distance = relative_truncation_distance;
   GridView& v = g->view;
   v.max_blocks = max_blocks;
+  // direct window: as many slots as the grid may hold blocks (rounded up to a power of two, at most
+  // 2^21 = a 128^3-block window), z gets the smallest share of the bits
+  {
+    uint32_t bits = 0;
+    while ((1u << bits) < max_blocks && bits < 21) ++bits;
+    if (bits < 3) bits = 3;
+    v.dir_bits[2] = bits / 3;
+    v.dir_bits[0] = (bits - v.dir_bits[2] + 1) / 2;
+    v.dir_bits[1] = bits - v.dir_bits[2] - v.dir_bits[0];
+    v.dir_blocks = 1u << bits;
+    v.pool_blocks = v.dir_blocks + max_blocks;
+  }
+  if (v.pool_blocks >= kSlotPending) {
+    delete g;
+    return HG_ERR_INVALID;
+  }
   g->table_capacity = next_pow2(std::max<uint32_t>(1024u, max_blocks * 2u));
   v.table_mask = g->table_capacity - 1;
   v.resolution = resolution;
@@ -250,15 +316,19 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
   hipError_t e;
   e = hipMalloc(reinterpret_cast<void**>(&v.table), sizeof(unsigned long long) * g->table_capacity);
   if (e == hipSuccess)
-    e = hipMalloc(reinterpret_cast<void**>(&v.voxels), sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(max_blocks));
+    e = hipMalloc(reinterpret_cast<void**>(&v.voxels), sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(v.pool_blocks));
   if (e == hipSuccess)
-    e = hipMalloc(reinterpret_cast<void**>(&v.block_keys), sizeof(unsigned long long) * max_blocks);
+    e = hipMalloc(reinterpret_cast<void**>(&v.block_keys), sizeof(unsigned long long) * v.pool_blocks);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v.counters), 256);
-  // bin_count | bin_offset | touched (u32 each); the apply work list lives in the context workspace
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&v.bin_count), sizeof(uint32_t) * 3 * static_cast<size_t>(max_blocks));
+  // per slot: bin_count | bin_offset; per block: touched | block_list (u32 each); the apply work list
+  // lives in the context workspace
+  if (e == hipSuccess)
+    e = hipMalloc(reinterpret_cast<void**>(&v.bin_count),
+                  sizeof(uint32_t) * (2 * static_cast<size_t>(v.pool_blocks) + 2 * static_cast<size_t>(max_blocks)));
   if (e == hipSuccess) {
-    v.bin_offset = v.bin_count + max_blocks;
-    v.touched = v.bin_offset + max_blocks;
+    v.bin_offset = v.bin_count + v.pool_blocks;
+    v.touched = v.bin_offset + v.pool_blocks;
+    v.block_list = v.touched + max_blocks;
     v.work = nullptr;
     v.work_capacity = 0;
   }
@@ -281,6 +351,7 @@ int hg_grid_destroy(hg_grid* g) {
   if (g->view.counters) (void)hipFree(g->view.counters);
   if (g->view.bin_count) (void)hipFree(g->view.bin_count);
   if (g->view.accum) (void)hipFree(g->view.accum);
+  g->pack.release();
   delete g;
   return HG_OK;
 }
@@ -288,15 +359,20 @@ int hg_grid_destroy(hg_grid* g) {
 int hg_grid_clear(hg_grid* g) {
   if (!g) return HG_ERR_INVALID;
   hipStream_t s = g->ctx->stream;
-  HG_HIP_CHECK(hipMemsetAsync(g->view.table, 0, sizeof(unsigned long long) * g->table_capacity, s));
-  HG_HIP_CHECK(hipMemsetAsync(g->view.voxels, 0,
-                              sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(g->view.max_blocks), s));
-  HG_HIP_CHECK(hipMemsetAsync(g->view.counters, 0, 256, s));
+  const GridView& v = g->view;
+  HG_HIP_CHECK(hipMemsetAsync(v.table, 0, sizeof(unsigned long long) * g->table_capacity, s));
+  HG_HIP_CHECK(hipMemsetAsync(v.voxels, 0, sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(v.pool_blocks), s));
+  HG_HIP_CHECK(hipMemsetAsync(v.block_keys, 0, sizeof(unsigned long long) * v.pool_blocks, s));
+  // counters: all zero except the running minimum of the block coordinates
+  static const uint32_t kInit[64] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  HG_HIP_CHECK(hipMemcpyAsync(v.counters, kInit, 256, hipMemcpyHostToDevice, s));
+  HG_HIP_CHECK(hipMemsetAsync(v.bin_count, 0, sizeof(uint32_t) * 2 * static_cast<size_t>(v.pool_blocks), s));
+  if (v.accum)
+    HG_HIP_CHECK(hipMemsetAsync(v.accum, 0, sizeof(unsigned long long) * kVoxelsPerBlock * static_cast<size_t>(v.pool_blocks), s));
   if (g->ctx->pinned) {  // a cleared grid starts without sticky errors
     HG_HIP_CHECK(hipStreamSynchronize(s));
     std::memset(static_cast<char*>(g->ctx->pinned) + 2048, 0, 16);
   }
-  HG_HIP_CHECK(hipMemsetAsync(g->view.bin_count, 0, sizeof(uint32_t) * 3 * static_cast<size_t>(g->view.max_blocks), s));
   return HG_OK;
 }
 
@@ -379,20 +455,12 @@ int hg_grid_read_cells(hg_grid* g, const int32_t* ijk, size_t m, uint16_t* tsd, 
 static int export_impl(hg_grid* g, int32_t* ijk, uint16_t* tsd, uint16_t* weight, size_t cap,
                        size_t* count) {
   hipStream_t s = g->ctx->stream;
-  uint32_t nb = 0;
-  int rc = hg_grid_num_blocks(g, &nb);
+  std::vector<uint32_t> order;
+  int rc = grid_block_order(g, &order);
   if (rc != HG_OK) return rc;
+  const uint32_t nb = static_cast<uint32_t>(order.size());
   *count = 0;
   if (nb == 0) return HG_OK;
-  std::vector<unsigned long long> keys(nb);
-  HG_HIP_CHECK(hipMemcpyAsync(keys.data(), g->view.block_keys, nb * sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, s));
-  HG_HIP_CHECK(hipStreamSynchronize(s));
-  std::vector<uint32_t> order(nb);
-  std::iota(order.begin(), order.end(), 0u);
-  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    return export_order_key(keys[a]) < export_order_key(keys[b]);
-  });
   DeviceBuffer& b = g->ctx->ws_misc;
   const size_t bytes_order = nb * sizeof(uint32_t);
   const size_t bytes_off = nb * sizeof(uint64_t);
@@ -450,9 +518,24 @@ int hg_grid_export(hg_grid* g, int32_t* ijk, uint16_t* tsd, uint16_t* weight, si
 
 int hg_grid_block_arrays(hg_grid* g, void** keys_dev, void** voxels_dev, uint32_t* num_blocks) {
   if (!g || !keys_dev || !voxels_dev || !num_blocks) return HG_ERR_INVALID;
-  *keys_dev = g->view.block_keys;
-  *voxels_dev = g->view.voxels;
-  return hg_grid_num_blocks(g, num_blocks);
+  *keys_dev = *voxels_dev = nullptr;
+  uint32_t nb = 0;
+  int rc = hg_grid_num_blocks(g, &nb);
+  if (rc != HG_OK) return rc;
+  *num_blocks = nb;
+  if (nb == 0) return HG_OK;
+  // packed copy in the grid's staging buffer (the pool slots of a grid's blocks are not contiguous)
+  const size_t bv = static_cast<size_t>(nb) * 2048, bk = static_cast<size_t>(nb) * sizeof(unsigned long long);
+  if ((rc = g->pack.reserve(bv + bk)) != HG_OK) return rc;
+  uint32_t* d_vox = g->pack.as<uint32_t>();
+  unsigned long long* d_keys = reinterpret_cast<unsigned long long*>(g->pack.as<char>() + bv);
+  const unsigned wg = 256, per = wg / kWave;
+  hipLaunchKernelGGL(k_pack_blocks, dim3((nb + per - 1) / per), dim3(wg), 0, g->ctx->stream, g->view, nb, d_keys, d_vox);
+  HG_HIP_CHECK(hipGetLastError());
+  HG_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+  *keys_dev = d_keys;
+  *voxels_dev = d_vox;
+  return HG_OK;
 }
 
 int hg_grid_import_blocks(hg_grid* g, const void* keys, const void* voxels, uint32_t nb,

@@ -387,7 +387,7 @@ __global__ void k_apply_runs(GridView g, InsertParams p, const unsigned long lon
   if (k == ~0ull) return;
   if (i > 0 && keys[i - 1] == k) return;  // not a run head
   const uint32_t slot = find_block(g, k >> 9);
-  if (slot >= g.max_blocks) return;  // capacity exceeded (flag already set)
+  if (slot >= g.pool_blocks) return;  // capacity exceeded (flag already set)
   uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + (k & 511u);
   uint32_t code = *cell;
   uint32_t applied = 0;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_apply_wave(PyramidIns P, const K* __res
       const int next = rest ? lane + 1 + __builtin_ctzll(rest) : kWave;
       len = min(next, nv) - lane;
       const uint32_t slot = find_block(L.g, KeyCodec<K>::block(L, k));
-      if (slot < L.g.max_blocks) {
+      if (slot < L.g.pool_blocks) {
         cell = L.g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + (static_cast<uint32_t>(k) & 511u);
         code = *cell;
       }
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const float* xy
   bool want[kMaxRuns];
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
-    want[k] = k < nr && slot[k] < L.g.max_blocks;
+    want[k] = k < nr && slot[k] < L.g.pool_blocks;
     wave_group(slot[k], want[k] ? static_cast<unsigned>(run_len[k]) : 0u, want[k], &leader[k],
                &prefix[k], &total[k]);
   }
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_accumulate(PyramidIns P, 
   // block would otherwise take thousands of same-address atomics.
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
-    const bool want = k < nr && slot[k] < L.g.max_blocks;
+    const bool want = k < nr && slot[k] < L.g.pool_blocks;
     unsigned long long todo = __ballot(want);
     bool leader = false;
     while (todo) {
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_accumulate(PyramidIns P, 
 #pragma unroll
         for (int k = 0; k < kMaxRuns; ++k)
           if (k < nr && run_key[k] == bk) sl = slot[k];
-        valid = sl < L.g.max_blocks;
+        valid = sl < L.g.pool_blocks;
         key = (sl << 9) | voxel_in_block(cx, cy, cz);
         units = static_cast<unsigned>(__float2int_rn((tsd + tau) * to_units));
       }
@@ -1891,7 +1891,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const float* d_xyz, u
 // HG_INSERT_FAST call and are all-zero between calls.
 int ensure_accumulators(hg_grid* grid) {
   if (grid->view.accum) return HG_OK;
-  const size_t bytes = sizeof(unsigned long long) * kVoxelsPerBlock * static_cast<size_t>(grid->view.max_blocks);
+  const size_t bytes = sizeof(unsigned long long) * kVoxelsPerBlock * static_cast<size_t>(grid->view.pool_blocks);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&grid->view.accum), bytes);
   if (e != hipSuccess) {
     grid->view.accum = nullptr;

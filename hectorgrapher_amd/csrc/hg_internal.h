@@ -145,9 +145,14 @@ int pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, int l
                         const double* d_pose_tq, int mode, int memspace, hg_insert_stats* stats);
 }
 
+namespace hg {
+int grid_block_order(hg_grid* g, std::vector<uint32_t>* order);
+}
+
 struct hg_grid {
   hg_ctx* ctx = nullptr;
   hg::GridView view{};
+  hg::DeviceBuffer pack;  // packed (keys, voxels) copy handed out by hg_grid_block_arrays
   uint32_t table_capacity = 0;
   float relative_truncation_distance = 0.f;
   hg_insert_stats last_stats{};

@@ -265,7 +265,7 @@ __device__ inline void fetch_voxels(const GridView& g, LevelFetch& f) {
       if ((e >> 24) == f.key[c] + 1ull) slot = static_cast<uint32_t>(e & 0xFFFFFFu);
       else slot = find_block(g, f.key[c]);  // first slot taken by another key: linear probing
     }
-    f.code[c] = (slot < g.max_blocks)
+    f.code[c] = (slot < g.pool_blocks)
                     ? g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + f.vox[c]] : 0u;
   }
 }
@@ -388,16 +388,222 @@ __device__ inline D3 pyramid_tsd_seq(const PyramidView& pv, double x, double y, 
   return r;
 }
 
-template <bool SEQ = false>
-__device__ inline D3 pyramid_tsd(const PyramidView& pv, double x, double y, double z) {
+// ------------------------------------------------------------------------------------------
+// Direct-window lookups: one memory round trip per return.
+//
+// While every block of a grid sits in its direct slot (no block in the overflow area) and the
+// blocks' bounding box fits the window (hg_device.h, GridView), the address of a voxel follows from
+// its cell index alone: no hash probe, no key / tag compare. A query outside the window anchored at
+// the bounding box minimum cannot hit a block (none exists there) and reads as unknown. The state of
+// the window is read from the grid's counters by every wavefront (uniform loads): inserts of the
+// same stream may have changed it since the host enqueued the launch, so only the device knows.
+// ------------------------------------------------------------------------------------------
+struct DirectPyramid {
+  uint32_t min_b[kMaxLevels][3];  // bounding-box minimum (block coordinates) = window anchor
+  bool ok;                        // every level of the lookup is directly addressable
+};
+
+__device__ inline DirectPyramid direct_pyramid(const PyramidView& pv) {
+  DirectPyramid d;
+  d.ok = true;
   const int levels = pv.multi_res ? pv.levels : 1;
-  if (SEQ && pv.multi_res && levels > 1) return pyramid_tsd_seq(pv, x, y, z);
-  switch (levels) {  // wave-uniform
-    case 1: return pyramid_tsd_n<1>(pv, x, y, z);
-    case 2: return pyramid_tsd_n<2>(pv, x, y, z);
-    case 3: return pyramid_tsd_n<3>(pv, x, y, z);
-    default: return pyramid_tsd_n<4>(pv, x, y, z);
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d.min_b[l][a] = 0;
+    if (l < levels) {
+      const GridView& g = pv.level[l];
+      const uint32_t* c = g.counters;
+      const uint32_t nblk = __builtin_amdgcn_readfirstlane(c[0]);
+      const uint32_t ovf = __builtin_amdgcn_readfirstlane(c[8]);
+      bool ok = ovf == 0u;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const uint32_t mn = __builtin_amdgcn_readfirstlane(c[9 + a]);
+        const uint32_t mx = __builtin_amdgcn_readfirstlane(c[12 + a]);
+        if (nblk != 0u) {
+          ok = ok && (mx - mn) < (1u << g.dir_bits[a]);
+          d.min_b[l][a] = mn;
+        }
+      }
+      d.ok = d.ok && ok;
+    }
   }
+  return d;
+}
+
+// 1 / den refined as the IEEE division sequence refines it (see div_in_range in hg_insert.hip).
+__device__ inline float refined_rcp(float den) {
+  const float r0 = __builtin_amdgcn_rcpf(den);
+  const float e0 = __builtin_fmaf(-den, r0, 1.0f);
+  return __builtin_fmaf(e0, r0, r0);
+}
+// lround(p / res) with the division spelled out: the Newton-Raphson sequence the compiler emits for
+// an IEEE fdiv, without the v_div_scale / v_div_fixup wrappers (same FMAs on the same operands, hence
+// the same bits) -- those only act on operands with extreme exponents, where the index is 0 or out
+// of range whichever way the last bits fall (callers reject |p| >= 1e30 beforehand). res and r are
+// uniform, so the reciprocal is refined once per wavefront instead of once per division.
+__device__ inline int cell_index_fast(float p, float res, float r) {
+  const float q0 = p * r;
+  const float rem0 = __builtin_fmaf(-res, q0, p);
+  const float q1 = __builtin_fmaf(rem0, r, q0);
+  const float rem1 = __builtin_fmaf(-res, q1, p);
+  return round_to_int(__builtin_fmaf(rem1, r, q1));
+}
+
+struct DirectFetch {
+  float c[3];        // centre of the lower corner voxel per axis (CenterOfLowerVoxel)
+  uint32_t code[8];  // corner order c = dx*4 + dy*2 + dz
+};
+
+// Lower-corner cell and the 8 voxel loads of one level (all independent: one round trip).
+__device__ inline void direct_fetch(const GridView& g, const uint32_t* wmin, bool usable, double x,
+                                    double y, double z, DirectFetch& f) {
+  const float res = g.resolution;
+  const float rr = refined_rcp(res);
+  const double w[3] = {x, y, z};
+  uint32_t off[3][2];
+  bool in = usable;
+  uint32_t shift = 9;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    // CenterOfLowerVoxel (interpolated_tsdf.h:176-192): float centre, compared against the double
+    int i0 = cell_index_fast(static_cast<float>(w[a]), res, rr);
+    float c = static_cast<float>(i0) * res;
+    if (static_cast<double>(c) > w[a]) { c -= res; i0 -= 1; }  // index of the lowered centre: see fetch_setup
+    f.c[a] = c;
+    const uint32_t mask = (1u << g.dir_bits[a]) - 1u;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const uint32_t s = static_cast<uint32_t>(i0 + d + kIndexOffset);
+      const uint32_t b = s >> 3;
+      in = in && (b - wmin[a]) <= mask;  // inside the window (implies inside the index range)
+      off[a][d] = ((b & mask) << shift) | ((s & 7u) << (3 * a));
+    }
+    shift += g.dir_bits[a];
+  }
+  const char* base = reinterpret_cast<const char*>(g.voxels);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint32_t o = off[0][c >> 2] | off[1][(c >> 1) & 1] | off[2][c & 1];
+    const uint32_t byte = in ? (o << 2) : 0u;  // the direct area is < 2^30 voxels: 32-bit byte offsets
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(base + byte);
+    f.code[c] = in ? v : 0u;
+  }
+}
+
+// InterpolatedTSDF::GetTSD (interpolated_tsdf.h:72-116) when all 8 weights are non-zero: every
+// InterpolateLinear takes its interpolating branch, so the validity tests and the weights drop out.
+// Same operations in the same order as interp_selected; terms that are exactly zero there (the
+// derivative slots no stage has touched yet) are left out, which can only change the sign of a zero.
+__device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offset, float min_tsd,
+                                      const float* c3, const uint32_t* code, double x, double y, double z) {
+  double q[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint32_t v = code[c] & 0x7FFFu;
+    q[c] = static_cast<double>(v == 0 ? min_tsd : static_cast<float>(v) * tsd_scale + tsd_offset);
+  }
+  const double x1 = c3[0], y1 = c3[1], z1 = c3[2];
+  const double x2 = c3[0] + res, y2 = c3[1] + res, z2 = c3[2] + res;  // float adds, as the reference
+  // Jet / double: Ceres multiplies by the inverse (jet.h operator/(Jet, T))
+  const double ix = 1.0 / (x2 - x1), iy = 1.0 / (y2 - y1), iz = 1.0 / (z2 - z1);
+  const double nx = (x - x1) * ix, ny = (y - y1) * iy, nz = (z - z1) * iz;
+  // along z: value and d/dz
+  double a1[4], dz1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double da = q[2 * k + 1] - q[2 * k];
+    a1[k] = da * nz + q[2 * k];
+    dz1[k] = da * iz;
+  }
+  // along y
+  double a2[2], dy2[2], dz2[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double da = a1[2 * k + 1] - a1[2 * k];
+    a2[k] = da * ny + a1[2 * k];
+    dy2[k] = da * iy;
+    dz2[k] = (dz1[2 * k + 1] - dz1[2 * k]) * ny + dz1[2 * k];
+  }
+  // along x
+  const double da = a2[1] - a2[0];
+  D3 r;
+  r.a = da * nx + a2[0];
+  r.d0 = da * ix;
+  r.d1 = (dy2[1] - dy2[0]) * nx + dy2[0];
+  r.d2 = (dz2[1] - dz2[0]) * nx + dz2[0];
+  return r;
+}
+
+template <int LEVELS>
+__device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectPyramid& dp, double x, double y,
+                                        double z) {
+  // a coordinate this large has no cell; NaN passes and indexes cell 0 like the general path
+  const bool usable = !(fabs(x) >= 1e30 || fabs(y) >= 1e30 || fabs(z) >= 1e30);
+  DirectFetch f[LEVELS];
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) direct_fetch(pv.level[l], dp.min_b[l], usable, x, y, z, f[l]);
+  if (!pv.multi_res) {
+    const GridView& g = pv.level[0];
+    LevelSel s;
+    s.x1 = f[0].c[0]; s.y1 = f[0].c[1]; s.z1 = f[0].c[2];
+    s.x2 = f[0].c[0] + g.resolution; s.y2 = f[0].c[1] + g.resolution; s.z2 = f[0].c[2] + g.resolution;
+    bool all_zero = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      s.code[c] = f[0].code[c];
+      all_zero = all_zero && ((s.code[c] >> 16) & 0x7FFFu) <= 1u;
+    }
+    s.tsd_scale = g.tsd_scale; s.tsd_offset = g.tsd_offset; s.min_tsd = g.min_tsd;
+    s.weight_scale = g.weight_scale; s.weight_offset = g.weight_offset;
+    const D3 r = interp_selected(s, -0.3, x, y, z);
+    if (all_zero) return {static_cast<double>(g.min_tsd), 0.0, 0.0, 0.0};  // :86-89
+    return r;
+  }
+  // first level whose 8 weights are all non-zero (interpolated_multi_resolution_tsdf.h:99-106)
+  float c3[3] = {f[0].c[0], f[0].c[1], f[0].c[2]};
+  uint32_t code[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) code[c] = f[0].code[c];
+  float res = pv.level[0].resolution, tsd_scale = pv.level[0].tsd_scale, tsd_offset = pv.level[0].tsd_offset,
+        min_tsd = pv.level[0].min_tsd;
+  bool found = false;
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) {
+    bool valid = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) valid = valid && ((f[l].code[c] >> 16) & 0x7FFFu) > 1u;
+    if (l > 0 && !found && valid) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) code[c] = f[l].code[c];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) c3[a] = f[l].c[a];
+      res = pv.level[l].resolution; tsd_scale = pv.level[l].tsd_scale; tsd_offset = pv.level[l].tsd_offset;
+      min_tsd = pv.level[l].min_tsd;
+    }
+    found = found || valid;
+  }
+  const D3 r = interp_all_valid(res, tsd_scale, tsd_offset, min_tsd, c3, code, x, y, z);
+  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
+  return r;
+}
+
+template <bool SEQ = false>
+__device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectPyramid& dp, double x, double y, double z) {
+  const int levels = pv.multi_res ? pv.levels : 1;
+  if (dp.ok) {  // wave-uniform
+    switch (levels) {
+      case 1: return pyramid_tsd_direct<1>(pv, dp, x, y, z);
+      case 2: return pyramid_tsd_direct<2>(pv, dp, x, y, z);
+      case 3: return pyramid_tsd_direct<3>(pv, dp, x, y, z);
+      default: return pyramid_tsd_direct<4>(pv, dp, x, y, z);
+    }
+  }
+  // general path (a block in the overflow area, or a map wider than the window): hash lookups, the
+  // levels one after the other
+  if (pv.multi_res && levels > 1) return pyramid_tsd_seq(pv, x, y, z);
+  return pyramid_tsd_n<1>(pv, x, y, z);
 }
 
 __device__ inline void cross3(const double* a, const double* b, double* c) {
@@ -409,8 +615,8 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
 // One return at transform (t, q): row8 = [d r / d(t, q) (7) | r]. The world point follows Eigen's
 // QuaternionBase::_transformVector, then + translation (rigid_transform.h:193-197).
 template <bool SEQ = false>
-__device__ __forceinline__ void return_row(const PyramidView& pv, const double* t, const double* q,
-                                           const double* v, double scaling, double* row8) {
+__device__ __forceinline__ void return_row(const PyramidView& pv, const DirectPyramid& dp, const double* t,
+                                           const double* q, const double* v, double scaling, double* row8) {
   const double qw = q[0];
   const double u[3] = {q[1], q[2], q[3]};
   double uv[3], c2[3];
@@ -420,7 +626,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const double* 
   const double wx = (v[0] + qw * uv[0] + c2[0]) + t[0];
   const double wy = (v[1] + qw * uv[1] + c2[1]) + t[1];
   const double wz = (v[2] + qw * uv[2] + c2[2]) + t[2];
-  const D3 tsd = pyramid_tsd<SEQ>(pv, wx, wy, wz);
+  const D3 tsd = pyramid_tsd<SEQ>(pv, dp, wx, wy, wz);
   const double r = scaling * tsd.a;
   const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
   // d world / d q = [uv | w*duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v)
@@ -450,10 +656,11 @@ __device__ __forceinline__ void tsdf_residuals_body(
   const unsigned i = wg * THREADS + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   BODY_STAMP(0);
+  const DirectPyramid dp = direct_pyramid(pv);
   if (i < n) {
     const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
                          static_cast<double>(xyz[3 * i + 2])};
-    return_row<SEQ>(pv, xf->t, xf->q, v, scaling, row8);
+    return_row<SEQ>(pv, dp, xf->t, xf->q, v, scaling, row8);
     if (residuals) residuals[i] = row8[7];
   }
   BODY_STAMP(4);
@@ -668,6 +875,7 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
   double row[13];
 #pragma unroll
   for (int k = 0; k < 13; ++k) row[k] = 0.0;
+  const DirectPyramid dp = direct_pyramid(pv);
   if (i < n) {
     const double f = factor[i];
     double pja[12], pjb[12];
@@ -681,7 +889,7 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
     const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
                          static_cast<double>(xyz[3 * i + 2])};
     double row8[8];
-    return_row(pv, t, q, v, scaling, row8);
+    return_row(pv, dp, t, q, v, scaling, row8);
     if (residuals) residuals[i] = row8[7];
     const double ma = 1.0 + (0.0 - 1.0) * f, mb = (1.0 - 0.0) * f;
 #pragma unroll

@@ -69,7 +69,7 @@ __global__ void k_xray_extract(GridView g, XrayParams P, const uint32_t* order, 
   const uint32_t slot = order[b];
   const uint32_t* vox = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock;
   int ox, oy, oz;
-  key_to_block_origin(g.block_keys[slot], &ox, &oy, &oz);
+  key_to_block_origin(g.block_keys[slot] - 1ull, &ox, &oy, &oz);
   const int by0 = st->min_y, bx1 = st->max_x, by1 = st->max_y;  // WRITE: the final box
   int lmin_x = INT_MAX, lmin_y = INT_MAX, lmax_x = INT_MIN, lmax_y = INT_MIN;
   unsigned lcount = 0;
@@ -226,20 +226,13 @@ extern "C" int hg_grid_xray(hg_grid* g, const double* global_submap_pose, uint8_
   *width = *height = 0;
   max_index_xy[0] = max_index_xy[1] = 0;
   *bytes = 0;
-  uint32_t nb = 0;
-  int rc = hg_grid_num_blocks(g, &nb);
+  // blocks in iterator order (as hg_grid_export)
+  std::vector<uint32_t> order;
+  int rc = grid_block_order(g, &order);
   if (rc != HG_OK) return rc;
+  const uint32_t nb = static_cast<uint32_t>(order.size());
   if (nb == 0) return HG_OK;
   if (nb >= (1u << 22)) return HG_ERR_CAPACITY;
-  // blocks in iterator order (as hg_grid_export)
-  std::vector<unsigned long long> bkeys(nb);
-  HG_HIP_CHECK(hipMemcpyAsync(bkeys.data(), g->view.block_keys, nb * sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, s));
-  HG_HIP_CHECK(hipStreamSynchronize(s));
-  std::vector<uint32_t> order(nb);
-  std::iota(order.begin(), order.end(), 0u);
-  std::sort(order.begin(), order.end(),
-            [&](uint32_t a, uint32_t b) { return export_order_key(bkeys[a]) < export_order_key(bkeys[b]); });
   DeviceBuffer& mb = c->ws_misc;
   if ((rc = mb.reserve(nb * sizeof(uint32_t) + 256)) != HG_OK) return rc;
   XrayState* d_st = mb.as<XrayState>();

@@ -135,7 +135,8 @@ int hg_prof_reset(hg_ctx* ctx);
 int hg_prof_read(hg_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);
 
 /* ---- grid: HybridGridTSDF --------------------------------------------------------------- */
-/* max_blocks = capacity of the 8x8x8-voxel block pool (2 KiB per block). */
+/* max_blocks = number of 8x8x8-voxel blocks (2 KiB each) the grid may hold, < 2^23. Device memory:
+ * about 2 * max_blocks blocks (a directly addressed window of blocks plus the overflow area). */
 int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_distance,
                    float max_weight, uint32_t max_blocks, hg_grid** out);
 int hg_grid_destroy(hg_grid* grid);
@@ -157,7 +158,9 @@ int hg_grid_count(hg_grid* grid, size_t* count);
 int hg_grid_export(hg_grid* grid, int32_t* ijk, uint16_t* tsd, uint16_t* weight, size_t cap,
                    size_t* count);
 int hg_grid_num_blocks(hg_grid* grid, uint32_t* num_blocks);
-/* Device views for the multi-GPU gather: keys[num_blocks] (u64) and voxels[num_blocks*512] (u32). */
+/* Packed device copy of the grid's blocks for the multi-GPU gather: keys[num_blocks] (u64 block
+ * keys) and voxels[num_blocks*512] (u32), in the form hg_grid_import_blocks takes. The arrays belong
+ * to the grid and stay valid until its next hg_grid_block_arrays / hg_grid_destroy. */
 int hg_grid_block_arrays(hg_grid* grid, void** keys_dev, void** voxels_dev, uint32_t* num_blocks);
 /* Merge blocks (e.g. received from another rank) into this grid; existing blocks are overwritten. */
 int hg_grid_import_blocks(hg_grid* grid, const void* keys, const void* voxels, uint32_t num_blocks,
