@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhg_mi355x.so")
+# HG_LIB_PATH: a diagnostic build of the same library (e.g. with in-kernel stamps, scripts/diag_*.py)
+LIB_PATH = os.environ.get("HG_LIB_PATH") or os.path.join(_HERE, "libhg_mi355x.so")
 
 HG_OK = 0
 HG_HOST, HG_DEVICE = 0, 1
@@ -24,7 +25,7 @@ SYMBOLS = [
     "hg_ctx_create", "hg_ctx_destroy", "hg_ctx_synchronize", "hg_ctx_stream", "hg_last_error",
     "hg_version", "hg_prof_enable", "hg_prof_reset", "hg_prof_read", "hg_grid_create", "hg_grid_destroy", "hg_grid_clear", "hg_grid_resolution", "hg_grid_params",
     "hg_grid_set_cells", "hg_grid_read_cells", "hg_grid_count", "hg_grid_export",
-    "hg_grid_num_blocks", "hg_grid_to_proto", "hg_grid_from_proto", "hg_grid_xray", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
+    "hg_grid_num_blocks", "hg_grid_window_status", "hg_grid_to_proto", "hg_grid_from_proto", "hg_grid_xray", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
     "hg_grid_insert_batch", "hg_pyramid_insert", "hg_pyramid_insert_batch", "hg_grid_status",
     "hg_voxel_filter", "hg_adaptive_voxel_filter", "hg_filter_last_device",
     "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
@@ -143,6 +144,7 @@ def load():
     L.hg_grid_count.argtypes = [vp, P(sz)]
     L.hg_grid_export.argtypes = [vp, vp, vp, vp, sz, P(sz)]
     L.hg_grid_num_blocks.argtypes = [vp, P(u32)]
+    L.hg_grid_window_status.argtypes = [vp, vp]
     L.hg_grid_to_proto.argtypes = [vp, vp, sz, P(sz)]
     L.hg_grid_from_proto.argtypes = [vp, vp, sz, u32, P(vp)]
     L.hg_grid_xray.argtypes = [vp, vp, vp, sz, P(i32), P(i32), vp, P(sz)]

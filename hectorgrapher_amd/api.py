@@ -191,6 +191,13 @@ class HybridGridTSDF:
         check(self._L.hg_grid_num_blocks(self._h, C.byref(n)), "hg_grid_num_blocks")
         return n.value
 
+    def window_status(self):
+        """hg_grid_window_status as a dict: blocks, overflow_blocks, window (x, y, z), extent (x, y, z), direct."""
+        out = (C.c_uint32 * 9)()
+        check(self._L.hg_grid_window_status(self._h, out), "hg_grid_window_status")
+        return {"blocks": out[0], "overflow_blocks": out[1], "window": tuple(out[2:5]),
+                "extent": tuple(out[5:8]), "direct": bool(out[8])}
+
     def export(self):
         """(ijk, tsd codes, weight codes) in the reference iterator order (ToProto order)."""
         n = self.count()

@@ -404,6 +404,23 @@ int hg_grid_num_blocks(hg_grid* g, uint32_t* num_blocks) {
   return HG_OK;
 }
 
+int hg_grid_window_status(hg_grid* g, uint32_t out[9]) {
+  if (!g || !out) return HG_ERR_INVALID;
+  uint32_t c[16];
+  HG_HIP_CHECK(hipMemcpyAsync(c, g->view.counters, sizeof(c), hipMemcpyDeviceToHost, g->ctx->stream));
+  HG_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+  out[0] = std::min(c[0], g->view.max_blocks);
+  out[1] = c[8];
+  bool ok = c[8] == 0;
+  for (int a = 0; a < 3; ++a) {
+    out[2 + a] = 1u << g->view.dir_bits[a];
+    out[5 + a] = c[0] ? c[12 + a] - c[9 + a] + 1u : 0u;
+    ok = ok && out[5 + a] <= out[2 + a];
+  }
+  out[8] = ok ? 1u : 0u;
+  return HG_OK;
+}
+
 int hg_grid_set_cells(hg_grid* g, const int32_t* ijk, size_t m, const float* tsd,
                       const float* weight) {
   if (!g || (m && (!ijk || !tsd || !weight))) return HG_ERR_INVALID;

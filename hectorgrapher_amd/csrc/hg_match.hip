@@ -398,12 +398,34 @@ __device__ inline D3 pyramid_tsd_seq(const PyramidView& pv, double x, double y, 
 // the window is read from the grid's counters by every wavefront (uniform loads): inserts of the
 // same stream may have changed it since the host enqueued the launch, so only the device knows.
 // ------------------------------------------------------------------------------------------
+struct DirectRaw {  // counters [8..15] of every level as loaded (same address in every lane)
+  uint4 lo[kMaxLevels];  // overflow blocks, bounding-box minimum x, y, z
+  uint4 hi[kMaxLevels];  // bounding-box maximum x, y, z, unused
+};
 struct DirectPyramid {
   uint32_t min_b[kMaxLevels][3];  // bounding-box minimum (block coordinates) = window anchor
   bool ok;                        // every level of the lookup is directly addressable
 };
 
-__device__ inline DirectPyramid direct_pyramid(const PyramidView& pv) {
+// Issues the loads; nothing waits for them until direct_resolve, which callers place behind the
+// voxel loads (those are addressed without the window anchor), so the counters' round trip is not
+// on the critical path of a lookup.
+__device__ inline DirectRaw direct_issue(const PyramidView& pv) {
+  DirectRaw r;
+  const int levels = pv.multi_res ? pv.levels : 1;
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) {
+    r.lo[l] = make_uint4(1u, 0u, 0u, 0u);
+    r.hi[l] = make_uint4(0u, 0u, 0u, 0u);
+    if (l < levels) {
+      const uint4* c = reinterpret_cast<const uint4*>(pv.level[l].counters);
+      r.lo[l] = c[2];
+      r.hi[l] = c[3];
+    }
+  }
+  return r;
+}
+__device__ inline DirectPyramid direct_resolve(const PyramidView& pv, const DirectRaw& r) {
   DirectPyramid d;
   d.ok = true;
   const int levels = pv.multi_res ? pv.levels : 1;
@@ -413,18 +435,16 @@ __device__ inline DirectPyramid direct_pyramid(const PyramidView& pv) {
     for (int a = 0; a < 3; ++a) d.min_b[l][a] = 0;
     if (l < levels) {
       const GridView& g = pv.level[l];
-      const uint32_t* c = g.counters;
-      const uint32_t nblk = __builtin_amdgcn_readfirstlane(c[0]);
-      const uint32_t ovf = __builtin_amdgcn_readfirstlane(c[8]);
-      bool ok = ovf == 0u;
+      auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+      const uint32_t mn[3] = {uni(r.lo[l].y), uni(r.lo[l].z), uni(r.lo[l].w)};
+      const uint32_t mx[3] = {uni(r.hi[l].x), uni(r.hi[l].y), uni(r.hi[l].z)};
+      bool ok = uni(r.lo[l].x) == 0u;  // no block in the overflow area
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const uint32_t mn = __builtin_amdgcn_readfirstlane(c[9 + a]);
-        const uint32_t mx = __builtin_amdgcn_readfirstlane(c[12 + a]);
-        if (nblk != 0u) {
-          ok = ok && (mx - mn) < (1u << g.dir_bits[a]);
-          d.min_b[l][a] = mn;
-        }
+        // a grid without blocks has min = 0xFFFFFFFF, max = 0: the test passes and every lookup reads
+        // the all-zero pool, which is the right answer
+        ok = ok && (mx[a] - mn[a]) < (1u << g.dir_bits[a]);
+        d.min_b[l][a] = mn[a];
       }
       d.ok = d.ok && ok;
     }
@@ -453,17 +473,19 @@ __device__ inline int cell_index_fast(float p, float res, float r) {
 
 struct DirectFetch {
   float c[3];        // centre of the lower corner voxel per axis (CenterOfLowerVoxel)
+  uint32_t s0[3];    // lower corner cell index + kIndexOffset per axis
+  uint32_t byte[8];  // byte offsets of the 8 corners inside the direct area
   uint32_t code[8];  // corner order c = dx*4 + dy*2 + dz
 };
 
-// Lower-corner cell and the 8 voxel loads of one level (all independent: one round trip).
-__device__ inline void direct_fetch(const GridView& g, const uint32_t* wmin, bool usable, double x,
-                                    double y, double z, DirectFetch& f) {
+// Lower-corner cell and the addresses of the 8 corners of one level. The offsets are masked into
+// the direct area, so the loads are safe wherever the point lies; whether they MEAN anything is
+// decided afterwards (direct_accept).
+__device__ inline void direct_setup(const GridView& g, double x, double y, double z, DirectFetch& f) {
   const float res = g.resolution;
   const float rr = refined_rcp(res);
   const double w[3] = {x, y, z};
   uint32_t off[3][2];
-  bool in = usable;
   uint32_t shift = 9;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -472,24 +494,49 @@ __device__ inline void direct_fetch(const GridView& g, const uint32_t* wmin, boo
     float c = static_cast<float>(i0) * res;
     if (static_cast<double>(c) > w[a]) { c -= res; i0 -= 1; }  // index of the lowered centre: see fetch_setup
     f.c[a] = c;
+    f.s0[a] = static_cast<uint32_t>(i0 + kIndexOffset);
     const uint32_t mask = (1u << g.dir_bits[a]) - 1u;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      const uint32_t s = static_cast<uint32_t>(i0 + d + kIndexOffset);
-      const uint32_t b = s >> 3;
-      in = in && (b - wmin[a]) <= mask;  // inside the window (implies inside the index range)
-      off[a][d] = ((b & mask) << shift) | ((s & 7u) << (3 * a));
+      const uint32_t s = f.s0[a] + d;
+      off[a][d] = (((s >> 3) & mask) << shift) | ((s & 7u) << (3 * a));
     }
     shift += g.dir_bits[a];
   }
-  const char* base = reinterpret_cast<const char*>(g.voxels);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const uint32_t o = off[0][c >> 2] | off[1][(c >> 1) & 1] | off[2][c & 1];
-    const uint32_t byte = in ? (o << 2) : 0u;  // the direct area is < 2^30 voxels: 32-bit byte offsets
-    const uint32_t v = *reinterpret_cast<const uint32_t*>(base + byte);
-    f.code[c] = in ? v : 0u;
+  for (int c = 0; c < 8; ++c)
+    f.byte[c] = (off[0][c >> 2] | off[1][(c >> 1) & 1] | off[2][c & 1]) << 2;  // direct area < 2^30 voxels
+}
+// The voxel loads of one level (independent of each other and of the other levels'). The two x
+// neighbours of a corner pair are adjacent words unless the pair crosses a block face (x & 7 == 7):
+// one 8-byte load fetches both, and only the lanes on a face load their second voxel separately --
+// half the requests the cache has to serve.
+__device__ inline void direct_load(const GridView& g, DirectFetch& f) {
+  const char* base = reinterpret_cast<const char*>(g.voxels);
+  const bool face = (f.s0[0] & 7u) == 7u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // corner k = (dy, dz) at dx = 0, corner 4 + k at dx = 1
+    typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(4)));
+    const u2 v = *reinterpret_cast<const u2*>(base + f.byte[k]);
+    f.code[k] = v.x;
+    f.code[4 + k] = v.y;
   }
+  if (face) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f.code[4 + k] = *reinterpret_cast<const uint32_t*>(base + f.byte[4 + k]);
+  }
+}
+// Inside the window anchored at the bounding-box minimum (which implies inside the index range)?
+// Outside it no block exists: the voxels read as unknown.
+__device__ inline void direct_accept(const GridView& g, const uint32_t* wmin, bool usable, DirectFetch& f) {
+  bool in = usable;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const uint32_t mask = (1u << g.dir_bits[a]) - 1u;
+    in = in && ((f.s0[a] >> 3) - wmin[a]) <= mask && (((f.s0[a] + 1u) >> 3) - wmin[a]) <= mask;
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) f.code[c] = in ? f.code[c] : 0u;
 }
 
 // InterpolatedTSDF::GetTSD (interpolated_tsdf.h:72-116) when all 8 weights are non-zero: every
@@ -537,13 +584,23 @@ __device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offs
 }
 
 template <int LEVELS>
-__device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectPyramid& dp, double x, double y,
-                                        double z) {
+__device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& raw, double x, double y,
+                                        double z, bool* ok) {
   // a coordinate this large has no cell; NaN passes and indexes cell 0 like the general path
   const bool usable = !(fabs(x) >= 1e30 || fabs(y) >= 1e30 || fabs(z) >= 1e30);
   DirectFetch f[LEVELS];
 #pragma unroll
-  for (int l = 0; l < LEVELS; ++l) direct_fetch(pv.level[l], dp.min_b[l], usable, x, y, z, f[l]);
+  for (int l = 0; l < LEVELS; ++l) direct_setup(pv.level[l], x, y, z, f[l]);
+  BODY_STAMP(1);
+  BODY_STAMP(2);
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) direct_load(pv.level[l], f[l]);
+  const DirectPyramid dp = direct_resolve(pv, raw);  // the counters have long arrived
+  *ok = dp.ok;
+  if (!dp.ok) return {0.0, 0.0, 0.0, 0.0};  // wave-uniform: the caller takes the general path
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) direct_accept(pv.level[l], dp.min_b[l], usable, f[l]);
+  BODY_STAMP(3);
   if (!pv.multi_res) {
     const GridView& g = pv.level[0];
     LevelSel s;
@@ -589,21 +646,29 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectPyram
   return r;
 }
 
-template <bool SEQ = false>
-__device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectPyramid& dp, double x, double y, double z) {
+// General path (a block in the overflow area, or a map wider than the window): hash lookups, the
+// levels one after the other. Not inlined: its registers are allocated apart from the direct path's.
+// The pyramid is passed BY VALUE: a reference would force the caller's kernel-argument copy into
+// private memory and turn every field access of the hot path into a scratch load.
+__device__ __attribute__((noinline)) D3 pyramid_tsd_general(const PyramidView pv, double x, double y, double z) {
   const int levels = pv.multi_res ? pv.levels : 1;
-  if (dp.ok) {  // wave-uniform
-    switch (levels) {
-      case 1: return pyramid_tsd_direct<1>(pv, dp, x, y, z);
-      case 2: return pyramid_tsd_direct<2>(pv, dp, x, y, z);
-      case 3: return pyramid_tsd_direct<3>(pv, dp, x, y, z);
-      default: return pyramid_tsd_direct<4>(pv, dp, x, y, z);
-    }
-  }
-  // general path (a block in the overflow area, or a map wider than the window): hash lookups, the
-  // levels one after the other
   if (pv.multi_res && levels > 1) return pyramid_tsd_seq(pv, x, y, z);
   return pyramid_tsd_n<1>(pv, x, y, z);
+}
+
+template <bool SEQ = false>
+__device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, double x, double y, double z) {
+  const int levels = pv.multi_res ? pv.levels : 1;
+  bool ok;
+  D3 r;
+  switch (levels) {  // wave-uniform
+    case 1: r = pyramid_tsd_direct<1>(pv, raw, x, y, z, &ok); break;
+    case 2: r = pyramid_tsd_direct<2>(pv, raw, x, y, z, &ok); break;
+    case 3: r = pyramid_tsd_direct<3>(pv, raw, x, y, z, &ok); break;
+    default: r = pyramid_tsd_direct<4>(pv, raw, x, y, z, &ok); break;
+  }
+  if (ok) return r;
+  return pyramid_tsd_general(pv, x, y, z);
 }
 
 __device__ inline void cross3(const double* a, const double* b, double* c) {
@@ -615,7 +680,7 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
 // One return at transform (t, q): row8 = [d r / d(t, q) (7) | r]. The world point follows Eigen's
 // QuaternionBase::_transformVector, then + translation (rigid_transform.h:193-197).
 template <bool SEQ = false>
-__device__ __forceinline__ void return_row(const PyramidView& pv, const DirectPyramid& dp, const double* t,
+__device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRaw& dp, const double* t,
                                            const double* q, const double* v, double scaling, double* row8) {
   const double qw = q[0];
   const double u[3] = {q[1], q[2], q[3]};
@@ -647,6 +712,28 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectPy
   row8[7] = r;
 }
 
+// A wavefront executes its LDS instructions in order, so lanes that exchange data through LDS with
+// lanes of the SAME wavefront only need the compiler not to move accesses across the point. (The LM
+// state machine runs in one wavefront; the X tiles of the X^T X reduction are per wavefront.)
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Partial sums travel from every workgroup to the one that runs the LM step. Stored write-through
+// (sc1) and read around the vector L1 (sc1), they need no release / acquire fence pair on the way
+// (MI355X_MICROARCH.md, "Valid forms": every store of the handed-off bytes sc1 and drained by the
+// storing wave's s_waitcnt vmcnt(0) before the workgroup's arrival is counted; every load of them sc1,
+// by the wavefront whose counter add came last after that add has returned, by the others after a
+// workgroup barrier that wavefront joins).
+__device__ inline void store_partial(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double load_partial(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // residuals of one block at its current transform + 36 partial sums per workgroup
 template <int THREADS = kEvalThreads, bool SEQ = false>
 __device__ __forceinline__ void tsdf_residuals_body(
@@ -656,7 +743,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
   const unsigned i = wg * THREADS + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   BODY_STAMP(0);
-  const DirectPyramid dp = direct_pyramid(pv);
+  const DirectRaw dp = direct_issue(pv);
   if (i < n) {
     const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
                          static_cast<double>(xyz[3 * i + 2])};
@@ -676,7 +763,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
 #pragma unroll
     for (int c = 0; c < 4; ++c) dst[c] = d2{row8[2 * c], row8[2 * c + 1]};
   }
-  __syncthreads();
+  wave_sync();  // xs[wave] is written and read by this wavefront only
   typedef double d4 __attribute__((ext_vector_type(4)));
   d4 cacc = {0.0, 0.0, 0.0, 0.0};
   const int mj = lane & 15, mk = lane >> 4;
@@ -708,7 +795,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < THREADS / kWave; ++wv) s += cs[wv][a * 8 + b];
-    partials[static_cast<size_t>(wg) * kAcc + threadIdx.x] = s;
+    store_partial(&partials[static_cast<size_t>(wg) * kAcc + threadIdx.x], s);
   }
   BODY_STAMP(5);
 }
@@ -875,7 +962,7 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
   double row[13];
 #pragma unroll
   for (int k = 0; k < 13; ++k) row[k] = 0.0;
-  const DirectPyramid dp = direct_pyramid(pv);
+  const DirectRaw dp = direct_issue(pv);
   if (i < n) {
     const double f = factor[i];
     double pja[12], pjb[12];
@@ -945,7 +1032,7 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += cs[wv][a * 16 + b];
-    partials[static_cast<size_t>(wg) * kAccU + threadIdx.x] = s;
+    store_partial(&partials[static_cast<size_t>(wg) * kAccU + threadIdx.x], s);
   }
 }
 
@@ -971,13 +1058,6 @@ struct LmShared {
   double red[kLmThreads];
 };
 
-// The LM state machine runs in ONE wavefront (the others have returned): a wavefront executes its
-// LDS instructions in order, so lanes only need the compiler not to move accesses across the point.
-__device__ inline void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __device__ inline double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -1809,7 +1889,7 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           const unsigned idx = w + u * stripes;
-          v[u] = idx < num_wg ? p[static_cast<size_t>(idx) * kAcc] : 0.0;
+          v[u] = idx < num_wg ? load_partial(&p[static_cast<size_t>(idx) * kAcc]) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc += v[u];
@@ -2391,22 +2471,17 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
                                xcd_chunk(wg_index, num_wg));
   EVAL_STAMP(1);
   __shared__ int s_last;
+  // hand-over of the partials without fences: sc1 stores drained here, one counted arrival per
+  // workgroup behind the barrier, sc1 loads in the tail (store_partial / load_partial)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = atomicAdd(ticket, 1u);
     s_last = (t == num_wg - 1u) ? 1 : 0;
+    if (s_last) *ticket = 0u;  // ready for the next iteration's launch
   }
-  __syncthreads();
+  __syncthreads();  // the arrival count has returned to wave 0 before any wave loads a partial
   if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *ticket = 0u;  // ready for the next iteration's launch
-  }
-  __syncthreads();
   EVAL_STAMP(2);
   lm_step_single(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), partials, num_wg);
   EVAL_STAMP(3);

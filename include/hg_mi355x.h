@@ -158,6 +158,12 @@ int hg_grid_count(hg_grid* grid, size_t* count);
 int hg_grid_export(hg_grid* grid, int32_t* ijk, uint16_t* tsd, uint16_t* weight, size_t cap,
                    size_t* count);
 int hg_grid_num_blocks(hg_grid* grid, uint32_t* num_blocks);
+/* State of the grid's directly addressed block window (synchronises): out[0] blocks held, out[1]
+ * blocks in the overflow area, out[2..4] window size in blocks per axis (x, y, z), out[5..7] extent
+ * of the blocks' bounding box in blocks per axis, out[8] = 1 while lookups take the direct path (no
+ * overflow block and the bounding box fits the window; otherwise they go through the hash: same
+ * results, one more memory round trip). A larger max_blocks gives a larger window. */
+int hg_grid_window_status(hg_grid* grid, uint32_t out[9]);
 /* Packed device copy of the grid's blocks for the multi-GPU gather: keys[num_blocks] (u64 block
  * keys) and voxels[num_blocks*512] (u32), in the form hg_grid_import_blocks takes. The arrays belong
  * to the grid and stay valid until its next hg_grid_block_arrays / hg_grid_destroy. */
