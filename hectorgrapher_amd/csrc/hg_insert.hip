@@ -326,14 +326,8 @@ struct UnitChain {
   __device__ inline void step(const GridView& g, float maximum_weight, float u) {
     if (fast) step_t<true>(g, maximum_weight, u); else step_t<false>(g, maximum_weight, u);
   }
-  // `count` consecutive steps on LDS values
-  __device__ inline void run(const GridView& g, float maximum_weight, const uint32_t* vals, unsigned count) {
-    if (fast) {
-      for (unsigned j = 0; j < count; ++j) step_t<true>(g, maximum_weight, __uint_as_float(vals[j]));
-    } else {
-      for (unsigned j = 0; j < count; ++j) step_t<false>(g, maximum_weight, __uint_as_float(vals[j]));
-    }
-  }
+  // `count` consecutive steps on LDS values (blocked prefetch, see chain_run below)
+  __device__ inline void run(const GridView& g, float maximum_weight, const uint32_t* vals, unsigned count);
   __device__ inline uint32_t end() const {
     if (!any) return code0;
     const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt));
@@ -344,19 +338,26 @@ struct UnitChain {
 
 // `count` consecutive UpdateCell calls with update weight 1 on one voxel (values vals[0..count)),
 // bit-identical to calling update_cell in a loop: codes stay in float form (code - 1 as a float)
-// between updates, so the dependent chain per update is ~30 instructions instead of ~75.
+// between updates. One update is a chain of 15 dependent fp32 operations through the TSD value
+// (about 7 cycles each for a wavefront on its own); everything else has to stay off that chain:
+//   * the values come from LDS four at a time, one block AHEAD of their use (a read issued and
+//     awaited inside an update exposes an LDS round trip, which used to double the time per update);
+//   * the weight follows its own recurrence, which does not depend on the TSD value; once it has
+//     reached its fixed point (the clamp at maximum_weight: the heavy voxels next to the sensor sit
+//     there from their second scan on) the weight arithmetic is skipped for as long as every lane of
+//     the wavefront that still has updates is there too.
+struct ChainState {
+  float d, w;    // decoded TSD value and weight
+  float rt, rw;  // their codes (lround(..) + 1) as floats, valid after the first update
+  bool fixed;    // the weight no longer changes under updates
+};
 template <bool FAST>
-__device__ inline uint32_t update_chain_unit_t(const GridView& g, float maximum_weight, uint32_t code,
-                                               const uint32_t* vals, unsigned count) {
-  const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
-  float d = tc == 0 ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
-  float w = wc == 0 ? 0.f : static_cast<float>(wc) * g.weight_scale + g.weight_offset;
-  float rt = 0.f, rw = 0.f;
+__device__ inline void chain_run(const GridView& g, float maximum_weight, ChainState& st, const uint32_t* vals,
+                                 unsigned count) {
+  float d = st.d, w = st.w, rt = st.rt, rw = st.rw;
+  bool fixed = st.fixed;
   const float res2_t = 2.0f * g.tsd_resolution, res2_w = 2.0f * g.weight_resolution;
-  uint32_t next = vals[0];
-  for (unsigned j = 0; j < count; ++j) {
-    const float u = __uint_as_float(next);
-    if (j + 1 < count) next = vals[j + 1];  // LDS read one update ahead of its use
+  auto step = [&](float u) {
     float uw = w + 1.0f;
     const float ud = FAST ? div_in_range(d * w + u, uw) : (d * w + u) / uw;  // u * 1.0f == u
     uw = (maximum_weight < uw) ? maximum_weight : uw;
@@ -366,11 +367,79 @@ __device__ inline uint32_t update_chain_unit_t(const GridView& g, float maximum_
     rw = round_nonneg_plus1((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * res2_w);
     // ValueToTSD / ValueToWeight of the codes (never 0)
     d = rt * g.tsd_scale + g.tsd_offset;
-    w = rw * g.weight_scale + g.weight_offset;
+    const float wn = rw * g.weight_scale + g.weight_offset;
+    fixed = wn == w;
+    w = wn;
+  };
+  constexpr unsigned K = 4;  // a block of 4 updates (~450 cycles) covers the LDS latency; 8 costs a workgroup per CU in registers
+  unsigned base = 0;
+  if (count >= K) {
+    uint32_t cur[K], nx[K];
+#pragma unroll
+    for (unsigned k = 0; k < K; ++k) cur[k] = vals[k];
+    while (base + K <= count) {
+      const unsigned nb = base + K;
+#pragma unroll
+      for (unsigned k = 0; k < K; ++k) nx[k] = vals[min(nb + k, count - 1u)];  // in flight during this block
+      if (__all(fixed)) {
+        // fixed weight: the update is d <- quantise((d * w + u) / (w + 1)) with constants w, 1 / (w + 1)
+        const float uw = w + 1.0f;
+        const float r0 = __builtin_amdgcn_rcpf(uw);
+        const float r = __builtin_fmaf(__builtin_fmaf(-uw, r0, 1.0f), r0, r0);
+#pragma unroll
+        for (unsigned k = 0; k < K; ++k) {
+          const float num = d * w + __uint_as_float(cur[k]);
+          float ud;
+          if (FAST) {  // div_in_range with the reciprocal hoisted
+            const float q0 = num * r;
+            const float q1 = __builtin_fmaf(__builtin_fmaf(-uw, q0, num), r, q0);
+            ud = __builtin_fmaf(__builtin_fmaf(-uw, q1, num), r, q1);
+          } else {
+            ud = num / uw;
+          }
+          rt = round_nonneg_plus1((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * res2_t);
+          d = rt * g.tsd_scale + g.tsd_offset;
+        }
+      } else {
+#pragma unroll
+        for (unsigned k = 0; k < K; ++k) step(__uint_as_float(cur[k]));
+      }
+#pragma unroll
+      for (unsigned k = 0; k < K; ++k) cur[k] = nx[k];
+      base = nb;
+    }
   }
-  const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt));
-  const uint32_t nw = static_cast<uint32_t>(static_cast<int>(rw));
+  if (base < count) {
+    uint32_t next = vals[base];
+    for (unsigned j = base; j < count; ++j) {
+      const float u = __uint_as_float(next);
+      if (j + 1 < count) next = vals[j + 1];
+      step(u);
+    }
+  }
+  st.d = d; st.w = w; st.rt = rt; st.rw = rw; st.fixed = fixed;
+}
+template <bool FAST>
+__device__ inline uint32_t update_chain_unit_t(const GridView& g, float maximum_weight, uint32_t code,
+                                               const uint32_t* vals, unsigned count) {
+  const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
+  ChainState st;
+  st.d = tc == 0 ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
+  st.w = wc == 0 ? 0.f : static_cast<float>(wc) * g.weight_scale + g.weight_offset;
+  st.rt = st.rw = 0.f;
+  st.fixed = false;
+  chain_run<FAST>(g, maximum_weight, st, vals, count);
+  const uint32_t nt = static_cast<uint32_t>(static_cast<int>(st.rt));
+  const uint32_t nw = static_cast<uint32_t>(static_cast<int>(st.rw));
   return (nt + kUpdateMarker) | (nw << 16);
+}
+__device__ inline void UnitChain::run(const GridView& g, float maximum_weight, const uint32_t* vals, unsigned count) {
+  if (count == 0) return;
+  ChainState st{d, w, rt, rw, false};
+  if (fast) chain_run<true>(g, maximum_weight, st, vals, count);
+  else chain_run<false>(g, maximum_weight, st, vals, count);
+  d = st.d; w = st.w; rt = st.rt; rw = st.rw;
+  any = true;
 }
 __device__ inline uint32_t update_chain_unit(const GridView& g, float maximum_weight, uint32_t code,
                                              const uint32_t* vals, unsigned count) {
