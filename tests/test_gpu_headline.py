@@ -69,3 +69,63 @@ def test_register_100k_point_scans_three_resolutions(po, hg, ctx):
         assert len(eo[1]) > 20000
         for x, y in zip(eo, eg):
             assert np.array_equal(x, y)
+
+
+def test_stream_of_100k_point_scans_equals_sequential_reference(po, hg, ctx):
+    """BASELINE.json configs[2]: a stream of 100 000-point scans handed over in ONE batched call
+    (hg_pyramid_insert_batch) equals the oracle inserting the scans one after the other: every voxel
+    code of the three grids, and the counters."""
+    import ctypes as C
+    import torch
+    from hectorgrapher_amd import _lib
+    dev = torch.device("cuda", 0)
+    B = 12
+    scans = bench.make_scans(RINGS, COLS, 50, B, 0)   # around the heavy end of the trajectory
+    og = [po.Grid(r) for r in bench.RESOLUTIONS]
+    ref = [[0, 0] for _ in og]
+    for pose, pts in scans:
+        loc = synth.transform_points(pose, pts)
+        for g, acc in zip(og, ref):
+            n_in, u = g.insert(pose[:3].astype(np.float32), loc)
+            acc[0] += n_in
+            acc[1] += u
+    gg = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in bench.RESOLUTIONS]
+    xyz = torch.from_numpy(np.concatenate([p for _, p in scans])).to(dev)
+    poses = np.array([pose for pose, _ in scans], np.float32)
+    origins = np.zeros((B, 3), np.float32)
+    offs = np.arange(B + 1, dtype=np.uint64) * (RINGS * COLS)
+    L = _lib.load()
+    garr = (C.c_void_p * 3)(*[g._h for g in gg])
+    opts = (hg.InsertOpts * 3)(*[hg.InsertOpts() for _ in gg])
+    st = (hg.InsertStats * 3)()
+    hg.check(L.hg_pyramid_insert_batch(garr, opts, 3, origins.ctypes.data_as(C.c_void_p), xyz.data_ptr(),
+                                       offs.ctypes.data_as(C.c_void_p), B, 0, poses.ctypes.data_as(C.c_void_p),
+                                       _lib.HG_INSERT_EXACT, 1, st), "hg_pyramid_insert_batch")
+    for o, g, s, r in zip(og, gg, st, ref):
+        assert (s.num_hits, s.num_updates) == tuple(r)
+        for x, y in zip(o.export(), g.export()):
+            assert np.array_equal(x, y)
+
+
+def test_stream_of_small_scans_shares_passes(po, hg, ctx):
+    """Small scans of one batched call are binned together (up to 2^17 returns per pass, seq = return
+    index * 8 + sample keeps the reference's update order across the scans of a pass): 40 scans of
+    10 000 points = 4 passes, bit-exact against the oracle inserting them one after the other."""
+    B, rings, cols = 40, 16, 625
+    og = [po.Grid(r) for r in bench.RESOLUTIONS]
+    gg = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in bench.RESOLUTIONS]
+    origins, clouds, offs = [], [], [0]
+    for k in range(B):
+        pose = synth.pose_k(k)
+        loc = synth.transform_points(pose, synth.generate_scan(pose, rings, cols, stream=k))
+        origins.append(pose[:3])
+        clouds.append(loc)
+        offs.append(offs[-1] + len(loc))
+        for g in og:
+            g.insert(pose[:3], loc)
+    ins = hg.TSDFRangeDataInserter3D()
+    for g in gg:
+        ins.InsertBatch(np.array(origins), np.concatenate(clouds), offs, g)
+    for o, g in zip(og, gg):
+        for x, y in zip(o.export(), g.export()):
+            assert np.array_equal(x, y)
