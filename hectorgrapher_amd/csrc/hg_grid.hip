@@ -230,6 +230,7 @@ int hg_ctx_destroy(hg_ctx* c) {
   prof_resolve(c);
   for (hipEvent_t e : c->prof_free_events) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return HG_OK;

@@ -86,6 +86,8 @@ struct hg_ctx {
   const float* filter_xyz = nullptr;
   size_t filter_count = 0;
   void* pinned = nullptr;  // small pinned host staging (4 KiB)
+  void* pinned_jobs = nullptr;  // pinned staging of a batched solve's job table
+  size_t jobs_capacity = 0;
   // words [0, 4) of the second half of `pinned`: sticky error flags that insert calls without a
   // stats read-back leave for the host (hg_register_scan, hg_pyramid_insert(stats = NULL)); checked
   // by the next call of the context that can return a status

@@ -43,6 +43,7 @@ constexpr int kHCap = 3240;
 constexpr int kAcc = 36;  // 28 (upper triangle of 7x7) + 7 + 1
 constexpr int kAccU = 91;  // unwarped blocks: 78 (upper triangle of 12x12) + 12 + 1
 constexpr int kEvalThreads = 512;
+constexpr int kBatchThreads = 256;   // workgroup of the batched residual pass (no LM tail: lean in registers)
 constexpr int kLmThreads = 64;   // the LM state machine runs in one wavefront
 constexpr int kLmBlock = 256;    // waves 1-3 only help summing the workgroup partials
 constexpr int kMaxStripes = 512 / kAcc;  // stripes of the partial reduction (block size / 36)
@@ -51,6 +52,7 @@ struct PyramidView {
   GridView level[kMaxLevels];
   int levels;
   int multi_res;
+  const PyramidView* self_mem;  // a copy of this struct in device memory (for code that takes it by address)
 };
 
 struct BlockXform {
@@ -646,14 +648,132 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   return r;
 }
 
-// General path (a block in the overflow area, or a map wider than the window): hash lookups, the
-// levels one after the other. Not inlined: its registers are allocated apart from the direct path's.
-// The pyramid is passed BY VALUE: a reference would force the caller's kernel-argument copy into
-// private memory and turn every field access of the hot path into a scratch load.
-__device__ __attribute__((noinline)) D3 pyramid_tsd_general(const PyramidView pv, double x, double y, double z) {
+// interp_selected for the general path: the same seven InterpolateLinear calls in the same order,
+// looped over arrays that live in private memory (run-time indices) so that the function needs a few
+// dozen registers instead of 160.
+__device__ inline D3 interp_selected_compact(const LevelSel& s, double both_invalid, double x, double y, double z) {
+  D3 node[8];
+  double wt[8];
+#pragma unroll 1
+  for (int c = 0; c < 8; ++c) {
+    wt[c] = static_cast<double>(sel_weight(s, s.code[c]));
+    node[c] = {static_cast<double>(sel_tsd(s, s.code[c])), 0.0, 0.0, 0.0};
+  }
+  const double ix_inv = 1.0 / (s.x2 - s.x1), iy_inv = 1.0 / (s.y2 - s.y1), iz_inv = 1.0 / (s.z2 - s.z1);
+  D3 axis[3];
+  axis[0] = {(z - s.z1) * iz_inv, 0.0, 0.0, iz_inv};
+  axis[1] = {(y - s.y1) * iy_inv, 0.0, iy_inv, 0.0};
+  axis[2] = {(x - s.x1) * ix_inv, ix_inv, 0.0, 0.0};
+  int count = 8;
+#pragma unroll 1
+  for (int stage = 0; stage < 3; ++stage) {
+    count >>= 1;
+#pragma unroll 1
+    for (int k = 0; k < count; ++k) {
+      D3 q;
+      double w;
+      interpolate_linear(both_invalid, node[2 * k], node[2 * k + 1], wt[2 * k], wt[2 * k + 1], axis[stage], q, w);
+      node[k] = q;
+      wt[k] = w;
+    }
+  }
+  return node[0];
+}
+
+// General path (a block in the overflow area, or a map wider than the window): hash lookups, one
+// corner after the other. It runs only for grids that have outgrown their window, so it is written
+// for a small register footprint, not for speed: the kernel's register allocation is the maximum over
+// everything it can call, and the direct path must not pay for this one. Not inlined; it reads the
+// pyramid from its copy in device memory (a reference to the caller's kernel argument would force that
+// into private memory and turn every field access of the hot path into a scratch load; by value it
+// would travel in a hundred registers).
+__device__ __attribute__((noinline)) D3 pyramid_tsd_general(const PyramidView* pv_mem, double x, double y, double z) {
+  const PyramidView& pv = *pv_mem;
   const int levels = pv.multi_res ? pv.levels : 1;
-  if (pv.multi_res && levels > 1) return pyramid_tsd_seq(pv, x, y, z);
-  return pyramid_tsd_n<1>(pv, x, y, z);
+  LevelSel s;
+  bool found = false;
+#pragma unroll 1
+  for (int l = 0; l < levels; ++l) {
+    const GridView& g = pv.level[l];
+    const float res = g.resolution;
+    // CenterOfLowerVoxel (interpolated_tsdf.h:176-192), as fetch_setup
+    int i0[3] = {cell_index_1d(static_cast<float>(x), res), cell_index_1d(static_cast<float>(y), res),
+                 cell_index_1d(static_cast<float>(z), res)};
+    float c[3] = {static_cast<float>(i0[0]) * res, static_cast<float>(i0[1]) * res, static_cast<float>(i0[2]) * res};
+    if (static_cast<double>(c[0]) > x) { c[0] -= res; i0[0] -= 1; }
+    if (static_cast<double>(c[1]) > y) { c[1] -= res; i0[1] -= 1; }
+    if (static_cast<double>(c[2]) > z) { c[2] -= res; i0[2] -= 1; }
+    uint32_t code[8];
+    bool valid = true;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+      code[k] = load_voxel(g, i0[0] + (k >> 2), i0[1] + ((k >> 1) & 1), i0[2] + (k & 1));
+      valid = valid && ((code[k] >> 16) & 0x7FFFu) > 1u;
+    }
+    if (!found && (valid || l == 0 || !pv.multi_res)) {  // level 0 stands in until a level is found
+      s.x1 = c[0]; s.y1 = c[1]; s.z1 = c[2];
+      s.x2 = c[0] + res; s.y2 = c[1] + res; s.z2 = c[2] + res;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s.code[k] = code[k];
+      s.tsd_scale = g.tsd_scale; s.tsd_offset = g.tsd_offset; s.min_tsd = g.min_tsd;
+      s.weight_scale = g.weight_scale; s.weight_offset = g.weight_offset;
+    }
+    found = found || valid;
+    if (!pv.multi_res) {
+      bool all_zero = true;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) all_zero = all_zero && ((code[k] >> 16) & 0x7FFFu) <= 1u;
+      const D3 r = interp_selected_compact(s, -0.3, x, y, z);
+      if (all_zero) return {static_cast<double>(g.min_tsd), 0.0, 0.0, 0.0};  // :86-89
+      return r;
+    }
+    if (__ballot(!found) == 0ull) break;
+  }
+  const D3 r = interp_selected_compact(s, static_cast<double>(s.min_tsd), x, y, z);
+  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
+  return r;
+}
+
+// Throughput form of the direct multi-resolution lookup (batched matching): the levels are visited
+// one after the other and only by the lanes that have not found a fully valid level yet -- a third
+// of the voxel loads of the all-at-once form (the mean return settles on level 1.33) and one level's
+// lookup state in registers instead of all of them, for more dependent round trips. Same selection,
+// same arithmetic, same result as pyramid_tsd_direct.
+__device__ inline D3 pyramid_tsd_direct_seq(const PyramidView& pv, const DirectPyramid& dp, double x, double y,
+                                            double z) {
+  const bool usable = !(fabs(x) >= 1e30 || fabs(y) >= 1e30 || fabs(z) >= 1e30);
+  float c3[3] = {0.f, 0.f, 0.f};
+  uint32_t code[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) code[c] = 0u;
+  float res = pv.level[0].resolution, tsd_scale = pv.level[0].tsd_scale, tsd_offset = pv.level[0].tsd_offset,
+        min_tsd = pv.level[0].min_tsd;
+  bool found = false;
+#pragma unroll 1
+  for (int l = 0; l < pv.levels; ++l) {
+    if (__ballot(!found) == 0ull) break;
+    if (!found) {
+      DirectFetch f;
+      direct_setup(pv.level[l], x, y, z, f);
+      direct_load(pv.level[l], f);
+      direct_accept(pv.level[l], dp.min_b[l], usable, f);
+      bool valid = true;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) valid = valid && ((f.code[c] >> 16) & 0x7FFFu) > 1u;
+      if (valid || l == 0) {  // level 0 stands in until a level is found
+#pragma unroll
+        for (int c = 0; c < 8; ++c) code[c] = f.code[c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c3[a] = f.c[a];
+        res = pv.level[l].resolution; tsd_scale = pv.level[l].tsd_scale; tsd_offset = pv.level[l].tsd_offset;
+        min_tsd = pv.level[l].min_tsd;
+      }
+      found = valid;
+    }
+  }
+  const D3 r = interp_all_valid(res, tsd_scale, tsd_offset, min_tsd, c3, code, x, y, z);
+  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
+  return r;
 }
 
 template <bool SEQ = false>
@@ -661,6 +781,16 @@ __device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, do
   const int levels = pv.multi_res ? pv.levels : 1;
   bool ok;
   D3 r;
+  if (SEQ && pv.multi_res && levels > 1) {
+    const DirectPyramid dp = direct_resolve(pv, raw);
+    if (dp.ok) return pyramid_tsd_direct_seq(pv, dp, x, y, z);
+    return pyramid_tsd_general(pv.self_mem, x, y, z);
+  }
+  if (SEQ) {  // single resolution in the throughput kernels: one instantiation only
+    r = pyramid_tsd_direct<1>(pv, raw, x, y, z, &ok);
+    if (ok) return r;
+    return pyramid_tsd_general(pv.self_mem, x, y, z);
+  }
   switch (levels) {  // wave-uniform
     case 1: r = pyramid_tsd_direct<1>(pv, raw, x, y, z, &ok); break;
     case 2: r = pyramid_tsd_direct<2>(pv, raw, x, y, z, &ok); break;
@@ -668,7 +798,7 @@ __device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, do
     default: r = pyramid_tsd_direct<4>(pv, raw, x, y, z, &ok); break;
   }
   if (ok) return r;
-  return pyramid_tsd_general(pv, x, y, z);
+  return pyramid_tsd_general(pv.self_mem, x, y, z);
 }
 
 __device__ inline void cross3(const double* a, const double* b, double* c) {
@@ -2509,13 +2639,41 @@ struct SingleJob {
   double scaling;
   unsigned n;
   unsigned num_wg;
+  const PinBox* box;  // the problem's mailbox (compact upload of its solver head)
+  unsigned up_words;
+  unsigned pad;
 };
 
+// Throughput form: the residual pass of all problems in one launch WITHOUT the LM step in its tail
+// (that step keeps the whole solver state in registers -- 256 VGPRs, one workgroup per CU -- which
+// is right for one latency-bound chain and wrong for a batch that has to hide memory latency with
+// occupancy), followed by one launch in which workgroup b runs problem b's LM step. Partials cross a
+// kernel boundary here, so no hand-over protocol is needed.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
+__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
   const SingleJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.num_wg) return;
-  single_eval<THREADS, true>(J.pv, J.xyz, J.n, J.scaling, J.xf, J.partials, J.G, J.ticket, blockIdx.x, J.num_wg);
+  if (J.G->h.done) return;
+  __shared__ __align__(16) unsigned char smem[(THREADS / kWave) * (kWave * 8 + 64) * sizeof(double)];
+  const PyramidView& pv = J.pv;  // read in place: the sequential lookup indexes the levels at run time
+  tsdf_residuals_body<THREADS, true>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
+                                     reinterpret_cast<double (*)[kWave][8]>(smem),
+                                     reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
+                                     xcd_chunk(blockIdx.x, J.num_wg));
+}
+// Uploads every problem's solver head from its mailbox and prepares its first transform (k_lm
+// MODE_PREPARE for all problems of a batch in one launch).
+__global__ __launch_bounds__(kLmBlock) void k_lm_prepare_batch(const SingleJob* __restrict__ jobs) {
+  __shared__ LmShared S;
+  const SingleJob& J = jobs[blockIdx.x];
+  lm_step(S, J.G, const_cast<BlockXform*>(J.xf), J.partials, nullptr, MODE_PREPARE, J.box, J.up_words);
+}
+__global__ __launch_bounds__(kEvalThreads) void k_lm_single_batch(const SingleJob* __restrict__ jobs) {
+  const SingleJob& J = jobs[blockIdx.x];
+  if (J.G->h.done) return;
+  constexpr size_t kTail = ((kEvalThreads / kAcc) + 1) * kAcc * sizeof(double) + sizeof(LmHead) + 36 * sizeof(double);
+  __shared__ __align__(16) unsigned char smem[kTail];
+  lm_step_single(reinterpret_cast<double*>(smem), J.G, const_cast<BlockXform*>(J.xf), J.partials, J.num_wg);
 }
 
 // Same launch protocol for a block with per-return interpolation factors. The staging tiles of
@@ -2657,6 +2815,8 @@ struct hg_problem {
   BlockXform* d_xf = nullptr;
   DeviceBuffer partials, residuals;
   bool solve_pending = false;
+  PyramidView* d_pv = nullptr;  // per block: its pyramid in device memory (PyramidView::self_mem)
+  PyramidView* h_pv = nullptr;  // pinned staging = what d_pv holds (re-uploaded only when it changes)
   EvalBlock* d_eval = nullptr;  // block table of the fused multi-block launch
   EvalBlock* h_eval = nullptr;  // pinned staging
   int num_eval = 0;             // active blocks in the table (>= 2 -> fused launch)
@@ -2769,9 +2929,23 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
     const hg_problem::Block& hb = p->blocks[b];
     EvalBlock& eb = p->h_eval[p->num_eval];
     std::memset(&eb, 0, sizeof(eb));
-    eb.pv.levels = static_cast<int>(hb.pyramid.size());
-    eb.pv.multi_res = hb.multi_res;
-    for (int l = 0; l < eb.pv.levels; ++l) eb.pv.level[l] = hb.pyramid[l]->view;
+    {
+      // the block's pyramid, also kept in device memory (uploaded when it differs from what is there)
+      PyramidView pv;
+      std::memset(&pv, 0, sizeof(pv));
+      pv.levels = static_cast<int>(hb.pyramid.size());
+      pv.multi_res = hb.multi_res;
+      for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
+      pv.self_mem = p->d_pv + b;
+      if (std::memcmp(&p->h_pv[b], &pv, sizeof(pv)) != 0) {
+        // the staging slot may still feed an earlier copy: drain the stream before rewriting it (rare:
+        // only when a block's pyramid changes)
+        HG_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+        p->h_pv[b] = pv;
+        HG_HIP_CHECK(hipMemcpyAsync(p->d_pv + b, &p->h_pv[b], sizeof(pv), hipMemcpyHostToDevice, p->ctx->stream));
+      }
+      eb.pv = pv;
+    }
     eb.xyz = hb.d_xyz;
     eb.factor = hb.d_factor;
     eb.scaling = bi.scaling;
@@ -2822,11 +2996,8 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
   if (fused_lm && p->single_threads && S.ncols == 6 && S.bw == 5 && S.blocks[0].active) {
     const BlockInfo& bi = S.blocks[0];
     const hg_problem::Block& hb = p->blocks[0];
-    PyramidView pv;
-    std::memset(&pv, 0, sizeof(pv));
-    pv.levels = static_cast<int>(hb.pyramid.size());
-    pv.multi_res = hb.multi_res;
-    for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
+    const PyramidView& pv = p->h_pv[0];
+    (void)hb;
     ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n, 1, !p->prof_grouped);
     hipLaunchKernelGGL(k_tsdf_residuals_single<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
                        hb.d_xyz, bi.n, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket);
@@ -2846,11 +3017,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
     const BlockInfo& bi = S.blocks[b];
     if (!bi.active) continue;
     const hg_problem::Block& hb = p->blocks[b];
-    PyramidView pv;
-    std::memset(&pv, 0, sizeof(pv));
-    pv.levels = static_cast<int>(hb.pyramid.size());
-    pv.multi_res = hb.multi_res;
-    for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
+    const PyramidView& pv = p->h_pv[b];
     ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n, 1, !p->prof_grouped);
     if (hb.d_factor) {
       hipLaunchKernelGGL(k_tsdf_residuals_unwarp, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
@@ -2910,6 +3077,9 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
     e = hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_box), p->h_box, 0);
   }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_eval), sizeof(EvalBlock) * kMaxBlocks);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_pv), sizeof(PyramidView) * kMaxBlocks);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_pv), sizeof(PyramidView) * kMaxBlocks);
+  if (e == hipSuccess) std::memset(p->h_pv, 0, sizeof(PyramidView) * kMaxBlocks);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_eval), sizeof(EvalBlock) * kMaxBlocks);
   if (e == hipSuccess) e = hipMemset(p->d_ticket, 0, 256);
   if (e != hipSuccess) {
@@ -2933,6 +3103,8 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->d_small) (void)hipFree(p->d_small);
   if (p->h_box) (void)hipHostFree(p->h_box);
   if (p->d_eval) (void)hipFree(p->d_eval);
+  if (p->d_pv) (void)hipFree(p->d_pv);
+  if (p->h_pv) (void)hipHostFree(p->h_pv);
   if (p->h_eval) (void)hipHostFree(p->h_eval);
   p->partials.release();
   p->residuals.release();
@@ -3315,7 +3487,7 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
   if (!problems || count < 1) return HG_ERR_INVALID;
   // the gather rate of the residual pass saturates at about 16 scans of 100k points in flight;
   // larger lists go through in groups (measured: 32 in one launch is slower than 2 x 16)
-  constexpr int kGroup = 16;
+  constexpr int kGroup = 64;
   if (count > kGroup) {
     for (int i0 = 0; i0 < count; i0 += kGroup) {
       const int rc = hg_problem_solve_batch(problems + i0, std::min(kGroup, count - i0), opts,
@@ -3349,7 +3521,17 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     }
     return HG_OK;
   }
-  std::vector<SingleJob> jobs(count);
+  // job table: pinned staging owned by the context (the previous batch has been fetched, so its copy
+  // has completed), one asynchronous copy, no stream synchronisation
+  if (c->jobs_capacity < static_cast<size_t>(count) * sizeof(SingleJob)) {
+    if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
+    c->pinned_jobs = nullptr;
+    c->jobs_capacity = 0;
+    const size_t cap = std::max<size_t>(64, count) * sizeof(SingleJob);
+    HG_HIP_CHECK(hipHostMalloc(&c->pinned_jobs, cap));
+    c->jobs_capacity = cap;
+  }
+  SingleJob* jobs = static_cast<SingleJob*>(c->pinned_jobs);
   unsigned max_wg = 0;
   unsigned long long units = 0;
   for (int i = 0; i < count; ++i) {
@@ -3359,33 +3541,36 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     const hg_problem::Block& hb = p->blocks[0];
     SingleJob& J = jobs[i];
     std::memset(&J, 0, sizeof(J));
-    J.pv.levels = static_cast<int>(hb.pyramid.size());
-    J.pv.multi_res = hb.multi_res;
-    for (int l = 0; l < J.pv.levels; ++l) J.pv.level[l] = hb.pyramid[l]->view;
+    J.pv = p->h_pv[0];  // built by upload_state; also resident at p->d_pv (self_mem)
+    (void)hb;
     J.xyz = hb.d_xyz;
     J.xf = p->d_xf;
+    J.num_wg = (bi.n + kBatchThreads - 1) / kBatchThreads;  // the batched pass has its own workgroup size
+    if ((rc = p->partials.reserve(static_cast<size_t>(J.num_wg) * kAcc * sizeof(double))) != HG_OK) return rc;
     J.partials = p->partials.as<double>();
     J.G = p->d_state;
     J.ticket = p->d_ticket;
     J.scaling = bi.scaling;
     J.n = bi.n;
-    J.num_wg = bi.num_wg;
-    max_wg = std::max(max_wg, bi.num_wg);
+    J.box = p->d_box;
+    J.up_words = p->up_words;
+    max_wg = std::max(max_wg, J.num_wg);
     units += bi.n;
     p->solve_pending = true;
-    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small,
-                       MODE_PREPARE, p->d_box, p->up_words);
   }
+  if ((rc = c->ws_misc.reserve(sizeof(SingleJob) * count)) != HG_OK) return rc;
+  HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs, sizeof(SingleJob) * count, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_lm_prepare_batch, dim3(count), dim3(kLmBlock), 0, s, static_cast<const SingleJob*>(c->ws_misc.ptr));
   HG_HIP_CHECK(hipGetLastError());
-  if ((rc = c->ws_misc.reserve(sizeof(SingleJob) * jobs.size())) != HG_OK) return rc;
-  HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs.data(), sizeof(SingleJob) * jobs.size(), hipMemcpyHostToDevice, s));
-  HG_HIP_CHECK(hipStreamSynchronize(s));  // `jobs` leaves scope below; the copy is from pageable memory
   const int max_it = problems[0]->h_state.h.opt.max_num_iterations;
   {
     ProfScope group(c, HG_K_RESIDUALS, units * (max_it + 1), static_cast<unsigned>(max_it + 1), true);
-    for (int it = 0; it <= max_it; ++it)
-      hipLaunchKernelGGL(k_tsdf_residuals_single_batch<kEvalThreads>, dim3(max_wg, count), dim3(kEvalThreads), 0, s,
+    for (int it = 0; it <= max_it; ++it) {
+      hipLaunchKernelGGL(k_tsdf_residuals_single_batch<kBatchThreads>, dim3(max_wg, count), dim3(kBatchThreads), 0, s,
                          static_cast<const SingleJob*>(c->ws_misc.ptr));
+      hipLaunchKernelGGL(k_lm_single_batch, dim3(count), dim3(kEvalThreads), 0, s,
+                         static_cast<const SingleJob*>(c->ws_misc.ptr));
+    }
   }
   HG_HIP_CHECK(hipGetLastError());
   for (int i = 0; i < count; ++i) {

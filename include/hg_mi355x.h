@@ -303,9 +303,10 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
  * search hands to CeresScanMatcher3D::Match one by one (mapping/internal/3d/scan_matching/
  * ceres_scan_matcher_3d.cc:72-118). Problems of the single-pose shape (one free pose, one TSDF
  * block, no odometry / IMU blocks) share their kernel launches (one grid row per problem); every
- * problem keeps its own solver state, so poses, costs and iteration counts are exactly those of
- * hg_problem_solve on each. Other shapes are solved one after the other. summaries: count entries
- * or NULL. */
+ * problem keeps its own solver state, so iteration counts and termination are those of
+ * hg_problem_solve on each, poses and costs agree with it to the rounding of the normal-equation sums
+ * (the batched pass sums over smaller workgroups: same terms, another association; observed 1e-12).
+ * Other shapes are solved one after the other. summaries: count entries or NULL. */
 int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solver_opts* opts,
                            hg_solver_summary* summaries);
 

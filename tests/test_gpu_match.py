@@ -456,10 +456,14 @@ def test_solve_batch_equals_individual_solves(po, hg, ctx):
     s_single = [p.solve() for p in single]
     batch = build()
     s_batch = hg.solve_batch(batch)
+    # the batched residual pass sums the normal equations over 256-return workgroups, the single
+    # solve over 512-return ones: same terms, another association, so the last bits may differ
     for a, b, sa, sb in zip(single, batch, s_single, s_batch):
-        assert np.array_equal(a.get_pose(0), b.get_pose(0))
-        assert (sa.num_iterations, sa.termination_type, sa.termination_reason, sa.final_cost, sa.initial_cost) == \
-               (sb.num_iterations, sb.termination_type, sb.termination_reason, sb.final_cost, sb.initial_cost)
+        np.testing.assert_allclose(b.get_pose(0), a.get_pose(0), rtol=0, atol=1e-9)
+        assert (sa.num_iterations, sa.termination_type, sa.termination_reason) == \
+               (sb.num_iterations, sb.termination_type, sb.termination_reason)
+        assert abs(sa.final_cost - sb.final_cost) <= 1e-12 * max(1.0, abs(sa.final_cost))
+        assert abs(sa.initial_cost - sb.initial_cost) <= 1e-12 * max(1.0, abs(sa.initial_cost))
     # against the oracle for the first case
     pr = po.Problem()
     i = pr.add_pose(cases[0][1])
