@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--cpu-scans", type=int, default=3)
     ap.add_argument("--max-blocks", type=int, default=1 << 18)
     ap.add_argument("--window", type=int, default=10, help="control points of --workload window")
-    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "register_filtered", "match_batch"],
+    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "register_filtered", "match_batch", "register_batch"],
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
@@ -50,6 +50,11 @@ def parse_args():
     ap.add_argument("--submaps", type=int, default=1,
                     help="--workload register: independent submaps mapped concurrently on ONE GPU, one process "
                          "each (BASELINE configs[3] at G = 1 puts all submaps on one GPU); 1 = the headline case")
+    ap.add_argument("--batch-submaps", type=int, default=8,
+                    help="--workload register_batch: independent submaps registered together in ONE process "
+                         "(hg_register_scan_batch: shared launches), BASELINE configs[3] at G = 1")
+    ap.add_argument("--batch-threads", type=int, default=1,
+                    help="--workload register_batch: host threads, each with its own context (stream) and an equal share of the submaps")
     ap.add_argument("--submap-index", type=int, default=-1, help=argparse.SUPPRESS)  # child of --submaps
     ap.add_argument("--prof-every", type=int, default=4,
                     help="HIP-event kernel timing on every N-th timed step (each event pair costs "
@@ -133,6 +138,12 @@ def cpu_baseline(args, map_scans, query_scans, gpu_steps):
 
 def main():
     args = parse_args()
+    # the timed loops are a few hundred microseconds per step: a generational collection of the
+    # interpreter (tens of milliseconds with torch loaded) in the middle of one would be measured as
+    # the library's time
+    import gc
+    gc.collect()
+    gc.disable()
     # libraries (RCCL banner, ...) may write to fd 1: keep stdout for the single JSON line
     sys.stdout.flush()
     saved_stdout = os.dup(1)
@@ -631,7 +642,126 @@ def run_match_batch(args):
     }
 
 
+def run_register_batch(args):
+    """BASELINE configs[3] on one GPU: S independent submaps mapped together in one process. One step
+    = one registration (multi-res LM match + exact 3-level insert of a 100k-point scan) for EVERY
+    submap through hg_register_scan_batch: the matches share their launches (grid row = submap), the
+    insertions run through kernels that take a table of pyramids. --batch-threads T splits the submaps
+    over T host threads with a context (HIP stream) each, so that one group's insertion kernels overlap
+    another group's match launches. Extra workload, not the headline."""
+    import threading
+    import torch
+    from hectorgrapher_amd import api, synth
+    dev = torch.device("cuda", 0)
+    n_pts = args.rings * args.cols
+    S, T = args.batch_submaps, max(1, min(args.batch_threads, args.batch_submaps))
+    total = args.warmup + args.steps
+    scale = 1.0 / np.sqrt(float(n_pts))
+
+    class Group:
+        def __init__(self, first, count):
+            self.ctx = api.Context(0)
+            self.ins = [api.TSDFRangeDataInserter3D() for _ in RESOLUTIONS]
+            self.pyramids, self.queries, self.guesses, self.problems = [], [], [], []
+            self.errs, self.its, self.evals, self.prof = [], [], 0, None
+            for j in range(first, first + count):
+                sb = 100000 * (j + 1)  # PRNG streams of submap j (as the children of --submaps)
+                grids = [api.HybridGridTSDF(self.ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+                for pose, pts in make_scans(args.rings, args.cols, 0, args.map_scans, sb):
+                    api.insert_pyramid(self.ins, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                                       pose_tq=pose.astype(np.float32))
+                q = make_scans(args.rings, args.cols, args.map_scans, total, sb)
+                self.pyramids.append(grids)
+                self.queries.append([(pose, torch.from_numpy(pts).to(dev)) for pose, pts in q])
+                self.guesses.append([synth.pose_mul(pose, synth.perturbation()) for pose, _ in q])
+                self.problems.append(api.Problem(self.ctx))
+
+        def step(self, i, sample):
+            n = len(self.problems)
+            for j in range(n):
+                p = self.problems[j]
+                p.reset()
+                p.add_pose(self.guesses[j][i])
+                p.add_block(self.queries[j][i][1], self.pyramids[j], scale, 0, multi_res=True)
+            poses, summ = api.register_scan_batch(self.problems, [0] * n, self.ins,
+                                                  [api.RangeData([0, 0, 0], self.queries[j][i][1]) for j in range(n)],
+                                                  self.pyramids)
+            for j in range(n):
+                self.errs.append(float(np.linalg.norm(poses[j][:3] - self.queries[j][i][0][:3])))
+                self.its.append(summ[j].num_iterations)
+                if sample:
+                    self.evals += summ[j].num_cost_evaluations
+
+        def run(self, start, done):
+            for i in range(args.warmup):
+                self.step(i, False)
+            self.errs.clear()
+            self.its.clear()
+            self.ctx.prof_reset()
+            self.ctx.synchronize()
+            start.wait()
+            for i in range(args.warmup, total):
+                sampling = args.prof_every > 0 and (i - args.warmup) % args.prof_every == 0
+                self.ctx.prof_enable(sampling)
+                self.step(i, sampling)
+            self.ctx.synchronize()
+            done.wait()
+            self.prof = self.ctx.prof_read()
+            self.ctx.prof_enable(False)
+
+    per = [S // T + (1 if t < S % T else 0) for t in range(T)]
+    groups, first = [], 0
+    for t in range(T):
+        groups.append(Group(first, per[t]))
+        first += per[t]
+    torch.cuda.synchronize()
+    start, done = threading.Barrier(T + 1), threading.Barrier(T + 1)
+    threads = [threading.Thread(target=g.run, args=(start, done)) for g in groups]
+    for th in threads:
+        th.start()
+    start.wait()
+    t0 = time.perf_counter()
+    done.wait()
+    elapsed = time.perf_counter() - t0
+    for th in threads:
+        th.join()
+    for g in groups:
+        for grids in g.pyramids:
+            for gr in grids:
+                gr.status()  # raises on sticky capacity / range flags
+    prof = {k: tuple(sum(g.prof[k][c] for g in groups) for c in range(3)) for k in groups[0].prof}
+    errs = sum((g.errs for g in groups), [])
+    its = sum((g.its for g in groups), [])
+    evals = sum(g.evals for g in groups)
+    n_launch = max(1, prof["residuals"][0])
+    avg_ms = prof["residuals"][1] / n_launch
+    lbar = 4.0 / 3.0
+    bytes_per_launch = n_pts * (12.0 + 32.0 * lbar) * (evals / n_launch)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    ins_ms = sum(prof[k][1] for k in ("ray_count", "scan", "ray_expand", "apply")) / max(1, prof["apply"][0])
+    return {
+        "metric": "scans/s (%d independent submaps mapped together on one GPU, 100k-pt scans, 3-res TSDF registration)" % S,
+        "value": args.steps * S / elapsed, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "register_batch: one registration step (multi-res LM match + exact insert x3 of a %d-pt scan) "
+                               "for each of %d independent submaps (hg_register_scan_batch, %d host thread(s) / stream(s))"
+                               % (n_pts, S, T),
+                   "submaps": S, "host_threads": T, "mean_lm_iterations": float(np.mean(its)),
+                   "mean_pose_error_m": float(np.mean(errs)), "insert_ms_per_call": ins_ms},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_tsdf_residuals_single_batch",
+                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "problems_evaluating_per_launch": evals / n_launch,
+                     "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
+                     "per_kernel_launches": {k: v[0] for k, v in prof.items()}},
+        "cpu_baseline": None,
+    }
+
+
 def run(args, out_fd=None):
+    if args.workload == "register_batch":
+        return run_register_batch(args)
     if args.workload == "match_batch":
         return run_match_batch(args)
     if args.workload == "insert_stream":

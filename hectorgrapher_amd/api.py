@@ -554,6 +554,33 @@ def register_scan(problem, pose_index, inserters, range_data, grids, **solver_kw
     return pose, s
 
 
+def register_scan_batch(problems, pose_indices, inserters, scans, pyramids, **solver_kw):
+    """hg_register_scan_batch: one registration step for each of len(problems) independent submaps
+    with shared launches. scans[j] = RangeData (device tensor returns) of submap j, pyramids[j] its
+    list of grids; inserters[l] carries the options of level l. Returns (poses [count, 7], summaries)."""
+    L = _lib.load()
+    o = SolverOpts()
+    L.hg_solver_default_opts(C.byref(o))
+    for k, v in solver_kw.items():
+        setattr(o, k, v)
+    count, n_l = len(problems), len(pyramids[0])
+    parr = (C.c_void_p * count)(*[p._h for p in problems])
+    garr = (C.c_void_p * (count * n_l))(*[g._h for pyr in pyramids for g in pyr])
+    opts = (InsertOpts * n_l)(*[i.options for i in inserters])
+    idx = (C.c_int * count)(*[int(i) for i in pose_indices])
+    origins = np.ascontiguousarray([s_.origin for s_ in scans], np.float32)
+    device = all(_is_device(s_.returns) for s_ in scans)
+    keep = [s_.returns if device else _host(s_.returns, np.float32, 3) for s_ in scans]
+    ptrs = (C.c_void_p * count)(*[(r.data_ptr() if device else r.ctypes.data) for r in keep])
+    ns = (C.c_size_t * count)(*[int(r.shape[0]) for r in keep])
+    poses = np.empty((count, 7), np.float64)
+    summ = (SolverSummary * count)()
+    check(L.hg_register_scan_batch(parr, count, C.byref(o), idx, garr, opts, n_l, _p(origins), ptrs, ns,
+                                   int(scans[0].width), _lib.HG_DEVICE if device else _lib.HG_HOST, _p(poses), summ),
+          "hg_register_scan_batch")
+    return poses, list(summ)
+
+
 def from_seconds(seconds):
     """common::FromSeconds (common/time.cc:30-33): 100 ns ticks, truncated toward zero."""
     return int(float(seconds) * 1e7)

@@ -225,12 +225,13 @@ int hg_ctx_destroy(hg_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DeviceBuffer* b : {&c->ws_points, &c->ws_scan_table, &c->ws_gate, &c->ws_counts,
                           &c->ws_offsets, &c->ws_keys_a, &c->ws_keys_b, &c->ws_vals_a,
-                          &c->ws_vals_b, &c->ws_temp, &c->ws_misc, &c->ws_filter})
+                          &c->ws_vals_b, &c->ws_temp, &c->ws_misc, &c->ws_filter, &c->ws_jobs})
     b->release();
   prof_resolve(c);
   for (hipEvent_t e : c->prof_free_events) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
+  if (c->pinned_ijobs) (void)hipHostFree(c->pinned_ijobs);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return HG_OK;

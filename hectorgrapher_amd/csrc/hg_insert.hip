@@ -870,11 +870,14 @@ __device__ inline void wave_group(uint32_t slot, unsigned cnt, bool want, int* l
   *total_out = my_total;
 }
 
-__global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
-                                                   const float* xyz, unsigned n, RunInfo* runs, unsigned* wg_hits) {
-  const int level = blockIdx.y;
+// Bodies of the four kernels of the binned path, shared by the single-pyramid launches (pyramid in
+// the kernel arguments) and the batched launches (a table of jobs in device memory, one job = one
+// pyramid with its own scan: hg_register_scan_batch). `bx` of `nbx` = workgroup index inside the job.
+__device__ __forceinline__ void bin_count_body(const PyramidIns& P, int level, unsigned bx, unsigned nbx,
+                                               const ScanTable* scans, uint32_t n_scans, const float* xyz,
+                                               unsigned n, RunInfo* runs, unsigned* wg_hits) {
   const LevelIns& L = P.lv[level];
-  const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;  // see hg_device.h
+  const unsigned i = xcd_chunk(bx, nbx) * 256u + threadIdx.x;  // see hg_device.h
   const int lane = threadIdx.x & (kWave - 1);
   __shared__ unsigned s_hits, s_first, s_first_base;
   if (threadIdx.x == 0) { s_hits = 0; s_first = 0; }
@@ -947,13 +950,38 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const ScanTable
   if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
   __syncthreads();
   if (threadIdx.x == 0) {
-    wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
+    wg_hits[level * nbx + bx] = s_hits;
     s_first_base = s_first ? atomicAdd(&L.g.counters[6], s_first) : 0u;
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k)
     if (first_pos[k] != 0xFFFFFFFFu) L.g.touched[s_first_base + first_pos[k]] = slot[k];
+}
+
+// One pyramid with its own scan inside a batched launch.
+struct InsertJob {
+  PyramidIns P;
+  const float* xyz;
+  RunInfo* runs;
+  uint32_t* rec_keys;
+  uint32_t* rec_vals;
+  unsigned* wg_hits;
+  unsigned n;                  // returns of the job's scan
+  unsigned nwg;                // workgroups of 256 returns
+  unsigned records_per_level;  // n * kSlots
+  unsigned pad;
+};
+
+__global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
+                                                   const float* xyz, unsigned n, RunInfo* runs, unsigned* wg_hits) {
+  bin_count_body(P, blockIdx.y, blockIdx.x, gridDim.x, scans, n_scans, xyz, n, runs, wg_hits);
+}
+// grid (max nwg, jobs * levels)
+__global__ __launch_bounds__(256) void k_bin_count_jobs(const InsertJob* __restrict__ jobs, int levels) {
+  const InsertJob& J = jobs[blockIdx.y / levels];
+  if (blockIdx.x >= J.nwg) return;
+  bin_count_body(J.P, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.wg_hits);
 }
 
 // ==========================================================================================
@@ -1266,8 +1294,8 @@ __device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* s_wave /*[
 // apply work list: a bin larger than one LDS pass is split into voxel slices handled by
 // different workgroups (voxels are independent of each other); slice k takes the voxels
 // v with v mod slices == k (see k_bin_apply).
-__global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned records_per_level) {
-  const LevelIns& L = P.lv[blockIdx.x];
+__device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level, unsigned records_per_level) {
+  const LevelIns& L = P.lv[level];
   __shared__ unsigned s_scan[16];
   __shared__ unsigned s_base, s_work;
   const unsigned nt = L.g.counters[6];
@@ -1302,7 +1330,7 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
       unsigned chunk_total = 0;
       if (round == 0) {
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
-        if (i < nt) L.g.bin_offset[slot] = blockIdx.x * records_per_level + s_base + excl;
+        if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
       }
       const bool large = cnt > 512u;
       if (i < nt && ((round == 0) == large)) {
@@ -1332,7 +1360,7 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
       unsigned chunk_total = 0;
       if (round == 0) {
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
-        if (i < nt) L.g.bin_offset[slot] = blockIdx.x * records_per_level + s_base + excl;
+        if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
       }
       const bool large = cnt > 512u;
       if (i < nt && ((round == 0) == large)) {
@@ -1359,16 +1387,25 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
     L.g.counters[6] = 0;                                // next call collects from scratch
     unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
     *upd = s_base + (P.accumulate ? *upd : 0ull);  // U of this call
-    publish_flags(P, blockIdx.x);
+    publish_flags(P, level);
   }
 }
 
-__global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
-                                                     const float* xyz, unsigned n, const RunInfo* runs,
-                                                     uint32_t* rec_keys, uint32_t* rec_vals) {
-  const int level = blockIdx.y;
+__global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned records_per_level) {
+  bin_offsets_body(P, blockIdx.x, records_per_level);
+}
+// grid (jobs * levels)
+__global__ __launch_bounds__(1024) void k_bin_offsets_jobs(const InsertJob* __restrict__ jobs, int levels) {
+  const InsertJob& J = jobs[blockIdx.x / levels];
+  bin_offsets_body(J.P, blockIdx.x % levels, J.records_per_level);
+}
+
+__device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, int level, unsigned bx, unsigned nbx,
+                                                 const ScanTable* scans, uint32_t n_scans, const float* xyz,
+                                                 unsigned n, const RunInfo* runs, uint32_t* rec_keys,
+                                                 uint32_t* rec_vals) {
   const LevelIns& L = P.lv[level];
-  const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+  const unsigned i = xcd_chunk(bx, nbx) * 256u + threadIdx.x;
   if (i >= n) return;
   const RunInfo info = runs[static_cast<size_t>(level) * n + i];
   if ((info.slot[0] | info.slot[1] | info.slot[2] | info.slot[3]) == 0u) return;
@@ -1391,6 +1428,17 @@ __global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const ScanTab
       ++q;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
+                                                     const float* xyz, unsigned n, const RunInfo* runs,
+                                                     uint32_t* rec_keys, uint32_t* rec_vals) {
+  bin_scatter_body(P, blockIdx.y, blockIdx.x, gridDim.x, scans, n_scans, xyz, n, runs, rec_keys, rec_vals);
+}
+__global__ __launch_bounds__(256) void k_bin_scatter_jobs(const InsertJob* __restrict__ jobs, int levels) {
+  const InsertJob& J = jobs[blockIdx.y / levels];
+  if (blockIdx.x >= J.nwg) return;
+  bin_scatter_body(J.P, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.rec_keys, J.rec_vals);
 }
 
 // Bitonic sort of m (power of two) key/value pairs in LDS by all kBinThreads threads. Keys are
@@ -1419,19 +1467,22 @@ constexpr unsigned kRankMaxGroup = 1024;  // larger per-voxel groups are ordered
 
 // grid (G, levels), 512 threads, loops over the level's work items (block, voxel range).
 #ifdef HG_BIN_STAMPS
-#define BIN_STAMP(i) do { if (threadIdx.x == 0) stamps[(static_cast<size_t>(blockIdx.y) * 4096 + wi) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define BIN_STAMP(i) do { if (threadIdx.x == 0) stamps[(static_cast<size_t>(order) * 4096 + wi) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define BIN_STAMP(i) do {} while (0)
 #endif
-__global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
-                                                          const uint32_t* __restrict__ rec_vals
+// `order` = position of the level in dispatch order (0 = coarsest), `bx` of `gstride` = workgroup of
+// the level's grid-stride loop over its work items.
+__device__ __forceinline__ void bin_apply_body(const PyramidIns& P, unsigned order, unsigned bx, unsigned gstride,
+                                               const uint32_t* __restrict__ rec_keys,
+                                               const uint32_t* __restrict__ rec_vals
 #ifdef HG_BIN_STAMPS
-                                                          , long long* stamps
+                                               , long long* stamps
 #endif
-                                                          ) {
-  // workgroups are dispatched in blockIdx order: the last (coarsest) level has the longest per-voxel
+                                               ) {
+  // workgroups are dispatched in index order: the last (coarsest) level has the longest per-voxel
   // chains, so it goes first
-  const LevelIns& L = P.lv[P.levels - 1 - blockIdx.y];
+  const LevelIns& L = P.lv[P.levels - 1 - order];
   const GridView& g = L.g;
   __shared__ unsigned hist[512];      // records per voxel (inside the item's voxel range)
   __shared__ unsigned base[512];      // exclusive prefix of hist
@@ -1442,7 +1493,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
   __shared__ unsigned s_hi;
   const unsigned nwork = g.counters[7];
   const unsigned tid = threadIdx.x;
-  for (unsigned wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+  for (unsigned wi = bx; wi < nwork; wi += gstride) {
     const uint4 item = g.work[wi];
     const uint32_t slot = item.x;
     const unsigned v_lo = item.y & 0xFFFFu;
@@ -1462,7 +1513,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
     const uint32_t* bv = rec_vals + g.bin_offset[slot];
     BIN_STAMP(0);
 #ifdef HG_BIN_STAMPS
-    if (threadIdx.x == 0) stamps[(static_cast<size_t>(blockIdx.y) * 4096 + wi) * 8 + 6] = n;
+    if (threadIdx.x == 0) stamps[(static_cast<size_t>(order) * 4096 + wi) * 8 + 6] = n;
 #endif
     hist[tid] = 0;
     __syncthreads();
@@ -1669,6 +1720,26 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
     BIN_STAMP(5);
   }
 }
+
+__global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
+                                                          const uint32_t* __restrict__ rec_vals
+#ifdef HG_BIN_STAMPS
+                                                          , long long* stamps
+#endif
+                                                          ) {
+  bin_apply_body(P, blockIdx.y, blockIdx.x, gridDim.x, rec_keys, rec_vals
+#ifdef HG_BIN_STAMPS
+                 , stamps
+#endif
+                 );
+}
+#ifndef HG_BIN_STAMPS
+// grid (G, levels * jobs): y = level order * jobs + job, so the coarse levels of ALL jobs go first
+__global__ __launch_bounds__(kBinThreads) void k_bin_apply_jobs(const InsertJob* __restrict__ jobs, int njobs) {
+  const InsertJob& J = jobs[blockIdx.y % njobs];
+  bin_apply_body(J.P, blockIdx.y / njobs, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals);
+}
+#endif
 
 }  // namespace hg
 
@@ -2055,9 +2126,124 @@ void host_transform(const float* pose, const float* in, float* out) {
 
 }  // namespace
 
-extern "C" {
-
-}  // extern "C"
+// Exact insertion of one scan into each of `count` pyramids with shared launches (the insertion half
+// of hg_register_scan_batch): job j inserts xyz[j] (n[j] returns, device memory, tracking frame) into
+// grids[j * levels .. ] at the fp64 pose d_poses[j] (device memory; cast to float on the device as
+// Rigid3d::cast<float>() does). Binned path only: HG_ERR_UNSUPPORTED for options outside it (the
+// caller then inserts pyramid by pyramid). No stats read-back: errors reach the host through the
+// context's mailbox (async_status).
+int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                            const float* origins, const float* const* xyz, const size_t* n, size_t width,
+                            const double* const* d_poses) {
+  if (!c || count < 1 || !grids || !opts || levels < 1 || levels > kMaxInsLevels || !origins || !xyz || !n || !d_poses)
+    return HG_ERR_INVALID;
+  for (int l = 0; l < levels; ++l) {
+    if (opts[l].num_free_space_voxels > 0 || !(opts[l].relative_truncation_distance <= 3.0) ||
+        !(static_cast<float>(opts[l].weight_function_epsilon) >= 1.0f) || opts[l].insertion_ratio < 1.0)
+      return HG_ERR_UNSUPPORTED;
+    if (opts[l].project_sdf_distance_to_scan_normal && opts[l].normal_computation_method != 1) return HG_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = c->stream;
+  HG_HIP_CHECK(hipSetDevice(c->device));
+  // pinned staging of the job table (the previous batch's copy has completed: its poses were fetched)
+  const size_t table_bytes = static_cast<size_t>(count) * sizeof(InsertJob);
+  if (c->ijobs_capacity < table_bytes) {
+    if (c->pinned_ijobs) (void)hipHostFree(c->pinned_ijobs);
+    c->pinned_ijobs = nullptr;
+    c->ijobs_capacity = 0;
+    const size_t cap = std::max<size_t>(16, count) * sizeof(InsertJob);
+    HG_HIP_CHECK(hipHostMalloc(&c->pinned_ijobs, cap));
+    c->ijobs_capacity = cap;
+  }
+  InsertJob* jobs = static_cast<InsertJob*>(c->pinned_ijobs);
+  // workspace layout
+  size_t rec_words = 0, run_items = 0, hit_words = 0, work_items = 0;
+  unsigned max_nwg = 0;
+  for (int j = 0; j < count; ++j) {
+    if (n[j] == 0 || n[j] >= (1ull << 20) || !xyz[j] || !d_poses[j]) return HG_ERR_UNSUPPORTED;
+    const unsigned nj = static_cast<unsigned>(n[j]);
+    const unsigned nwg = (nj + 255u) / 256u;
+    max_nwg = std::max(max_nwg, nwg);
+    rec_words += static_cast<size_t>(nj) * kSlots * levels;
+    run_items += static_cast<size_t>(nj) * levels;
+    hit_words += static_cast<size_t>(nwg) * kMaxInsLevels;
+    size_t max_pool = 0;
+    for (int l = 0; l < levels; ++l) {
+      hg_grid* g = grids[j * levels + l];
+      if (!g || g->ctx != c) return HG_ERR_INVALID;
+      max_pool = std::max<size_t>(max_pool, g->view.max_blocks);
+    }
+    work_items += (std::min<size_t>(static_cast<size_t>(nj) * kMaxRuns, max_pool) + static_cast<size_t>(nj) * kSlots / 256u + 64u) * levels;
+  }
+  int rc;
+  if ((rc = c->ws_keys_a.reserve(sizeof(uint32_t) * rec_words)) != HG_OK) return rc;
+  if ((rc = c->ws_vals_a.reserve(sizeof(uint32_t) * rec_words)) != HG_OK) return rc;
+  if ((rc = c->ws_keys_b.reserve(sizeof(RunInfo) * run_items)) != HG_OK) return rc;
+  if ((rc = c->ws_counts.reserve(sizeof(unsigned) * hit_words)) != HG_OK) return rc;
+  if ((rc = c->ws_offsets.reserve(sizeof(uint4) * work_items)) != HG_OK) return rc;
+  if ((rc = c->ws_jobs.reserve(table_bytes)) != HG_OK) return rc;
+  size_t rec_off = 0, run_off = 0, hit_off = 0, work_off = 0;
+  for (int j = 0; j < count; ++j) {
+    InsertJob& J = jobs[j];
+    std::memset(&J, 0, sizeof(J));
+    const unsigned nj = static_cast<unsigned>(n[j]);
+    J.n = nj;
+    J.nwg = (nj + 255u) / 256u;
+    J.records_per_level = nj * kSlots;
+    J.xyz = xyz[j];
+    J.rec_keys = c->ws_keys_a.as<uint32_t>() + rec_off;
+    J.rec_vals = c->ws_vals_a.as<uint32_t>() + rec_off;
+    J.runs = c->ws_keys_b.as<RunInfo>() + run_off;
+    J.wg_hits = c->ws_counts.as<unsigned>() + hit_off;
+    rec_off += static_cast<size_t>(nj) * kSlots * levels;
+    run_off += static_cast<size_t>(nj) * levels;
+    hit_off += static_cast<size_t>(J.nwg) * kMaxInsLevels;
+    PyramidIns& P = J.P;
+    P.levels = levels;
+    P.d_pose = d_poses[j];
+    P.accumulate = 0;
+    P.host_flags = c->async_flags;
+    P.scan0.begin = 0;
+    P.scan0.count = nj;
+    std::memcpy(P.scan0.origin, origins + 3 * j, sizeof(P.scan0.origin));
+    size_t max_pool = 0;
+    for (int l = 0; l < levels; ++l) max_pool = std::max<size_t>(max_pool, grids[j * levels + l]->view.max_blocks);
+    const size_t per_level = std::min<size_t>(static_cast<size_t>(nj) * kMaxRuns, max_pool) + static_cast<size_t>(nj) * kSlots / 256u + 64u;
+    for (int l = 0; l < levels; ++l) {
+      LevelIns& L = P.lv[l];
+      L.g = grids[j * levels + l]->view;
+      L.p = make_params(opts[l], grids[j * levels + l], true, width);
+      L.gate = nullptr;
+      L.g.work = c->ws_offsets.as<uint4>() + work_off + per_level * l;
+      L.g.work_capacity = static_cast<uint32_t>(per_level);
+    }
+    work_off += per_level * levels;
+  }
+  const InsertJob* d_jobs = c->ws_jobs.as<InsertJob>();
+  HG_HIP_CHECK(hipMemcpyAsync(c->ws_jobs.ptr, jobs, table_bytes, hipMemcpyHostToDevice, s));
+  unsigned long long units = 0;
+  for (int j = 0; j < count; ++j) units += n[j] * static_cast<unsigned long long>(levels);
+  {
+    ProfScope ps(c, HG_K_RAY_COUNT, units);
+    hipLaunchKernelGGL(k_bin_count_jobs, dim3(max_nwg, count * levels), dim3(256), 0, s, d_jobs, levels);
+  }
+  {
+    ProfScope ps(c, HG_K_SCAN, count * levels);
+    hipLaunchKernelGGL(k_bin_offsets_jobs, dim3(count * levels), dim3(1024), 0, s, d_jobs, levels);
+  }
+  {
+    ProfScope ps(c, HG_K_RAY_EXPAND, units);
+    hipLaunchKernelGGL(k_bin_scatter_jobs, dim3(max_nwg, count * levels), dim3(256), 0, s, d_jobs, levels);
+  }
+  {
+    ProfScope ps(c, HG_K_APPLY, units * kSlots);
+#ifndef HG_BIN_STAMPS
+    hipLaunchKernelGGL(k_bin_apply_jobs, dim3(count <= 2 ? 1024 : 512, levels * count), dim3(kBinThreads), 0, s, d_jobs, count);
+#endif
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  return HG_OK;
+}
 
 extern "C" {
 

@@ -81,13 +81,15 @@ struct hg_ctx {
   bool own_stream = false;
   // insertion workspace
   hg::DeviceBuffer ws_points, ws_scan_table, ws_gate, ws_counts, ws_offsets, ws_keys_a, ws_keys_b,
-      ws_vals_a, ws_vals_b, ws_temp, ws_misc, ws_filter;
+      ws_vals_a, ws_vals_b, ws_temp, ws_misc, ws_filter, ws_jobs;
   const uint32_t* filter_idx = nullptr;  // results of the last voxel-filter call (device)
   const float* filter_xyz = nullptr;
   size_t filter_count = 0;
   void* pinned = nullptr;  // small pinned host staging (4 KiB)
   void* pinned_jobs = nullptr;  // pinned staging of a batched solve's job table
   size_t jobs_capacity = 0;
+  void* pinned_ijobs = nullptr;  // pinned staging of a batched insertion's job table
+  size_t ijobs_capacity = 0;
   // words [0, 4) of the second half of `pinned`: sticky error flags that insert calls without a
   // stats read-back leave for the host (hg_register_scan, hg_pyramid_insert(stats = NULL)); checked
   // by the next call of the context that can return a status
@@ -141,6 +143,9 @@ inline int async_status(const hg_ctx* c) {
   for (int l = 0; l < 4; ++l) f |= w[l];
   return f ? flags_to_status(f) : HG_OK;
 }
+int pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                        const float* origins, const float* const* xyz, const size_t* n, size_t width,
+                        const double* const* d_poses);
 int pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                         const float* origins, const float* xyz, const uint64_t* scan_offsets,
                         size_t n_scans, size_t width, const float* poses_tq,

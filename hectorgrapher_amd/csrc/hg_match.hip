@@ -2654,8 +2654,8 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_batch(const S
   const SingleJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.num_wg) return;
   if (J.G->h.done) return;
-  __shared__ __align__(16) unsigned char smem[(THREADS / kWave) * (kWave * 8 + 64) * sizeof(double)];
   const PyramidView& pv = J.pv;  // read in place: the sequential lookup indexes the levels at run time
+  __shared__ __align__(16) unsigned char smem[(THREADS / kWave) * (kWave * 8 + 64) * sizeof(double)];
   tsdf_residuals_body<THREADS, true>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
                                      reinterpret_cast<double (*)[kWave][8]>(smem),
                                      reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
@@ -3482,20 +3482,17 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
   return hg_problem_fetch(p, summary);
 }
 
-int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solver_opts* opts,
-                           hg_solver_summary* summaries) {
-  if (!problems || count < 1) return HG_ERR_INVALID;
-  // the gather rate of the residual pass saturates at about 16 scans of 100k points in flight;
-  // larger lists go through in groups (measured: 32 in one launch is slower than 2 x 16)
-  constexpr int kGroup = 64;
-  if (count > kGroup) {
-    for (int i0 = 0; i0 < count; i0 += kGroup) {
-      const int rc = hg_problem_solve_batch(problems + i0, std::min(kGroup, count - i0), opts,
-                                            summaries ? summaries + i0 : nullptr);
-      if (rc != HG_OK) return rc;
-    }
-    return HG_OK;
-  }
+}  // extern "C"
+
+namespace {
+// The gather rate of the residual pass saturates well below this; larger lists go through in groups.
+constexpr int kBatchGroup = 64;
+
+// Uploads every problem and, if all of them have the single-pose shape, enqueues their solves with
+// shared launches (*batched = true; results are collected by hg_problem_fetch on each problem).
+// Otherwise nothing is enqueued (*batched = false). count <= kBatchGroup.
+int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_opts* opts, bool* batched) {
+  *batched = false;
   for (int i = 0; i < count; ++i)
     if (!problems[i] || problems[i]->ctx != problems[0]->ctx) return HG_ERR_INVALID;
   hg_ctx* c = problems[0]->ctx;
@@ -3514,20 +3511,14 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
       batchable = false;
   }
   if (rc != HG_OK) return rc;
-  if (!batchable) {
-    for (int i = 0; i < count; ++i) {
-      rc = hg_problem_solve(problems[i], opts, summaries ? summaries + i : nullptr);
-      if (rc != HG_OK) return rc;
-    }
-    return HG_OK;
-  }
+  if (!batchable) return HG_OK;
   // job table: pinned staging owned by the context (the previous batch has been fetched, so its copy
   // has completed), one asynchronous copy, no stream synchronisation
   if (c->jobs_capacity < static_cast<size_t>(count) * sizeof(SingleJob)) {
     if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
     c->pinned_jobs = nullptr;
     c->jobs_capacity = 0;
-    const size_t cap = std::max<size_t>(64, count) * sizeof(SingleJob);
+    const size_t cap = std::max<size_t>(kBatchGroup, count) * sizeof(SingleJob);
     HG_HIP_CHECK(hipHostMalloc(&c->pinned_jobs, cap));
     c->jobs_capacity = cap;
   }
@@ -3538,12 +3529,10 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     hg_problem* p = problems[i];
     const LmHead& S = p->h_state.h;
     const BlockInfo& bi = S.blocks[0];
-    const hg_problem::Block& hb = p->blocks[0];
     SingleJob& J = jobs[i];
     std::memset(&J, 0, sizeof(J));
     J.pv = p->h_pv[0];  // built by upload_state; also resident at p->d_pv (self_mem)
-    (void)hb;
-    J.xyz = hb.d_xyz;
+    J.xyz = p->blocks[0].d_xyz;
     J.xf = p->d_xf;
     J.num_wg = (bi.n + kBatchThreads - 1) / kBatchThreads;  // the batched pass has its own workgroup size
     if ((rc = p->partials.reserve(static_cast<size_t>(J.num_wg) * kAcc * sizeof(double))) != HG_OK) return rc;
@@ -3556,7 +3545,6 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     J.up_words = p->up_words;
     max_wg = std::max(max_wg, J.num_wg);
     units += bi.n;
-    p->solve_pending = true;
   }
   if ((rc = c->ws_misc.reserve(sizeof(SingleJob) * count)) != HG_OK) return rc;
   HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs, sizeof(SingleJob) * count, hipMemcpyHostToDevice, s));
@@ -3566,6 +3554,9 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
   {
     ProfScope group(c, HG_K_RESIDUALS, units * (max_it + 1), static_cast<unsigned>(max_it + 1), true);
     for (int it = 0; it <= max_it; ++it) {
+      // (a direct-only kernel at 117 VGPRs with a general-only twin launched behind it was measured 3-5 %
+      // slower than this one at 144 VGPRs with the general path as a cold call: the window test up
+      // front and the second launch cost more than the fourth wavefront per SIMD brings)
       hipLaunchKernelGGL(k_tsdf_residuals_single_batch<kBatchThreads>, dim3(max_wg, count), dim3(kBatchThreads), 0, s,
                          static_cast<const SingleJob*>(c->ws_misc.ptr));
       hipLaunchKernelGGL(k_lm_single_batch, dim3(count), dim3(kEvalThreads), 0, s,
@@ -3573,9 +3564,106 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     }
   }
   HG_HIP_CHECK(hipGetLastError());
+  for (int i = 0; i < count; ++i) problems[i]->solve_pending = true;
+  *batched = true;
+  return HG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solver_opts* opts,
+                           hg_solver_summary* summaries) {
+  if (!problems || count < 1) return HG_ERR_INVALID;
+  if (count > kBatchGroup) {
+    for (int i0 = 0; i0 < count; i0 += kBatchGroup) {
+      const int rc = hg_problem_solve_batch(problems + i0, std::min(kBatchGroup, count - i0), opts,
+                                            summaries ? summaries + i0 : nullptr);
+      if (rc != HG_OK) return rc;
+    }
+    return HG_OK;
+  }
+  bool batched = false;
+  int rc = solve_batch_enqueue(problems, count, opts, &batched);
+  if (rc != HG_OK) return rc;
+  if (!batched) {
+    for (int i = 0; i < count; ++i) {
+      rc = hg_problem_solve(problems[i], opts, summaries ? summaries + i : nullptr);
+      if (rc != HG_OK) return rc;
+    }
+    return HG_OK;
+  }
   for (int i = 0; i < count; ++i) {
     const int r2 = hg_problem_fetch(problems[i], summaries ? summaries + i : nullptr);
     if (r2 != HG_OK) rc = r2;
+  }
+  return rc;
+}
+
+int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solver_opts* sopts,
+                           const int* pose_index, hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
+                           const float* origins, const float* const* xyz, const size_t* n, size_t width,
+                           int memspace, double* poses_out, hg_solver_summary* summaries) {
+  if (!problems || count < 1 || !pose_index || !grids || !iopts || levels < 1 || !origins || !xyz || !n)
+    return HG_ERR_INVALID;
+  for (int j = 0; j < count; ++j)
+    if (!problems[j] || pose_index[j] < 0 || pose_index[j] >= static_cast<int>(problems[j]->poses.size()))
+      return HG_ERR_INVALID;
+  if (count > kBatchGroup) {
+    for (int j0 = 0; j0 < count; j0 += kBatchGroup) {
+      const int m = std::min(kBatchGroup, count - j0);
+      const int rc = hg_register_scan_batch(problems + j0, m, sopts, pose_index + j0, grids + j0 * levels, iopts, levels,
+                                            origins + 3 * j0, xyz + j0, n + j0, width, memspace,
+                                            poses_out ? poses_out + 7 * j0 : nullptr, summaries ? summaries + j0 : nullptr);
+      if (rc != HG_OK) return rc;
+    }
+    return HG_OK;
+  }
+  hg_ctx* c = problems[0]->ctx;
+  int rc = async_status(c);  // an insertion of an earlier step that failed reports here
+  if (rc != HG_OK) return rc;
+  bool batched = false;
+  const auto dbg0 = std::chrono::steady_clock::now();
+  if (memspace == HG_DEVICE) {
+    rc = solve_batch_enqueue(problems, count, sopts, &batched);
+    if (rc != HG_OK) return rc;
+  }
+  const auto dbg1 = std::chrono::steady_clock::now();
+  if (!batched) {  // other problem shapes, host points, a single submap: one registration after the other
+    for (int j = 0; j < count; ++j) {
+      rc = hg_register_scan_mode(problems[j], sopts, pose_index[j], grids + j * levels, iopts, levels, origins + 3 * j,
+                                 xyz[j], n[j], width, memspace, HG_INSERT_EXACT, poses_out ? poses_out + 7 * j : nullptr,
+                                 summaries ? summaries + j : nullptr);
+      if (rc != HG_OK) return rc;
+    }
+    return HG_OK;
+  }
+  // insertion of every scan at the pose its solve leaves in device memory, with shared launches
+  std::vector<const double*> d_poses(count);
+  for (int j = 0; j < count; ++j) d_poses[j] = &problems[j]->d_state->h.x[pose_index[j]][0];
+  rc = pyramid_insert_jobs(c, count, grids, iopts, levels, origins, xyz, n, width, d_poses.data());
+  if (rc == HG_ERR_UNSUPPORTED) {  // insertion options outside the binned path: pyramid by pyramid
+    rc = HG_OK;
+    for (int j = 0; j < count && rc == HG_OK; ++j) {
+      float approx[7];
+      for (int k = 0; k < 7; ++k) approx[k] = static_cast<float>(problems[j]->poses[pose_index[j]][k]);
+      const uint64_t offsets[2] = {0, n[j]};
+      rc = pyramid_insert_impl(grids + j * levels, iopts, levels, origins + 3 * j, xyz[j], offsets, 1, width, approx,
+                               d_poses[j], HG_INSERT_EXACT, memspace, nullptr);
+    }
+  }
+  const auto dbg2 = std::chrono::steady_clock::now();
+  for (int j = 0; j < count; ++j) {
+    const int r2 = hg_problem_fetch(problems[j], summaries ? summaries + j : nullptr);
+    if (rc == HG_OK) rc = r2;
+    if (r2 == HG_OK && poses_out) std::memcpy(poses_out + 7 * j, problems[j]->poses[pose_index[j]].data(), sizeof(double) * 7);
+  }
+  if (std::getenv("HG_DEBUG_BATCH")) {
+    const auto dbg3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    if (ms(dbg0, dbg3) > 3.0)
+      fprintf(stderr, "register_scan_batch: solve enqueue %.2f ms, insert enqueue %.2f ms, fetch %.2f ms\n", ms(dbg0, dbg1),
+              ms(dbg1, dbg2), ms(dbg2, dbg3));
   }
   return rc;
 }

@@ -334,6 +334,20 @@ int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_i
                           const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
                           int insert_mode, double pose_out[7], hg_solver_summary* summary);
 
+/* The registration step of `count` INDEPENDENT submaps with shared launches (offline batch mapping puts
+ * several submaps on one GPU: one registration chain is latency-bound and fills a fraction of the
+ * chip). Submap j: problems[j] prepared as for hg_register_scan (single-pose shape), its pyramid
+ * grids[j * levels .. j * levels + levels), its scan xyz[j] (n[j] returns in the frame of pose
+ * pose_index[j], HG_DEVICE memory), origin origins + 3 j; iopts[levels] are shared. Poses, iteration
+ * counts and termination are those of hg_register_scan on every submap (poses agree to the rounding
+ * of the normal-equation sums, see hg_problem_solve_batch); voxel codes are the reference's for the
+ * poses returned. Other problem shapes, host memory or count == 1 run one registration after the
+ * other. poses_out: count x 7 or NULL; summaries: count entries or NULL. Exact insert mode. */
+int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solver_opts* sopts,
+                           const int* pose_index, hg_grid* const* grids, const hg_insert_opts* iopts,
+                           int levels, const float* origins, const float* const* xyz, const size_t* n,
+                           size_t width, int memspace, double* poses_out, hg_solver_summary* summaries);
+
 /* ---- one-block convenience (CeresScanMatcher3D::{Evaluate,Match} shape) ----------------- */
 int hg_match_evaluate(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_res,
                       const float* xyz, size_t n, int memspace, double scaling_factor,

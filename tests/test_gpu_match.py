@@ -480,3 +480,73 @@ def test_solve_batch_equals_individual_solves(po, hg, ctx):
     s_mixed = hg.solve_batch(mixed + [p2])
     assert np.array_equal(mixed[0].get_pose(0), single[0].get_pose(0))
     assert s_mixed[2].num_iterations >= 1
+
+
+def test_register_scan_batch_equals_individual_registrations(po, hg, ctx):
+    """hg_register_scan_batch: the registration step of several independent submaps with shared
+    launches (batched matcher + insert kernels over a table of pyramids) gives every submap what
+    hg_register_scan gives it on its own: same iteration counts and termination, poses equal to the
+    rounding of the normal-equation sums, and -- the float casts of those poses being equal --
+    bit-identical voxel codes; submap 0 is also checked against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    res = [0.05, 0.10, 0.20]
+    S, rings, cols, steps = 3, 16, 625, 3
+    sets = {}
+    for name in ("batch", "single"):
+        sets[name] = [[hg.HybridGridTSDF(ctx, r, max_blocks=1 << 15) for r in res] for _ in range(S)]
+    ins = [hg.TSDFRangeDataInserter3D() for _ in res]
+    og = [po.Grid(r) for r in res]
+    for j in range(S):
+        for k in range(4):
+            pose = synth.pose_k(7 * j + k)
+            pts = synth.generate_scan(pose, rings, cols, stream=100 * j + k)
+            for name in sets:
+                hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), sets[name][j], pose_tq=pose.astype(np.float32))
+            if j == 0:
+                loc = synth.transform_points(pose, pts)
+                for g in og:
+                    g.insert(pose[:3], loc)
+    pb = [hg.Problem(ctx) for _ in range(S)]
+    ps = [hg.Problem(ctx) for _ in range(S)]
+    scale = 1.0 / np.sqrt(float(rings * cols))
+    for step in range(steps):
+        scans, guesses = [], []
+        for j in range(S):
+            pose = synth.pose_k(7 * j + 4 + step)
+            pts = synth.generate_scan(pose, rings, cols, stream=100 * j + 4 + step)
+            scans.append((pts, torch.from_numpy(pts).to(dev)))
+            guesses.append(synth.pose_mul(pose, synth.perturbation()))
+        for j in range(S):
+            for p, grids in ((pb[j], sets["batch"][j]), (ps[j], sets["single"][j])):
+                p.reset()
+                p.add_pose(guesses[j])
+                p.add_block(scans[j][1], grids, scale, 0, multi_res=True)
+        poses, summ = hg.register_scan_batch(pb, [0] * S, ins, [hg.RangeData([0, 0, 0], d) for _, d in scans],
+                                             sets["batch"])
+        for j in range(S):
+            est, s1 = hg.register_scan(ps[j], 0, ins, hg.RangeData([0, 0, 0], scans[j][1]), sets["single"][j])
+            np.testing.assert_allclose(poses[j], est, rtol=0, atol=1e-9)
+            assert (summ[j].num_iterations, summ[j].termination_type, summ[j].termination_reason) == \
+                   (s1.num_iterations, s1.termination_type, s1.termination_reason)
+            assert np.array_equal(poses[j].astype(np.float32), est.astype(np.float32))
+        # oracle: submap 0
+        op = po.Problem()
+        op.add_pose(guesses[0])
+        op.add_block(scans[0][0], og, scale, 0, multi_res=True)
+        so = op.solve()
+        ref = op.get_pose(0)
+        assert np.abs(ref - poses[0]).max() < 1e-9 and so.num_iterations == summ[0].num_iterations
+        at = ref if np.array_equal(ref.astype(np.float32), poses[0].astype(np.float32)) else poses[0]
+        loc = synth.transform_points(at, scans[0][0])
+        for g in og:
+            g.insert(at[:3].astype(np.float32), loc)
+    ctx.synchronize()
+    for j in range(S):
+        for a, b in zip(sets["batch"][j], sets["single"][j]):
+            a.status()
+            for x, y in zip(a.export(), b.export()):
+                assert np.array_equal(x, y)
+    for o, g in zip(og, sets["batch"][0]):
+        for x, y in zip(o.export(), g.export()):
+            assert np.array_equal(x, y)
