@@ -7,7 +7,9 @@
 // The reference's DynamicGrid/NestedGrid pointer tree (:144-407) is replaced
 // by this flat pool; export restores the tree's iteration order.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -200,7 +202,23 @@ int hg_ctx_create(int device, void* stream, hg_ctx** out) {
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // Contexts of one process (a host thread per trajectory, each with its context) must not share a
+    // hardware queue: HIP deals its streams onto a small pool of them (GPU_MAX_HW_QUEUES, 4 by default)
+    // and two streams that land on the same one run strictly one after the other -- two threads
+    // measured 0.98x of one thread, three 1.8x, depending on creation order. Every priority level has
+    // its own pool, so successive contexts take successive priority levels (2 threads: 1.57x). The
+    // levels only order work that competes for the same CUs; HG_STREAM_PRIORITY=<n> pins one instead.
+    hipError_t e;
+    {
+      static std::atomic<int> counter{0};
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      const int span = least - greatest + 1;
+      int prio = greatest + (span > 0 ? counter++ % span : 0);
+      if (const char* pin = std::getenv("HG_STREAM_PRIORITY")) prio = std::atoi(pin);
+      e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
+      if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) {
       set_last_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
       delete c;

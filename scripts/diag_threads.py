@@ -1,6 +1,6 @@
 """Diagnostic (not part of the product): S submaps registered by S host threads of ONE process, one
 context / stream each, against the same work done by one thread."""
-import os, sys, threading, time
+import gc, os, sys, threading, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -40,6 +40,8 @@ class Job:
         self.ctx.synchronize()
 
 
+gc.collect()
+gc.disable()   # a generational collection with torch loaded takes 30-60 ms: it would be measured as a stall
 jobs = [Job(j) for j in range(S)]
 for jb in jobs:
     jb.step(0); jb.step(1); jb.ctx.synchronize(); jb.t.clear()
