@@ -918,10 +918,10 @@ def run(args, out_fd=None):
     dom = max(fam, key=lambda k: fam[k][2])
     avg_ms, bytes_per, _ = fam[dom]
     # HBM traffic of the dominant kernel from the committed PMC passes of this same command
-    # (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs)
+    # (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             pmc = json.load(f)["kernels"]
         if dom == "k_tsdf_residuals":
             # the single-pose registration step runs the k_tsdf_residuals_single<512> instantiation

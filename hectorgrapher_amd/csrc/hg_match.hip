@@ -620,26 +620,33 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
     if (all_zero) return {static_cast<double>(g.min_tsd), 0.0, 0.0, 0.0};  // :86-89
     return r;
   }
-  // first level whose 8 weights are all non-zero (interpolated_multi_resolution_tsdf.h:99-106)
+  // first level whose 8 weights are all non-zero (interpolated_multi_resolution_tsdf.h:99-106).
+  // The per-level codec constants are pinned to scalar registers (readfirstlane): left as plain
+  // kernel-argument loads the compiler built a lookup table of them in PRIVATE memory and indexed it
+  // per lane (eight scratch stores per lane at kernel start: 3 MB of writes per launch).
+  auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
   float c3[3] = {f[0].c[0], f[0].c[1], f[0].c[2]};
   uint32_t code[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) code[c] = f[0].code[c];
-  float res = pv.level[0].resolution, tsd_scale = pv.level[0].tsd_scale, tsd_offset = pv.level[0].tsd_offset,
-        min_tsd = pv.level[0].min_tsd;
+  float res = uni(pv.level[0].resolution), tsd_scale = uni(pv.level[0].tsd_scale),
+        tsd_offset = uni(pv.level[0].tsd_offset), min_tsd = uni(pv.level[0].min_tsd);
   bool found = false;
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) {
     bool valid = true;
 #pragma unroll
     for (int c = 0; c < 8; ++c) valid = valid && ((f[l].code[c] >> 16) & 0x7FFFu) > 1u;
-    if (l > 0 && !found && valid) {
+    if (l > 0) {
+      const bool take = !found && valid;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) code[c] = f[l].code[c];
+      for (int c = 0; c < 8; ++c) code[c] = take ? f[l].code[c] : code[c];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) c3[a] = f[l].c[a];
-      res = pv.level[l].resolution; tsd_scale = pv.level[l].tsd_scale; tsd_offset = pv.level[l].tsd_offset;
-      min_tsd = pv.level[l].min_tsd;
+      for (int a = 0; a < 3; ++a) c3[a] = take ? f[l].c[a] : c3[a];
+      res = take ? uni(pv.level[l].resolution) : res;
+      tsd_scale = take ? uni(pv.level[l].tsd_scale) : tsd_scale;
+      tsd_offset = take ? uni(pv.level[l].tsd_offset) : tsd_offset;
+      min_tsd = take ? uni(pv.level[l].min_tsd) : min_tsd;
     }
     found = found || valid;
   }

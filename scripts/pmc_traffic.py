@@ -1,6 +1,6 @@
 """Aggregates two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as the MI355X guide
 prescribes) of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` into
-profiles/r01_pmc_traffic.json: HBM-side bytes per launch and kernel.
+profiles/r02_pmc_traffic.json (or the path given as third argument): HBM-side bytes per launch and kernel.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o p -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o p -- python3 bench.py ...
@@ -50,7 +50,8 @@ def main():
                 "kernel (solver already terminated) are excluded",
         "kernels": kernels,
     }
-    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w") as fh:
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    with open(out, "w") as fh:
         json.dump(doc, fh, indent=1)
     for k, v in kernels.items():
         print("%-44s %10.0f B fetch %10.0f B write (%d launches)" % (k[:44], v["FETCH_SIZE"], v["WRITE_SIZE"], v["launches_sampled"]))
