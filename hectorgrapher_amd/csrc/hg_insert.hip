@@ -493,6 +493,7 @@ struct PyramidIns {
   int accumulate;        // not the first chunk of a call: hit / update counters add up
   uint32_t* host_flags;  // mapped pinned words [kMaxInsLevels]: sticky error flags of calls that do not
                          // read their stats back (written only when a flag is set)
+  int slice_records;     // records per voxel slice of a large bin (0 = 512), see k_bin_offsets
 };
 
 // One thread per level: hands the level's sticky error flags to the host without a read-back.
@@ -1296,6 +1297,11 @@ __device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* s_wave /*[
 // v with v mod slices == k (see k_bin_apply).
 __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level, unsigned records_per_level) {
   const LevelIns& L = P.lv[level];
+  // a bin of more than `slice_records` records is cut into voxel slices of about that many records
+  // each: 512 puts the long per-voxel chains of a heavy bin on as many workgroups as possible (one
+  // registration chain: latency), 2048 = one LDS pass per slice reads every bin four times less often
+  // (batched registration: throughput)
+  const unsigned slice_records = P.slice_records ? static_cast<unsigned>(P.slice_records) : 512u;
   __shared__ unsigned s_scan[16];
   __shared__ unsigned s_base, s_work;
   const unsigned nt = L.g.counters[6];
@@ -1332,10 +1338,10 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
         if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
       }
-      const bool large = cnt > 512u;
+      const bool large = cnt > slice_records;
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
-        while (slices < 128 && cnt > slices * 512u) slices <<= 1;
+        while (slices < 128 && cnt > slices * slice_records) slices <<= 1;
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -1362,10 +1368,10 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
         if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
       }
-      const bool large = cnt > 512u;
+      const bool large = cnt > slice_records;
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
-        while (slices < 128 && cnt > slices * 512u) slices <<= 1;
+        while (slices < 128 && cnt > slices * slice_records) slices <<= 1;
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -2203,6 +2209,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
     P.d_pose = d_poses[j];
     P.accumulate = 0;
     P.host_flags = c->async_flags;
+    P.slice_records = count >= 4 ? 2048 : 512;
     P.scan0.begin = 0;
     P.scan0.count = nj;
     std::memcpy(P.scan0.origin, origins + 3 * j, sizeof(P.scan0.origin));

@@ -491,7 +491,7 @@ def test_register_scan_batch_equals_individual_registrations(po, hg, ctx):
     import torch
     dev = torch.device("cuda", 0)
     res = [0.05, 0.10, 0.20]
-    S, rings, cols, steps = 3, 16, 625, 3
+    S, rings, cols, steps = 4, 16, 625, 3   # 4 submaps: the batched insertion cuts large bins into 2048-record slices
     sets = {}
     for name in ("batch", "single"):
         sets[name] = [[hg.HybridGridTSDF(ctx, r, max_blocks=1 << 15) for r in res] for _ in range(S)]
