@@ -780,6 +780,7 @@ __global__ void k_sum_stats(PyramidIns P, const unsigned* wg_hits, unsigned n_ex
 // ==========================================================================================
 constexpr int kBinCap = 2048;       // records per LDS pass of k_bin_apply (4 per thread)
 constexpr int kBinThreads = 512;    // one thread per voxel of a block
+constexpr unsigned kSmallBin = 512; // a bin of at most this many records is one wavefront's work (k_bin_apply_small)
 constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
 
 enum : uint32_t { kFlagBinOverflow = 8u, kFlagWorkOverflow = 16u };
@@ -1303,9 +1304,9 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
   // (batched registration: throughput)
   const unsigned slice_records = P.slice_records ? static_cast<unsigned>(P.slice_records) : 512u;
   __shared__ unsigned s_scan[16];
-  __shared__ unsigned s_base, s_work;
+  __shared__ unsigned s_base, s_work, s_large;
   const unsigned nt = L.g.counters[6];
-  if (threadIdx.x == 0) { s_base = 0; s_work = 0; }
+  if (threadIdx.x == 0) { s_base = 0; s_work = 0; s_large = 0; }
   __syncthreads();
   // two rounds over the touched list: round 0 assigns offsets and emits the work items of large
   // bins (their long per-voxel chains are the critical path, so they are scheduled first),
@@ -1338,10 +1339,10 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
         if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
       }
-      const bool large = cnt > slice_records;
+      const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
-        while (slices < 128 && cnt > slices * slice_records) slices <<= 1;
+        while (slices < 128 && cnt > slices * slice_records) slices <<= 1;  // 1 slice while cnt <= slice_records
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -1368,10 +1369,10 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
         if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
       }
-      const bool large = cnt > slice_records;
+      const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
       if (i < nt && ((round == 0) == large)) {
         unsigned slices = 1;
-        while (slices < 128 && cnt > slices * slice_records) slices <<= 1;
+        while (slices < 128 && cnt > slices * slice_records) slices <<= 1;  // 1 slice while cnt <= slice_records
         const unsigned w0 = atomicAdd(&s_work, slices);
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
@@ -1387,8 +1388,12 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
       __syncthreads();
     }
     __syncthreads();
+    if (round == 0 && threadIdx.x == 0) s_large = s_work;  // items [0, s_large): slices of large bins
   }
   if (threadIdx.x == 0) {
+    // items [counters[15], counters[7]) are whole bins for k_bin_apply_small (batched inserts); one
+    // registration chain keeps them in k_bin_apply: a second kernel behind it costs more than it saves
+    L.g.counters[15] = min(P.slice_records >= 2048 ? s_large : s_work, L.g.work_capacity);
     L.g.counters[7] = min(s_work, L.g.work_capacity);  // consumed by k_bin_apply
     L.g.counters[6] = 0;                                // next call collects from scratch
     unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
@@ -1477,6 +1482,149 @@ constexpr unsigned kRankMaxGroup = 1024;  // larger per-voxel groups are ordered
 #else
 #define BIN_STAMP(i) do {} while (0)
 #endif
+// A bin of at most kSmallBin records is handled by ONE wavefront with wavefront-level LDS traffic only
+// (no workgroup barrier): most touched blocks of a scan are of this kind (mean bin size 280 / 700
+// records at 0.05 / 0.10 m), and as 512-thread work items they spent their time in a dozen barriers
+// around a few hundred records each while holding a third of a CU. Same steps as the workgroup path:
+// voxel histogram, exclusive scan, grouping by voxel, rank by seq inside each group, one chain per
+// voxel in reference order (the non-empty voxels are dealt out to the lanes 64 at a time).
+__device__ inline void wave_sync_lds() {  // lanes of ONE wavefront exchanging data through LDS
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ inline void apply_small_bin(const GridView& g, float maximum_weight, uint32_t slot, unsigned n,
+                                       const uint32_t* __restrict__ bk, const uint32_t* __restrict__ bv,
+                                       uint32_t* lds) {
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  uint32_t* cb = lds;                 // per voxel: count (after the scan: count | base << 16)
+  uint32_t* gk = lds + kSmallBin;     // records grouped by voxel; later the list of non-empty voxels
+  uint32_t* gv = gk + kSmallBin;
+  uint32_t* sv = gv + kSmallBin;      // values in (voxel, seq) order
+  constexpr unsigned kPer = kSmallBin / kWave;  // 8
+#pragma unroll
+  for (unsigned i = 0; i < kPer; ++i) cb[lane + kWave * i] = 0u;
+  wave_sync_lds();
+  uint32_t k[kPer];
+#pragma unroll
+  for (unsigned i = 0; i < kPer; ++i) {
+    const unsigned r = lane + kWave * i;
+    k[i] = r < n ? bk[r] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (unsigned i = 0; i < kPer; ++i)
+    if (k[i] != 0xFFFFFFFFu) atomicAdd(&cb[k[i] >> kSeqBits], 1u);
+  wave_sync_lds();
+  // exclusive scan over the 512 counts: lane l owns voxels [8 l, 8 l + 8)
+  {
+    uint32_t c[kPer];
+    unsigned sum = 0;
+#pragma unroll
+    for (unsigned j = 0; j < kPer; ++j) { c[j] = cb[kPer * lane + j]; sum += c[j]; }
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned t = __shfl_up(incl, off);
+      if (static_cast<int>(lane) >= off) incl += t;
+    }
+    unsigned run = incl - sum;
+#pragma unroll
+    for (unsigned j = 0; j < kPer; ++j) { cb[kPer * lane + j] = c[j] | (run << 16); run += c[j]; }
+  }
+  wave_sync_lds();
+  // group by voxel: the base half of the voxel's word doubles as its cursor (it ends at base + count)
+  {
+    uint32_t v[kPer];
+#pragma unroll
+    for (unsigned i = 0; i < kPer; ++i) {
+      const unsigned r = lane + kWave * i;
+      v[i] = r < n ? bv[r] : 0u;
+    }
+#pragma unroll
+    for (unsigned i = 0; i < kPer; ++i) {
+      if (k[i] != 0xFFFFFFFFu) {
+        const unsigned p = atomicAdd(&cb[k[i] >> kSeqBits], 0x10000u) >> 16;
+        gk[p] = k[i];
+        gv[p] = v[i];
+      }
+    }
+  }
+  wave_sync_lds();
+  // rank inside the voxel's group = number of its records with a smaller seq (groups are small); a
+  // lane ranks the records at the positions it owns in the grouped arrays
+#pragma unroll 1
+  for (unsigned i = 0; i < kPer; ++i) {
+    const unsigned p = lane + kWave * i;
+    if (p < n) {
+      const uint32_t key = gk[p];
+      const uint32_t e = cb[key >> kSeqBits];
+      const unsigned b1 = e >> 16, b0 = b1 - (e & 0xFFFFu);
+      unsigned rank = 0;
+      for (unsigned j = b0; j < b1; j += 8) {  // 8 independent LDS reads in flight
+        uint32_t a[8];
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u) a[u] = gk[min(j + u, b1 - 1u)];
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u) rank += (j + u < b1 && a[u] < key) ? 1u : 0u;
+      }
+      sv[b0 + rank] = gv[p];
+    }
+  }
+  wave_sync_lds();
+  // list of the non-empty voxels (gk is free now), then one chain per voxel, 64 voxels at a time
+  unsigned m;
+  {
+    unsigned mine = 0;
+#pragma unroll
+    for (unsigned j = 0; j < kPer; ++j) mine += (cb[kPer * lane + j] & 0xFFFFu) ? 1u : 0u;
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned t = __shfl_up(incl, off);
+      if (static_cast<int>(lane) >= off) incl += t;
+    }
+    m = __shfl(incl, kWave - 1);
+    unsigned pos = incl - mine;
+#pragma unroll
+    for (unsigned j = 0; j < kPer; ++j)
+      if (cb[kPer * lane + j] & 0xFFFFu) gk[pos++] = kPer * lane + j;
+  }
+  wave_sync_lds();
+  uint32_t* vox = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock;
+  for (unsigned base = 0; base < m; base += kWave) {
+    const unsigned idx = base + lane;
+    if (idx < m) {
+      const unsigned vx = gk[idx];
+      const uint32_t e = cb[vx];
+      vox[vx] = update_chain_unit(g, maximum_weight, vox[vx], sv + ((e >> 16) - (e & 0xFFFFu)), e & 0xFFFFu);
+    }
+  }
+  wave_sync_lds();  // the next bin of this wavefront reuses the arrays
+}
+
+// The whole bins of a level (work items [counters[15], counters[7])), one wavefront each (batched inserts).
+constexpr int kSmallThreads = 128;  // two bins per workgroup
+__device__ __forceinline__ void bin_apply_small_body(const PyramidIns& P, int level, unsigned bx, unsigned gstride,
+                                                     const uint32_t* __restrict__ rec_keys,
+                                                     const uint32_t* __restrict__ rec_vals) {
+  const LevelIns& L = P.lv[level];
+  const GridView& g = L.g;
+  __shared__ uint32_t smem[(kSmallThreads / kWave) * 4 * kSmallBin];
+  const unsigned nwork = g.counters[7], n_large = min(g.counters[15], nwork);
+  const unsigned wave = threadIdx.x / kWave;
+  for (unsigned idx = n_large + bx * (kSmallThreads / kWave) + wave; idx < nwork; idx += gstride * (kSmallThreads / kWave)) {
+    const uint4 it = g.work[idx];
+    apply_small_bin(g, L.p.maximum_weight, it.x, it.z, rec_keys + g.bin_offset[it.x], rec_vals + g.bin_offset[it.x],
+                    smem + wave * 4 * kSmallBin);
+  }
+}
+// grid (G, jobs * levels)
+__global__ __launch_bounds__(kSmallThreads) void k_bin_apply_small_jobs(const InsertJob* __restrict__ jobs, int levels) {
+  const InsertJob& J = jobs[blockIdx.y / levels];
+  bin_apply_small_body(J.P, blockIdx.y % levels, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals);
+}
+
 // `order` = position of the level in dispatch order (0 = coarsest), `bx` of `gstride` = workgroup of
 // the level's grid-stride loop over its work items.
 __device__ __forceinline__ void bin_apply_body(const PyramidIns& P, unsigned order, unsigned bx, unsigned gstride,
@@ -1497,7 +1645,7 @@ __device__ __forceinline__ void bin_apply_body(const PyramidIns& P, unsigned ord
   __shared__ uint32_t gv[kBinCap];
   __shared__ uint32_t sv[kBinCap];    // values in (voxel, seq) order
   __shared__ unsigned s_hi;
-  const unsigned nwork = g.counters[7];
+  const unsigned nwork = min(g.counters[15], g.counters[7]);  // the slices of large bins; whole bins: k_bin_apply_small
   const unsigned tid = threadIdx.x;
   for (unsigned wi = bx; wi < nwork; wi += gstride) {
     const uint4 item = g.work[wi];
@@ -2247,6 +2395,8 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
 #ifndef HG_BIN_STAMPS
     hipLaunchKernelGGL(k_bin_apply_jobs, dim3(count <= 2 ? 1024 : 512, levels * count), dim3(kBinThreads), 0, s, d_jobs, count);
 #endif
+    if (count >= 4)  // as P.slice_records: throughput mode
+      hipLaunchKernelGGL(k_bin_apply_small_jobs, dim3(512, count * levels), dim3(kSmallThreads), 0, s, d_jobs, levels);
   }
   HG_HIP_CHECK(hipGetLastError());
   return HG_OK;
