@@ -189,88 +189,6 @@ __device__ inline void interpolate_linear(double both_invalid, const D3& q1, con
   }
 }
 
-// Geometry + memory addresses of one level's 2x2x2 lookup, split into phases so that the hash
-// probes and the voxel loads of ALL corners (and all pyramid levels) are in flight together:
-// the per-return cost is two memory round trips instead of up to 16 dependent ones.
-struct LevelFetch {
-  double x1, y1, z1, x2, y2, z2;
-  unsigned long long key[8];
-  unsigned long long entry[8];
-  uint32_t hash[8];
-  uint32_t vox[8];
-  uint32_t code[8];
-  bool in_range[8];
-};
-
-__device__ inline void fetch_setup(const GridView& g, double x, double y, double z, LevelFetch& f) {
-  const float res = g.resolution;
-  // CenterOfLowerVoxel (interpolated_tsdf.h:176-192): float centre, compared against the double
-  int i0[3] = {cell_index_1d(static_cast<float>(x), res), cell_index_1d(static_cast<float>(y), res),
-               cell_index_1d(static_cast<float>(z), res)};
-  float cx = static_cast<float>(i0[0]) * res;
-  float cy = static_cast<float>(i0[1]) * res;
-  float cz = static_cast<float>(i0[2]) * res;
-  // GetCellIndex of the lowered centre (:99-101 via GetWeight/GetTSD) is the index minus one:
-  // (i * res -+ res) / res is within 1e-2 of an integer for |i| <= 8192, far from a rounding tie
-  if (static_cast<double>(cx) > x) { cx -= res; i0[0] -= 1; }
-  if (static_cast<double>(cy) > y) { cy -= res; i0[1] -= 1; }
-  if (static_cast<double>(cz) > z) { cz -= res; i0[2] -= 1; }
-  f.x1 = cx; f.y1 = cy; f.z1 = cz;
-  f.x2 = cx + res; f.y2 = cy + res; f.z2 = cz + res;
-  // per-axis pieces of key / hash / voxel index for index i and i + 1
-  uint32_t kb[3][2], hs[3][2], vx[3][2];
-  bool ok[3][2];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const unsigned s = static_cast<unsigned>(i0[a] + d + kIndexOffset);
-      ok[a][d] = s < 16384u;
-      kb[a][d] = (s >> 3) & 2047u;
-      vx[a][d] = s & 7u;
-    }
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    hs[0][d] = hash_x(kb[0][d]);
-    hs[1][d] = hash_y(kb[1][d]);
-    hs[2][d] = hash_z(kb[2][d]);
-  }
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    // corner order: c = dx*4 + dy*2 + dz  (111,112,121,122,211,212,221,222)
-    const int dx = c >> 2, dy = (c >> 1) & 1, dz = c & 1;
-    f.in_range[c] = ok[0][dx] && ok[1][dy] && ok[2][dz];
-    f.key[c] = (static_cast<unsigned long long>(kb[2][dz]) << 22) | ((kb[1][dy] << 11) | kb[0][dx]);
-    f.hash[c] = hash_mix(hs[0][dx] ^ hs[1][dy] ^ hs[2][dz]);
-    f.vox[c] = (vx[2][dz] << 6) | (vx[1][dy] << 3) | vx[0][dx];
-  }
-}
-__device__ inline void fetch_probe(const GridView& g, LevelFetch& f) {
-  // the 8 corners lie in one block unless an axis crosses a block face (1/8 per axis): only the
-  // corners whose block differs from corner 0's take their own probe (2.4 instead of 8 lane-loads
-  // per return and level; the residual pass is bound by the rate of divergent gathers)
-  const unsigned long long e0 = g.table[f.hash[0] & g.table_mask];
-  f.entry[0] = e0;
-#pragma unroll
-  for (int c = 1; c < 8; ++c) {
-    unsigned long long e = e0;
-    if (f.key[c] != f.key[0]) e = g.table[f.hash[c] & g.table_mask];
-    f.entry[c] = e;
-  }
-}
-__device__ inline void fetch_voxels(const GridView& g, LevelFetch& f) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    uint32_t slot = 0xFFFFFFFFu;
-    const unsigned long long e = f.entry[c];
-    if (f.in_range[c] && e != 0ull) {
-      if ((e >> 24) == f.key[c] + 1ull) slot = static_cast<uint32_t>(e & 0xFFFFFFu);
-      else slot = find_block(g, f.key[c]);  // first slot taken by another key: linear probing
-    }
-    f.code[c] = (slot < g.pool_blocks)
-                    ? g.voxels[static_cast<size_t>(slot) * kVoxelsPerBlock + f.vox[c]] : 0u;
-  }
-}
 // Codec constants + geometry + codes of the level a lane interpolates on.
 struct LevelSel {
   double x1, y1, z1, x2, y2, z2;
@@ -312,82 +230,6 @@ __device__ inline D3 interp_selected(const LevelSel& s, double both_invalid, dou
   interpolate_linear(both_invalid, q21, q22, w21, w22, ny, q2, w2);
   interpolate_linear(both_invalid, q1, q2, w1, w2, nx, qq, ww);
   return qq;
-}
-
-__device__ inline void select_level(const GridView& g, const LevelFetch& f, LevelSel& s) {
-  s.x1 = f.x1; s.y1 = f.y1; s.z1 = f.z1; s.x2 = f.x2; s.y2 = f.y2; s.z2 = f.z2;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) s.code[c] = f.code[c];
-  s.tsd_scale = g.tsd_scale; s.tsd_offset = g.tsd_offset; s.min_tsd = g.min_tsd;
-  s.weight_scale = g.weight_scale; s.weight_offset = g.weight_offset;
-}
-
-// All levels are fetched together; every lane then interpolates exactly once, on the level the
-// reference would have chosen (first level whose 8 weights are all non-zero, :99-106), so a
-// wavefront does not run the interpolation once per level.
-template <int LEVELS>
-__device__ inline D3 pyramid_tsd_n(const PyramidView& pv, double x, double y, double z) {
-  LevelFetch f[LEVELS];
-#pragma unroll
-  for (int l = 0; l < LEVELS; ++l) fetch_setup(pv.level[l], x, y, z, f[l]);
-  BODY_STAMP(1);
-#pragma unroll
-  for (int l = 0; l < LEVELS; ++l) fetch_probe(pv.level[l], f[l]);
-  BODY_STAMP(2);
-#pragma unroll
-  for (int l = 0; l < LEVELS; ++l) fetch_voxels(pv.level[l], f[l]);
-  BODY_STAMP(3);
-  LevelSel s;
-  select_level(pv.level[0], f[0], s);
-  if (!pv.multi_res) {
-    bool all_zero = true;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) all_zero = all_zero && ((s.code[c] >> 16) & 0x7FFFu) <= 1u;
-    // weight code 0 (unknown) and code 1 (exactly 0.0) both decode to 0.0
-    const D3 r = interp_selected(s, -0.3, x, y, z);
-    if (all_zero) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :86-89
-    return r;
-  }
-  bool found = false;
-#pragma unroll
-  for (int l = 0; l < LEVELS; ++l) {
-    bool valid = true;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) valid = valid && ((f[l].code[c] >> 16) & 0x7FFFu) > 1u;
-    if (!found && valid) {
-      select_level(pv.level[l], f[l], s);
-      found = true;
-    }
-  }
-  const D3 r = interp_selected(s, static_cast<double>(s.min_tsd), x, y, z);
-  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
-  return r;
-}
-
-// Throughput form of the multi-resolution lookup (batched matching): the levels are visited one
-// after the other and only by the lanes that have not found a fully valid level yet — fewer
-// gathers and registers (two workgroups per CU) for more dependent round trips. Same selection,
-// same arithmetic, same result as pyramid_tsd_n.
-__device__ inline D3 pyramid_tsd_seq(const PyramidView& pv, double x, double y, double z) {
-  LevelSel s;
-  bool found = false;
-  for (int l = 0; l < pv.levels; ++l) {
-    if (__ballot(!found) == 0ull) break;
-    if (!found) {
-      LevelFetch f;
-      fetch_setup(pv.level[l], x, y, z, f);
-      fetch_probe(pv.level[l], f);
-      fetch_voxels(pv.level[l], f);
-      bool valid = true;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) valid = valid && ((f.code[c] >> 16) & 0x7FFFu) > 1u;
-      if (valid || l == 0) select_level(pv.level[l], f, s);  // level 0 stands in until a level is found
-      found = valid;
-    }
-  }
-  const D3 r = interp_selected(s, static_cast<double>(s.min_tsd), x, y, z);
-  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
-  return r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -494,7 +336,9 @@ __device__ inline void direct_setup(const GridView& g, double x, double y, doubl
     // CenterOfLowerVoxel (interpolated_tsdf.h:176-192): float centre, compared against the double
     int i0 = cell_index_fast(static_cast<float>(w[a]), res, rr);
     float c = static_cast<float>(i0) * res;
-    if (static_cast<double>(c) > w[a]) { c -= res; i0 -= 1; }  // index of the lowered centre: see fetch_setup
+    // GetCellIndex of the lowered centre (:99-101 via GetWeight/GetTSD) is the index minus one:
+    // (i * res -+ res) / res is within 1e-2 of an integer for |i| <= 8192, far from a rounding tie
+    if (static_cast<double>(c) > w[a]) { c -= res; i0 -= 1; }
     f.c[a] = c;
     f.s0[a] = static_cast<uint32_t>(i0 + kIndexOffset);
     const uint32_t mask = (1u << g.dir_bits[a]) - 1u;
@@ -703,7 +547,7 @@ __device__ __attribute__((noinline)) D3 pyramid_tsd_general(const PyramidView* p
   for (int l = 0; l < levels; ++l) {
     const GridView& g = pv.level[l];
     const float res = g.resolution;
-    // CenterOfLowerVoxel (interpolated_tsdf.h:176-192), as fetch_setup
+    // CenterOfLowerVoxel (interpolated_tsdf.h:176-192), as direct_setup
     int i0[3] = {cell_index_1d(static_cast<float>(x), res), cell_index_1d(static_cast<float>(y), res),
                  cell_index_1d(static_cast<float>(z), res)};
     float c[3] = {static_cast<float>(i0[0]) * res, static_cast<float>(i0[1]) * res, static_cast<float>(i0[2]) * res};
@@ -741,63 +585,10 @@ __device__ __attribute__((noinline)) D3 pyramid_tsd_general(const PyramidView* p
   return r;
 }
 
-// Throughput form of the direct multi-resolution lookup (batched matching): the levels are visited
-// one after the other and only by the lanes that have not found a fully valid level yet -- a third
-// of the voxel loads of the all-at-once form (the mean return settles on level 1.33) and one level's
-// lookup state in registers instead of all of them, for more dependent round trips. Same selection,
-// same arithmetic, same result as pyramid_tsd_direct.
-__device__ inline D3 pyramid_tsd_direct_seq(const PyramidView& pv, const DirectPyramid& dp, double x, double y,
-                                            double z) {
-  const bool usable = !(fabs(x) >= 1e30 || fabs(y) >= 1e30 || fabs(z) >= 1e30);
-  float c3[3] = {0.f, 0.f, 0.f};
-  uint32_t code[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) code[c] = 0u;
-  float res = pv.level[0].resolution, tsd_scale = pv.level[0].tsd_scale, tsd_offset = pv.level[0].tsd_offset,
-        min_tsd = pv.level[0].min_tsd;
-  bool found = false;
-#pragma unroll 1
-  for (int l = 0; l < pv.levels; ++l) {
-    if (__ballot(!found) == 0ull) break;
-    if (!found) {
-      DirectFetch f;
-      direct_setup(pv.level[l], x, y, z, f);
-      direct_load(pv.level[l], f);
-      direct_accept(pv.level[l], dp.min_b[l], usable, f);
-      bool valid = true;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) valid = valid && ((f.code[c] >> 16) & 0x7FFFu) > 1u;
-      if (valid || l == 0) {  // level 0 stands in until a level is found
-#pragma unroll
-        for (int c = 0; c < 8; ++c) code[c] = f.code[c];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) c3[a] = f.c[a];
-        res = pv.level[l].resolution; tsd_scale = pv.level[l].tsd_scale; tsd_offset = pv.level[l].tsd_offset;
-        min_tsd = pv.level[l].min_tsd;
-      }
-      found = valid;
-    }
-  }
-  const D3 r = interp_all_valid(res, tsd_scale, tsd_offset, min_tsd, c3, code, x, y, z);
-  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
-  return r;
-}
-
-template <bool SEQ = false>
 __device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, double x, double y, double z) {
   const int levels = pv.multi_res ? pv.levels : 1;
   bool ok;
   D3 r;
-  if (SEQ && pv.multi_res && levels > 1) {
-    const DirectPyramid dp = direct_resolve(pv, raw);
-    if (dp.ok) return pyramid_tsd_direct_seq(pv, dp, x, y, z);
-    return pyramid_tsd_general(pv.self_mem, x, y, z);
-  }
-  if (SEQ) {  // single resolution in the throughput kernels: one instantiation only
-    r = pyramid_tsd_direct<1>(pv, raw, x, y, z, &ok);
-    if (ok) return r;
-    return pyramid_tsd_general(pv.self_mem, x, y, z);
-  }
   switch (levels) {  // wave-uniform
     case 1: r = pyramid_tsd_direct<1>(pv, raw, x, y, z, &ok); break;
     case 2: r = pyramid_tsd_direct<2>(pv, raw, x, y, z, &ok); break;
@@ -816,7 +607,6 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
 
 // One return at transform (t, q): row8 = [d r / d(t, q) (7) | r]. The world point follows Eigen's
 // QuaternionBase::_transformVector, then + translation (rigid_transform.h:193-197).
-template <bool SEQ = false>
 __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRaw& dp, const double* t,
                                            const double* q, const double* v, double scaling, double* row8) {
   const double qw = q[0];
@@ -828,7 +618,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRa
   const double wx = (v[0] + qw * uv[0] + c2[0]) + t[0];
   const double wy = (v[1] + qw * uv[1] + c2[1]) + t[1];
   const double wz = (v[2] + qw * uv[2] + c2[2]) + t[2];
-  const D3 tsd = pyramid_tsd<SEQ>(pv, dp, wx, wy, wz);
+  const D3 tsd = pyramid_tsd(pv, dp, wx, wy, wz);
   const double r = scaling * tsd.a;
   const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
   // d world / d q = [uv | w*duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v)
@@ -872,7 +662,7 @@ __device__ inline double load_partial(const double* p) {
 }
 
 // residuals of one block at its current transform + 36 partial sums per workgroup
-template <int THREADS = kEvalThreads, bool SEQ = false>
+template <int THREADS = kEvalThreads>
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
@@ -884,7 +674,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
   if (i < n) {
     const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
                          static_cast<double>(xyz[3 * i + 2])};
-    return_row<SEQ>(pv, dp, xf->t, xf->q, v, scaling, row8);
+    return_row(pv, dp, xf->t, xf->q, v, scaling, row8);
     if (residuals) residuals[i] = row8[7];
   }
   BODY_STAMP(4);
@@ -2588,7 +2378,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
 // the register-resident LM step in the tail, in a kernel of its own so that its LDS footprint is
 // the X tiles (36 KB) instead of the general solver's working set (139 KB). (256-thread workgroups
 // — 391 of them, on all 256 CUs — were measured slower: twice the partials for the tail to sum.)
-template <int THREADS, bool SEQ = false>
+template <int THREADS>
 __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* __restrict__ xyz, unsigned n,
                                             double scaling, const BlockXform* __restrict__ xf,
                                             double* __restrict__ partials, LmState* G, unsigned* ticket,
@@ -2602,7 +2392,7 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
   constexpr size_t kTiles = (THREADS / kWave) * (kWave * 8 + 64) * sizeof(double);
   constexpr size_t kTail = ((THREADS / kAcc) + 1) * kAcc * sizeof(double) + sizeof(LmHead) + 36 * sizeof(double);
   __shared__ __align__(16) unsigned char smem[kTiles > kTail ? kTiles : kTail];
-  tsdf_residuals_body<THREADS, SEQ>(pv, xyz, n, scaling, xf, partials, nullptr,
+  tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, partials, nullptr,
                                reinterpret_cast<double (*)[kWave][8]>(smem),
                                reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
                                xcd_chunk(wg_index, num_wg));
@@ -2661,9 +2451,9 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_batch(const S
   const SingleJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.num_wg) return;
   if (J.G->h.done) return;
-  const PyramidView& pv = J.pv;  // read in place: the sequential lookup indexes the levels at run time
+  const PyramidView& pv = J.pv;
   __shared__ __align__(16) unsigned char smem[(THREADS / kWave) * (kWave * 8 + 64) * sizeof(double)];
-  tsdf_residuals_body<THREADS, true>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
+  tsdf_residuals_body<THREADS>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
                                      reinterpret_cast<double (*)[kWave][8]>(smem),
                                      reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
                                      xcd_chunk(blockIdx.x, J.num_wg));
