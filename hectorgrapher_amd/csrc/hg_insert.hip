@@ -1296,6 +1296,22 @@ __device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* s_wave /*[
 // apply work list: a bin larger than one LDS pass is split into voxel slices handled by
 // different workgroups (voxels are independent of each other); slice k takes the voxels
 // v with v mod slices == k (see k_bin_apply).
+// Reserves `mine` consecutive work items for every lane with ONE LDS atomic per wavefront (a prefix
+// sum over the lanes): thousands of same-address atomics of a level's touched blocks serialised.
+__device__ inline unsigned reserve_items(unsigned* counter, unsigned mine) {
+  const int lane = threadIdx.x & (kWave - 1);
+  unsigned incl = mine;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const unsigned total = __shfl(incl, kWave - 1);
+  unsigned base = 0;
+  if (lane == kWave - 1 && total) base = atomicAdd(counter, total);
+  return __shfl(base, kWave - 1) + incl - mine;
+}
+
 __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level, unsigned records_per_level) {
   const LevelIns& L = P.lv[level];
   // a bin of more than `slice_records` records is cut into voxel slices of about that many records
@@ -1340,10 +1356,11 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
         if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
       }
       const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
-      if (i < nt && ((round == 0) == large)) {
-        unsigned slices = 1;
-        while (slices < 128 && cnt > slices * slice_records) slices <<= 1;  // 1 slice while cnt <= slice_records
-        const unsigned w0 = atomicAdd(&s_work, slices);
+      const bool emit = i < nt && ((round == 0) == large);
+      unsigned slices = emit ? 1u : 0u;
+      while (emit && slices < 128 && cnt > slices * slice_records) slices <<= 1;  // 1 slice while cnt <= slice_records
+      const unsigned w0 = reserve_items(&s_work, slices);
+      if (emit) {
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
           if (w0 + k < L.g.work_capacity)
@@ -1370,10 +1387,11 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
         if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
       }
       const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
-      if (i < nt && ((round == 0) == large)) {
-        unsigned slices = 1;
-        while (slices < 128 && cnt > slices * slice_records) slices <<= 1;  // 1 slice while cnt <= slice_records
-        const unsigned w0 = atomicAdd(&s_work, slices);
+      const bool emit = i < nt && ((round == 0) == large);
+      unsigned slices = emit ? 1u : 0u;
+      while (emit && slices < 128 && cnt > slices * slice_records) slices <<= 1;  // 1 slice while cnt <= slice_records
+      const unsigned w0 = reserve_items(&s_work, slices);
+      if (emit) {
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
           if (w0 + k < L.g.work_capacity)
