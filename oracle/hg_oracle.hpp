@@ -488,10 +488,10 @@ class TSDFRangeDataInserter3D {
 
   // ref :395-404,698-723 (default branch). `returns` is N x 3 floats already
   // in the grid (submap) frame.
-  void Insert(const Vec3f& origin, const float* returns, size_t n, size_t /*width*/,
+  void Insert(const Vec3f& origin, const float* returns, size_t n, size_t width,
               HybridGridTSDF* tsdf, InsertStats* stats) const {
     if (options_.project_sdf_distance_to_scan_normal) {
-      InsertWithCloudStructureNormals(origin, returns, n, 0, tsdf, stats);
+      InsertWithCloudStructureNormals(origin, returns, n, width, tsdf, stats);
       return;
     }
     size_t num_inserted_points = 0;
