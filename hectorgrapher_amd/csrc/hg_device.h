@@ -38,6 +38,10 @@ struct GridView {
                               // [6] touched blocks being collected, [7] touched blocks to apply,
                               // [8] blocks in the overflow area, [9..11] min / [12..14] max block
                               // coordinate (x, y, z) over all blocks
+  uint32_t* call;             // counters of the running binned insert: [0] touched blocks being collected,
+                              // [1] apply work items, [2] of which slices of large bins (by default words
+                              // of `counters`; a scan stream gives every scan in flight its own, as well
+                              // as its own bin_count / bin_offset / touched arrays)
   uint32_t* bin_count;        // per block slot: records of the current insert call
   uint32_t* bin_offset;       // per block slot: first record of its bin
   uint32_t* touched;          // slots touched by the current insert call

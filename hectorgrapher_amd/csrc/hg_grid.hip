@@ -243,13 +243,24 @@ int hg_ctx_destroy(hg_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (DeviceBuffer* b : {&c->ws_points, &c->ws_scan_table, &c->ws_gate, &c->ws_counts,
                           &c->ws_offsets, &c->ws_keys_a, &c->ws_keys_b, &c->ws_vals_a,
-                          &c->ws_vals_b, &c->ws_temp, &c->ws_misc, &c->ws_filter, &c->ws_jobs})
+                          &c->ws_vals_b, &c->ws_temp, &c->ws_misc, &c->ws_filter, &c->ws_jobs,
+                          &c->ws_keys_c, &c->ws_vals_c, &c->ws_offsets_b, &c->ws_sjobs, &c->ws_shadow})
     b->release();
+  if (c->apply_stream) {
+    (void)hipStreamSynchronize(c->apply_stream);
+    (void)hipStreamDestroy(c->apply_stream);
+    for (int i = 0; i < 2; ++i) {
+      if (c->ev_front[i]) (void)hipEventDestroy(c->ev_front[i]);
+      if (c->ev_apply[i]) (void)hipEventDestroy(c->ev_apply[i]);
+    }
+  }
   prof_resolve(c);
   for (hipEvent_t e : c->prof_free_events) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
   if (c->pinned_ijobs) (void)hipHostFree(c->pinned_ijobs);
+  if (c->pinned_sjobs) (void)hipHostFree(c->pinned_sjobs);
+  if (c->ev_sjobs) (void)hipEventDestroy(c->ev_sjobs);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return HG_OK;
@@ -346,6 +357,7 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
     e = hipMalloc(reinterpret_cast<void**>(&v.bin_count),
                   sizeof(uint32_t) * (2 * static_cast<size_t>(v.pool_blocks) + 2 * static_cast<size_t>(max_blocks)));
   if (e == hipSuccess) {
+    v.call = v.counters + 16;
     v.bin_offset = v.bin_count + v.pool_blocks;
     v.touched = v.bin_offset + v.pool_blocks;
     v.block_list = v.touched + max_blocks;

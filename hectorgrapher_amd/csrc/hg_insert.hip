@@ -494,6 +494,8 @@ struct PyramidIns {
   uint32_t* host_flags;  // mapped pinned words [kMaxInsLevels]: sticky error flags of calls that do not
                          // read their stats back (written only when a flag is set)
   int slice_records;     // records per voxel slice of a large bin (0 = 512), see k_bin_offsets
+  int shared;            // several scans in flight on the same grids (scan stream): per-call statistics are
+                         // added atomically
 };
 
 // One thread per level: hands the level's sticky error flags to the host without a read-back.
@@ -953,7 +955,7 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, int level, u
   __syncthreads();
   if (threadIdx.x == 0) {
     wg_hits[level * nbx + bx] = s_hits;
-    s_first_base = s_first ? atomicAdd(&L.g.counters[6], s_first) : 0u;
+    s_first_base = s_first ? atomicAdd(&L.g.call[0], s_first) : 0u;
   }
   __syncthreads();
 #pragma unroll
@@ -1321,7 +1323,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
   const unsigned slice_records = P.slice_records ? static_cast<unsigned>(P.slice_records) : 512u;
   __shared__ unsigned s_scan[16];
   __shared__ unsigned s_base, s_work, s_large;
-  const unsigned nt = L.g.counters[6];
+  const unsigned nt = L.g.call[0];
   if (threadIdx.x == 0) { s_base = 0; s_work = 0; s_large = 0; }
   __syncthreads();
   // two rounds over the touched list: round 0 assigns offsets and emits the work items of large
@@ -1351,9 +1353,13 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
       const unsigned i = c0 + threadIdx.x;
       const unsigned slot = r_slot[c], cnt = r_cnt[c];
       unsigned chunk_total = 0;
+      unsigned bin_off = 0;  // carried by the work items: the apply pass does not read bin_offset[]
       if (round == 0) {
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
-        if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
+        bin_off = static_cast<unsigned>(level) * records_per_level + s_base + excl;
+        if (i < nt) L.g.bin_offset[slot] = bin_off;
+      } else if (i < nt) {
+        bin_off = L.g.bin_offset[slot];  // written by this thread in round 0
       }
       const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
       const bool emit = i < nt && ((round == 0) == large);
@@ -1364,7 +1370,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
           if (w0 + k < L.g.work_capacity)
-            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 16), cnt, 0u);
+            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 16), cnt, bin_off);
           else
             atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
@@ -1382,9 +1388,13 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
       unsigned cnt = 0;
       cnt = i < nt ? L.g.bin_count[slot] : 0u;
       unsigned chunk_total = 0;
+      unsigned bin_off = 0;  // carried by the work items: the apply pass does not read bin_offset[]
       if (round == 0) {
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
-        if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * records_per_level + s_base + excl;
+        bin_off = static_cast<unsigned>(level) * records_per_level + s_base + excl;
+        if (i < nt) L.g.bin_offset[slot] = bin_off;
+      } else if (i < nt) {
+        bin_off = L.g.bin_offset[slot];  // written by this thread in round 0
       }
       const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
       const bool emit = i < nt && ((round == 0) == large);
@@ -1395,7 +1405,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
           if (w0 + k < L.g.work_capacity)
-            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 16), cnt, 0u);
+            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 16), cnt, bin_off);
           else
             atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
@@ -1409,13 +1419,14 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
     if (round == 0 && threadIdx.x == 0) s_large = s_work;  // items [0, s_large): slices of large bins
   }
   if (threadIdx.x == 0) {
-    // items [counters[15], counters[7]) are whole bins for k_bin_apply_small (batched inserts); one
+    // items [call[2], call[1]) are whole bins for k_bin_apply_small (batched inserts); one
     // registration chain keeps them in k_bin_apply: a second kernel behind it costs more than it saves
-    L.g.counters[15] = min(P.slice_records >= 2048 ? s_large : s_work, L.g.work_capacity);
-    L.g.counters[7] = min(s_work, L.g.work_capacity);  // consumed by k_bin_apply
-    L.g.counters[6] = 0;                                // next call collects from scratch
+    L.g.call[2] = min(P.slice_records >= 2048 ? s_large : s_work, L.g.work_capacity);
+    L.g.call[1] = min(s_work, L.g.work_capacity);  // consumed by k_bin_apply
+    L.g.call[0] = 0;                               // next call collects from scratch
     unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
-    *upd = s_base + (P.accumulate ? *upd : 0ull);  // U of this call
+    if (P.shared) atomicAdd(upd, static_cast<unsigned long long>(s_base));
+    else *upd = s_base + (P.accumulate ? *upd : 0ull);  // U of this call
     publish_flags(P, level);
   }
 }
@@ -1621,40 +1632,40 @@ __device__ inline void apply_small_bin(const GridView& g, float maximum_weight, 
   wave_sync_lds();  // the next bin of this wavefront reuses the arrays
 }
 
-// The whole bins of a level (work items [counters[15], counters[7])), one wavefront each (batched inserts).
+// The whole bins of a level (work items [call[2], call[1])), one wavefront each (batched inserts).
 constexpr int kSmallThreads = 128;  // two bins per workgroup
-__device__ __forceinline__ void bin_apply_small_body(const PyramidIns& P, int level, unsigned bx, unsigned gstride,
+__device__ __forceinline__ void bin_apply_small_body(const LevelIns& L, unsigned bx, unsigned gstride,
                                                      const uint32_t* __restrict__ rec_keys,
                                                      const uint32_t* __restrict__ rec_vals) {
-  const LevelIns& L = P.lv[level];
   const GridView& g = L.g;
   __shared__ uint32_t smem[(kSmallThreads / kWave) * 4 * kSmallBin];
-  const unsigned nwork = g.counters[7], n_large = min(g.counters[15], nwork);
+  const unsigned nwork = g.call[1], n_large = min(g.call[2], nwork);
   const unsigned wave = threadIdx.x / kWave;
   for (unsigned idx = n_large + bx * (kSmallThreads / kWave) + wave; idx < nwork; idx += gstride * (kSmallThreads / kWave)) {
     const uint4 it = g.work[idx];
-    apply_small_bin(g, L.p.maximum_weight, it.x, it.z, rec_keys + g.bin_offset[it.x], rec_vals + g.bin_offset[it.x],
+    apply_small_bin(g, L.p.maximum_weight, it.x, it.z, rec_keys + it.w, rec_vals + it.w,
                     smem + wave * 4 * kSmallBin);
   }
 }
 // grid (G, jobs * levels)
 __global__ __launch_bounds__(kSmallThreads) void k_bin_apply_small_jobs(const InsertJob* __restrict__ jobs, int levels) {
+  // the level's description is copied out of the job table: read through the table pointer the
+  // compiler reloads it inside the loops (possible aliasing with the voxel stores), which made the
+  // apply pass 40 % slower than with the pyramid as a kernel argument
   const InsertJob& J = jobs[blockIdx.y / levels];
-  bin_apply_small_body(J.P, blockIdx.y % levels, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals);
+  const LevelIns L = J.P.lv[blockIdx.y % levels];
+  bin_apply_small_body(L, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals);
 }
 
 // `order` = position of the level in dispatch order (0 = coarsest), `bx` of `gstride` = workgroup of
 // the level's grid-stride loop over its work items.
-__device__ __forceinline__ void bin_apply_body(const PyramidIns& P, unsigned order, unsigned bx, unsigned gstride,
+__device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order, unsigned bx, unsigned gstride,
                                                const uint32_t* __restrict__ rec_keys,
                                                const uint32_t* __restrict__ rec_vals
 #ifdef HG_BIN_STAMPS
                                                , long long* stamps
 #endif
                                                ) {
-  // workgroups are dispatched in index order: the last (coarsest) level has the longest per-voxel
-  // chains, so it goes first
-  const LevelIns& L = P.lv[P.levels - 1 - order];
   const GridView& g = L.g;
   __shared__ unsigned hist[512];      // records per voxel (inside the item's voxel range)
   __shared__ unsigned base[512];      // exclusive prefix of hist
@@ -1662,8 +1673,10 @@ __device__ __forceinline__ void bin_apply_body(const PyramidIns& P, unsigned ord
   __shared__ uint32_t gk[kBinCap];    // grouped by voxel, arbitrary order inside a group
   __shared__ uint32_t gv[kBinCap];
   __shared__ uint32_t sv[kBinCap];    // values in (voxel, seq) order
-  __shared__ unsigned s_hi;
-  const unsigned nwork = min(g.counters[15], g.counters[7]);  // the slices of large bins; whole bins: k_bin_apply_small
+  __shared__ uint32_t tk[kBinCap];    // keys of the slice's records as read (compact list)
+  uint32_t* tv = sv;                  // their values: sv is free until the rank step
+  __shared__ unsigned s_hi, s_m;
+  const unsigned nwork = min(g.call[2], g.call[1]);  // the slices of large bins; whole bins: k_bin_apply_small
   const unsigned tid = threadIdx.x;
   for (unsigned wi = bx; wi < nwork; wi += gstride) {
     const uint4 item = g.work[wi];
@@ -1681,32 +1694,51 @@ __device__ __forceinline__ void bin_apply_body(const PyramidIns& P, unsigned ord
     auto to_pv = [&](unsigned v) { return (v & s_mask) * per_slice + (v >> s_bits); };
     auto from_pv = [&](unsigned pv) { return ((pv & (per_slice - 1u)) << s_bits) | (pv / per_slice); };
     const uint32_t seq_mask_all = (1u << kSeqBits) - 1u;
-    const uint32_t* bk = rec_keys + g.bin_offset[slot];
-    const uint32_t* bv = rec_vals + g.bin_offset[slot];
+    const uint32_t* bk = rec_keys + item.w;
+    const uint32_t* bv = rec_vals + item.w;
     BIN_STAMP(0);
 #ifdef HG_BIN_STAMPS
     if (threadIdx.x == 0) stamps[(static_cast<size_t>(order) * 4096 + wi) * 8 + 6] = n;
 #endif
     hist[tid] = 0;
+    if (tid == 0) s_m = 0;
     __syncthreads();
     const bool single = n <= static_cast<unsigned>(kBinCap);  // whole bin in registers: one read
     uint32_t rk4[4], rv4[4];
-    for (unsigned i0 = 0; i0 < n; i0 += 4 * kBinThreads) {  // 4 loads in flight per thread
-      uint32_t k4[4];
+    // A slice of a larger bin scans the WHOLE bin for its voxels' records: that scan, not the chain,
+    // was most of a heavy slice's time when it ran twice (histogram, then grouping). The records of
+    // the slice are therefore copied to LDS (tk / tv) during the histogram pass; when they fit one
+    // pass (they do unless a voxel holds thousands of records) the grouping reads them from there.
+    for (unsigned i0 = 0; i0 < n; i0 += 4 * kBinThreads) {  // 4 records (8 loads) in flight per thread
+      uint32_t k4[4], v4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const unsigned i = i0 + u * kBinThreads + tid;
         k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
-        if (single) rv4[u] = i < n ? bv[i] : 0u;
+        v4[u] = i < n ? bv[i] : 0u;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (single) rk4[u] = k4[u];
+        if (single) { rk4[u] = k4[u]; rv4[u] = v4[u]; }
         const unsigned v = to_pv(k4[u] >> kSeqBits);
-        if (k4[u] != 0xFFFFFFFFu && v >= v_lo && v < v_hi) atomicAdd(&hist[v], 1u);
+        const bool mine = k4[u] != 0xFFFFFFFFu && v >= v_lo && v < v_hi;
+        if (mine) atomicAdd(&hist[v], 1u);
+        if (!single) {  // append to the slice's compact list: one LDS atomic per wavefront
+          const unsigned long long mb = __ballot(mine);
+          if (mb) {
+            const int first = __builtin_ctzll(mb);
+            unsigned p0 = 0;
+            if (static_cast<int>(tid & (kWave - 1)) == first) p0 = atomicAdd(&s_m, static_cast<unsigned>(__popcll(mb)));
+            p0 = __shfl(p0, first);
+            const unsigned p = p0 + static_cast<unsigned>(__popcll(mb & ((1ull << (tid & (kWave - 1))) - 1ull)));
+            if (mine && p < static_cast<unsigned>(kBinCap)) { tk[p] = k4[u]; tv[p] = v4[u]; }
+          }
+        }
       }
     }
     __syncthreads();
+    const unsigned m_slice = s_m;
+    const bool compact = !single && m_slice <= static_cast<unsigned>(kBinCap);
     BIN_STAMP(1);
     // exclusive prefix of hist over the 512 voxels -> base
     {
@@ -1815,7 +1847,16 @@ __device__ __forceinline__ void bin_apply_body(const PyramidIns& P, unsigned ord
       __syncthreads();
       if (cnt) {
         // group by voxel (arbitrary order inside a group)
-        for (unsigned i0 = 0; i0 < n; i0 += 4 * kBinThreads) {
+        for (unsigned i = tid; compact && i < m_slice; i += kBinThreads) {
+          const uint32_t k = tk[i];
+          const unsigned v = to_pv(k >> kSeqBits);
+          if (v >= lo && v < hi) {
+            const unsigned p = base[v] - b_lo + atomicAdd(&cursor[v], 1u);
+            gk[p] = (v << kSeqBits) | (k & seq_mask_all);
+            gv[p] = tv[i];
+          }
+        }
+        for (unsigned i0 = 0; !compact && i0 < n; i0 += 4 * kBinThreads) {
           uint32_t k4[4], v4[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -1893,13 +1934,15 @@ __device__ __forceinline__ void bin_apply_body(const PyramidIns& P, unsigned ord
   }
 }
 
-__global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
+__global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
                                                           const uint32_t* __restrict__ rec_vals
 #ifdef HG_BIN_STAMPS
                                                           , long long* stamps
 #endif
                                                           ) {
-  bin_apply_body(P, blockIdx.y, blockIdx.x, gridDim.x, rec_keys, rec_vals
+  // workgroups are dispatched in index order: the last (coarsest) level has the longest per-voxel
+  // chains, so it goes first
+  bin_apply_body(P.lv[P.levels - 1 - blockIdx.y], blockIdx.y, blockIdx.x, gridDim.x, rec_keys, rec_vals
 #ifdef HG_BIN_STAMPS
                  , stamps
 #endif
@@ -1907,9 +1950,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_apply(PyramidIns P, const u
 }
 #ifndef HG_BIN_STAMPS
 // grid (G, levels * jobs): y = level order * jobs + job, so the coarse levels of ALL jobs go first
-__global__ __launch_bounds__(kBinThreads) void k_bin_apply_jobs(const InsertJob* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply_jobs(const InsertJob* __restrict__ jobs, int njobs) {
   const InsertJob& J = jobs[blockIdx.y % njobs];
-  bin_apply_body(J.P, blockIdx.y / njobs, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals);
+  const unsigned order = blockIdx.y / njobs;
+  const LevelIns L = J.P.lv[J.P.levels - 1 - order];  // a copy, see k_bin_apply_small_jobs
+  bin_apply_body(L, order, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals);
 }
 #endif
 
@@ -2081,11 +2126,50 @@ int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans,
 }
 
 // ---- binned path (single scan, unit weight) ------------------------------------------------
+// The apply stream of a pipelined scan stream, created on first use. It gets a priority level other
+// than the context's stream so that the two do not share a hardware queue (see hg_ctx_create).
+int ensure_apply_stream(hg_ctx* c) {
+  if (c->apply_stream) return HG_OK;
+  int least = 0, greatest = 0, mine = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  (void)hipStreamGetPriority(c->stream, &mine);
+  int prio = mine == greatest ? std::min(least, greatest + 1) : greatest;
+  if (const char* pin = std::getenv("HG_APPLY_PRIORITY")) prio = std::atoi(pin);
+  hipError_t e = hipStreamCreateWithPriority(&c->apply_stream, hipStreamNonBlocking, prio);
+  if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->apply_stream, hipStreamNonBlocking);
+  HG_HIP_CHECK(e);
+  for (int i = 0; i < 2; ++i) {
+    HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_front[i], hipEventDisableTiming));
+    HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_apply[i], hipEventDisableTiming));
+  }
+  return HG_OK;
+}
+
+// `pipe` >= 0: chunk number of a pipelined scan stream (several binned chunks in one call). The front
+// end (count, offsets, scatter) of chunk k runs on the context's stream, its apply pass on the apply
+// stream: with known poses the front end of scan k + 1 does not depend on the apply pass of scan k,
+// which is a few long per-voxel chains on an otherwise idle chip. Records, work list and work
+// counters are double buffered (chunk parity); applies stay in scan order on their stream; the caller
+// makes the context's stream wait for the last apply before it returns. pipe < 0: everything on the
+// context's stream.
 int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_scans, uint32_t n_scans,
-                        const float* d_xyz, unsigned long long n, bool want_stats) {
+                        const float* d_xyz, unsigned long long n, bool want_stats, int pipe = -1) {
   hipStream_t s = c->stream;
   const unsigned records_per_level = static_cast<unsigned>(n) * kSlots;
   PyramidIns P = P_in;
+  const int parity = pipe >= 0 ? (pipe & 1) : 0;
+  for (int l = 0; l < P.levels; ++l) P.lv[l].g.call = P.lv[l].g.counters + 16 + 4 * parity;
+  DeviceBuffer& buf_work = parity ? c->ws_offsets_b : c->ws_offsets;
+  DeviceBuffer& buf_keys = parity ? c->ws_keys_c : c->ws_keys_a;
+  DeviceBuffer& buf_vals = parity ? c->ws_vals_c : c->ws_vals_a;
+  hipStream_t sa = s;
+  if (pipe >= 0) {
+    int prc = ensure_apply_stream(c);
+    if (prc != HG_OK) return prc;
+    sa = c->apply_stream;
+    // the buffers of this parity were last read by the apply pass of chunk pipe - 2
+    if (pipe >= 2) HG_HIP_CHECK(hipStreamWaitEvent(s, c->ev_apply[parity], 0));
+  }
   const size_t slots = static_cast<size_t>(records_per_level) * P.levels;
   int rc;
   // Apply work list, per level: one item per touched bin (a return touches at most kMaxRuns blocks)
@@ -2097,20 +2181,20 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
     for (int l = 0; l < P.levels; ++l) max_pool = std::max<size_t>(max_pool, P.lv[l].g.max_blocks);
     const size_t per_level = std::min<size_t>(static_cast<size_t>(n) * kMaxRuns, max_pool) +
                              records_per_level / 256u + 64u;
-    if ((rc = c->ws_offsets.reserve(sizeof(uint4) * per_level * P.levels)) != HG_OK) return rc;
+    if ((rc = buf_work.reserve(sizeof(uint4) * per_level * P.levels)) != HG_OK) return rc;
     for (int l = 0; l < P.levels; ++l) {
-      P.lv[l].g.work = c->ws_offsets.as<uint4>() + per_level * l;
+      P.lv[l].g.work = buf_work.as<uint4>() + per_level * l;
       P.lv[l].g.work_capacity = static_cast<uint32_t>(per_level);
     }
   }
-  if ((rc = c->ws_keys_a.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
-  if ((rc = c->ws_vals_a.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
+  if ((rc = buf_keys.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
+  if ((rc = buf_vals.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
   const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
   if ((rc = c->ws_counts.reserve(sizeof(unsigned) * static_cast<size_t>(nwg_e) * kMaxInsLevels)) != HG_OK) return rc;
   if ((rc = c->ws_keys_b.reserve(sizeof(RunInfo) * n * P.levels)) != HG_OK) return rc;
   unsigned* wg_hits = c->ws_counts.as<unsigned>();
-  uint32_t* rk = c->ws_keys_a.as<uint32_t>();
-  uint32_t* rv = c->ws_vals_a.as<uint32_t>();
+  uint32_t* rk = buf_keys.as<uint32_t>();
+  uint32_t* rv = buf_vals.as<uint32_t>();
   RunInfo* runs = c->ws_keys_b.as<RunInfo>();
   {
     ProfScope ps(c, HG_K_RAY_COUNT, n * P.levels);
@@ -2129,8 +2213,16 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
                        static_cast<unsigned>(n), runs, rk, rv);
   }
   HG_HIP_CHECK(hipGetLastError());
+  if (pipe >= 0) {
+    if (want_stats) {  // wg_hits is reused by the next chunk's front end: sum on the front stream
+      hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, nullptr, 0u);
+      HG_HIP_CHECK(hipGetLastError());
+    }
+    HG_HIP_CHECK(hipEventRecord(c->ev_front[parity], s));
+    HG_HIP_CHECK(hipStreamWaitEvent(sa, c->ev_front[parity], 0));
+  }
   {
-    ProfScope ps(c, HG_K_APPLY, slots);
+    ProfScope ps(c, HG_K_APPLY, slots, 1, true, sa);
 #ifdef HG_BIN_STAMPS
     static long long* d_st = nullptr;
     if (!d_st) hipMalloc(reinterpret_cast<void**>(&d_st), 3 * 4096 * 8 * sizeof(long long));
@@ -2189,10 +2281,14 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
       }
     }
 #else
-    hipLaunchKernelGGL(k_bin_apply, dim3(1024, P.levels), dim3(kBinThreads), 0, s, P, rk, rv);
+    hipLaunchKernelGGL(k_bin_apply, dim3(1024, P.levels), dim3(kBinThreads), 0, sa, P, rk, rv);
 #endif
   }
   HG_HIP_CHECK(hipGetLastError());
+  if (pipe >= 0) {
+    HG_HIP_CHECK(hipEventRecord(c->ev_apply[parity], sa));
+    return HG_OK;
+  }
   if (want_stats) {
     // hits from the per-workgroup counts; updates were written by k_bin_offsets
     hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, nullptr, 0u);
@@ -2376,6 +2472,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
     P.accumulate = 0;
     P.host_flags = c->async_flags;
     P.slice_records = count >= 4 ? 2048 : 512;
+    P.shared = 0;
     P.scan0.begin = 0;
     P.scan0.count = nj;
     std::memcpy(P.scan0.origin, origins + 3 * j, sizeof(P.scan0.origin));
@@ -2419,6 +2516,185 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
   HG_HIP_CHECK(hipGetLastError());
   return HG_OK;
 }
+
+namespace {
+
+// A stream of scans with known poses into ONE pyramid (hg_pyramid_insert_batch, exact binned path).
+// Scan after scan, the four insert kernels are each a short dependent chain that leaves most of the
+// chip idle. Here the FRONT ENDS (count, offsets, scatter) of a group of scans share their launches
+// (k_bin_*_jobs): they do not depend on the map's voxels, only the apply passes do. Every scan of a
+// group has its own bin arrays, touched list, work list and records, so the per-scan bins -- and with
+// them every voxel's update order -- are exactly those of scan-by-scan insertion. The apply passes
+// then run one launch per scan, in scan order. Per 100k-point scan the front end drops from 72 to
+// 29 us (groups of 8). Running the next group's front end NEXT TO the apply passes (second stream,
+// also with the front end confined to half of the CUs by a CU mask) was measured and dropped: the
+// apply pass slows down 2.5x under the front end's atomics and scattered writes, no net gain.
+int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins, const float* d_xyz,
+                          const uint64_t* scan_offsets, size_t n_scans, const float* poses_tq,
+                          bool want_stats) {
+  hipStream_t s = c->stream;
+  const int levels = P0.levels;
+  int group = 8;
+  if (const char* e = getenv("HG_STREAM_GROUP")) group = std::max(1, std::min(32, std::atoi(e)));
+  std::vector<size_t> scans;  // the non-empty scans
+  for (size_t i = 0; i < n_scans; ++i)
+    if (scan_offsets[i + 1] > scan_offsets[i]) scans.push_back(i);
+  const int count = static_cast<int>(scans.size());
+  if (count == 0) return HG_OK;
+  int rc;
+  // job table staging
+  const size_t table_bytes = static_cast<size_t>(count) * sizeof(InsertJob);
+  if (c->sjobs_pending) {
+    HG_HIP_CHECK(hipEventSynchronize(c->ev_sjobs));  // the previous call's table copy has left the staging
+    c->sjobs_pending = false;
+  }
+  if (!c->ev_sjobs) HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sjobs, hipEventDisableTiming));
+  if (c->sjobs_capacity < table_bytes) {
+    if (c->pinned_sjobs) (void)hipHostFree(c->pinned_sjobs);
+    c->pinned_sjobs = nullptr;
+    c->sjobs_capacity = 0;
+    HG_HIP_CHECK(hipHostMalloc(&c->pinned_sjobs, table_bytes + table_bytes / 2));
+    c->sjobs_capacity = table_bytes + table_bytes / 2;
+  }
+  InsertJob* jobs = static_cast<InsertJob*>(c->pinned_sjobs);
+  // workspace sizes: the largest group decides
+  size_t max_pool = 0, max_blocks = 0;
+  for (int l = 0; l < levels; ++l) {
+    max_pool = std::max<size_t>(max_pool, P0.lv[l].g.pool_blocks);
+    max_blocks = std::max<size_t>(max_blocks, P0.lv[l].g.max_blocks);
+  }
+  size_t rec_words = 0, run_items = 0, hit_words = 0, work_items = 0;
+  unsigned n_max = 0;
+  for (int g0 = 0; g0 < count; g0 += group) {
+    size_t rw = 0, ri = 0, hw = 0, wi = 0;
+    for (int j = g0; j < std::min(count, g0 + group); ++j) {
+      const unsigned long long nj = scan_offsets[scans[j] + 1] - scan_offsets[scans[j]];
+      n_max = std::max(n_max, static_cast<unsigned>(nj));
+      rw += nj * kSlots * levels;
+      ri += nj * levels;
+      hw += ((nj + 255u) / 256u) * kMaxInsLevels;
+      wi += (std::min<size_t>(nj * kMaxRuns, max_blocks) + nj * kSlots / 256u + 64u) * levels;
+    }
+    rec_words = std::max(rec_words, rw);
+    run_items = std::max(run_items, ri);
+    hit_words = std::max(hit_words, hw);
+    work_items = std::max(work_items, wi);
+  }
+  const size_t touched_cap = std::min<size_t>(static_cast<size_t>(n_max) * kMaxRuns, max_blocks) + 64u;
+  // shadow layout: [group][levels] call counters (4 words), then per (job slot, level)
+  // bin_count[pool], bin_offset[pool], touched[touched_cap]
+  const size_t call_words = static_cast<size_t>(group) * levels * 4u;
+  const size_t per_slot_level = 2u * max_pool + touched_cap;
+  const size_t shadow_words = call_words + per_slot_level * levels * group;
+  if ((rc = c->ws_keys_a.reserve(sizeof(uint32_t) * rec_words)) != HG_OK) return rc;
+  if ((rc = c->ws_vals_a.reserve(sizeof(uint32_t) * rec_words)) != HG_OK) return rc;
+  if ((rc = c->ws_offsets.reserve(sizeof(uint4) * work_items)) != HG_OK) return rc;
+  if ((rc = c->ws_keys_b.reserve(sizeof(RunInfo) * run_items)) != HG_OK) return rc;
+  if ((rc = c->ws_counts.reserve(sizeof(unsigned) * hit_words)) != HG_OK) return rc;
+  if ((rc = c->ws_sjobs.reserve(table_bytes)) != HG_OK) return rc;
+  if ((rc = c->ws_shadow.reserve(sizeof(uint32_t) * shadow_words)) != HG_OK) return rc;
+  if (c->shadow_zeroed != c->ws_shadow.ptr) {
+    // bin counts and call counters are all-zero between calls (k_bin_offsets restores that)
+    HG_HIP_CHECK(hipMemsetAsync(c->ws_shadow.ptr, 0, c->ws_shadow.bytes, s));
+    c->shadow_zeroed = c->ws_shadow.ptr;
+  }
+  uint32_t* shadow = c->ws_shadow.as<uint32_t>();
+  unsigned max_nwg_all = 0;
+  for (int j = 0; j < count; ++j) {
+    const int g = j / group, q = j % group;
+    const size_t i = scans[j];
+    const unsigned long long first = scan_offsets[i] - scan_offsets[0];
+    const unsigned nj = static_cast<unsigned>(scan_offsets[i + 1] - scan_offsets[i]);
+    InsertJob& J = jobs[j];
+    std::memset(&J, 0, sizeof(J));
+    J.n = nj;
+    J.nwg = (nj + 255u) / 256u;
+    max_nwg_all = std::max(max_nwg_all, J.nwg);
+    J.records_per_level = nj * kSlots;
+    J.xyz = d_xyz + 3 * first;
+    // offsets inside the group's buffers
+    size_t rec_off = 0, run_off = 0, hit_off = 0, work_off = 0;
+    for (int k = g * group; k < j; ++k) {
+      const unsigned long long nk = scan_offsets[scans[k] + 1] - scan_offsets[scans[k]];
+      rec_off += nk * kSlots * levels;
+      run_off += nk * levels;
+      hit_off += ((nk + 255u) / 256u) * kMaxInsLevels;
+      work_off += (std::min<size_t>(nk * kMaxRuns, max_blocks) + nk * kSlots / 256u + 64u) * levels;
+    }
+    J.rec_keys = c->ws_keys_a.as<uint32_t>() + rec_off;
+    J.rec_vals = c->ws_vals_a.as<uint32_t>() + rec_off;
+    J.runs = c->ws_keys_b.as<RunInfo>() + run_off;
+    J.wg_hits = c->ws_counts.as<unsigned>() + hit_off;
+    PyramidIns& P = J.P;
+    P = P0;
+    P.d_pose = nullptr;
+    P.accumulate = 1;
+    P.shared = 1;
+    P.slice_records = 0;
+    P.scan0.begin = 0;
+    P.scan0.count = nj;
+    std::memcpy(P.scan0.origin, origins + 3 * i, sizeof(P.scan0.origin));
+    if (poses_tq) std::memcpy(P.scan0.pose, poses_tq + 7 * i, sizeof(P.scan0.pose));
+    else std::memset(P.scan0.pose, 0, sizeof(P.scan0.pose));
+    const size_t per_level = std::min<size_t>(static_cast<size_t>(nj) * kMaxRuns, max_blocks) +
+                             static_cast<size_t>(nj) * kSlots / 256u + 64u;
+    for (int l = 0; l < levels; ++l) {
+      LevelIns& L = P.lv[l];
+      if (L.gate) L.gate += first;
+      L.g.work = c->ws_offsets.as<uint4>() + work_off + per_level * l;
+      L.g.work_capacity = static_cast<uint32_t>(per_level);
+      L.g.call = shadow + (static_cast<size_t>(q) * levels + l) * 4u;
+      uint32_t* base = shadow + call_words + (static_cast<size_t>(q) * levels + l) * per_slot_level;
+      L.g.bin_count = base;
+      L.g.bin_offset = base + max_pool;
+      L.g.touched = base + 2u * max_pool;
+    }
+  }
+  if (!P0.accumulate)  // hits and updates of this call start from zero; the jobs add to them
+    for (int l = 0; l < levels; ++l)
+      HG_HIP_CHECK(hipMemsetAsync(P0.lv[l].g.counters + 2, 0, 4 * sizeof(uint32_t), s));
+  const InsertJob* d_jobs = c->ws_sjobs.as<InsertJob>();
+  HG_HIP_CHECK(hipMemcpyAsync(c->ws_sjobs.ptr, jobs, table_bytes, hipMemcpyHostToDevice, s));
+  HG_HIP_CHECK(hipEventRecord(c->ev_sjobs, s));
+  c->sjobs_pending = true;
+  for (int g0 = 0; g0 < count; g0 += group) {
+    const int gn = std::min(group, count - g0);
+    unsigned max_nwg = 0;
+    unsigned long long units = 0;
+    for (int j = g0; j < g0 + gn; ++j) {
+      max_nwg = std::max(max_nwg, jobs[j].nwg);
+      units += static_cast<unsigned long long>(jobs[j].n) * levels;
+    }
+    {
+      ProfScope ps(c, HG_K_RAY_COUNT, units);
+      hipLaunchKernelGGL(k_bin_count_jobs, dim3(max_nwg, gn * levels), dim3(256), 0, s, d_jobs + g0, levels);
+    }
+    {
+      ProfScope ps(c, HG_K_SCAN, gn * levels);
+      hipLaunchKernelGGL(k_bin_offsets_jobs, dim3(gn * levels), dim3(1024), 0, s, d_jobs + g0, levels);
+    }
+    {
+      ProfScope ps(c, HG_K_RAY_EXPAND, units);
+      hipLaunchKernelGGL(k_bin_scatter_jobs, dim3(max_nwg, gn * levels), dim3(256), 0, s, d_jobs + g0, levels);
+    }
+    if (want_stats)
+      for (int j = g0; j < g0 + gn; ++j)
+        hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, jobs[j].P, jobs[j].wg_hits, jobs[j].nwg, nullptr, 0u);
+    HG_HIP_CHECK(hipGetLastError());
+    {
+      ProfScope ps(c, HG_K_APPLY, units * kSlots, static_cast<unsigned>(gn));
+#ifndef HG_BIN_STAMPS
+      for (int j = g0; j < g0 + gn; ++j)  // pyramid as kernel argument (scalar registers), as scan by scan
+        hipLaunchKernelGGL(k_bin_apply, dim3(1024, levels), dim3(kBinThreads), 0, s, jobs[j].P, jobs[j].rec_keys,
+                           jobs[j].rec_vals);
+#endif
+    }
+    HG_HIP_CHECK(hipGetLastError());
+  }
+  return HG_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -2572,6 +2848,26 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   size_t s0 = 0;
   int rc = HG_OK;
   bool chunk_launched = false;
+  // A call that carries a stream of scans (known poses) on the exact binned path:
+  //  - scans of >= 2^14 returns: front ends grouped, one apply launch per scan (insert_stream_grouped;
+  //    HG_STREAM_GROUP = scans per group, 0 = off);
+  //  - many small scans: multi-scan chunks of up to 2^17 returns, pipelined over two streams: front
+  //    end of chunk k + 1 next to the apply pass of chunk k (HG_INSERT_PIPELINE=0: one stream).
+  bool pipelined = false;
+  if (binned_ok && !fast && n_scans > 1 && n_total > (1ull << 17)) {
+    bool fits = true;  // every scan within the 23-bit seq of the binned records
+    for (size_t i = 0; i < n_scans; ++i)
+      if (scan_offsets[i + 1] - scan_offsets[i] >= (1ull << 20)) fits = false;
+    const char* ge = getenv("HG_STREAM_GROUP");
+    const char* pe = getenv("HG_INSERT_PIPELINE");
+    if (fits && n_total / n_scans >= (1ull << 14) && !(ge && ge[0] == '0')) {
+      rc = insert_stream_grouped(c, P, origins, d_xyz, scan_offsets, n_scans, poses_tq, stats != nullptr);
+      s0 = n_scans;  // done (or failed)
+    } else {
+      pipelined = fits && !(pe && pe[0] == '0');
+    }
+  }
+  int pipe_chunks = 0;
   while (s0 < n_scans && rc == HG_OK) {
     size_t s1 = s0;
     unsigned long long pts = 0;
@@ -2618,7 +2914,8 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
                                stats != nullptr);
       } else if (binned_ok && pts < (1ull << 20)) {
         rc = insert_chunk_binned(c, Pc, table.size() > 1 ? d_scans : nullptr, static_cast<uint32_t>(table.size()),
-                                 d_xyz + 3 * first, pts, stats != nullptr);
+                                 d_xyz + 3 * first, pts, stats != nullptr, pipelined ? pipe_chunks : -1);
+        if (pipelined && rc == HG_OK) ++pipe_chunks;
       } else if (fixed_ok) {
         const bool ws = stats != nullptr;
         if (key32 && unit_weight)
@@ -2636,6 +2933,8 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     }
     s0 = s1;
   }
+  if (pipe_chunks > 0)  // later work on the context's stream is ordered after the last apply pass
+    HG_HIP_CHECK(hipStreamWaitEvent(s, c->ev_apply[(pipe_chunks - 1) & 1], 0));
   if (rc != HG_OK) return rc;
   if (stats) {
     for (int l = 0; l < levels; ++l) {

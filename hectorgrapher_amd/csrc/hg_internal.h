@@ -82,6 +82,19 @@ struct hg_ctx {
   // insertion workspace
   hg::DeviceBuffer ws_points, ws_scan_table, ws_gate, ws_counts, ws_offsets, ws_keys_a, ws_keys_b,
       ws_vals_a, ws_vals_b, ws_temp, ws_misc, ws_filter, ws_jobs;
+  // second set of record / work-list buffers and the apply stream of the pipelined scan stream
+  // (insert_chunk_binned with `pipe`): the front end of scan k + 1 runs next to the apply pass of scan k
+  hg::DeviceBuffer ws_keys_c, ws_vals_c, ws_offsets_b;
+  // grouped scan stream (insert_stream_grouped): job table of the whole call (pinned staging + device
+  // copy; ev_sjobs marks the staging free again) and the per-scan bin arrays of the scans in flight
+  hg::DeviceBuffer ws_sjobs, ws_shadow;
+  void* shadow_zeroed = nullptr;  // ws_shadow.ptr when its zero-initialisation was enqueued
+  void* pinned_sjobs = nullptr;
+  size_t sjobs_capacity = 0;
+  hipEvent_t ev_sjobs = nullptr;
+  bool sjobs_pending = false;
+  hipStream_t apply_stream = nullptr;
+  hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr};
   const uint32_t* filter_idx = nullptr;  // results of the last voxel-filter call (device)
   const float* filter_xyz = nullptr;
   size_t filter_count = 0;
@@ -103,8 +116,10 @@ struct ProfScope {
   hipEvent_t stop = nullptr;
   // `launches` back-to-back launches of the same kernel may share one event pair (every event
   // costs ~4 us of stream serialisation); `enabled` = false makes the scope a no-op.
-  ProfScope(hg_ctx* ctx, int kernel, unsigned long long units, unsigned launches = 1, bool enabled = true)
-      : c(ctx) {
+  hipStream_t stream;
+  ProfScope(hg_ctx* ctx, int kernel, unsigned long long units, unsigned launches = 1, bool enabled = true,
+            hipStream_t on = nullptr)
+      : c(ctx), stream(on ? on : ctx->stream) {
     if (!c->prof_on || !enabled) return;
     ProfRecord r;
     r.kernel = kernel;
@@ -122,12 +137,12 @@ struct ProfScope {
     };
     r.start = get();
     r.stop = get();
-    (void)hipEventRecord(r.start, c->stream);
+    (void)hipEventRecord(r.start, stream);
     stop = r.stop;
     c->prof_records.push_back(r);
   }
   ~ProfScope() {
-    if (stop) (void)hipEventRecord(stop, c->stream);
+    if (stop) (void)hipEventRecord(stop, stream);
   }
 };
 }  // namespace hg
