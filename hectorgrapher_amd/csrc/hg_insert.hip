@@ -877,10 +877,9 @@ __device__ inline void wave_group(uint32_t slot, unsigned cnt, bool want, int* l
 // Bodies of the four kernels of the binned path, shared by the single-pyramid launches (pyramid in
 // the kernel arguments) and the batched launches (a table of jobs in device memory, one job = one
 // pyramid with its own scan: hg_register_scan_batch). `bx` of `nbx` = workgroup index inside the job.
-__device__ __forceinline__ void bin_count_body(const PyramidIns& P, int level, unsigned bx, unsigned nbx,
+__device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelIns& L, int level, unsigned bx, unsigned nbx,
                                                const ScanTable* scans, uint32_t n_scans, const float* xyz,
                                                unsigned n, RunInfo* runs, unsigned* wg_hits) {
-  const LevelIns& L = P.lv[level];
   const unsigned i = xcd_chunk(bx, nbx) * 256u + threadIdx.x;  // see hg_device.h
   const int lane = threadIdx.x & (kWave - 1);
   __shared__ unsigned s_hits, s_first, s_first_base;
@@ -979,13 +978,14 @@ struct InsertJob {
 
 __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
                                                    const float* xyz, unsigned n, RunInfo* runs, unsigned* wg_hits) {
-  bin_count_body(P, blockIdx.y, blockIdx.x, gridDim.x, scans, n_scans, xyz, n, runs, wg_hits);
+  bin_count_body(P, P.lv[blockIdx.y], blockIdx.y, blockIdx.x, gridDim.x, scans, n_scans, xyz, n, runs, wg_hits);
 }
 // grid (max nwg, jobs * levels)
 __global__ __launch_bounds__(256) void k_bin_count_jobs(const InsertJob* __restrict__ jobs, int levels) {
   const InsertJob& J = jobs[blockIdx.y / levels];
   if (blockIdx.x >= J.nwg) return;
-  bin_count_body(J.P, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.wg_hits);
+  const LevelIns L = J.P.lv[blockIdx.y % levels];  // a copy, see k_bin_apply_small_jobs
+  bin_count_body(J.P, L, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.wg_hits);
 }
 
 // ==========================================================================================
@@ -1314,8 +1314,7 @@ __device__ inline unsigned reserve_items(unsigned* counter, unsigned mine) {
   return __shfl(base, kWave - 1) + incl - mine;
 }
 
-__device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level, unsigned records_per_level) {
-  const LevelIns& L = P.lv[level];
+__device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const LevelIns& L, int level, unsigned records_per_level) {
   // a bin of more than `slice_records` records is cut into voxel slices of about that many records
   // each: 512 puts the long per-voxel chains of a heavy bin on as many workgroups as possible (one
   // registration chain: latency), 2048 = one LDS pass per slice reads every bin four times less often
@@ -1432,19 +1431,19 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, int level,
 }
 
 __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned records_per_level) {
-  bin_offsets_body(P, blockIdx.x, records_per_level);
+  bin_offsets_body(P, P.lv[blockIdx.x], blockIdx.x, records_per_level);
 }
 // grid (jobs * levels)
 __global__ __launch_bounds__(1024) void k_bin_offsets_jobs(const InsertJob* __restrict__ jobs, int levels) {
   const InsertJob& J = jobs[blockIdx.x / levels];
-  bin_offsets_body(J.P, blockIdx.x % levels, J.records_per_level);
+  const LevelIns L = J.P.lv[blockIdx.x % levels];
+  bin_offsets_body(J.P, L, blockIdx.x % levels, J.records_per_level);
 }
 
-__device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, int level, unsigned bx, unsigned nbx,
+__device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, const LevelIns& L, int level, unsigned bx, unsigned nbx,
                                                  const ScanTable* scans, uint32_t n_scans, const float* xyz,
                                                  unsigned n, const RunInfo* runs, uint32_t* rec_keys,
                                                  uint32_t* rec_vals) {
-  const LevelIns& L = P.lv[level];
   const unsigned i = xcd_chunk(bx, nbx) * 256u + threadIdx.x;
   if (i >= n) return;
   const RunInfo info = runs[static_cast<size_t>(level) * n + i];
@@ -1473,12 +1472,13 @@ __device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, int level,
 __global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
                                                      const float* xyz, unsigned n, const RunInfo* runs,
                                                      uint32_t* rec_keys, uint32_t* rec_vals) {
-  bin_scatter_body(P, blockIdx.y, blockIdx.x, gridDim.x, scans, n_scans, xyz, n, runs, rec_keys, rec_vals);
+  bin_scatter_body(P, P.lv[blockIdx.y], blockIdx.y, blockIdx.x, gridDim.x, scans, n_scans, xyz, n, runs, rec_keys, rec_vals);
 }
 __global__ __launch_bounds__(256) void k_bin_scatter_jobs(const InsertJob* __restrict__ jobs, int levels) {
   const InsertJob& J = jobs[blockIdx.y / levels];
   if (blockIdx.x >= J.nwg) return;
-  bin_scatter_body(J.P, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.rec_keys, J.rec_vals);
+  const LevelIns L = J.P.lv[blockIdx.y % levels];
+  bin_scatter_body(J.P, L, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.rec_keys, J.rec_vals);
 }
 
 // Bitonic sort of m (power of two) key/value pairs in LDS by all kBinThreads threads. Keys are
