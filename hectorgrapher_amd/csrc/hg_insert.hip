@@ -493,7 +493,7 @@ struct PyramidIns {
   int accumulate;        // not the first chunk of a call: hit / update counters add up
   uint32_t* host_flags;  // mapped pinned words [kMaxInsLevels]: sticky error flags of calls that do not
                          // read their stats back (written only when a flag is set)
-  int slice_records;     // records per voxel slice of a large bin (0 = 512), see k_bin_offsets
+  int slice_records;     // records per voxel slice of a large bin (0 = by bin size), see k_bin_offsets
   int shared;            // several scans in flight on the same grids (scan stream): per-call statistics are
                          // added atomically
 };
@@ -1315,11 +1315,14 @@ __device__ inline unsigned reserve_items(unsigned* counter, unsigned mine) {
 }
 
 __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const LevelIns& L, int level, unsigned records_per_level) {
-  // a bin of more than `slice_records` records is cut into voxel slices of about that many records
-  // each: 512 puts the long per-voxel chains of a heavy bin on as many workgroups as possible (one
-  // registration chain: latency), 2048 = one LDS pass per slice reads every bin four times less often
-  // (batched registration: throughput)
-  const unsigned slice_records = P.slice_records ? static_cast<unsigned>(P.slice_records) : 512u;
+  // A large bin is cut into voxel slices (voxels are independent). Single registration chain
+  // (slice_records = 0, latency): bins of up to 2048 records stay one item (one LDS pass), up to 4096
+  // records slices of 1024, beyond that slices of 512 records -- the long per-voxel chains of a heavy
+  // bin then sit on as many workgroups as possible, while the many mid-size bins are not read by four
+  // workgroups each (measured against 512 throughout: +2.5 % per registration step). Batched
+  // registration (slice_records = 2048, throughput): one LDS pass per slice, every bin read four times
+  // less often.
+  const unsigned slice_records = P.slice_records > 0 ? static_cast<unsigned>(P.slice_records) : 512u;
   __shared__ unsigned s_scan[16];
   __shared__ unsigned s_base, s_work, s_large;
   const unsigned nt = L.g.call[0];
@@ -1363,7 +1366,8 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
       const bool emit = i < nt && ((round == 0) == large);
       unsigned slices = emit ? 1u : 0u;
-      while (emit && slices < 128 && cnt > slices * slice_records) slices <<= 1;  // 1 slice while cnt <= slice_records
+      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt <= 2048u ? 2048u : (cnt < 4096u ? 1024u : 512u));
+      while (emit && slices < 128 && cnt > slices * per_slice) slices <<= 1;  // 1 slice while cnt <= per_slice
       const unsigned w0 = reserve_items(&s_work, slices);
       if (emit) {
         const unsigned step = 512u / slices;
@@ -1398,7 +1402,8 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
       const bool emit = i < nt && ((round == 0) == large);
       unsigned slices = emit ? 1u : 0u;
-      while (emit && slices < 128 && cnt > slices * slice_records) slices <<= 1;  // 1 slice while cnt <= slice_records
+      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt <= 2048u ? 2048u : (cnt < 4096u ? 1024u : 512u));
+      while (emit && slices < 128 && cnt > slices * per_slice) slices <<= 1;  // 1 slice while cnt <= per_slice
       const unsigned w0 = reserve_items(&s_work, slices);
       if (emit) {
         const unsigned step = 512u / slices;
@@ -2471,7 +2476,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
     P.d_pose = d_poses[j];
     P.accumulate = 0;
     P.host_flags = c->async_flags;
-    P.slice_records = count >= 4 ? 2048 : 512;
+    P.slice_records = count >= 4 ? 2048 : 0;
     P.shared = 0;
     P.scan0.begin = 0;
     P.scan0.count = nj;
