@@ -1316,10 +1316,11 @@ __device__ inline unsigned reserve_items(unsigned* counter, unsigned mine) {
 
 __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const LevelIns& L, int level, unsigned records_per_level) {
   // A large bin is cut into voxel slices (voxels are independent). Single registration chain
-  // (slice_records = 0, latency): bins of up to 2048 records stay one item (one LDS pass), up to 4096
-  // records slices of 1024, beyond that slices of 512 records -- the long per-voxel chains of a heavy
+  // (slice_records = 0, latency): bins below 4096 records are cut into slices of up to 2048 records
+  // (one LDS pass each), larger ones into slices of 512 records -- the long per-voxel chains of a heavy
   // bin then sit on as many workgroups as possible, while the many mid-size bins are not read by four
-  // workgroups each (measured against 512 throughout: +2.5 % per registration step). Batched
+  // to eight workgroups each (measured against 512 throughout: +3 % per registration step, +13 % on
+  // the scan stream; 1024 / 768 / 384 / 256-record slices and thresholds 3072 - 8192 were worse). Batched
   // registration (slice_records = 2048, throughput): one LDS pass per slice, every bin read four times
   // less often.
   const unsigned slice_records = P.slice_records > 0 ? static_cast<unsigned>(P.slice_records) : 512u;
@@ -1366,7 +1367,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
       const bool emit = i < nt && ((round == 0) == large);
       unsigned slices = emit ? 1u : 0u;
-      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt <= 2048u ? 2048u : (cnt < 4096u ? 1024u : 512u));
+      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < 4096u ? 2048u : 512u);
       while (emit && slices < 128 && cnt > slices * per_slice) slices <<= 1;  // 1 slice while cnt <= per_slice
       const unsigned w0 = reserve_items(&s_work, slices);
       if (emit) {
@@ -1402,7 +1403,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
       const bool emit = i < nt && ((round == 0) == large);
       unsigned slices = emit ? 1u : 0u;
-      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt <= 2048u ? 2048u : (cnt < 4096u ? 1024u : 512u));
+      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < 4096u ? 2048u : 512u);
       while (emit && slices < 128 && cnt > slices * per_slice) slices <<= 1;  // 1 slice while cnt <= per_slice
       const unsigned w0 = reserve_items(&s_work, slices);
       if (emit) {
