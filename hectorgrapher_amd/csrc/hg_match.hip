@@ -666,7 +666,8 @@ template <int THREADS = kEvalThreads>
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
-    double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64], unsigned wg) {
+    double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64], unsigned wg,
+    const double* pose_tq = nullptr /* the transform when it does not come from xf (first launch) */) {
   const unsigned i = wg * THREADS + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   BODY_STAMP(0);
@@ -674,7 +675,8 @@ __device__ __forceinline__ void tsdf_residuals_body(
   if (i < n) {
     const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
                          static_cast<double>(xyz[3 * i + 2])};
-    return_row(pv, dp, xf->t, xf->q, v, scaling, row8);
+    if (pose_tq) return_row(pv, dp, pose_tq, pose_tq + 3, v, scaling, row8);
+    else return_row(pv, dp, xf->t, xf->q, v, scaling, row8);
     if (residuals) residuals[i] = row8[7];
   }
   BODY_STAMP(4);
@@ -1788,8 +1790,9 @@ __device__ unsigned long long g_tail_stamps[8];
 #endif
 __device__ inline int b6(int i, int j) { return i * 6 + 5 - (i - j); }  // band_index(i, j, W = 6), j <= i
 
+template <bool FIRST = false>
 __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, BlockXform* xf, const double* partials,
-                               unsigned num_wg) {
+                               unsigned num_wg, const PinBox* host_up = nullptr, unsigned up_words = 0) {
   const int t = threadIdx.x;
   LmHead& gh = G->h;
   TAIL_STAMP(0);
@@ -1798,7 +1801,23 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   const int stripes0 = static_cast<int>(blockDim.x) / kAcc;
   LmHead& sh = *reinterpret_cast<LmHead*>(scratch + (stripes0 + 1) * kAcc);
   double* sH = reinterpret_cast<double*>(&sh + 1);
-  {
+  constexpr int kUp = 3;  // mailbox words per thread (512-thread workgroups)
+  static_assert(sizeof(LmHead) / 8 <= kUp * kEvalThreads, "head upload");
+  unsigned long long up_val[FIRST ? kUp : 1];
+  unsigned up_idx[FIRST ? kUp : 1];
+  if (FIRST) {
+    // the head arrives as its non-zero words in the host's mailbox: reads in flight now, scattered
+    // into the zeroed LDS head behind the first barrier below
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&sh);
+#pragma unroll
+    for (int u = 0; u < kUp; ++u) {
+      const unsigned w = t + u * blockDim.x;
+      up_idx[u] = w < up_words ? host_up->up_idx[w] : 0xFFFFFFFFu;
+      up_val[u] = w < up_words ? host_up->up_val[w] : 0ull;
+    }
+    for (unsigned i = t; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = 0ull;
+    if (t < 36) sH[t] = 0.0;
+  } else {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&gh);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&sh);
     for (unsigned i = t; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
@@ -1824,6 +1843,12 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
       scratch[j * kAcc + k] = acc;
     }
     __syncthreads();
+    if (FIRST) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&sh);
+#pragma unroll
+      for (int u = 0; u < kUp; ++u)
+        if (up_idx[u] < sizeof(LmHead) / 8) dst[up_idx[u]] = up_val[u];
+    }
     if (t < kAcc) {
       double sum = 0.0;
       for (int jj = 0; jj < stripes; ++jj) sum += scratch[jj * kAcc + t];
@@ -1831,6 +1856,13 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
     }
     __syncthreads();
     if (t >= kLmThreads) return;
+    if (FIRST) {
+      // the whole head goes to device memory for the following launches; the fields this step changes
+      // are stored again at the end by the same wavefront (stores of one wavefront stay in order)
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&sh);
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(&gh);
+      for (unsigned i = t; i < sizeof(LmHead) / 8; i += kLmThreads) dst[i] = src[i];
+    }
     scratch += stripes * kAcc;
   }
   TAIL_STAMP(1);
@@ -2378,12 +2410,24 @@ __global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
 // the register-resident LM step in the tail, in a kernel of its own so that its LDS footprint is
 // the X tiles (36 KB) instead of the general solver's working set (139 KB). (256-thread workgroups
 // — 391 of them, on all 256 CUs — were measured slower: twice the partials for the tail to sum.)
-template <int THREADS>
+// The first launch of a solve carries the initial pose and the mailbox of the solver head as
+// kernel arguments (FirstUpload): no separate upload kernel in front of the solve (it cost 5 us plus a
+// launch gap per registration). The workgroups take the transform from the arguments; the tail
+// builds the head from the mailbox words (one host-link round trip, in flight together with the
+// partial loads) and stores it to device memory for the following launches.
+struct FirstUpload {
+  double pose[7];
+  const PinBox* box;
+  unsigned up_words;
+  unsigned pad;
+};
+
+template <int THREADS, bool FIRST = false>
 __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* __restrict__ xyz, unsigned n,
                                             double scaling, const BlockXform* __restrict__ xf,
                                             double* __restrict__ partials, LmState* G, unsigned* ticket,
-                                            unsigned wg_index, unsigned num_wg) {
-  if (G->h.done) return;
+                                            unsigned wg_index, unsigned num_wg, const FirstUpload* up = nullptr) {
+  if (!FIRST && G->h.done) return;
 #ifdef HG_EVAL_STAMPS
   const int eval_it = G->h.iteration;
   if (threadIdx.x == 0 && blockIdx.x == 0) g_tail_stamps[7] = eval_it;
@@ -2395,7 +2439,7 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
   tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, partials, nullptr,
                                reinterpret_cast<double (*)[kWave][8]>(smem),
                                reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
-                               xcd_chunk(wg_index, num_wg));
+                               xcd_chunk(wg_index, num_wg), FIRST ? up->pose : nullptr);
   EVAL_STAMP(1);
   __shared__ int s_last;
   // hand-over of the partials without fences: sc1 stores drained here, one counted arrival per
@@ -2410,7 +2454,8 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
   __syncthreads();  // the arrival count has returned to wave 0 before any wave loads a partial
   if (!s_last) return;
   EVAL_STAMP(2);
-  lm_step_single(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), partials, num_wg);
+  lm_step_single<FIRST>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), partials, num_wg,
+                        FIRST ? up->box : nullptr, FIRST ? up->up_words : 0u);
   EVAL_STAMP(3);
 }
 
@@ -2419,6 +2464,13 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
     PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket) {
   single_eval<THREADS>(pv, xyz, n, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x);
+}
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_first(
+    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
+    const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket,
+    FirstUpload up) {
+  single_eval<THREADS, true>(pv, xyz, n, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x, &up);
 }
 
 // Several INDEPENDENT single-pose problems per launch (blockIdx.y = problem): each keeps its own
@@ -2779,7 +2831,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   return HG_OK;
 }
 
-int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
+int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm, bool first = false) {
   hipStream_t s = p->ctx->stream;
   const LmHead& S = p->h_state.h;
   if (S.num_small > 0) {
@@ -2796,8 +2848,18 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm) {
     const PyramidView& pv = p->h_pv[0];
     (void)hb;
     ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n, 1, !p->prof_grouped);
-    hipLaunchKernelGGL(k_tsdf_residuals_single<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
-                       hb.d_xyz, bi.n, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket);
+    if (first) {
+      FirstUpload up;
+      std::memcpy(up.pose, S.cand[0], sizeof(up.pose));
+      up.box = p->d_box;
+      up.up_words = p->up_words;
+      up.pad = 0;
+      hipLaunchKernelGGL(k_tsdf_residuals_single_first<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
+                         hb.d_xyz, bi.n, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket, up);
+    } else {
+      hipLaunchKernelGGL(k_tsdf_residuals_single<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
+                         hb.d_xyz, bi.n, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket);
+    }
     HG_HIP_CHECK(hipGetLastError());
     return HG_OK;
   }
@@ -3141,8 +3203,14 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
   p->solve_pending = true;
   if (S0.ncols == 0) return HG_OK;
   const int max_it = S0.opt.max_num_iterations;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
-  HG_HIP_CHECK(hipGetLastError());
+  // the single-pose registration shape uploads its head inside the first residual launch (FirstUpload)
+  const bool first_uploads = p->single_threads && S0.ncols == 6 && S0.bw == 5 && S0.num_blocks == 1 &&
+                             S0.blocks[0].active && S0.num_small == 0 && p->num_eval < 2 &&
+                             !std::getenv("HG_PREPARE_KERNEL");
+  if (!first_uploads) {
+    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
+    HG_HIP_CHECK(hipGetLastError());
+  }
   bool any_active = false;
   unsigned launches_per_it = 0;
   unsigned long long units_per_it = 0;
@@ -3167,7 +3235,7 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
     }
     if (any_active) {
       // residuals of every block at the candidate + (tail of the last workgroup) one LM step
-      rc = launch_eval(p, nullptr, true);
+      rc = launch_eval(p, nullptr, true, first_uploads && it == 0);
       if (rc != HG_OK) return rc;
     } else {
       ProfScope ps(p->ctx, HG_K_LM, 1);
