@@ -944,7 +944,7 @@ def run(args, out_fd=None):
         families[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved": gbs,
                           "frac": gbs / HBM_PEAK_GBS}
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/r02_profile.sh), not collected by this run", "kernel": dom,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per,
                 "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
                 "per_kernel_launches": {k: v[0] for k, v in prof.items()},

@@ -154,7 +154,7 @@ class HybridGridTSDF {
  public:
   HybridGridTSDF(Context* ctx, float resolution, float relative_truncation_distance, float max_weight,
                  uint32_t max_blocks = 1u << 18)
-      : resolution_(resolution) {
+      : resolution_(resolution), relative_truncation_distance_(relative_truncation_distance), max_weight_(max_weight) {
     Check(hg_grid_create(ctx->get(), resolution, relative_truncation_distance, max_weight, max_blocks, &grid_),
           "hg_grid_create");
   }
@@ -162,6 +162,8 @@ class HybridGridTSDF {
   HybridGridTSDF(const HybridGridTSDF&) = delete;
   HybridGridTSDF& operator=(const HybridGridTSDF&) = delete;
   float resolution() const { return resolution_; }
+  float relative_truncation_distance() const { return relative_truncation_distance_; }
+  float max_weight() const { return max_weight_; }
   std::array<int, 3> GetCellIndex(const Point& p) const {
     return {{static_cast<int>(std::lround(p[0] / resolution_)), static_cast<int>(std::lround(p[1] / resolution_)),
              static_cast<int>(std::lround(p[2] / resolution_))}};
@@ -187,7 +189,7 @@ class HybridGridTSDF {
   }
   hg_grid* get() const { return grid_; }
  private:
-  float resolution_;
+  float resolution_, relative_truncation_distance_, max_weight_;
   hg_grid* grid_ = nullptr;
 };
 

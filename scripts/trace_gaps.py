@@ -1,7 +1,7 @@
 """Diagnostic (not part of the product): where the GPU idles inside a registration step.
 
 Reads a rocprofv3 kernel trace (csv) of `python3 bench.py ...` and prints, for the last STEPS steps
-(a step starts at every launch of the marker kernel, default k_lm; third argument), busy and idle time per step and the idle time by (previous
+(a step starts at every launch of the marker kernel, default k_bin_count: the first kernel of an insertion; third argument), busy and idle time per step and the idle time by (previous
 kernel -> next kernel) pair.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/t -o t -- python3 bench.py --steps 20 --no-cpu-baseline
@@ -23,10 +23,10 @@ def main():
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    marker = sys.argv[3] if len(sys.argv) > 3 else "k_lm"
+    marker = sys.argv[3] if len(sys.argv) > 3 else "k_bin_count"
     starts = [i for i, r in enumerate(rows) if r[2] == marker]
     if len(starts) < steps + 1:
-        print("only", len(starts), "k_lm launches found")
+        print("only", len(starts), marker, "launches found")
         return
     first = starts[-steps - 1]
     last = starts[-1]

@@ -60,3 +60,38 @@ def test_cpp_local_trajectory_builder_example():
     assert flt, out.stdout
     n0, n1, n2 = (int(flt.group(i)) for i in (1, 2, 3))
     assert n0 == 61200 and 300 < n1 < 2000 and 150 <= n2 <= n1
+
+
+def _build_gather():
+    exe = os.path.join(CPP, "example_gather")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-D__HIP_PLATFORM_AMD__", "-DHG_WITH_RCCL",
+                               "-I/opt/rocm/include", os.path.join(CPP, "example_gather.cc"),
+                               "-L" + os.path.join(ROOT, "hectorgrapher_amd"), "-lhg_mi355x", "-L/opt/rocm/lib",
+                               "-lamdhip64", "-lrccl", "-Wl,-rpath," + os.path.join(ROOT, "hectorgrapher_amd"),
+                               "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_cpp_gather_two_ranks_on_one_gpu():
+    """hg_gather.h (the multi-GPU exchange step for a C++ host): two rank processes on this GPU map
+    their own submaps, rank 0 gathers both pyramids through the pipe transport, imports them into fresh
+    grids and finds their exports equal to the owners' (count + hash of cells and codes)."""
+    out = subprocess.run([_build_gather(), "pipe", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"^gather ok: ranks 2 levels 3 blocks (\d+) voxels (\d+)", out.stdout, re.M)
+    assert m, out.stdout
+    assert int(m.group(1)) > 500 and int(m.group(2)) > 50000
+    per_rank = re.findall(r"^rank (\d): (\d+) (\d+) (\d+) blocks", out.stdout, re.M)
+    assert [r[0] for r in per_rank] == ["0", "1"]
+    assert all(int(r[1]) > int(r[2]) > int(r[3]) > 0 for r in per_rank)   # finer levels hold more blocks
+
+
+def test_cpp_gather_rccl_transport_single_rank():
+    """The RCCL transport of the same example with a one-rank communicator: ncclCommInitRank,
+    all-gather of the counts and the import / export check of rank 0's own pyramid run through RCCL
+    (peers need more GPUs than this box has; the driver's multi-GPU node runs those)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([_build_gather(), "rccl"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert re.search(r"^gather ok: ranks 1 levels 3", out.stdout, re.M), out.stdout
