@@ -783,6 +783,7 @@ __global__ void k_sum_stats(PyramidIns P, const unsigned* wg_hits, unsigned n_ex
 constexpr int kBinCap = 2048;       // records per LDS pass of k_bin_apply (4 per thread)
 constexpr int kBinThreads = 512;    // one thread per voxel of a block
 constexpr unsigned kSmallBin = 512; // a bin of at most this many records is one wavefront's work (k_bin_apply_small)
+constexpr unsigned kSmallBinInKernel = 256;  // the same inside k_bin_apply
 constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
 
 enum : uint32_t { kFlagBinOverflow = 8u, kFlagWorkOverflow = 16u };
@@ -1324,6 +1325,9 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
   // registration (slice_records = 2048, throughput): one LDS pass per slice, every bin read four times
   // less often.
   const unsigned slice_records = P.slice_records > 0 ? static_cast<unsigned>(P.slice_records) : 512u;
+  // one wavefront per small bin: inside k_bin_apply (eight per workgroup, LDS for 256 records each) or,
+  // batched registration, in k_bin_apply_small_jobs (512 records)
+  const unsigned small_cap = P.slice_records == 0 ? kSmallBinInKernel : kSmallBin;
   __shared__ unsigned s_scan[16];
   __shared__ unsigned s_base, s_work, s_large;
   const unsigned nt = L.g.call[0];
@@ -1364,7 +1368,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       } else if (i < nt) {
         bin_off = L.g.bin_offset[slot];  // written by this thread in round 0
       }
-      const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
+      const bool large = cnt > small_cap;  // smaller bins are whole-bin items for one wavefront each
       const bool emit = i < nt && ((round == 0) == large);
       unsigned slices = emit ? 1u : 0u;
       const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < 4096u ? 2048u : 512u);
@@ -1400,7 +1404,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       } else if (i < nt) {
         bin_off = L.g.bin_offset[slot];  // written by this thread in round 0
       }
-      const bool large = cnt > kSmallBin;  // whole bins of <= kSmallBin records go to k_bin_apply_small
+      const bool large = cnt > small_cap;  // smaller bins are whole-bin items for one wavefront each
       const bool emit = i < nt && ((round == 0) == large);
       unsigned slices = emit ? 1u : 0u;
       const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < 4096u ? 2048u : 512u);
@@ -1426,7 +1430,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
   if (threadIdx.x == 0) {
     // items [call[2], call[1]) are whole bins for k_bin_apply_small (batched inserts); one
     // registration chain keeps them in k_bin_apply: a second kernel behind it costs more than it saves
-    L.g.call[2] = min(P.slice_records >= 2048 ? s_large : s_work, L.g.work_capacity);
+    L.g.call[2] = min((P.slice_records >= 2048 || P.slice_records == 0) ? s_large : s_work, L.g.work_capacity);
     L.g.call[1] = min(s_work, L.g.work_capacity);  // consumed by k_bin_apply
     L.g.call[0] = 0;                               // next call collects from scratch
     unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
@@ -1529,17 +1533,21 @@ __device__ inline void wave_sync_lds() {  // lanes of ONE wavefront exchanging d
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// CAP = records the bin may hold (512, or 256 inside k_bin_apply where eight wavefronts share the
+// workgroup's LDS); lds: 512 + 3 * CAP words.
+template <unsigned CAP>
 __device__ inline void apply_small_bin(const GridView& g, float maximum_weight, uint32_t slot, unsigned n,
                                        const uint32_t* __restrict__ bk, const uint32_t* __restrict__ bv,
                                        uint32_t* lds) {
   const unsigned lane = threadIdx.x & (kWave - 1);
   uint32_t* cb = lds;                 // per voxel: count (after the scan: count | base << 16)
-  uint32_t* gk = lds + kSmallBin;     // records grouped by voxel; later the list of non-empty voxels
-  uint32_t* gv = gk + kSmallBin;
-  uint32_t* sv = gv + kSmallBin;      // values in (voxel, seq) order
-  constexpr unsigned kPer = kSmallBin / kWave;  // 8
+  uint32_t* gk = lds + kVoxelsPerBlock;  // records grouped by voxel; later the list of non-empty voxels
+  uint32_t* gv = gk + CAP;
+  uint32_t* sv = gv + CAP;            // values in (voxel, seq) order
+  constexpr unsigned kPer = CAP / kWave;              // records per lane
+  constexpr unsigned kVox = kVoxelsPerBlock / kWave;  // voxels per lane: 8
 #pragma unroll
-  for (unsigned i = 0; i < kPer; ++i) cb[lane + kWave * i] = 0u;
+  for (unsigned i = 0; i < kVox; ++i) cb[lane + kWave * i] = 0u;
   wave_sync_lds();
   uint32_t k[kPer];
 #pragma unroll
@@ -1553,10 +1561,10 @@ __device__ inline void apply_small_bin(const GridView& g, float maximum_weight, 
   wave_sync_lds();
   // exclusive scan over the 512 counts: lane l owns voxels [8 l, 8 l + 8)
   {
-    uint32_t c[kPer];
+    uint32_t c[kVox];
     unsigned sum = 0;
 #pragma unroll
-    for (unsigned j = 0; j < kPer; ++j) { c[j] = cb[kPer * lane + j]; sum += c[j]; }
+    for (unsigned j = 0; j < kVox; ++j) { c[j] = cb[kVox * lane + j]; sum += c[j]; }
     unsigned incl = sum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -1565,7 +1573,7 @@ __device__ inline void apply_small_bin(const GridView& g, float maximum_weight, 
     }
     unsigned run = incl - sum;
 #pragma unroll
-    for (unsigned j = 0; j < kPer; ++j) { cb[kPer * lane + j] = c[j] | (run << 16); run += c[j]; }
+    for (unsigned j = 0; j < kVox; ++j) { cb[kVox * lane + j] = c[j] | (run << 16); run += c[j]; }
   }
   wave_sync_lds();
   // group by voxel: the base half of the voxel's word doubles as its cursor (it ends at base + count)
@@ -1612,7 +1620,7 @@ __device__ inline void apply_small_bin(const GridView& g, float maximum_weight, 
   {
     unsigned mine = 0;
 #pragma unroll
-    for (unsigned j = 0; j < kPer; ++j) mine += (cb[kPer * lane + j] & 0xFFFFu) ? 1u : 0u;
+    for (unsigned j = 0; j < kVox; ++j) mine += (cb[kVox * lane + j] & 0xFFFFu) ? 1u : 0u;
     unsigned incl = mine;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -1622,8 +1630,8 @@ __device__ inline void apply_small_bin(const GridView& g, float maximum_weight, 
     m = __shfl(incl, kWave - 1);
     unsigned pos = incl - mine;
 #pragma unroll
-    for (unsigned j = 0; j < kPer; ++j)
-      if (cb[kPer * lane + j] & 0xFFFFu) gk[pos++] = kPer * lane + j;
+    for (unsigned j = 0; j < kVox; ++j)
+      if (cb[kVox * lane + j] & 0xFFFFu) gk[pos++] = kVox * lane + j;
   }
   wave_sync_lds();
   uint32_t* vox = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock;
@@ -1649,8 +1657,8 @@ __device__ __forceinline__ void bin_apply_small_body(const LevelIns& L, unsigned
   const unsigned wave = threadIdx.x / kWave;
   for (unsigned idx = n_large + bx * (kSmallThreads / kWave) + wave; idx < nwork; idx += gstride * (kSmallThreads / kWave)) {
     const uint4 it = g.work[idx];
-    apply_small_bin(g, L.p.maximum_weight, it.x, it.z, rec_keys + it.w, rec_vals + it.w,
-                    smem + wave * 4 * kSmallBin);
+    apply_small_bin<kSmallBin>(g, L.p.maximum_weight, it.x, it.z, rec_keys + it.w, rec_vals + it.w,
+                               smem + wave * 4 * kSmallBin);
   }
 }
 // grid (G, jobs * levels)
@@ -1667,19 +1675,25 @@ __global__ __launch_bounds__(kSmallThreads) void k_bin_apply_small_jobs(const In
 // the level's grid-stride loop over its work items.
 __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order, unsigned bx, unsigned gstride,
                                                const uint32_t* __restrict__ rec_keys,
-                                               const uint32_t* __restrict__ rec_vals
+                                               const uint32_t* __restrict__ rec_vals, bool small_in_kernel
 #ifdef HG_BIN_STAMPS
                                                , long long* stamps
 #endif
                                                ) {
   const GridView& g = L.g;
-  __shared__ unsigned hist[512];      // records per voxel (inside the item's voxel range)
-  __shared__ unsigned base[512];      // exclusive prefix of hist
-  __shared__ unsigned cursor[512];
-  __shared__ uint32_t gk[kBinCap];    // grouped by voxel, arbitrary order inside a group
-  __shared__ uint32_t gv[kBinCap];
-  __shared__ uint32_t sv[kBinCap];    // values in (voxel, seq) order
-  __shared__ uint32_t tk[kBinCap];    // keys of the slice's records as read (compact list)
+  // one LDS pool, laid out for a workgroup item (3 x 512 + 4 x kBinCap words) or for eight small bins
+  // (one per wavefront, 512 + 3 x 256 words each)
+  constexpr unsigned kSmallWords = kVoxelsPerBlock + 3u * kSmallBinInKernel;
+  constexpr unsigned kItemWords = 3u * 512u + 4u * kBinCap;
+  constexpr unsigned kPoolWords = kItemWords > (kBinThreads / kWave) * kSmallWords ? kItemWords : (kBinThreads / kWave) * kSmallWords;
+  __shared__ uint32_t pool[kPoolWords];
+  unsigned* hist = pool;              // records per voxel (inside the item's voxel range)
+  unsigned* base = pool + 512;        // exclusive prefix of hist
+  unsigned* cursor = pool + 1024;
+  uint32_t* gk = pool + 1536;         // grouped by voxel, arbitrary order inside a group
+  uint32_t* gv = gk + kBinCap;
+  uint32_t* sv = gv + kBinCap;        // values in (voxel, seq) order
+  uint32_t* tk = sv + kBinCap;        // keys of the slice's records as read (compact list)
   uint32_t* tv = sv;                  // their values: sv is free until the rank step
   __shared__ unsigned s_hi, s_m;
   const unsigned nwork = min(g.call[2], g.call[1]);  // the slices of large bins; whole bins: k_bin_apply_small
@@ -1938,6 +1952,19 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
     __syncthreads();
     BIN_STAMP(5);
   }
+  if (small_in_kernel) {
+    // the whole small bins of the level, one wavefront each: most touched blocks of a scan are of
+    // this kind (65 % / 45 % of the bins at 0.05 / 0.10 m hold <= 256 records), and as 512-thread
+    // items they queued for workgroup slots with a dozen barriers around a few hundred records
+    const unsigned n_all = g.call[1];
+    const unsigned wave = tid / kWave;
+    constexpr unsigned kWaves = kBinThreads / kWave;
+    for (unsigned idx = nwork + bx * kWaves + wave; idx < n_all; idx += gstride * kWaves) {
+      const uint4 it = g.work[idx];
+      apply_small_bin<kSmallBinInKernel>(g, L.p.maximum_weight, it.x, it.z, rec_keys + it.w, rec_vals + it.w,
+                                         pool + wave * kSmallWords);
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
@@ -1948,7 +1975,8 @@ __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply(PyramidIns P, cons
                                                           ) {
   // workgroups are dispatched in index order: the last (coarsest) level has the longest per-voxel
   // chains, so it goes first
-  bin_apply_body(P.lv[P.levels - 1 - blockIdx.y], blockIdx.y, blockIdx.x, gridDim.x, rec_keys, rec_vals
+  bin_apply_body(P.lv[P.levels - 1 - blockIdx.y], blockIdx.y, blockIdx.x, gridDim.x, rec_keys, rec_vals,
+                 P.slice_records == 0
 #ifdef HG_BIN_STAMPS
                  , stamps
 #endif
@@ -1960,7 +1988,7 @@ __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply_jobs(const InsertJ
   const InsertJob& J = jobs[blockIdx.y % njobs];
   const unsigned order = blockIdx.y / njobs;
   const LevelIns L = J.P.lv[J.P.levels - 1 - order];  // a copy, see k_bin_apply_small_jobs
-  bin_apply_body(L, order, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals);
+  bin_apply_body(L, order, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals, J.P.slice_records == 0);
 }
 #endif
 
