@@ -203,20 +203,33 @@ int hg_ctx_create(int device, void* stream, hg_ctx** out) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {
     // Contexts of one process (a host thread per trajectory, each with its context) must not share a
-    // hardware queue: HIP deals its streams onto a small pool of them (GPU_MAX_HW_QUEUES, 4 by default)
-    // and two streams that land on the same one run strictly one after the other -- two threads
-    // measured 0.98x of one thread, three 1.8x, depending on creation order. Every priority level has
-    // its own pool, so successive contexts take successive priority levels (2 threads: 1.57x). The
-    // levels only order work that competes for the same CUs; HG_STREAM_PRIORITY=<n> pins one instead.
-    hipError_t e;
+    // hardware queue: HIP deals its streams onto a small pool of them (GPU_MAX_HW_QUEUES, 4 by default,
+    // per priority level) and two streams that land on the same one run strictly one after the other --
+    // measured with four C++ host threads: two of them at half the speed of the others, 1.4x of one
+    // thread in total, whichever priorities the streams had. A stream created with a CU mask gets a
+    // hardware queue of its own, so every context takes one with ALL CUs enabled (four threads: 2.2x,
+    // all at the same pace). HG_STREAM_PRIORITY=<n> asks for an ordinary stream of that priority
+    // instead; that is also the fallback (successive contexts then take successive priority levels,
+    // whose queue pools are separate).
+    hipError_t e = hipErrorUnknown;
     {
       static std::atomic<int> counter{0};
       int least = 0, greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       const int span = least - greatest + 1;
       int prio = greatest + (span > 0 ? counter++ % span : 0);
-      if (const char* pin = std::getenv("HG_STREAM_PRIORITY")) prio = std::atoi(pin);
-      e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
+      const char* pin = std::getenv("HG_STREAM_PRIORITY");
+      if (pin) prio = std::atoi(pin);
+      if (!pin) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+          std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
+          for (int cu = 0; cu < prop.multiProcessorCount; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+          e = hipExtStreamCreateWithCUMask(&c->stream, static_cast<uint32_t>(mask.size()), mask.data());
+          if (e != hipSuccess) (void)hipGetLastError();
+        }
+      }
+      if (e != hipSuccess) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
       if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     }
     if (e != hipSuccess) {

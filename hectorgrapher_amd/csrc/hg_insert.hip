@@ -2160,16 +2160,19 @@ int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans,
 }
 
 // ---- binned path (single scan, unit weight) ------------------------------------------------
-// The apply stream of a pipelined scan stream, created on first use. It gets a priority level other
-// than the context's stream so that the two do not share a hardware queue (see hg_ctx_create).
+// The apply stream of a pipelined scan stream, created on first use: a stream with a CU mask of all
+// CUs, which gets a hardware queue of its own (see hg_ctx_create); ordinary streams may share one
+// with the context's stream and then run strictly after it.
 int ensure_apply_stream(hg_ctx* c) {
   if (c->apply_stream) return HG_OK;
-  int least = 0, greatest = 0, mine = 0;
-  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  (void)hipStreamGetPriority(c->stream, &mine);
-  int prio = mine == greatest ? std::min(least, greatest + 1) : greatest;
-  if (const char* pin = std::getenv("HG_APPLY_PRIORITY")) prio = std::atoi(pin);
-  hipError_t e = hipStreamCreateWithPriority(&c->apply_stream, hipStreamNonBlocking, prio);
+  hipError_t e = hipErrorUnknown;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) {
+    std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
+    for (int cu = 0; cu < prop.multiProcessorCount; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+    e = hipExtStreamCreateWithCUMask(&c->apply_stream, static_cast<uint32_t>(mask.size()), mask.data());
+    if (e != hipSuccess) (void)hipGetLastError();
+  }
   if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->apply_stream, hipStreamNonBlocking);
   HG_HIP_CHECK(e);
   for (int i = 0; i < 2; ++i) {

@@ -3260,9 +3260,13 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
     // enqueued behind the solve (the insertion of hg_register_scan) keeps running meanwhile
     volatile unsigned long long* flag = &p->h_box->flag;
     bool arrived = false;
+    // the stream is queried (for errors, or a drained stream) only every 2^20 polls: the flag is what
+    // the host waits for
+    constexpr unsigned long long query_mask = 0xFFFFFull;
     for (unsigned long long spin = 0; !arrived; ++spin) {
       if (*flag == p->seq) { arrived = true; break; }
-      if ((spin & 0x3FFFu) == 0x3FFFu) {
+      __builtin_ia32_pause();
+      if ((spin & query_mask) == query_mask) {
         const hipError_t q = hipStreamQuery(s);
         if (q == hipSuccess) break;  // stream drained: decide below
         if (q != hipErrorNotReady) {

@@ -2,8 +2,8 @@
 runs a thread per trajectory: four threads registering 100k-point scans into their own submaps get
 through clearly more than one thread does, without the multi-millisecond stalls or the slower-than-one
 outcome round 1 saw (those were the Python collector inside the timed loop and contexts whose streams
-HIP had put on one hardware queue: hg_ctx_create now spreads contexts over the priority levels' queue
-pools). The steady-state gain saturates near 2x: the chains share one GPU."""
+HIP had put on one hardware queue: hg_ctx_create now gives every context a stream with a hardware queue
+of its own). The steady-state gain saturates near 2x: the chains share one GPU."""
 import os
 import re
 import subprocess
@@ -32,3 +32,29 @@ def test_threads_with_a_context_each_scale():
     assert gain2 > 1.2, gain2        # 0.98x when both streams shared a hardware queue; 1.5-1.6x measured
     assert gain4 > 1.35, gain4       # 1.8-1.9x measured
     assert worst2 < 10.0 and worst4 < 15.0   # no step of tens of milliseconds (ms)
+
+
+def test_cpp_host_threads_scale_and_keep_pace():
+    """A C++ host with one thread and one context per trajectory (the reference's deployment): every
+    context's stream has a hardware queue of its own (hg_ctx_create), so two threads reach > 1.5x and
+    four > 1.7x of one thread, and no thread runs at half the pace of the others (the symptom of two
+    streams sharing a queue: 0.83 vs 0.39 ms per step)."""
+    import re
+    cpp = os.path.join(ROOT, "hectorgrapher_amd", "cpp")
+    exe = os.path.join(cpp, "example_threads")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               os.path.join(cpp, "example_threads.cc"), "-L" + os.path.join(ROOT, "hectorgrapher_amd"),
+                               "-lhg_mi355x", "-L/opt/rocm/lib", "-lamdhip64",
+                               "-Wl,-rpath," + os.path.join(ROOT, "hectorgrapher_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                               "-o", exe])
+    out = subprocess.run([exe, "60"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = {int(m.group(1)): (float(m.group(2)), float(m.group(3)), [float(v) for v in m.group(4).split()])
+            for m in re.finditer(r"^threads (\d): \d+ scans/s .*?gain (\S+), max pose error (\S+) m; ms per step by thread:(.*)$",
+                                 out.stdout, re.M)}
+    assert set(rows) == {1, 2, 3, 4}, out.stdout
+    assert rows[2][0] > 1.5 and rows[4][0] > 1.7, out.stdout
+    for t, (gain, err, per_thread) in rows.items():
+        assert err < 0.02                                   # every trajectory still registers correctly
+        assert max(per_thread) < 1.35 * min(per_thread), out.stdout
