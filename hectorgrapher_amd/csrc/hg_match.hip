@@ -3492,12 +3492,10 @@ int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solv
   int rc = async_status(c);  // an insertion of an earlier step that failed reports here
   if (rc != HG_OK) return rc;
   bool batched = false;
-  const auto dbg0 = std::chrono::steady_clock::now();
   if (memspace == HG_DEVICE) {
     rc = solve_batch_enqueue(problems, count, sopts, &batched);
     if (rc != HG_OK) return rc;
   }
-  const auto dbg1 = std::chrono::steady_clock::now();
   if (!batched) {  // other problem shapes, host points, a single submap: one registration after the other
     for (int j = 0; j < count; ++j) {
       rc = hg_register_scan_mode(problems[j], sopts, pose_index[j], grids + j * levels, iopts, levels, origins + 3 * j,
@@ -3521,18 +3519,10 @@ int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solv
                                d_poses[j], HG_INSERT_EXACT, memspace, nullptr);
     }
   }
-  const auto dbg2 = std::chrono::steady_clock::now();
   for (int j = 0; j < count; ++j) {
     const int r2 = hg_problem_fetch(problems[j], summaries ? summaries + j : nullptr);
     if (rc == HG_OK) rc = r2;
     if (r2 == HG_OK && poses_out) std::memcpy(poses_out + 7 * j, problems[j]->poses[pose_index[j]].data(), sizeof(double) * 7);
-  }
-  if (std::getenv("HG_DEBUG_BATCH")) {
-    const auto dbg3 = std::chrono::steady_clock::now();
-    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    if (ms(dbg0, dbg3) > 3.0)
-      fprintf(stderr, "register_scan_batch: solve enqueue %.2f ms, insert enqueue %.2f ms, fetch %.2f ms\n", ms(dbg0, dbg1),
-              ms(dbg1, dbg2), ms(dbg2, dbg3));
   }
   return rc;
 }
