@@ -781,13 +781,25 @@ def run(args, out_fd=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1 or os.environ.get("HG_FORCE_DIST") == "1":
+    # one rank launched by torch.distributed.run (RANK / MASTER_ADDR set) still goes through RCCL: the
+    # gather and its import / export check then run at N = 1 too
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or launched or os.environ.get("HG_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        try:
+            if os.environ.get("HG_DIST_BACKEND") == "gloo":
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+        except Exception as e:
+            if world > 1:
+                raise
+            sys.stderr.write("process group of one rank not initialised (%r): running without it\n" % (e,))
+            dist = None
     from hectorgrapher_amd import api, synth
     from hectorgrapher_amd import distributed as hgd
 
@@ -837,8 +849,32 @@ def run(args, out_fd=None):
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    def steps(lo, hi, prof_every):
+        """Steps [lo, hi) in ONE library call (hg_register_scan_sequence: the loop a C++ host runs per scan;
+        the interpreter's per-step work and its GIL hand-overs stay out of the timed region). Kernel
+        durations are sampled with HIP events on every prof_every-th step: the residual family each time,
+        the insert kernels on every fifth of those (an event pair costs ~8 us of stream serialisation)."""
+        scans = [api.RangeData([0, 0, 0], d_scans[i]) for i in range(lo, hi)]
+        call = api.register_scan_sequence(problem, inserters, scans, guesses[lo:hi], grids, scale,
+                                          multi_res=True, prof_every=prof_every, prepare_only=True)
+
+        def collect(result):
+            poses, summ = result[0], result[1]
+            for k, i in enumerate(range(lo, hi)):
+                errs.append(float(np.linalg.norm(poses[k][:3] - query[i][0][:3])))
+                gpu_steps.append((poses[k].copy(), summ[k].num_iterations, summ[k].termination_type,
+                                  summ[k].termination_reason))
+                if prof_every > 0 and k % prof_every == 0:
+                    stats["evals"] += summ[k].num_cost_evaluations  # launches that evaluated (the rest exit early)
+        return call, collect
+
+    if os.environ.get("HG_BENCH_PYTHON_LOOP") == "1":
+        for i in range(args.warmup):
+            step(i)
+    else:
+        call, collect = steps(0, args.warmup, 0)
+        collect(call())
+    timed_call, timed_collect = steps(args.warmup, args.warmup + args.steps, args.prof_every)  # marshalled here
     stats = {"U": 0, "N_in": 0, "evals": 0}
     errs.clear()
     ctx.prof_reset()
@@ -848,14 +884,19 @@ def run(args, out_fd=None):
         sys.stdin.readline()
     t_start = time.time()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        # kernel durations are sampled with HIP events on every prof_every-th step of the timed region
-        sampling[0] = args.prof_every > 0 and (i - args.warmup) % args.prof_every == 0
-        ctx.prof_enable(sampling[0])
-        step(i)
+    if os.environ.get("HG_BENCH_PYTHON_LOOP") == "1":
+        for i in range(args.warmup, args.warmup + args.steps):
+            sampling[0] = args.prof_every > 0 and (i - args.warmup) % args.prof_every == 0
+            ctx.prof_enable(sampling[0])
+            step(i)
+        timed_result = None
+    else:
+        timed_result = timed_call()
     barrier()
     elapsed = time.perf_counter() - t0
     t_end = time.time()
+    if timed_result is not None:
+        timed_collect(timed_result)
     prof = ctx.prof_read()
     ctx.prof_enable(False)
     # accounting pass (untimed): N_in and U of one more scan of the same workload
@@ -866,7 +907,7 @@ def run(args, out_fd=None):
     stats["N_in"] = sum(a.num_hits for a in acc)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -877,7 +918,7 @@ def run(args, out_fd=None):
         try:
             barrier()
             tg = time.perf_counter()
-            gathered = hgd.gather_grids(grids, dist, rank, world, dev)
+            gathered = hgd.gather_grids(grids, dist, rank, world, dev, host=dist.get_backend() != "nccl")
             barrier()
             gather_ms = (time.perf_counter() - tg) * 1e3
             # rank 0 imports every peer's blocks into fresh grids; their export must equal the peer's own
@@ -949,7 +990,8 @@ def run(args, out_fd=None):
                 "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
                 "per_kernel_launches": {k: v[0] for k, v in prof.items()},
                 "families": families,
-                "hip_event_sampling": "every %d-th of the %d timed steps" % (max(1, args.prof_every), args.steps),
+                "hip_event_sampling": "residual family on every %d-th of the %d timed steps, insert kernels on every %d-th"
+                                      % (max(1, args.prof_every), args.steps, 5 * max(1, args.prof_every)),
                 "residual_launches_evaluating": active_share}
 
     out = {

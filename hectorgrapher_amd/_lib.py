@@ -34,7 +34,7 @@ SYMBOLS = [
     "hg_problem_add_unwarped_block",
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
     "hg_solver_default_opts", "hg_problem_solve", "hg_problem_solve_batch", "hg_problem_solve_async", "hg_problem_fetch",
-    "hg_register_scan", "hg_register_scan_mode", "hg_register_scan_batch", "hg_match_evaluate", "hg_match_solve",
+    "hg_register_scan", "hg_register_scan_mode", "hg_register_scan_batch", "hg_register_scan_sequence", "hg_match_evaluate", "hg_match_solve",
 ]
 
 
@@ -184,6 +184,7 @@ def load():
     L.hg_register_scan_mode.argtypes = [vp, P(SolverOpts), i32, vp, vp, i32, vp, vp, sz, sz, i32, i32, vp,
                                         P(SolverSummary)]
     L.hg_register_scan_batch.argtypes = [vp, i32, P(SolverOpts), vp, vp, vp, i32, vp, vp, vp, sz, i32, vp, vp]
+    L.hg_register_scan_sequence.argtypes = [vp, P(SolverOpts), vp, vp, i32, i32, vp, vp, vp, vp, sz, i32, i32, vp, i32, i32, vp, vp]
     L.hg_match_evaluate.argtypes = [vp, vp, i32, i32, vp, sz, i32, f64, vp, vp, f64, vp, vp, vp, vp]
     L.hg_match_solve.argtypes = [vp, vp, i32, i32, vp, sz, i32, f64, vp, vp, i32, f64,
                                  P(SolverOpts), P(SolverSummary)]

@@ -581,6 +581,46 @@ def register_scan_batch(problems, pose_indices, inserters, scans, pyramids, **so
     return poses, list(summ)
 
 
+def register_scan_sequence(problem, inserters, scans, guesses, pyramid, scaling, multi_res=True, prof_every=0,
+                           prepare_only=False, **solver_kw):
+    """hg_register_scan_sequence: len(scans) registration steps of ONE trajectory in one call (step k:
+    one free pose = guesses[k], one block over scans[k] with scaling[k], solve, insert at the solved
+    pose). Returns (poses [count, 7], summaries). The per-step interpreter work of calling
+    register_scan in a loop stays out of the way. prepare_only=True marshals the arguments and returns a
+    function that makes the call (a benchmark keeps the marshalling out of its timed region)."""
+    L = _lib.load()
+    o = SolverOpts()
+    L.hg_solver_default_opts(C.byref(o))
+    for k, v in solver_kw.items():
+        setattr(o, k, v)
+    count, n_l = len(scans), len(pyramid)
+    garr = (C.c_void_p * n_l)(*[g._h for g in pyramid])
+    opts = (InsertOpts * n_l)(*[i.options for i in inserters])
+    origins = np.ascontiguousarray([s_.origin for s_ in scans], np.float32).reshape(-1, 3)
+    device = all(_is_device(s_.returns) for s_ in scans)
+    keep = [s_.returns if device else _host(s_.returns, np.float32, 3) for s_ in scans]
+    ptrs = (C.c_void_p * max(1, count))(*[(r.data_ptr() if device else r.ctypes.data) for r in keep])
+    ns = (C.c_size_t * max(1, count))(*[int(r.shape[0]) for r in keep])
+    sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scaling, np.float64), (count,)))
+    gs = np.ascontiguousarray(guesses, np.float64).reshape(-1, 7)
+    poses = np.empty((count, 7), np.float64)
+    summ = (SolverSummary * max(1, count))()
+    mode = inserters[0].mode if hasattr(inserters[0], "mode") else _lib.HG_INSERT_EXACT
+    args = (problem._h, C.byref(o), garr, opts, n_l, 1 if multi_res else 0, _p(origins), ptrs, ns, _p(sc),
+            int(scans[0].width) if count else 0, _lib.HG_DEVICE if device else _lib.HG_HOST, int(mode), _p(gs), count,
+            int(prof_every), _p(poses), summ)
+    keep_alive = (o, garr, opts, origins, keep, ptrs, ns, sc, gs)
+
+    def run():
+        """The library call alone (arguments are marshalled already); returns (poses, summaries)."""
+        check(L.hg_register_scan_sequence(*args), "hg_register_scan_sequence")
+        return poses, list(summ)[:count], keep_alive
+
+    if prepare_only:
+        return run
+    return run()[:2]
+
+
 def from_seconds(seconds):
     """common::FromSeconds (common/time.cc:30-33): 100 ns ticks, truncated toward zero."""
     return int(float(seconds) * 1e7)

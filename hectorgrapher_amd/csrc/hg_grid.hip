@@ -291,7 +291,7 @@ int hg_prof_enable(hg_ctx* c, int on) {
   if (!c) return HG_ERR_INVALID;
   // only a flag: pending event pairs are resolved (stream synchronisation) by read / reset, so
   // sampling can be switched on and off between steps without stalling the stream
-  c->prof_on = on != 0;
+  c->prof_on = on == 2 ? 2 : (on != 0 ? 1 : 0);
   return HG_OK;
 }
 

@@ -71,7 +71,7 @@ inline uint64_t export_order_key(unsigned long long key) {
 
 struct hg_ctx {
   int device = 0;
-  bool prof_on = false;
+  int prof_on = 0;  // 0 off, 1 every kernel family, 2 the residual family only
   std::vector<hg::ProfRecord> prof_records;   // pending (not yet resolved)
   std::vector<hipEvent_t> prof_free_events;   // recycled events
   unsigned long long prof_launches[16] = {0};
@@ -121,6 +121,7 @@ struct ProfScope {
             hipStream_t on = nullptr)
       : c(ctx), stream(on ? on : ctx->stream) {
     if (!c->prof_on || !enabled) return;
+    if (c->prof_on == 2 && kernel != HG_K_RESIDUALS) return;
     ProfRecord r;
     r.kernel = kernel;
     r.units = units;

@@ -3527,6 +3527,28 @@ int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solv
   return rc;
 }
 
+int hg_register_scan_sequence(hg_problem* p, const hg_solver_opts* sopts, hg_grid* const* grids,
+                              const hg_insert_opts* iopts, int levels, int multi_res, const float* origins,
+                              const float* const* xyz, const size_t* n, const double* scaling, size_t width,
+                              int memspace, int insert_mode, const double* guesses, int count,
+                              int prof_every, double* poses_out, hg_solver_summary* summaries) {
+  if (!p || !grids || !iopts || !origins || !xyz || !n || !scaling || !guesses || count < 0) return HG_ERR_INVALID;
+  for (int k = 0; k < count; ++k) {
+    int rc = hg_problem_reset(p);
+    if (rc != HG_OK) return rc;
+    const int pi = hg_problem_add_pose(p, guesses + 7 * k, 0);
+    if (pi < 0) return pi;
+    rc = hg_problem_add_block(p, xyz[k], n[k], memspace, grids, levels, multi_res, scaling[k], pi, -1, 0.0);
+    if (rc != HG_OK) return rc;
+    if (prof_every > 0) p->ctx->prof_on = (k % prof_every) ? 0 : ((k % (5 * prof_every)) ? 2 : 1);
+    rc = hg_register_scan_mode(p, sopts, pi, grids, iopts, levels, origins + 3 * k, xyz[k], n[k], width, memspace,
+                               insert_mode, poses_out ? poses_out + 7 * k : nullptr, summaries ? summaries + k : nullptr);
+    if (rc != HG_OK) return rc;
+  }
+  if (prof_every > 0) p->ctx->prof_on = 0;
+  return HG_OK;
+}
+
 int hg_register_scan(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
                      hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
                      const float origin[3], const float* xyz, size_t n, size_t width, int memspace,

@@ -127,8 +127,8 @@ enum {
   HG_K_RAY_COUNT = 0, HG_K_RAY_EXPAND = 1, HG_K_SORT = 2, HG_K_ALLOC = 3, HG_K_APPLY = 4,
   HG_K_RESIDUALS = 5, HG_K_LM = 6, HG_K_SCAN = 7, HG_K_COUNT = 8
 };
-/* on != 0: bracket every launch of the kernels above with hipEvents (costs ~2 event records per
- * launch). hg_prof_read synchronises the stream and returns launches / summed milliseconds since
+/* on = 1: bracket every launch of the kernels above with hipEvents (costs ~2 event records per
+ * launch); on = 2: only the residual family (HG_K_RESIDUALS); 0: off. hg_prof_read synchronises the stream and returns launches / summed milliseconds since
  * the last hg_prof_reset; `units` sums the per-launch work items (points, records). */
 int hg_prof_enable(hg_ctx* ctx, int on);
 int hg_prof_reset(hg_ctx* ctx);
@@ -347,6 +347,22 @@ int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solv
                            const int* pose_index, hg_grid* const* grids, const hg_insert_opts* iopts,
                            int levels, const float* origins, const float* const* xyz, const size_t* n,
                            size_t width, int memspace, double* poses_out, hg_solver_summary* summaries);
+
+/* `count` registration steps of ONE trajectory, one after the other, in one call: what a C++
+ * LocalTrajectoryBuilder3D does per scan (AddRangeData: predicted pose -> scan match -> insert,
+ * local_trajectory_builder_3d.cc / optimizing_local_trajectory_builder.cc:1283,1437-1499) with the
+ * predictions given up front. Step k: problem reset, one free pose = guesses + 7 k, one
+ * [MultiResolution]TSDFSpaceCostFunction3D block over scan xyz[k] (n[k] returns, scaling[k]), solve,
+ * insert the scan at the solved pose (hg_register_scan). Results are those of calling the steps one by
+ * one; hosts whose per-step overhead matters (an interpreter) use this form. prof_every > 0: HIP-event
+ * sampling (hg_prof_*) is switched on for every prof_every-th step, for the residual family only
+ * except on every (5 prof_every)-th step, and off otherwise; 0 leaves the profiling state alone.
+ * poses_out: count x 7 or NULL; summaries: count entries or NULL. */
+int hg_register_scan_sequence(hg_problem* p, const hg_solver_opts* sopts, hg_grid* const* grids,
+                              const hg_insert_opts* iopts, int levels, int multi_res, const float* origins,
+                              const float* const* xyz, const size_t* n, const double* scaling, size_t width,
+                              int memspace, int insert_mode, const double* guesses, int count,
+                              int prof_every, double* poses_out, hg_solver_summary* summaries);
 
 /* ---- one-block convenience (CeresScanMatcher3D::{Evaluate,Match} shape) ----------------- */
 int hg_match_evaluate(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_res,

@@ -550,3 +550,40 @@ def test_register_scan_batch_equals_individual_registrations(po, hg, ctx):
     for o, g in zip(og, sets["batch"][0]):
         for x, y in zip(o.export(), g.export()):
             assert np.array_equal(x, y)
+
+
+def test_register_scan_sequence_equals_step_by_step(hg, ctx):
+    """hg_register_scan_sequence (the per-scan loop of a trajectory builder in one call) gives exactly what
+    calling the steps one by one gives: the same poses bit for bit, the same summaries, the same maps."""
+    import torch
+    dev = torch.device("cuda", 0)
+    res = [0.05, 0.10, 0.20]
+    rings, cols, steps = 16, 625, 5
+    sets = {name: [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 15) for r in res] for name in ("seq", "loop")}
+    ins = [hg.TSDFRangeDataInserter3D() for _ in res]
+    for k in range(3):
+        pose = synth.pose_k(k)
+        pts = synth.generate_scan(pose, rings, cols, stream=k)
+        for grids in sets.values():
+            hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), grids, pose_tq=pose.astype(np.float32))
+    scans, guesses = [], []
+    for k in range(3, 3 + steps):
+        pose = synth.pose_k(k)
+        scans.append(hg.RangeData([0, 0, 0], torch.from_numpy(synth.generate_scan(pose, rings, cols, stream=k)).to(dev)))
+        guesses.append(synth.pose_mul(pose, synth.perturbation()))
+    scale = 1.0 / np.sqrt(float(rings * cols))
+    ps, pl = hg.Problem(ctx), hg.Problem(ctx)
+    poses, summ = hg.register_scan_sequence(ps, ins, scans, guesses, sets["seq"], scale, multi_res=True)
+    for k in range(steps):
+        pl.reset()
+        pi = pl.add_pose(guesses[k])
+        pl.add_block(scans[k].returns, sets["loop"], scale, pi, multi_res=True)
+        est, s1 = hg.register_scan(pl, pi, ins, scans[k], sets["loop"])
+        assert np.array_equal(poses[k], est)
+        assert (summ[k].num_iterations, summ[k].num_successful_steps, summ[k].termination_type,
+                summ[k].termination_reason, summ[k].final_cost) == \
+               (s1.num_iterations, s1.num_successful_steps, s1.termination_type, s1.termination_reason, s1.final_cost)
+    for a, b in zip(sets["seq"], sets["loop"]):
+        a.status()
+        for x, y in zip(a.export(), b.export()):
+            assert np.array_equal(x, y)
