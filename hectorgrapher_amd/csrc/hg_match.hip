@@ -1867,7 +1867,7 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   }
   TAIL_STAMP(1);
   // --- solver state (uniform loads) ---
-  const hg_solver_opts opt = sh.opt;
+  const hg_solver_opts& opt = sh.opt;  // read from LDS where used: the step is short of registers
   PinBox* const box = sh.box;
   const unsigned long long seq = sh.seq;
   int iteration = sh.iteration, phase = sh.phase, step_is_successful = sh.step_is_successful;
@@ -1879,15 +1879,14 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   double radius = sh.radius, decrease_factor = sh.decrease_factor, x_cost = sh.x_cost;
   double model_cost_change = sh.model_cost_change, gradient_max = sh.gradient_max_norm;
   double initial_cost = sh.initial_cost;
-  double x[7], cand[7], scale[6], diagonal[6], g[6], H[21];
+  double x[7], cand[7], scale[6], diagonal[6], g[6];
+  // H (J^T J at x) stays in LDS (sH, band layout b6): 21 doubles fewer in registers -- the step kept
+  // more state than the 256 VGPRs hold and spilled 50 of them to scratch inside this serial path
+#define HX(i, j) sH[b6(i, j)]
 #pragma unroll
   for (int k = 0; k < 7; ++k) { x[k] = sh.x[0][k]; cand[k] = sh.cand[0][k]; }
 #pragma unroll
   for (int k = 0; k < 6; ++k) { scale[k] = sh.scale[k]; diagonal[k] = sh.diagonal[k]; g[k] = sh.g[k]; }
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j) H[i * (i + 1) / 2 + j] = sH[b6(i, j)];
 
   TAIL_STAMP(2);
   // A7 (symmetric 7 x 7), b7 = J^T r, c = r^T r from the 36 sums (constant indices after unrolling)
@@ -1968,11 +1967,13 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   TAIL_STAMP(3);
   if (phase == PHASE_INIT) {
 #pragma unroll
-    for (int i = 0; i < 21; ++i) H[i] = Hc[i];
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) HX(i, j) = Hc[i * (i + 1) / 2 + j];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       g[k] = gc[k];
-      scale[k] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[k * (k + 1) / 2 + k])) : 1.0;
+      scale[k] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(Hc[k * (k + 1) / 2 + k])) : 1.0;
     }
     ++num_cost_evals;
     ++num_jac_evals;
@@ -2007,7 +2008,9 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
     } else {
       if (accept) {
 #pragma unroll
-        for (int i = 0; i < 21; ++i) H[i] = Hc[i];
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) HX(i, j) = Hc[i * (i + 1) / 2 + j];
 #pragma unroll
         for (int k = 0; k < 6; ++k) g[k] = gc[k];
 #pragma unroll
@@ -2046,7 +2049,7 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
     if (!reuse_diagonal) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        const double sd = H[k * (k + 1) / 2 + k] * scale[k] * scale[k];
+        const double sd = HX(k, k) * scale[k] * scale[k];
         diagonal[k] = fmin(fmax(sd, opt.min_lm_diagonal), opt.max_lm_diagonal);
       }
     }
@@ -2067,7 +2070,7 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
       for (int b = 0; b <= a; ++b) {
-        double v = H[a * (a + 1) / 2 + b] * scale[a] * scale[b];
+        double v = HX(a, b) * scale[a] * scale[b];
         if (a == b) v += lm2[a];
         L[a][b] = v;
       }
@@ -2118,7 +2121,7 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           const int hi = a > b ? a : b, lo = a > b ? b : a;
-          row += H[hi * (hi + 1) / 2 + lo] * scale[a] * scale[b] * step[b];
+          row += HX(hi, lo) * scale[a] * scale[b] * step[b];
         }
         part += step[a] * (g[a] * scale[a]) + 0.5 * (step[a] * row);
       }
@@ -2171,7 +2174,7 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int j = 0; j <= i; ++j) G->H[b6(i, j)] = H[i * (i + 1) / 2 + j];
+        for (int j = 0; j <= i; ++j) G->H[b6(i, j)] = HX(i, j);
     }
     if (!done) {
 #pragma unroll
