@@ -1460,21 +1460,35 @@ __device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, const Leve
   if ((info.slot[0] | info.slot[1] | info.slot[2] | info.slot[3]) == 0u) return;
   const ScanTable sc = scans ? scans[find_scan(scans, n_scans, i)] : scan_of(P);
   const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
+  // One pass over the sample positions for all lanes (the per-run loops made a wavefront walk
+  // every run as long as its longest lane: ~10-12 sample evaluations where 8 suffice). The runs of a ray
+  // are consecutive stretches of in-range samples inside one block, in position order, so a lane only
+  // tracks which run it is in and how many of that run's samples it has written.
+  unsigned dst[kMaxRuns];
+  int len[kMaxRuns];
 #pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k) {
-    const int len = static_cast<int>(info.slot[k] >> 28);
-    if (len == 0) continue;
-    const int begin = static_cast<int>((info.slot[k] >> 24) & 15u);
-    const unsigned dst = L.g.bin_offset[info.slot[k] & 0xFFFFFFu] + info.off[k];
-    int q = 0;
-    for (int pos = begin; q < len; ++pos) {
-      int cx, cy, cz;
-      float tsd, w;
-      ray_sample(L.g, L.p, r, pos, cx, cy, cz, tsd, w);
-      if (!cell_in_range(cx, cy, cz)) continue;  // skipped inside the run by ray_block_runs
-      rec_keys[dst + q] = (voxel_in_block(cx, cy, cz) << kSeqBits) | (i * kSlots + pos);
-      rec_vals[dst + q] = __float_as_uint(tsd);
-      ++q;
+  for (int k = 0; k < kMaxRuns; ++k) {  // the four bin offsets in flight together
+    len[k] = static_cast<int>(info.slot[k] >> 28);
+    dst[k] = len[k] ? L.g.bin_offset[info.slot[k] & 0xFFFFFFu] + info.off[k] : 0u;
+  }
+  int k = 0, q = 0;
+  while (k < kMaxRuns && len[k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 2 : 3))] == 0) ++k;  // leading empty entries (none in practice)
+  for (int pos = 0; pos < kSlots; ++pos) {
+    if (pos > r.n || k >= kMaxRuns) continue;
+    int cx, cy, cz;
+    float tsd, w;
+    ray_sample(L.g, L.p, r, pos, cx, cy, cz, tsd, w);
+    if (!cell_in_range(cx, cy, cz)) continue;  // breaks a run (ray_block_runs), never inside one
+    const int lk = k == 0 ? len[0] : (k == 1 ? len[1] : (k == 2 ? len[2] : len[3]));
+    const unsigned dk = k == 0 ? dst[0] : (k == 1 ? dst[1] : (k == 2 ? dst[2] : dst[3]));
+    const int bk = static_cast<int>(((k == 0 ? info.slot[0] : (k == 1 ? info.slot[1] : (k == 2 ? info.slot[2] : info.slot[3]))) >> 24) & 15u);
+    if (pos < bk) continue;  // a run whose block could not be allocated left no entry: its samples are skipped
+    rec_keys[dk + q] = (voxel_in_block(cx, cy, cz) << kSeqBits) | (i * kSlots + pos);
+    rec_vals[dk + q] = __float_as_uint(tsd);
+    if (++q == lk) {
+      q = 0;
+      ++k;
+      while (k < kMaxRuns && (k == 1 ? len[1] : (k == 2 ? len[2] : (k == 3 ? len[3] : 0))) == 0) ++k;
     }
   }
 }
