@@ -850,22 +850,26 @@ __device__ inline void wave_group(uint32_t slot, unsigned cnt, bool want, int* l
   int my_leader = lane;
   unsigned my_prefix = 0, my_total = cnt;
   unsigned long long pending = __ballot(want);
+  // cnt <= 15 (a run holds at most kSlots samples): the prefix sum inside a group is taken bit by bit
+  // with ballots and population counts (v_mbcnt) -- no cross-lane data movement. The shuffle scan that
+  // stood here (six dependent ds_bpermute per group, ~14 groups per wavefront and kernel) was a third of
+  // k_bin_count's time.
   while (pending) {
     const int leader = __builtin_ctzll(pending);
     const uint32_t ls = __shfl(slot, leader);
     const bool mine = want && slot == ls;
     const unsigned long long grp = __ballot(mine);
-    unsigned incl = mine ? cnt : 0u;
-    const unsigned v = incl;
+    unsigned prefix = 0, total = 0;
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const unsigned t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
+    for (int b = 0; b < 4; ++b) {
+      const unsigned long long mb = __ballot(mine && ((cnt >> b) & 1u));
+      prefix += __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mb >> 32),
+                                          __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mb), 0u)) << b;
+      total += static_cast<unsigned>(__popcll(mb)) << b;
     }
-    const unsigned total = __shfl(incl, 63);
     if (mine) {
       my_leader = leader;
-      my_prefix = incl - v;
+      my_prefix = prefix;
       my_total = total;
     }
     pending &= ~grp;
