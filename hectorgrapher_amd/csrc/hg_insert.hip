@@ -841,44 +841,6 @@ struct RunInfo {
   uint32_t off[kMaxRuns];
 };
 
-// Groups the lanes of a wavefront by `slot` (lanes with want == false stay out): returns the
-// group's lowest lane, the exclusive prefix of `cnt` inside the group in lane order and the
-// group total. Pure cross-lane work (ballot / shuffles), no memory traffic.
-__device__ inline void wave_group(uint32_t slot, unsigned cnt, bool want, int* leader_out,
-                                  unsigned* prefix_out, unsigned* total_out) {
-  const int lane = threadIdx.x & (kWave - 1);
-  int my_leader = lane;
-  unsigned my_prefix = 0, my_total = cnt;
-  unsigned long long pending = __ballot(want);
-  // cnt <= 15 (a run holds at most kSlots samples): the prefix sum inside a group is taken bit by bit
-  // with ballots and population counts (v_mbcnt) -- no cross-lane data movement. The shuffle scan that
-  // stood here (six dependent ds_bpermute per group, ~14 groups per wavefront and kernel) was a third of
-  // k_bin_count's time.
-  while (pending) {
-    const int leader = __builtin_ctzll(pending);
-    const uint32_t ls = __shfl(slot, leader);
-    const bool mine = want && slot == ls;
-    const unsigned long long grp = __ballot(mine);
-    unsigned prefix = 0, total = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const unsigned long long mb = __ballot(mine && ((cnt >> b) & 1u));
-      prefix += __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mb >> 32),
-                                          __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mb), 0u)) << b;
-      total += static_cast<unsigned>(__popcll(mb)) << b;
-    }
-    if (mine) {
-      my_leader = leader;
-      my_prefix = prefix;
-      my_total = total;
-    }
-    pending &= ~grp;
-  }
-  *leader_out = my_leader;
-  *prefix_out = my_prefix;
-  *total_out = my_total;
-}
-
 // Bodies of the four kernels of the binned path, shared by the single-pyramid launches (pyramid in
 // the kernel arguments) and the batched launches (a table of jobs in device memory, one job = one
 // pyramid with its own scan: hg_register_scan_batch). `bx` of `nbx` = workgroup index inside the job.
@@ -923,37 +885,62 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
         slot[k] = insert_block_shared(L.g, run_key[k]);
     }
   }
-  // one atomic per (wavefront, block, round); all rounds' atomics in flight together
-  int leader[kMaxRuns];
-  unsigned prefix[kMaxRuns], total[kMaxRuns], base[kMaxRuns];
+  // Record ranges inside the bins: the runs of the WORKGROUP are added up per block in an LDS hash
+  // table (one LDS atomic per run: it returns the run's offset inside the workgroup's share, in any
+  // order -- the order of the records inside a bin is free, the apply pass orders them by seq), then ONE
+  // device-scope atomic per (workgroup, block) reserves the share in the bin. Grouping the lanes of every
+  // wavefront by block with ballots and issuing one atomic per (wavefront, block, run index) took a
+  // third of this kernel and four times as many returning atomics.
+  constexpr unsigned kTable = 1024u;  // entries; a workgroup has at most 1024 runs, a few dozen distinct blocks
+  constexpr unsigned kNone = 0xFFFFFFFFu;
+  __shared__ uint32_t t_key[kTable];  // slot + 1, 0 = free
+  __shared__ uint32_t t_cnt[kTable];  // records of the workgroup in the block; after the scan: their base in the bin
+  for (unsigned e = threadIdx.x; e < kTable; e += 256u) { t_key[e] = 0u; t_cnt[e] = 0u; }
+  __syncthreads();
   bool want[kMaxRuns];
+  unsigned ent[kMaxRuns], prefix[kMaxRuns];
+  unsigned first_pos[kMaxRuns + kTable / 256u], first_slot[kMaxRuns + kTable / 256u];
+#pragma unroll
+  for (int j = 0; j < kMaxRuns + static_cast<int>(kTable / 256u); ++j) first_pos[j] = kNone;
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
     want[k] = k < nr && slot[k] < L.g.pool_blocks;
-    wave_group(slot[k], want[k] ? static_cast<unsigned>(run_len[k]) : 0u, want[k], &leader[k],
-               &prefix[k], &total[k]);
+    ent[k] = kNone;
+    prefix[k] = 0;
+    if (want[k]) {
+      unsigned h = (slot[k] * 2654435761u) >> 22;  // 10 bits
+      for (int tries = 0; tries < 32; ++tries) {
+        const uint32_t old = atomicCAS(&t_key[h], 0u, slot[k] + 1u);
+        if (old == 0u || old == slot[k] + 1u) { ent[k] = h; break; }
+        h = (h + 1u) & (kTable - 1u);
+      }
+      if (ent[k] != kNone) {
+        prefix[k] = atomicAdd(&t_cnt[ent[k]], static_cast<unsigned>(run_len[k]));
+      } else {  // table region crowded (cannot happen with <= 1024 runs and 32 probes in practice): reserve directly
+        prefix[k] = atomicAdd(&L.g.bin_count[slot[k]], static_cast<unsigned>(run_len[k]));
+        if (prefix[k] == 0u) { first_pos[k] = atomicAdd(&s_first, 1u); first_slot[k] = slot[k]; }
+      }
+    }
+  }
+  __syncthreads();
+  // one returning device-scope atomic per occupied entry, all of a thread's in flight together
+  uint32_t e_key[kTable / 256u], e_base[kTable / 256u];
+#pragma unroll
+  for (unsigned j = 0; j < kTable / 256u; ++j) {
+    const unsigned e = threadIdx.x + 256u * j;
+    e_key[j] = t_key[e];
+    e_base[j] = e_key[j] ? atomicAdd(&L.g.bin_count[e_key[j] - 1u], t_cnt[e]) : 0u;
   }
 #pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k) {
-    base[k] = 0;
-    if (want[k] && lane == leader[k]) base[k] = atomicAdd(&L.g.bin_count[slot[k]], total[k]);
+  for (unsigned j = 0; j < kTable / 256u; ++j) {
+    const unsigned e = threadIdx.x + 256u * j;
+    if (e_key[j]) {
+      t_cnt[e] = e_base[j];
+      // blocks that receive their first records of this call are enlisted in `touched`. The list's
+      // cursor is ONE device-wide word: the workgroup reserves its entries with a single atomic
+      if (e_base[j] == 0u) { first_pos[kMaxRuns + j] = atomicAdd(&s_first, 1u); first_slot[kMaxRuns + j] = e_key[j] - 1u; }
+    }
   }
-  RunInfo info;
-  // blocks that receive their first records of this call are enlisted in `touched`. The list's
-  // cursor is ONE device-wide word: the workgroup reserves its entries with a single atomic (one
-  // per first-touch would put ~10^4 same-address atomics per level on the kernel's critical path)
-  unsigned first_pos[kMaxRuns];
-#pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k) {
-    const unsigned b = __shfl(base[k], leader[k]);
-    first_pos[k] = 0xFFFFFFFFu;
-    if (want[k] && lane == leader[k] && b == 0u) first_pos[k] = atomicAdd(&s_first, 1u);
-    info.slot[k] = want[k] ? (slot[k] | (static_cast<uint32_t>(run_begin[k]) << 24) |
-                              (static_cast<uint32_t>(run_len[k]) << 28))
-                           : 0u;
-    info.off[k] = b + prefix[k];
-  }
-  if (i < n) runs[static_cast<size_t>(level) * n + i] = info;
   const unsigned long long m = __ballot(hit);
   if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
   __syncthreads();
@@ -961,11 +948,21 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
     wg_hits[level * nbx + bx] = s_hits;
     s_first_base = s_first ? atomicAdd(&L.g.call[0], s_first) : 0u;
   }
+  RunInfo info;
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) {
+    info.slot[k] = want[k] ? (slot[k] | (static_cast<uint32_t>(run_begin[k]) << 24) |
+                              (static_cast<uint32_t>(run_len[k]) << 28))
+                           : 0u;
+    info.off[k] = (ent[k] != kNone ? t_cnt[ent[k]] : 0u) + prefix[k];
+  }
+  if (i < n) runs[static_cast<size_t>(level) * n + i] = info;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k)
-    if (first_pos[k] != 0xFFFFFFFFu) L.g.touched[s_first_base + first_pos[k]] = slot[k];
+  for (int j = 0; j < kMaxRuns + static_cast<int>(kTable / 256u); ++j)
+    if (first_pos[j] != kNone) L.g.touched[s_first_base + first_pos[j]] = first_slot[j];
 }
+
 
 // One pyramid with its own scan inside a batched launch.
 struct InsertJob {
