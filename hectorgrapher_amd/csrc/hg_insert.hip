@@ -1785,17 +1785,20 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
     while (lo < v_hi) {
       // voxel range [lo, hi): the longest prefix of voxels whose records fit one LDS pass
       const unsigned b_lo = base[lo];
-      if (tid == 0) s_hi = 1024;
-      __syncthreads();
-      {
-        const unsigned end_v = base[tid] + hist[tid] - b_lo;  // records in [lo, tid]
-        const bool fits = tid >= lo && tid < v_hi && end_v <= static_cast<unsigned>(kBinCap);
-        const bool next_fits = tid + 1 < v_hi && (base[tid + 1] + hist[tid + 1] - b_lo) <= static_cast<unsigned>(kBinCap);
-        if (fits && !next_fits) s_hi = tid + 1;
-        if (tid == lo && !fits) s_hi = lo;  // the first voxel alone does not fit
+      unsigned hi = v_hi;
+      if (!(single || compact)) {  // (a whole small bin, or a slice whose records fit one pass, is ONE range)
+        if (tid == 0) s_hi = 1024;
+        __syncthreads();
+        {
+          const unsigned end_v = base[tid] + hist[tid] - b_lo;  // records in [lo, tid]
+          const bool fits = tid >= lo && tid < v_hi && end_v <= static_cast<unsigned>(kBinCap);
+          const bool next_fits = tid + 1 < v_hi && (base[tid + 1] + hist[tid + 1] - b_lo) <= static_cast<unsigned>(kBinCap);
+          if (fits && !next_fits) s_hi = tid + 1;
+          if (tid == lo && !fits) s_hi = lo;  // the first voxel alone does not fit
+        }
+        __syncthreads();
+        hi = s_hi;
       }
-      __syncthreads();
-      unsigned hi = s_hi;
       unsigned cnt = 0;
       if (hi == lo) {
         // One voxel alone holds more records than an LDS pass (degenerate geometry: thousands of
