@@ -1710,7 +1710,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
   uint32_t* sv = gv + kBinCap;        // values in (voxel, seq) order
   uint32_t* tk = sv + kBinCap;        // keys of the slice's records as read (compact list)
   uint32_t* tv = sv;                  // their values: sv is free until the rank step
-  __shared__ unsigned s_hi, s_m;
+  __shared__ unsigned s_hi, s_m, s_big, s_scan16[16];
   const unsigned nwork = min(g.call[2], g.call[1]);  // the slices of large bins; whole bins: k_bin_apply_small
   const unsigned tid = threadIdx.x;
   for (unsigned wi = bx; wi < nwork; wi += gstride) {
@@ -1736,7 +1736,8 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
     if (threadIdx.x == 0) stamps[(static_cast<size_t>(order) * 4096 + wi) * 8 + 6] = n;
 #endif
     hist[tid] = 0;
-    if (tid == 0) s_m = 0;
+    cursor[tid] = 0;  // (the first pass of the item finds it zero; later passes clear it again)
+    if (tid == 0) { s_m = 0; s_big = 0; }
     __syncthreads();
     const bool single = n <= static_cast<unsigned>(kBinCap);  // whole bin in registers: one read
     uint32_t rk4[4], rv4[4];
@@ -1778,7 +1779,9 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
     // exclusive prefix of hist over the 512 voxels -> base
     {
       unsigned tot;
-      base[tid] = block_exclusive_scan(hist[tid], cursor, &tot);
+      // (a voxel group too large for the rank step sends the item's passes through the bitonic sort)
+      if (hist[tid] > kRankMaxGroup) s_big = 1;  // benign race: same value
+      base[tid] = block_exclusive_scan(hist[tid], s_scan16, &tot);
     }
     __syncthreads();
     unsigned lo = v_lo;
@@ -1834,7 +1837,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
             __syncthreads();
             {
               unsigned tot;
-              const unsigned excl = block_exclusive_scan(bucket[tid], cursor, &tot);
+              const unsigned excl = block_exclusive_scan(bucket[tid], s_scan16, &tot);
               bucket_pre[tid] = excl;
               // number of leading buckets whose records fit one pass
               if (excl + bucket[tid] <= static_cast<unsigned>(kBinCap)) atomicMax(&s_hi, tid + 1u);
@@ -1881,8 +1884,10 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
       } else {
         cnt = base[hi - 1] + hist[hi - 1] - b_lo;
       }
-      cursor[tid] = 0;
-      __syncthreads();
+      if (lo != v_lo) {  // not the first pass: the grouping of the previous one left its cursors behind
+        cursor[tid] = 0;
+        __syncthreads();
+      }
       if (cnt) {
         // group by voxel (arbitrary order inside a group)
         for (unsigned i = tid; compact && i < m_slice; i += kBinThreads) {
@@ -1917,12 +1922,9 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
             }
           }
         }
-        if (tid == 0) s_hi = 0;
         __syncthreads();
         BIN_STAMP(2);
-        if (tid >= lo && tid < hi && hist[tid] > kRankMaxGroup) s_hi = 1;  // benign race: same value
-        __syncthreads();
-        if (s_hi) {
+        if (s_big) {
           // large groups: one bitonic sort of the whole pass by (voxel, seq); the groups keep their
           // places because the grouped layout is already ordered by voxel
           unsigned m2 = 2;
@@ -1967,8 +1969,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
       }
       lo = hi;
     }
-    __syncthreads();
-    BIN_STAMP(5);
+    BIN_STAMP(5);  // (every pass ends behind a barrier)
   }
   if (small_in_kernel) {
     // the whole small bins of the level, one wavefront each: most touched blocks of a scan are of
