@@ -240,11 +240,24 @@ int hg_ctx_create(int device, void* stream, hg_ctx** out) {
     c->own_stream = true;
   }
   if (hipHostMalloc(&c->pinned, 4096, hipHostMallocMapped) != hipSuccess) c->pinned = nullptr;
-  if (c->pinned) {
-    std::memset(c->pinned, 0, 4096);
+  if (c->pinned) std::memset(c->pinned, 0, 4096);
+  {
+    void* hp = nullptr;
     void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, c->pinned, 0) == hipSuccess)
-      c->async_flags = reinterpret_cast<uint32_t*>(static_cast<char*>(dp) + 2048);
+    if (hipHostMalloc(&hp, hg_ctx::kFlagSlots * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+      std::memset(hp, 0, hg_ctx::kFlagSlots * sizeof(uint32_t));
+      if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+        c->flag_words = static_cast<volatile uint32_t*>(hp);
+        c->async_flags = static_cast<uint32_t*>(dp);
+      } else {
+        (void)hipHostFree(hp);
+      }
+    }
+    if (!c->flag_words) {
+      set_last_error("hipHostMalloc: mapped page of the per-grid error flags");
+      hg_ctx_destroy(c);
+      return HG_ERR_HIP;
+    }
   }
   *out = c;
   return HG_OK;
@@ -270,6 +283,7 @@ int hg_ctx_destroy(hg_ctx* c) {
   prof_resolve(c);
   for (hipEvent_t e : c->prof_free_events) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->flag_words) (void)hipHostFree(const_cast<uint32_t*>(c->flag_words));
   if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
   if (c->pinned_ijobs) (void)hipHostFree(c->pinned_ijobs);
   if (c->pinned_sjobs) (void)hipHostFree(c->pinned_sjobs);
@@ -325,6 +339,16 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
   hg_grid* g = new hg_grid();
   g->ctx = ctx;
   g->relative_truncation_distance = relative_truncation_distance;
+  if (!ctx->flag_free.empty()) {
+    g->flag_slot = ctx->flag_free.back();
+    ctx->flag_free.pop_back();
+  } else if (ctx->flag_next < hg_ctx::kFlagSlots) {
+    g->flag_slot = ctx->flag_next++;
+  } else {
+    set_last_error("too many grids on one context (4096 sticky-error words)");
+    delete g;
+    return HG_ERR_CAPACITY;
+  }
   GridView& v = g->view;
   v.max_blocks = max_blocks;
   // direct window: as many slots as the grid may hold blocks (rounded up to a power of two, at most
@@ -397,6 +421,10 @@ int hg_grid_destroy(hg_grid* g) {
   if (g->view.bin_count) (void)hipFree(g->view.bin_count);
   if (g->view.accum) (void)hipFree(g->view.accum);
   g->pack.release();
+  if (g->flag_slot < hg_ctx::kFlagSlots) {  // the stream has drained: nothing writes the word any more
+    g->ctx->flag_words[g->flag_slot] = 0u;
+    g->ctx->flag_free.push_back(static_cast<uint16_t>(g->flag_slot));
+  }
   delete g;
   return HG_OK;
 }
@@ -414,10 +442,14 @@ int hg_grid_clear(hg_grid* g) {
   HG_HIP_CHECK(hipMemsetAsync(v.bin_count, 0, sizeof(uint32_t) * 2 * static_cast<size_t>(v.pool_blocks), s));
   if (v.accum)
     HG_HIP_CHECK(hipMemsetAsync(v.accum, 0, sizeof(unsigned long long) * kVoxelsPerBlock * static_cast<size_t>(v.pool_blocks), s));
-  if (g->ctx->pinned) {  // a cleared grid starts without sticky errors
+  // a cleared grid starts without sticky errors: its own word only. An insertion still in flight could
+  // publish into it after the host has cleared it, so the stream is drained first -- unless it is idle
+  // already (the usual case: grids are cleared between maps, not between scans)
+  if (hipStreamQuery(s) != hipSuccess) {
+    (void)hipGetLastError();
     HG_HIP_CHECK(hipStreamSynchronize(s));
-    std::memset(static_cast<char*>(g->ctx->pinned) + 2048, 0, 16);
   }
+  g->ctx->flag_words[g->flag_slot] = 0u;
   return HG_OK;
 }
 

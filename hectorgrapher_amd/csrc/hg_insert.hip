@@ -491,8 +491,9 @@ struct PyramidIns {
   const double* d_pose;  // optional: pose (t xyz, q wxyz, fp64) in device memory, e.g. the pose a
                          // solve left there; cast to float as Rigid3d::cast<float>() does
   int accumulate;        // not the first chunk of a call: hit / update counters add up
-  uint32_t* host_flags;  // mapped pinned words [kMaxInsLevels]: sticky error flags of calls that do not
-                         // read their stats back (written only when a flag is set)
+  uint32_t* host_flags;  // the context's mapped pinned flag words: sticky error flags of calls that do not
+                         // read their stats back (written only when a flag is set), one word per grid
+  uint16_t flag_slot[kMaxInsLevels];  // word of each level's grid
   int slice_records;     // records per voxel slice of a large bin (0 = by bin size), see k_bin_offsets
   int shared;            // several scans in flight on the same grids (scan stream): per-call statistics are
                          // added atomically
@@ -502,7 +503,7 @@ struct PyramidIns {
 __device__ inline void publish_flags(const PyramidIns& P, int level) {
   const uint32_t f = P.lv[level].g.counters[1];
   if (f != 0u && P.host_flags) {
-    P.host_flags[level] = f;
+    P.host_flags[P.flag_slot[level]] = f;
     __threadfence_system();
   }
 }
@@ -1427,6 +1428,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
     }
     __syncthreads();
     if (round == 0 && threadIdx.x == 0) s_large = s_work;  // items [0, s_large): slices of large bins
+    __syncthreads();  // snapshot taken before any wavefront reserves round-1 items
   }
   if (threadIdx.x == 0) {
     // items [call[2], call[1]) are whole bins for k_bin_apply_small (batched inserts); one
@@ -1972,6 +1974,10 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
     BIN_STAMP(5);  // (every pass ends behind a barrier)
   }
   if (small_in_kernel) {
+    // the wavefronts' small-bin scratch aliases hist / base of the work items above, and an item whose
+    // slice holds no records ends without a barrier: none may start on a small bin before all have left
+    // the last item
+    __syncthreads();
     // the whole small bins of the level, one wavefront each: most touched blocks of a scan are of
     // this kind (65 % / 45 % of the bins at 0.05 / 0.10 m hold <= 256 records), and as 512-thread
     // items they queued for workgroup slots with a dozen barriers around a few hundred records
@@ -2398,6 +2404,13 @@ int insert_chunk_fast(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans, 
 
 }  // namespace
 // Sticky error flags of a grid -> status code + message.
+int hg::async_status_grids(hg_grid* const* grids, int count) {
+  uint32_t f = 0;
+  for (int i = 0; i < count; ++i)
+    if (grids[i] && grids[i]->ctx->flag_words) f |= grids[i]->ctx->flag_words[grids[i]->flag_slot];
+  return f ? flags_to_status(f) : HG_OK;
+}
+
 int hg::flags_to_status(uint32_t flags) {
   if (flags & kFlagCapacity) {
     set_last_error("block pool exhausted: raise max_blocks");
@@ -2538,6 +2551,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
     for (int l = 0; l < levels; ++l) {
       LevelIns& L = P.lv[l];
       L.g = grids[j * levels + l]->view;
+      P.flag_slot[l] = static_cast<uint16_t>(grids[j * levels + l]->flag_slot);
       L.p = make_params(opts[l], grids[j * levels + l], true, width);
       L.gate = nullptr;
       L.g.work = c->ws_offsets.as<uint4>() + work_off + per_level * l;
@@ -2649,10 +2663,17 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   if ((rc = c->ws_counts.reserve(sizeof(unsigned) * hit_words)) != HG_OK) return rc;
   if ((rc = c->ws_sjobs.reserve(table_bytes)) != HG_OK) return rc;
   if ((rc = c->ws_shadow.reserve(sizeof(uint32_t) * shadow_words)) != HG_OK) return rc;
-  if (c->shadow_zeroed != c->ws_shadow.ptr) {
-    // bin counts and call counters are all-zero between calls (k_bin_offsets restores that)
-    HG_HIP_CHECK(hipMemsetAsync(c->ws_shadow.ptr, 0, c->ws_shadow.bytes, s));
-    c->shadow_zeroed = c->ws_shadow.ptr;
+  {
+    // bin counts and call counters are all-zero between calls of ONE layout (k_bin_offsets restores
+    // that); bin offsets and touched lists keep their last values, so a call that lays the buffer out
+    // differently (other scan sizes, pyramid, pool, group) must start from zeroes again
+    const unsigned long long layout[7] = {reinterpret_cast<unsigned long long>(c->ws_shadow.ptr), c->ws_shadow.bytes,
+                                          call_words, per_slot_level, max_pool, static_cast<unsigned long long>(levels),
+                                          static_cast<unsigned long long>(group)};
+    if (std::memcmp(layout, c->shadow_layout, sizeof(layout)) != 0) {
+      HG_HIP_CHECK(hipMemsetAsync(c->ws_shadow.ptr, 0, c->ws_shadow.bytes, s));
+      std::memcpy(c->shadow_layout, layout, sizeof(layout));
+    }
   }
   uint32_t* shadow = c->ws_shadow.as<uint32_t>();
   unsigned max_nwg_all = 0;
@@ -2786,8 +2807,8 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   }
   hipStream_t s = c->stream;
   HG_HIP_CHECK(hipSetDevice(c->device));
-  if (!stats) {  // asynchronous call: report what earlier asynchronous calls have left behind
-    const int arc = async_status(c);
+  if (!stats) {  // asynchronous call: report what earlier asynchronous calls on these grids have left behind
+    const int arc = async_status_grids(grids, levels);
     if (arc != HG_OK) return arc;
   }
   const unsigned long long n_total = scan_offsets[n_scans] - scan_offsets[0];
@@ -2877,6 +2898,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   for (int l = 0; l < levels; ++l) {
     LevelIns& L = P.lv[l];
     L.g = grids[l]->view;
+    P.flag_slot[l] = static_cast<uint16_t>(grids[l]->flag_slot);
     L.p = make_params(opts[l], grids[l], poses_tq != nullptr, width);
     L.gate = d_gate[l];
     const float res = L.g.resolution;

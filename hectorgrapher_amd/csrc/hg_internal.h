@@ -88,7 +88,10 @@ struct hg_ctx {
   // grouped scan stream (insert_stream_grouped): job table of the whole call (pinned staging + device
   // copy; ev_sjobs marks the staging free again) and the per-scan bin arrays of the scans in flight
   hg::DeviceBuffer ws_sjobs, ws_shadow;
-  void* shadow_zeroed = nullptr;  // ws_shadow.ptr when its zero-initialisation was enqueued
+  // layout of ws_shadow whose all-zero state (bin counts, call counters) the last grouped call left:
+  // {ptr, bytes, call words, words per (slot, level), pool slots, levels, group}. Another layout in the
+  // same buffer would alias bin counts with stale offsets / touched lists, so any change re-zeroes it.
+  unsigned long long shadow_layout[7] = {0, 0, 0, 0, 0, 0, 0};
   void* pinned_sjobs = nullptr;
   size_t sjobs_capacity = 0;
   hipEvent_t ev_sjobs = nullptr;
@@ -103,10 +106,16 @@ struct hg_ctx {
   size_t jobs_capacity = 0;
   void* pinned_ijobs = nullptr;  // pinned staging of a batched insertion's job table
   size_t ijobs_capacity = 0;
-  // words [0, 4) of the second half of `pinned`: sticky error flags that insert calls without a
-  // stats read-back leave for the host (hg_register_scan, hg_pyramid_insert(stats = NULL)); checked
-  // by the next call of the context that can return a status
-  uint32_t* async_flags = nullptr;  // device address of those words
+  // Sticky error flags that insert calls without a stats read-back leave for the host
+  // (hg_register_scan, hg_pyramid_insert(stats = NULL)): ONE mapped pinned word per grid of the context
+  // (slot = hg_grid::flag_slot), so that a full grid neither fails calls on other grids nor has its error
+  // dropped when another grid is cleared. Checked by the next call that works on the grid
+  // (async_status_grids) and by hg_ctx_synchronize (async_status: any grid of the context).
+  static constexpr uint32_t kFlagSlots = 4096;
+  volatile uint32_t* flag_words = nullptr;  // host address of the kFlagSlots words
+  uint32_t* async_flags = nullptr;          // their device address
+  uint32_t flag_next = 0;                   // slots [0, flag_next) have been handed out at some time
+  std::vector<uint16_t> flag_free;          // released slots
 };
 
 namespace hg {
@@ -153,12 +162,13 @@ int flags_to_status(uint32_t flags);
 // Status of the asynchronous insert calls issued so far on this context (HG_OK or the error of a
 // sticky flag that has arrived in the mailbox words).
 inline int async_status(const hg_ctx* c) {
-  if (!c->pinned) return HG_OK;
+  if (!c->flag_words) return HG_OK;
   uint32_t f = 0;
-  const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(static_cast<const char*>(c->pinned) + 2048);
-  for (int l = 0; l < 4; ++l) f |= w[l];
+  for (uint32_t i = 0; i < c->flag_next; ++i) f |= c->flag_words[i];
   return f ? flags_to_status(f) : HG_OK;
 }
+// The same for the grids a call works on (errors of other grids of the context do not concern it).
+int async_status_grids(hg_grid* const* grids, int count);
 int pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                         const float* origins, const float* const* xyz, const size_t* n, size_t width,
                         const double* const* d_poses);
@@ -178,5 +188,6 @@ struct hg_grid {
   hg::DeviceBuffer pack;  // packed (keys, voxels) copy handed out by hg_grid_block_arrays
   uint32_t table_capacity = 0;
   float relative_truncation_distance = 0.f;
+  uint32_t flag_slot = 0xFFFFFFFFu;  // this grid's sticky-error word in the context's mapped flag page
   hg_insert_stats last_stats{};
 };

@@ -3492,7 +3492,9 @@ int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solv
     return HG_OK;
   }
   hg_ctx* c = problems[0]->ctx;
-  int rc = async_status(c);  // an insertion of an earlier step that failed reports here
+  for (int j = 0; j < count; ++j)
+    if (problems[j]->ctx != c) return HG_ERR_INVALID;  // one job table, one stream
+  int rc = async_status_grids(grids, count * levels);  // an insertion of an earlier step that failed reports here
   if (rc != HG_OK) return rc;
   bool batched = false;
   if (memspace == HG_DEVICE) {
@@ -3536,6 +3538,13 @@ int hg_register_scan_sequence(hg_problem* p, const hg_solver_opts* sopts, hg_gri
                               int memspace, int insert_mode, const double* guesses, int count,
                               int prof_every, double* poses_out, hg_solver_summary* summaries) {
   if (!p || !grids || !iopts || !origins || !xyz || !n || !scaling || !guesses || count < 0) return HG_ERR_INVALID;
+  // prof_every > 0 samples kernel durations on some steps; the caller's own hg_prof_enable state comes
+  // back on every exit path
+  struct ProfRestore {
+    hg_ctx* c;
+    int saved;
+    ~ProfRestore() { c->prof_on = saved; }
+  } restore{p->ctx, p->ctx->prof_on};
   for (int k = 0; k < count; ++k) {
     int rc = hg_problem_reset(p);
     if (rc != HG_OK) return rc;
@@ -3548,7 +3557,6 @@ int hg_register_scan_sequence(hg_problem* p, const hg_solver_opts* sopts, hg_gri
                                insert_mode, poses_out ? poses_out + 7 * k : nullptr, summaries ? summaries + k : nullptr);
     if (rc != HG_OK) return rc;
   }
-  if (prof_every > 0) p->ctx->prof_on = 0;
   return HG_OK;
 }
 
@@ -3575,7 +3583,8 @@ int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_i
 #endif
   // an insertion of an earlier step that ran out of blocks (or left the index range) reports here:
   // those steps return before their insertion has finished
-  int rc = async_status(p->ctx);
+  if (levels < 1) return HG_ERR_INVALID;
+  int rc = async_status_grids(grids, levels);
   if (rc != HG_OK) return rc;
   rc = hg_problem_solve_async(p, sopts);
   if (rc != HG_OK) return rc;

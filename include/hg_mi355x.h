@@ -116,7 +116,9 @@ typedef struct hg_solver_summary {
 int hg_ctx_create(int device, void* stream, hg_ctx** out);
 int hg_ctx_destroy(hg_ctx* ctx);
 /* Waits for the context's stream. Also returns the error (HG_ERR_CAPACITY, HG_ERR_RANGE, ...) an
- * insertion that ran without a stats read-back has raised since the grids were last cleared. */
+ * insertion that ran without a stats read-back has raised on ANY grid of the context since that grid
+ * was last cleared (the flags are kept per grid: hg_grid_clear / hg_grid_destroy reset only the grid's
+ * own). */
 int hg_ctx_synchronize(hg_ctx* ctx);
 void* hg_ctx_stream(hg_ctx* ctx);
 const char* hg_last_error(void);
@@ -135,8 +137,13 @@ int hg_prof_reset(hg_ctx* ctx);
 int hg_prof_read(hg_ctx* ctx, int kernel, uint64_t* launches, double* total_ms, uint64_t* units);
 
 /* ---- grid: HybridGridTSDF --------------------------------------------------------------- */
-/* max_blocks = number of 8x8x8-voxel blocks (2 KiB each) the grid may hold, < 2^23. Device memory:
- * about 2 * max_blocks blocks (a directly addressed window of blocks plus the overflow area). */
+/* max_blocks = number of 8x8x8-voxel blocks (2 KiB each) the grid may hold, < 2^22. Device memory:
+ * the pool has next_pow2(max_blocks) (at most 2^21) directly addressed slots -- a toroidal window of
+ * blocks that lets the matcher address voxels without a hash probe -- plus max_blocks overflow slots,
+ * i.e. 2..3 * max_blocks * (2 KiB voxels + 24 B bookkeeping): 2^18 -> 1 GiB, 2^16 -> 256 MiB, 2^12 ->
+ * 16 MiB per grid (+ 8 B per voxel of the pool after the first HG_INSERT_FAST call). hg_grid_clear
+ * memsets all of it. Size grids that only receive an import (hg_grid_import_blocks, hg_grid_from_proto)
+ * or a gather by their block count, not by the mapping default. At most 4096 grids per context. */
 int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_distance,
                    float max_weight, uint32_t max_blocks, hg_grid** out);
 int hg_grid_destroy(hg_grid* grid);
@@ -211,8 +218,9 @@ int hg_grid_insert_batch(hg_grid* grid, const hg_insert_opts* opts, const float*
  * grids of Submap3D::InsertData, submap_3d.cc:441-444) with per-level options opts[levels], in one
  * fused device pass. stats: array[levels] or NULL. With stats == NULL the call does not synchronise;
  * errors (capacity, range) raised on the device then surface as the return value of the next
- * hg_pyramid_insert* (stats == NULL), hg_register_scan* or hg_ctx_synchronize call of the context
- * (the kernels leave the sticky flags in a host-mapped mailbox), and of hg_grid_status. */
+ * hg_pyramid_insert* (stats == NULL) or hg_register_scan* call on one of THESE grids, of
+ * hg_ctx_synchronize (any grid of the context) and of hg_grid_status (the kernels leave the sticky
+ * flags in a host-mapped word per grid; calls on other grids of the context are not affected). */
 int hg_pyramid_insert(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                       const float origin[3], const float* xyz, size_t n, size_t width,
                       const float* pose_tq, int mode, int memspace, hg_insert_stats* stats);

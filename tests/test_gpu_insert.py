@@ -381,3 +381,91 @@ def test_async_insert_errors_reach_the_next_call(hg, ctx):
     g.clear()        # a cleared grid starts without sticky errors
     ctx.synchronize()
     g.close()
+
+
+def _stream_call(hg, grids, scans, mode_exact=True):
+    """hg_pyramid_insert_batch of `scans` [(pose, points in the sensor frame)] into `grids`."""
+    import ctypes as C
+    import torch
+    from hectorgrapher_amd import _lib
+    B = len(scans)
+    xyz = torch.from_numpy(np.concatenate([p for _, p in scans])).to(torch.device("cuda", 0))
+    poses = np.array([pose for pose, _ in scans], np.float32)
+    origins = np.zeros((B, 3), np.float32)
+    offs = np.concatenate([[0], np.cumsum([len(p) for _, p in scans])]).astype(np.uint64)
+    L = _lib.load()
+    n = len(grids)
+    garr = (C.c_void_p * n)(*[g._h for g in grids])
+    opts = (hg.InsertOpts * n)(*[hg.InsertOpts() for _ in grids])
+    st = (hg.InsertStats * n)()
+    hg.check(L.hg_pyramid_insert_batch(garr, opts, n, origins.ctypes.data_as(C.c_void_p), xyz.data_ptr(),
+                                       offs.ctypes.data_as(C.c_void_p), B, 0, poses.ctypes.data_as(C.c_void_p),
+                                       _lib.HG_INSERT_EXACT, 1, st), "hg_pyramid_insert_batch")
+    return st
+
+
+def test_grouped_stream_calls_of_different_layouts_on_one_context(po, hg):
+    """The grouped scan stream keeps per-scan bin arrays in a context workspace that is all-zero between
+    calls of ONE layout. Calls that lay it out differently (scan sizes, number of levels, pool size) on
+    the same context must not see each other's leftovers: every call equals the oracle inserting its
+    scans one after the other."""
+    c = hg.Context(0)
+    try:
+        def scans_of(sizes, first):
+            out = []
+            for j, (rings, cols) in enumerate(sizes):
+                pose = synth.pose_k(first + j)
+                out.append((pose, synth.generate_scan(pose, rings, cols, stream=900 + first + j)))
+            return out
+
+        def oracle(ogrids, scans):
+            for pose, pts in scans:
+                loc = synth.transform_points(pose, pts)
+                for g in ogrids:
+                    g.insert(pose[:3].astype(np.float32), loc)
+
+        res3 = [0.05, 0.10, 0.20]
+        pyr = [hg.HybridGridTSDF(c, r, max_blocks=1 << 15) for r in res3]
+        opyr = [po.Grid(r) for r in res3]
+        single = [hg.HybridGridTSDF(c, 0.10, max_blocks=1 << 13)]
+        osingle = [po.Grid(0.10)]
+        # 1: ten 40k-point scans, three levels  2: nine 20k-point scans into ONE other grid (smaller pool)
+        # 3: scans of 17k..48k points into the pyramid again  4: the single grid again with larger scans
+        calls = [(pyr, opyr, scans_of([(16, 2500)] * 10, 0)),
+                 (single, osingle, scans_of([(10, 2000)] * 9, 3)),
+                 (pyr, opyr, scans_of([(16, 1100), (16, 3000), (20, 1500), (12, 1500), (16, 2000), (24, 2000)], 10)),
+                 (single, osingle, scans_of([(16, 2500)] * 5, 12))]
+        for gg, og, scans in calls:
+            _stream_call(hg, gg, scans)
+            oracle(og, scans)
+            for o, g in zip(og, gg):
+                assert_grids_equal(o, g)
+    finally:
+        c.close()
+
+
+def test_async_insert_errors_are_per_grid(hg):
+    """A full grid reports its sticky error through calls that work on IT (and hg_ctx_synchronize); other
+    grids of the context keep working, and clearing one of them does not drop the full grid's error."""
+    c = hg.Context(0)
+    try:
+        full = hg.HybridGridTSDF(c, 0.1, max_blocks=4)
+        fine = hg.HybridGridTSDF(c, 0.1, max_blocks=1 << 12)
+        ins = [hg.TSDFRangeDataInserter3D()]
+        pts = synth.generate_scan(synth.pose_k(0), 8, 128)
+        assert hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), [full], want_stats=False) is None
+        with pytest.raises(hg.HgError, match="HG_ERR_CAPACITY"):
+            c.synchronize()
+        # the other grid is not concerned ...
+        assert hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), [fine], want_stats=False) is None
+        fine.status()
+        fine.clear()  # ... and clearing it leaves the full grid's error in place
+        with pytest.raises(hg.HgError, match="HG_ERR_CAPACITY"):
+            hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), [full], want_stats=False)
+        with pytest.raises(hg.HgError, match="HG_ERR_CAPACITY"):
+            full.status()
+        full.close()  # a destroyed grid takes its error with it
+        c.synchronize()
+        fine.close()
+    finally:
+        c.close()
