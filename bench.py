@@ -409,28 +409,42 @@ def run_window(args):
     d_scans = [torch.from_numpy(p).to(dev) for p in scans]
     torch.cuda.synchronize()
     problem = api.Problem(ctx)
-    its = []
+    its, evals, inserted_at, solved = [], [], [], []
 
-    def step(s):
+    def step(s, sample=False):
         problem.reset()
         first = args.map_scans - 1 + s  # control point 0 sits on the last inserted scan
         window_problem(problem, synth, first, n_cp, d_scans[s:s + n_cp - 1], grids, n_pts)
         summ = problem.solve()
         its.append(summ.num_iterations)
-        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d_scans[s]), grids,
-                           pose_tq=problem.get_pose(1).astype(np.float32), want_stats=False)
+        if sample:
+            evals.append(summ.num_cost_evaluations)
+        solved.append((np.array([problem.get_pose(i) for i in range(n_cp)]), summ.num_iterations,
+                       summ.termination_type, summ.termination_reason))
+        at = problem.get_pose(1).astype(np.float32)
+        inserted_at.append(at)
+        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d_scans[s]), grids, pose_tq=at, want_stats=False)
 
     for s_ in range(args.warmup):
         step(s_)
     its.clear()
+    ctx.prof_reset()
     ctx.synchronize()
     t0 = time.perf_counter()
     for s_ in range(args.warmup, total):
-        step(s_)
+        on = args.prof_every > 0 and (s_ - args.warmup) % args.prof_every == 0
+        ctx.prof_enable(on)
+        step(s_, on)
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
     base = None
+    parity = None
+    lbar = 4.0 / 3.0
     if not args.no_cpu_baseline:
+        # the oracle replays the FIRST TIMED step: same map (the warm-up scans inserted where the GPU
+        # inserted them), same window, same guesses -> its poses are the parity gate of that step
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle as po
         og = [po.Grid(r) for r in RESOLUTIONS]
@@ -438,17 +452,43 @@ def run_window(args):
             loc = synth.transform_points(pose, pts)
             for g in og:
                 g.insert(pose[:3], loc)
+        for w in range(args.warmup):
+            loc = synth.transform_points(inserted_at[w], scans[w])
+            for g in og:
+                g.insert(inserted_at[w][:3], loc)
+        s0 = args.warmup
         t1 = time.perf_counter()
         pr = po.Problem()
-        window_problem(pr, synth, args.map_scans - 1, n_cp, scans[:n_cp - 1], og, n_pts)
+        window_problem(pr, synth, args.map_scans - 1 + s0, n_cp, scans[s0:s0 + n_cp - 1], og, n_pts)
         so = pr.solve()
         est = pr.get_pose(1)
-        loc = synth.transform_points(est, scans[0])
+        loc = synth.transform_points(est, scans[s0])
         for g in og:
             g.insert(est[:3].astype(np.float32), loc)
         cpu_s = time.perf_counter() - t1
+        lk, pb = pr.lookup_stats()
+        lbar = pb / max(1, lk)
+        g_poses, g_it, g_tt, g_tr = solved[s0]
+        max_dt = max_dr = 0.0
+        for i in range(n_cp):
+            o = pr.get_pose(i)
+            max_dt = max(max_dt, float(np.linalg.norm(o[:3] - g_poses[i][:3])))
+            max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(np.dot(o[3:], g_poses[i][3:])))))))
+        parity = {"max_dt_m": max_dt, "max_dr_rad": max_dr, "windows": 1, "control_points": n_cp, "tolerance": 1e-4,
+                  "same_iterations_and_termination": bool((so.num_iterations, so.termination_type, so.termination_reason)
+                                                          == (g_it, g_tt, g_tr)),
+                  "step": "first timed step, %d x %d-pt blocks" % (n_cp - 1, n_pts)}
+        if not (max_dt <= 1e-4 and max_dr <= 1e-4):
+            raise SystemExit("bench.py: parity gate failed, GPU and oracle window poses differ: %r" % (parity,))
         base = {"value": 1.0 / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
                 "sample": "1 window of the same workload (solve %d iterations + insert), oracle -O3 1 thread" % so.num_iterations}
+    # roofline of the window pass (k_window_residuals): every launch evaluates all blocks of the window;
+    # launches behind the solve's termination exit at once and move no bytes
+    n_launch = max(1, prof["residuals"][0])
+    avg_ms = prof["residuals"][1] / n_launch
+    share = min(1.0, sum(evals) / n_launch) if evals else 1.0
+    bytes_per_launch = (n_cp - 1) * n_pts * (12.0 + 32.0 * lbar) * share
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     return {
         "metric": "scans/s (sliding window of %d control points over %d x 100k-pt scans, 3-res TSDF)" % (n_cp, n_cp - 1),
         "value": args.steps / elapsed, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
@@ -456,7 +496,15 @@ def run_window(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "window: %d control points (81 free columns at 10), %d multi-res scan blocks + IMU/odometry blocks per solve, exact insert of the scan leaving the window"
                                % (n_cp, n_cp - 1), "mean_lm_iterations": float(np.mean(its))},
-        "roofline": None, "cpu_baseline": base,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_window_residuals<false>",
+                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "launches_evaluating": share, "mean_levels_probed": lbar,
+                     "lm_avg_launch_ms": prof["lm"][1] / max(1, prof["lm"][0]),
+                     "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
+                     "per_kernel_launches": {k: v[0] for k, v in prof.items()},
+                     "hip_event_sampling": "every %d-th of the %d timed steps" % (max(1, args.prof_every), args.steps)},
+        "parity": parity, "cpu_baseline": base,
         "gpu_over_cpu": (args.steps / elapsed) / base["value"] if base else None,
     }
 

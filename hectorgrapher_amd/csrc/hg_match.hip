@@ -45,7 +45,8 @@ constexpr int kAccU = 91;  // unwarped blocks: 78 (upper triangle of 12x12) + 12
 constexpr int kEvalThreads = 512;
 constexpr int kBatchThreads = 256;   // workgroup of the batched residual pass (no LM tail: lean in registers)
 constexpr int kLmThreads = 64;   // the LM state machine runs in one wavefront
-constexpr int kLmBlock = 256;    // waves 1-3 only help summing the workgroup partials
+constexpr int kLmBlock = 512;    // waves 1-7 only help summing the workgroup partials
+constexpr int kMaxTiles = 16;    // 256-return tiles one workgroup of the window pass walks at most
 constexpr int kMaxStripes = 512 / kAcc;  // stripes of the partial reduction (block size / 36)
 
 struct PyramidView {
@@ -877,69 +878,163 @@ __device__ __forceinline__ void prepare_block(const BlockInfo& b, const double (
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Window pass (every problem but the single-pose registration step): lean residual bodies without a
+// solver tail. A workgroup of 256 threads walks `tiles` consecutive 256-return tiles of ONE block and
+// keeps X^T X in the MFMA accumulators across them, so a window of nine 100k-point scans is ~700
+// resident workgroups (one round on the chip, three per CU) that leave 36 sums each, instead of 1800
+// workgroups of 512 threads at one per CU. The partials cross a kernel boundary to k_lm.
+// ------------------------------------------------------------------------------------------
+struct EvalBlock {
+  PyramidView pv;
+  const float* xyz;
+  const double* factor;  // per-return interpolation ratios, or nullptr
+  double scaling;
+  unsigned n, wg_begin, num_wg, partial_offset, row_offset;
+  int pose_a, pose_b, index;
+};
+
+// Per-scan blocks (one transform per block; the map to the local parameters is applied after the
+// reduction, in k_lm): X = [d r / d(t, q) | r], 64 x 8 per wavefront and tile.
+__device__ __forceinline__ void window_body_plain(const EvalBlock& eb, const BlockXform* __restrict__ xf,
+                                                  double* __restrict__ partials, double* __restrict__ residuals,
+                                                  unsigned wg, unsigned tiles, unsigned char* smem) {
+  constexpr int kWaves = kBatchThreads / kWave;
+  double (*xs)[kWave][8] = reinterpret_cast<double (*)[kWave][8]>(smem);
+  double (*cs)[64] = reinterpret_cast<double (*)[64]>(smem + kWaves * kWave * 8 * sizeof(double));
+  const PyramidView& pv = eb.pv;
+  const DirectRaw dp = direct_issue(pv);
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int mj = lane & 15, mk = lane >> 4;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d4 cacc = {0.0, 0.0, 0.0, 0.0};
+  const unsigned n = eb.n;
+  const double scaling = eb.scaling;
+  const unsigned first = xcd_chunk(wg, eb.num_wg) * tiles;
+  for (unsigned tile = 0; tile < tiles; ++tile) {
+    const unsigned base = (first + tile) * kBatchThreads;
+    if (base >= n) break;  // uniform
+    const unsigned i = base + threadIdx.x;
+    double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (i < n) {
+      const double v[3] = {static_cast<double>(eb.xyz[3 * i]), static_cast<double>(eb.xyz[3 * i + 1]),
+                           static_cast<double>(eb.xyz[3 * i + 2])};
+      return_row(pv, dp, xf->t, xf->q, v, scaling, row8);
+      if (residuals) residuals[i] = row8[7];
+    }
+    d2* dst = reinterpret_cast<d2*>(&xs[wave][lane][0]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = d2{row8[2 * c], row8[2 * c + 1]};
+    wave_sync();  // xs[wave] is written and read by this wavefront only
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double a = (mj < 8) ? xs[wave][4 * s + mk][mj] : 0.0;
+      cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+    }
+    wave_sync();  // the operand reads are done before the next tile overwrites the tile
+  }
+  if (mj < 8) {  // rows 0..7 of D sit in accumulator registers 0 and 1 (row = l/16 + 4v)
+    cs[wave][mk * 8 + mj] = cacc[0];
+    cs[wave][(mk + 4) * 8 + mj] = cacc[1];
+  }
+  __syncthreads();
+  if (threadIdx.x < kAcc) {
+    // partial layout: 28 upper-triangle entries of the 7x7 block (row-major), 7 x J^T r, r^T r
+    int a, b;
+    if (threadIdx.x < 28) {
+      int t = threadIdx.x;
+      a = 0;
+      while (t >= 7 - a) { t -= 7 - a; ++a; }
+      b = a + t;
+    } else if (threadIdx.x < 35) {
+      a = threadIdx.x - 28;
+      b = 7;
+    } else {
+      a = 7;
+      b = 7;
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv) sum += cs[wv][a * 8 + b];
+    partials[static_cast<size_t>(wg) * kAcc + threadIdx.x] = sum;
+  }
+}
+
 // Block with one interpolation factor per return (per-point unwarping: the subdivision blocks of
 // AddPerPointMatchingResiduals, optimizing_local_trajectory_builder.cc:513-612, and
 // InterpolatedTSDFPerPointSpaceCostFunction3D): every lane interpolates its own transform between
 // control points a and b and forms its Jacobian row directly over the 12 local columns
 // [pose_a 6 | pose_b 6]; X = [row12 | r] (64 x 13, padded to 16) goes through the same MFMA X^T X
 // reduction. 91 partial sums per workgroup: upper triangle of the 12 x 12 block, J^T r, r^T r.
-__device__ __forceinline__ void tsdf_residuals_unwarp_body(
-    const PyramidView& pv, const float* __restrict__ xyz, const double* __restrict__ factor,
-    unsigned n, double scaling, const double* pa, const double* pb, double* __restrict__ partials,
-    double* __restrict__ residuals, double (*xs)[kWave][16], double (*cs)[256], unsigned wg) {
-  const unsigned i = wg * kEvalThreads + threadIdx.x;
-  double row[13];
-#pragma unroll
-  for (int k = 0; k < 13; ++k) row[k] = 0.0;
+__device__ __forceinline__ void window_body_unwarp(const EvalBlock& eb, const double* pa, const double* pb,
+                                                   double* __restrict__ partials, double* __restrict__ residuals,
+                                                   unsigned wg, unsigned tiles, unsigned char* smem) {
+  constexpr int kWaves = kBatchThreads / kWave;
+  double (*xs)[kWave][16] = reinterpret_cast<double (*)[kWave][16]>(smem);
+  double (*cs)[256] = reinterpret_cast<double (*)[256]>(smem + kWaves * kWave * 16 * sizeof(double));
+  const PyramidView& pv = eb.pv;
   const DirectRaw dp = direct_issue(pv);
-  if (i < n) {
-    const double f = factor[i];
-    double pja[12], pjb[12];
-    quaternion_plus_jacobian(pa + 3, pja);
-    quaternion_plus_jacobian(pb + 3, pjb);
-    double t[3], q[4];
-    for (int k = 0; k < 3; ++k) t[k] = pa[k] + (pb[k] - pa[k]) * f;
-    DJ<8> qj[4];
-    slerp_jets(pa + 3, pb + 3, f, qj);
-    for (int r = 0; r < 4; ++r) q[r] = qj[r].a;
-    const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
-                         static_cast<double>(xyz[3 * i + 2])};
-    double row8[8];
-    return_row(pv, dp, t, q, v, scaling, row8);
-    if (residuals) residuals[i] = row8[7];
-    const double ma = 1.0 + (0.0 - 1.0) * f, mb = (1.0 - 0.0) * f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      row[c] = row8[c] * ma;
-      row[6 + c] = row8[c] * mb;
-      double ja = 0.0, jb = 0.0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double sa = 0.0, sb = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          sa += qj[r].v[j] * pja[j * 3 + c];
-          sb += qj[r].v[4 + j] * pjb[j * 3 + c];
-        }
-        ja += row8[3 + r] * sa;
-        jb += row8[3 + r] * sb;
-      }
-      row[3 + c] = ja;
-      row[9 + c] = jb;
-    }
-    row[12] = row8[7];
-  }
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) xs[wave][lane][c] = c < 13 ? row[c] : 0.0;
-  __syncthreads();
+  const int mj = lane & 15, mk = lane >> 4;
   typedef double d4 __attribute__((ext_vector_type(4)));
   d4 cacc = {0.0, 0.0, 0.0, 0.0};
-  const int mj = lane & 15, mk = lane >> 4;
+  const unsigned n = eb.n;
+  const double scaling = eb.scaling;
+  const unsigned first = xcd_chunk(wg, eb.num_wg) * tiles;
+  for (unsigned tile = 0; tile < tiles; ++tile) {
+    const unsigned base = (first + tile) * kBatchThreads;
+    if (base >= n) break;  // uniform
+    const unsigned i = base + threadIdx.x;
+    double row[13];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const double a = xs[wave][4 * s + mk][mj];
-    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+    for (int k = 0; k < 13; ++k) row[k] = 0.0;
+    if (i < n) {
+      const double f = eb.factor[i];
+      double pja[12], pjb[12];
+      quaternion_plus_jacobian(pa + 3, pja);
+      quaternion_plus_jacobian(pb + 3, pjb);
+      double t[3], q[4];
+      for (int k = 0; k < 3; ++k) t[k] = pa[k] + (pb[k] - pa[k]) * f;
+      DJ<8> qj[4];
+      slerp_jets(pa + 3, pb + 3, f, qj);
+      for (int r = 0; r < 4; ++r) q[r] = qj[r].a;
+      const double v[3] = {static_cast<double>(eb.xyz[3 * i]), static_cast<double>(eb.xyz[3 * i + 1]),
+                           static_cast<double>(eb.xyz[3 * i + 2])};
+      double row8[8];
+      return_row(pv, dp, t, q, v, scaling, row8);
+      if (residuals) residuals[i] = row8[7];
+      const double ma = 1.0 + (0.0 - 1.0) * f, mb = (1.0 - 0.0) * f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        row[c] = row8[c] * ma;
+        row[6 + c] = row8[c] * mb;
+        double ja = 0.0, jb = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double sa = 0.0, sb = 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sa += qj[r].v[j] * pja[j * 3 + c];
+            sb += qj[r].v[4 + j] * pjb[j * 3 + c];
+          }
+          ja += row8[3 + r] * sa;
+          jb += row8[3 + r] * sb;
+        }
+        row[3 + c] = ja;
+        row[9 + c] = jb;
+      }
+      row[12] = row8[7];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) xs[wave][lane][c] = c < 13 ? row[c] : 0.0;
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const double a = xs[wave][4 * s + mk][mj];
+      cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+    }
+    wave_sync();
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) cs[wave][(mk + 4 * r) * 16 + mj] = cacc[r];  // D[l/16 + 4v][l%16]
@@ -958,10 +1053,10 @@ __device__ __forceinline__ void tsdf_residuals_unwarp_body(
       a = 12;
       b = 12;
     }
-    double s = 0.0;
+    double sum = 0.0;
 #pragma unroll
-    for (int wv = 0; wv < kEvalThreads / kWave; ++wv) s += cs[wv][a * 16 + b];
-    store_partial(&partials[static_cast<size_t>(wg) * kAccU + threadIdx.x], s);
+    for (int wv = 0; wv < kWaves; ++wv) sum += cs[wv][a * 16 + b];
+    partials[static_cast<size_t>(wg) * kAccU + threadIdx.x] = sum;
   }
 }
 
@@ -2253,9 +2348,9 @@ __device__ inline LJRigid lj_mul(const LJRigid& a, const LJRigid& b) {  // :184-
   return {{t.x + a.t.x, t.y + a.t.y, t.z + a.t.z}, lj_qnormalized(lj_qmul(a.q, b.q))};
 }
 
-__global__ __launch_bounds__(kWave) void k_small_blocks(LmState* G, SmallOut* out, double* residuals) {
-  if (G->h.done) return;
-  const int b = blockIdx.x, lane = threadIdx.x;
+// One wavefront (lanes 0..63 of the calling workgroup; the arrays are its own).
+__device__ __forceinline__ void small_block_eval(const LmState* G, int b, SmallOut* out, double* residuals) {
+  const int lane = threadIdx.x;
   const SmallBlockDev sb = G->h.small[b];
   if (!sb.active) return;
   __shared__ double Ja[9][20];   // ambient Jacobian rows
@@ -2310,7 +2405,7 @@ __global__ __launch_bounds__(kWave) void k_small_blocks(LmState* G, SmallOut* ou
     for (int i = 0; i < 9; ++i) Ja[i][lane] = (i < rows) ? r[i].v : 0.0;
   if (lane == 0)
     for (int i = 0; i < 9; ++i) rs[i] = (i < rows) ? r[i].a : 0.0;
-  __syncthreads();
+  wave_sync();
   // ambient -> local columns [t_a 3 | rot_a 3 | v_a 3 | t_b 3 | rot_b 3 | v_b 3]
   if (lane < 18) {
     double pj[12];
@@ -2332,7 +2427,7 @@ __global__ __launch_bounds__(kWave) void k_small_blocks(LmState* G, SmallOut* ou
       Jl[i][c] = v;
     }
   }
-  __syncthreads();
+  wave_sync();
   SmallOut& o = out[b];
   for (int idx = lane; idx < 18 * 18; idx += kWave) {
     const int c1 = idx / 18, c2 = idx % 18;
@@ -2354,11 +2449,12 @@ __global__ __launch_bounds__(kWave) void k_small_blocks(LmState* G, SmallOut* ou
   }
 }
 
+__global__ __launch_bounds__(kWave) void k_small_blocks(LmState* G, SmallOut* out, double* residuals) {
+  if (G->h.done) return;
+  small_block_eval(G, blockIdx.x, out, residuals);
+}
 
-// Residual kernel of one block. With `G` set, the last workgroup of the iteration (a ticket counts
-// the workgroups of all blocks' launches) runs the LM step in its tail, so an iteration is ONE
-// launch: release/acquire at agent scope around the ticket makes the other workgroups' partials
-// visible to it (cdna_hip_programming.md Guideline 16).
+
 #ifdef HG_EVAL_STAMPS
 // diagnostic build only: per-workgroup timeline of the last k_tsdf_residuals launch (100 MHz clock)
 __device__ unsigned long long g_eval_stamps[1024][4];
@@ -2366,48 +2462,6 @@ __device__ unsigned long long g_eval_stamps[1024][4];
 #else
 #define EVAL_STAMP(i) do {} while (0)
 #endif
-__global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals(
-    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
-    const BlockXform* __restrict__ xf, double* __restrict__ partials,
-    double* __restrict__ residuals, LmState* G, BlockXform* xf_all, const double* partials_all,
-    const SmallOut* small_out, unsigned* ticket, unsigned total_wg) {
-  if (G && G->h.done) return;
-#ifdef HG_EVAL_STAMPS
-  const int eval_it = G ? G->h.iteration : -1;
-  if (threadIdx.x == 0 && blockIdx.x == 0) g_tail_stamps[7] = eval_it;
-#endif
-  EVAL_STAMP(0);
-  // the staging tiles of the X^T X reduction and the LM tail's working set share one LDS allocation
-  __shared__ __align__(16) unsigned char smem[sizeof(LmShared)];
-  static_assert(sizeof(LmShared) >= (kEvalThreads / kWave) * (kWave * 8 + 64) * sizeof(double),
-                "LDS tile aliasing");
-  tsdf_residuals_body(pv, xyz, n, scaling, xf, partials, residuals,
-                      reinterpret_cast<double (*)[kWave][8]>(smem),
-                      reinterpret_cast<double (*)[64]>(smem + (kEvalThreads / kWave) * kWave * 8 * sizeof(double)),
-                      xcd_chunk(blockIdx.x, gridDim.x));
-  if (!G) return;
-  EVAL_STAMP(1);
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = atomicAdd(ticket, 1u);
-    s_last = (t == total_wg - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *ticket = 0u;  // ready for the next iteration's launches
-  }
-  __syncthreads();
-  EVAL_STAMP(2);
-  lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
-  EVAL_STAMP(3);
-}
 
 // The single-pose registration step (one free pose, one per-scan block): the same evaluation with
 // the register-resident LM step in the tail, in a kernel of its own so that its LDS footprint is
@@ -2528,104 +2582,46 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm_single_batch(const SingleJo
   lm_step_single(reinterpret_cast<double*>(smem), J.G, const_cast<BlockXform*>(J.xf), J.partials, J.num_wg);
 }
 
-// Same launch protocol for a block with per-return interpolation factors. The staging tiles of
-// the X^T X reduction and the LM tail's working set share one LDS allocation.
-__global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals_unwarp(
-    PyramidView pv, const float* __restrict__ xyz, const double* __restrict__ factor, unsigned n,
-    double scaling, int pose_a, int pose_b, double* __restrict__ partials,
-    double* __restrict__ residuals, LmState* G, BlockXform* xf_all, const double* partials_all,
-    const SmallOut* small_out, unsigned* ticket, unsigned total_wg) {
+// All residual blocks of a problem in ONE launch per LM iteration: workgroup -> (block, local
+// workgroup) through the device block table (entries of one kind: per-scan blocks, or blocks with a
+// ratio per return; a problem holding both kinds launches the kernel once per kind). Every block's
+// first workgroup is a multiple of 8, so that blockIdx % 8 -- the XCD -- is also the local index % 8
+// (xcd_chunk). Workgroups behind the last block evaluate the odometry / IMU blocks (one wavefront
+// each): their 15 us of serial Jet arithmetic run in the shadow of the TSDF blocks instead of in a
+// launch of their own. No solver tail: k_lm follows as its own launch.
+#ifndef HG_WINDOW_WAVES
+#define HG_WINDOW_WAVES 4  // workgroups per CU the per-scan body is compiled for (register budget 512 / waves)
+#endif
+template <bool UNWARP>
+__global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals(
+    const EvalBlock* __restrict__ blocks, int num_eval, unsigned tiles, double* __restrict__ residuals,
+    LmState* G, const BlockXform* __restrict__ xf_all, double* __restrict__ partials_all, SmallOut* small_out,
+    unsigned tsdf_wg) {
   if (G->h.done) return;
-  __shared__ __align__(16) unsigned char smem[sizeof(LmShared)];
-  static_assert(sizeof(LmShared) >= (kEvalThreads / kWave) * (kWave * 16 + 256) * sizeof(double),
-                "LDS tile aliasing");
-  double (*xs)[kWave][16] = reinterpret_cast<double (*)[kWave][16]>(smem);
-  double (*cs)[256] = reinterpret_cast<double (*)[256]>(smem + (kEvalThreads / kWave) * kWave * 16 * sizeof(double));
-  tsdf_residuals_unwarp_body(pv, xyz, factor, n, scaling, G->h.cand[pose_a], G->h.cand[pose_b],
-                             partials, residuals, xs, cs, xcd_chunk(blockIdx.x, gridDim.x));
-  if (!ticket) return;
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = atomicAdd(ticket, 1u);
-    s_last = (t == total_wg - 1u) ? 1 : 0;
+  if (blockIdx.x >= tsdf_wg) {
+#ifndef HG_NO_SMALL_FOLD
+    if (threadIdx.x < kWave) small_block_eval(G, static_cast<int>(blockIdx.x - tsdf_wg), small_out, residuals);
+#endif
+    return;
   }
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *ticket = 0u;
-  }
-  __syncthreads();
-  lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
-}
-
-// All residual blocks of a problem in ONE launch per LM iteration (sliding windows: one block per
-// scan in the window): workgroup -> (block, local workgroup) through the device block table.
-struct EvalBlock {
-  PyramidView pv;
-  const float* xyz;
-  const double* factor;  // per-return interpolation ratios, or nullptr
-  double scaling;
-  unsigned n, wg_begin, partial_offset, row_offset;
-  int pose_a, pose_b, index, pad;
-};
-
-__global__ __launch_bounds__(kEvalThreads) void k_tsdf_residuals_multi(
-    const EvalBlock* __restrict__ blocks, int num_eval, double* __restrict__ residuals, LmState* G,
-    BlockXform* xf_all, double* partials_all, const SmallOut* small_out, unsigned* ticket,
-    unsigned total_wg) {
-  if (G->h.done) return;
-  __shared__ __align__(16) unsigned char smem[sizeof(LmShared)];
+  constexpr size_t kTile = (kBatchThreads / kWave) * (kWave * (UNWARP ? 16 : 8) + (UNWARP ? 256 : 64)) * sizeof(double);
+  __shared__ __align__(16) unsigned char smem[kTile];
   // block of this workgroup: every lane reads one table entry's first workgroup, one ballot
   int b;
   {
     const int lane = threadIdx.x % kWave;
     const bool le = lane < num_eval && blocks[lane].wg_begin <= blockIdx.x;
-    b = __popcll(__ballot(le)) - 1;  // wg_begin ascends; entry 0 starts at 0
+    b = __builtin_amdgcn_readfirstlane(__popcll(__ballot(le)) - 1);  // wg_begin ascends; entry 0 starts at 0
   }
-  // by-value copy: the table entry is read once (uniform loads), not at every use in the body
-  const PyramidView pv = blocks[b].pv;
-  const EvalBlock eb = {PyramidView(), blocks[b].xyz, blocks[b].factor, blocks[b].scaling, blocks[b].n,
-                        blocks[b].wg_begin, blocks[b].partial_offset, blocks[b].row_offset,
-                        blocks[b].pose_a, blocks[b].pose_b, blocks[b].index, 0};
+  const EvalBlock& eb = blocks[b];
   const unsigned wg = blockIdx.x - eb.wg_begin;
+  if (wg >= eb.num_wg) return;  // padding up to the next block's multiple of 8
   double* res = residuals ? residuals + eb.row_offset : nullptr;
-  if (eb.factor) {
-    double (*xs)[kWave][16] = reinterpret_cast<double (*)[kWave][16]>(smem);
-    double (*cs)[256] = reinterpret_cast<double (*)[256]>(smem + (kEvalThreads / kWave) * kWave * 16 * sizeof(double));
-    tsdf_residuals_unwarp_body(pv, eb.xyz, eb.factor, eb.n, eb.scaling, G->h.cand[eb.pose_a],
-                               G->h.cand[eb.pose_b], partials_all + eb.partial_offset, res, xs, cs, wg);
-  } else {
-    tsdf_residuals_body(pv, eb.xyz, eb.n, eb.scaling, xf_all + eb.index,
-                        partials_all + eb.partial_offset, res,
-                        reinterpret_cast<double (*)[kWave][8]>(smem),
-                        reinterpret_cast<double (*)[64]>(smem + (kEvalThreads / kWave) * kWave * 8 * sizeof(double)),
-                        wg);
-  }
-  if (!ticket) return;
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = atomicAdd(ticket, 1u);
-    s_last = (t == total_wg - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *ticket = 0u;
-  }
-  __syncthreads();
-  lm_step(*reinterpret_cast<LmShared*>(smem), G, xf_all, partials_all, small_out, MODE_STEP);
+  if (UNWARP)
+    window_body_unwarp(eb, G->h.cand[eb.pose_a], G->h.cand[eb.pose_b], partials_all + eb.partial_offset, res, wg,
+                       tiles, smem);
+  else
+    window_body_plain(eb, xf_all + eb.index, partials_all + eb.partial_offset, res, wg, tiles, smem);
 }
 
 __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
@@ -2669,9 +2665,13 @@ struct hg_problem {
   bool solve_pending = false;
   PyramidView* d_pv = nullptr;  // per block: its pyramid in device memory (PyramidView::self_mem)
   PyramidView* h_pv = nullptr;  // pinned staging = what d_pv holds (re-uploaded only when it changes)
-  EvalBlock* d_eval = nullptr;  // block table of the fused multi-block launch
+  EvalBlock* d_eval = nullptr;  // block table of the window pass: per-scan blocks first, then the unwarped ones
   EvalBlock* h_eval = nullptr;  // pinned staging
-  int num_eval = 0;             // active blocks in the table (>= 2 -> fused launch)
+  int num_eval = 0;             // active blocks in the table
+  int num_plain = 0, num_unwarp = 0;  // of which per-scan blocks / blocks with a ratio per return
+  unsigned wg_plain = 0, wg_unwarp = 0;  // workgroups of the two launches (blocks start at multiples of 8)
+  unsigned tiles = 1;           // 256-return tiles per workgroup of the window pass
+  unsigned cap_plain = 0, cap_unwarp = 0;  // workgroups of k_window_residuals the device holds at once
   PinBox* h_box = nullptr;   // mapped pinned mailbox: upload source and result sink
   PinBox* d_box = nullptr;   // its device address
   unsigned long long seq = 0;
@@ -2719,7 +2719,32 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       !p->blocks[0].d_factor && p->blocks[0].pose_b < 0 && p->blocks[0].n > 0 && std::getenv("HG_LM_GENERAL") == nullptr) {
     p->single_threads = kEvalThreads;  // 256-thread workgroups were measured 19 % slower per step
   }
-  const unsigned eval_threads = p->single_threads ? static_cast<unsigned>(p->single_threads) : kEvalThreads;
+  // Window pass: a workgroup walks `tiles` tiles of 256 returns, chosen so that all workgroups of an
+  // iteration are resident at once (one round on the chip, no tail round).
+  p->tiles = 1;
+  if (!p->single_threads) {
+    if (!p->cap_plain) {
+      int cus = 0, occ_p = 0, occ_u = 0;
+      HG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->ctx->device));
+      HG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_p, k_window_residuals<false>, kBatchThreads, 0));
+      HG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_u, k_window_residuals<true>, kBatchThreads, 0));
+      p->cap_plain = static_cast<unsigned>(std::max(1, cus) * std::max(1, occ_p));
+      p->cap_unwarp = static_cast<unsigned>(std::max(1, cus) * std::max(1, occ_u));
+      if (const char* e = std::getenv("HG_WINDOW_CAPACITY")) p->cap_plain = p->cap_unwarp = std::max(1, std::atoi(e));
+    }
+    unsigned long long tiles_plain = 0, tiles_unwarp = 0;
+    for (const hg_problem::Block& hb : p->blocks)
+      if (block_active(p, hb)) (hb.d_factor ? tiles_unwarp : tiles_plain) += (hb.n + kBatchThreads - 1) / kBatchThreads;
+    // every block rounds its workgroups up (and to a multiple of 8 in the grid): leave room for that
+    const unsigned slack = 8u * static_cast<unsigned>(p->blocks.size());
+    const unsigned long long tp = (tiles_plain + std::max(1u, p->cap_plain - std::min(p->cap_plain - 1u, slack)) - 1) /
+                                  std::max(1u, p->cap_plain - std::min(p->cap_plain - 1u, slack));
+    const unsigned long long tu = (tiles_unwarp + std::max(1u, p->cap_unwarp - std::min(p->cap_unwarp - 1u, slack)) - 1) /
+                                  std::max(1u, p->cap_unwarp - std::min(p->cap_unwarp - 1u, slack));
+    p->tiles = static_cast<unsigned>(std::min<unsigned long long>(kMaxTiles, std::max<unsigned long long>(1, std::max(tp, tu))));
+    if (const char* e = std::getenv("HG_WINDOW_TILES")) p->tiles = std::max(1, std::min(kMaxTiles, std::atoi(e)));
+  }
+  const unsigned eval_threads = p->single_threads ? static_cast<unsigned>(p->single_threads) : kBatchThreads * p->tiles;
   unsigned wg_off = 0, row = 0;
   for (int b = 0; b < S.num_blocks; ++b) {
     const hg_problem::Block& hb = p->blocks[b];
@@ -2773,45 +2798,52 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   if (rc != HG_OK) return rc;
   // the pinned buffer may still be the source of the previous (finished) upload: solves are
   // synchronised by their fetch before the next upload
-  // block table of the fused launch (two or more active blocks)
-  p->num_eval = 0;
-  for (int b = 0; b < S.num_blocks; ++b) {
-    const BlockInfo& bi = S.blocks[b];
-    if (!bi.active) continue;
-    const hg_problem::Block& hb = p->blocks[b];
-    EvalBlock& eb = p->h_eval[p->num_eval];
-    std::memset(&eb, 0, sizeof(eb));
-    {
-      // the block's pyramid, also kept in device memory (uploaded when it differs from what is there)
-      PyramidView pv;
-      std::memset(&pv, 0, sizeof(pv));
-      pv.levels = static_cast<int>(hb.pyramid.size());
-      pv.multi_res = hb.multi_res;
-      for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
-      pv.self_mem = p->d_pv + b;
-      if (std::memcmp(&p->h_pv[b], &pv, sizeof(pv)) != 0) {
-        // the staging slot may still feed an earlier copy: drain the stream before rewriting it (rare:
-        // only when a block's pyramid changes)
-        HG_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
-        p->h_pv[b] = pv;
-        HG_HIP_CHECK(hipMemcpyAsync(p->d_pv + b, &p->h_pv[b], sizeof(pv), hipMemcpyHostToDevice, p->ctx->stream));
+  // block table of the window pass: per-scan blocks first, then the blocks with a ratio per return
+  p->num_eval = p->num_plain = p->num_unwarp = 0;
+  p->wg_plain = p->wg_unwarp = 0;
+  for (int kind = 0; kind < 2; ++kind) {
+    unsigned wg_next = 0;
+    for (int b = 0; b < S.num_blocks; ++b) {
+      const BlockInfo& bi = S.blocks[b];
+      const hg_problem::Block& hb = p->blocks[b];
+      if (!bi.active || (hb.d_factor != nullptr) != (kind == 1)) continue;
+      EvalBlock& eb = p->h_eval[p->num_eval];
+      std::memset(&eb, 0, sizeof(eb));
+      {
+        // the block's pyramid, also kept in device memory (uploaded when it differs from what is there)
+        PyramidView pv;
+        std::memset(&pv, 0, sizeof(pv));
+        pv.levels = static_cast<int>(hb.pyramid.size());
+        pv.multi_res = hb.multi_res;
+        for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
+        pv.self_mem = p->d_pv + b;
+        if (std::memcmp(&p->h_pv[b], &pv, sizeof(pv)) != 0) {
+          // the staging slot may still feed an earlier copy: drain the stream before rewriting it (rare:
+          // only when a block's pyramid changes)
+          HG_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+          p->h_pv[b] = pv;
+          HG_HIP_CHECK(hipMemcpyAsync(p->d_pv + b, &p->h_pv[b], sizeof(pv), hipMemcpyHostToDevice, p->ctx->stream));
+        }
+        eb.pv = pv;
       }
-      eb.pv = pv;
+      eb.xyz = hb.d_xyz;
+      eb.factor = hb.d_factor;
+      eb.scaling = bi.scaling;
+      eb.n = bi.n;
+      eb.wg_begin = wg_next;
+      eb.num_wg = bi.num_wg;
+      wg_next += (bi.num_wg + 7u) & ~7u;
+      eb.partial_offset = bi.partial_offset;
+      eb.row_offset = bi.row_offset;
+      eb.pose_a = bi.pose_a;
+      eb.pose_b = bi.pose_b;
+      eb.index = b;
+      ++p->num_eval;
+      ++(kind ? p->num_unwarp : p->num_plain);
     }
-    eb.xyz = hb.d_xyz;
-    eb.factor = hb.d_factor;
-    eb.scaling = bi.scaling;
-    eb.n = bi.n;
-    eb.wg_begin = p->num_eval ? p->h_eval[p->num_eval - 1].wg_begin +
-                                    (p->h_eval[p->num_eval - 1].n + kEvalThreads - 1) / kEvalThreads : 0u;
-    eb.partial_offset = bi.partial_offset;
-    eb.row_offset = bi.row_offset;
-    eb.pose_a = bi.pose_a;
-    eb.pose_b = bi.pose_b;
-    eb.index = b;
-    ++p->num_eval;
+    (kind ? p->wg_unwarp : p->wg_plain) = wg_next;
   }
-  if (p->num_eval >= 2)
+  if (p->num_eval >= 1 && !p->single_threads)
     HG_HIP_CHECK(hipMemcpyAsync(p->d_eval, p->h_eval, sizeof(EvalBlock) * p->num_eval,
                                 hipMemcpyHostToDevice, p->ctx->stream));
   S.box = p->d_box;
@@ -2834,18 +2866,13 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   return HG_OK;
 }
 
-int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm, bool first = false) {
+// One evaluation of every residual block at the candidate. with_lm: followed by one LM step (the
+// single-pose registration shape runs it in the tail of its residual launch, every other problem as a
+// k_lm launch behind the window pass).
+int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = false) {
   hipStream_t s = p->ctx->stream;
   const LmHead& S = p->h_state.h;
-  if (S.num_small > 0) {
-    // odometry / IMU blocks at the candidate; stream order puts their results before the LM step
-    hipLaunchKernelGGL(k_small_blocks, dim3(S.num_small), dim3(kWave), 0, s, p->d_state, p->d_small,
-                       d_residuals);
-    HG_HIP_CHECK(hipGetLastError());
-  }
-  unsigned total_wg = 0;
-  for (int b = 0; b < S.num_blocks; ++b) total_wg += S.blocks[b].num_wg;
-  if (fused_lm && p->single_threads && S.ncols == 6 && S.bw == 5 && S.blocks[0].active) {
+  if (with_lm && p->single_threads && S.ncols == 6 && S.bw == 5 && S.blocks[0].active) {
     const BlockInfo& bi = S.blocks[0];
     const hg_problem::Block& hb = p->blocks[0];
     const PyramidView& pv = p->h_pv[0];
@@ -2866,37 +2893,43 @@ int launch_eval(hg_problem* p, double* d_residuals, bool fused_lm, bool first = 
     HG_HIP_CHECK(hipGetLastError());
     return HG_OK;
   }
-  if (p->num_eval >= 2) {
-    // all blocks of the window in one launch per iteration
-    ProfScope ps(p->ctx, HG_K_RESIDUALS, 0, 1, !p->prof_grouped);
-    hipLaunchKernelGGL(k_tsdf_residuals_multi, dim3(total_wg), dim3(kEvalThreads), 0, s, p->d_eval,
-                       p->num_eval, d_residuals, p->d_state, p->d_xf, p->partials.as<double>(),
-                       p->d_small, fused_lm ? p->d_ticket : nullptr, total_wg);
+  // window pass: all blocks of a kind in one launch; the odometry / IMU blocks ride on the first one
+  unsigned small_left = static_cast<unsigned>(S.num_small);
+#ifdef HG_NO_SMALL_FOLD
+  if (small_left > 0) {
+    hipLaunchKernelGGL(k_small_blocks, dim3(small_left), dim3(kWave), 0, s, p->d_state, p->d_small, d_residuals);
     HG_HIP_CHECK(hipGetLastError());
-    return HG_OK;
+    small_left = 0;
   }
-  for (int b = 0; b < S.num_blocks; ++b) {
-    const BlockInfo& bi = S.blocks[b];
-    if (!bi.active) continue;
-    const hg_problem::Block& hb = p->blocks[b];
-    const PyramidView& pv = p->h_pv[b];
-    ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n, 1, !p->prof_grouped);
-    if (hb.d_factor) {
-      hipLaunchKernelGGL(k_tsdf_residuals_unwarp, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
-                         hb.d_xyz, hb.d_factor, bi.n, bi.scaling, bi.pose_a, bi.pose_b,
-                         p->partials.as<double>() + bi.partial_offset,
-                         d_residuals ? d_residuals + bi.row_offset : nullptr, p->d_state, p->d_xf,
-                         p->partials.as<double>(), p->d_small, fused_lm ? p->d_ticket : nullptr,
-                         total_wg);
-      HG_HIP_CHECK(hipGetLastError());
-      continue;
-    }
-    hipLaunchKernelGGL(k_tsdf_residuals, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv, hb.d_xyz,
-                       bi.n, bi.scaling, p->d_xf + b,
-                       p->partials.as<double>() + bi.partial_offset,
-                       d_residuals ? d_residuals + bi.row_offset : nullptr,
-                       fused_lm ? p->d_state : nullptr, p->d_xf, p->partials.as<double>(),
-                       p->d_small, p->d_ticket, total_wg);
+#endif
+  unsigned long long units_plain = 0, units_unwarp = 0;
+  for (int b = 0; b < S.num_blocks; ++b)
+    if (S.blocks[b].active) (p->blocks[b].d_factor ? units_unwarp : units_plain) += S.blocks[b].n;
+  if (p->num_plain > 0) {
+    ProfScope ps(p->ctx, HG_K_RESIDUALS, units_plain);
+    hipLaunchKernelGGL(k_window_residuals<false>, dim3(p->wg_plain + small_left), dim3(kBatchThreads), 0, s,
+                       static_cast<const EvalBlock*>(p->d_eval), p->num_plain, p->tiles, d_residuals, p->d_state,
+                       static_cast<const BlockXform*>(p->d_xf), p->partials.as<double>(), p->d_small, p->wg_plain);
+    HG_HIP_CHECK(hipGetLastError());
+    small_left = 0;
+  }
+  if (p->num_unwarp > 0) {
+    ProfScope ps(p->ctx, HG_K_RESIDUALS, units_unwarp);
+    hipLaunchKernelGGL(k_window_residuals<true>, dim3(p->wg_unwarp + small_left), dim3(kBatchThreads), 0, s,
+                       static_cast<const EvalBlock*>(p->d_eval + p->num_plain), p->num_unwarp, p->tiles, d_residuals,
+                       p->d_state, static_cast<const BlockXform*>(p->d_xf), p->partials.as<double>(), p->d_small,
+                       p->wg_unwarp);
+    HG_HIP_CHECK(hipGetLastError());
+    small_left = 0;
+  }
+  if (small_left > 0) {  // a problem of odometry / IMU blocks only
+    hipLaunchKernelGGL(k_small_blocks, dim3(small_left), dim3(kWave), 0, s, p->d_state, p->d_small, d_residuals);
+    HG_HIP_CHECK(hipGetLastError());
+  }
+  if (with_lm) {
+    ProfScope ps(p->ctx, HG_K_LM, 1);
+    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small,
+                       MODE_STEP, static_cast<const PinBox*>(nullptr), 0u);
     HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
@@ -3214,37 +3247,15 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
     hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
     HG_HIP_CHECK(hipGetLastError());
   }
-  bool any_active = false;
-  unsigned launches_per_it = 0;
-  unsigned long long units_per_it = 0;
-  for (int b = 0; b < S0.num_blocks; ++b) {
-    any_active = any_active || S0.blocks[b].active;
-    if (S0.blocks[b].active) {
-      ++launches_per_it;
-      units_per_it += S0.blocks[b].n;
-    }
-  }
-  if (p->num_eval >= 2) launches_per_it = 1;
-  // without odometry / IMU launches in between, the residual launches of the solve are
-  // back-to-back: one event pair brackets all of them
-  p->prof_grouped = any_active && S0.num_small == 0;
-  ProfScope group(p->ctx, HG_K_RESIDUALS, units_per_it * (max_it + 1), launches_per_it * (max_it + 1),
-                  p->prof_grouped);
+  // the launches of the single-pose registration step are back-to-back: one event pair brackets all
+  // of them (an event pair costs ~8 us of stream serialisation); the window pass is bracketed per launch
+  p->prof_grouped = first_uploads || (p->single_threads && S0.ncols == 6 && S0.bw == 5 && S0.blocks[0].active);
+  ProfScope group(p->ctx, HG_K_RESIDUALS, static_cast<unsigned long long>(S0.blocks[0].n) * (max_it + 1),
+                  static_cast<unsigned>(max_it + 1), p->prof_grouped);
   for (int it = 0; it <= max_it; ++it) {
-    if (!any_active && S0.num_small > 0) {
-      hipLaunchKernelGGL(k_small_blocks, dim3(S0.num_small), dim3(kWave), 0, s, p->d_state, p->d_small,
-                         static_cast<double*>(nullptr));
-      HG_HIP_CHECK(hipGetLastError());
-    }
-    if (any_active) {
-      // residuals of every block at the candidate + (tail of the last workgroup) one LM step
-      rc = launch_eval(p, nullptr, true, first_uploads && it == 0);
-      if (rc != HG_OK) return rc;
-    } else {
-      ProfScope ps(p->ctx, HG_K_LM, 1);
-      hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_STEP, static_cast<const PinBox*>(nullptr), 0u);
-      HG_HIP_CHECK(hipGetLastError());
-    }
+    // residuals of every block at the candidate + one LM step
+    rc = launch_eval(p, nullptr, true, first_uploads && it == 0);
+    if (rc != HG_OK) return rc;
   }
   p->prof_grouped = false;
   return HG_OK;
