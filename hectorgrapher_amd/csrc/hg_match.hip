@@ -47,7 +47,6 @@ constexpr int kBatchThreads = 256;   // workgroup of the batched residual pass (
 constexpr int kLmThreads = 64;   // the LM state machine runs in one wavefront
 constexpr int kLmBlock = 512;    // waves 1-7 only help summing the workgroup partials
 constexpr int kMaxTiles = 16;    // 256-return tiles one workgroup of the window pass walks at most
-constexpr int kMaxStripes = 512 / kAcc;  // stripes of the partial reduction (block size / 36)
 
 struct PyramidView {
   GridView level[kMaxLevels];
@@ -87,13 +86,13 @@ struct SmallBlockDev {
   double delta[7];
 };
 
-// Per small block: J^T J (18 x 18 over the local columns [pose_a 6 | vel_a 3 | pose_b 6 | vel_b 3]),
-// J^T r and r^T r, written by k_small_blocks, consumed by the LM step.
+// Per small block: its local normal equations over the columns [pose_a 6 | vel_a 3 | pose_b 6 | vel_b 3]:
+// lower triangle of J^T J (row-major, entry (r, c), c <= r, at r (r + 1) / 2 + c), then J^T r (18) and
+// r^T r -- written by the block's wavefront, staged into LDS as it stands by the LM step.
+constexpr int kSmallTri = 18 * 19 / 2;
+constexpr int kSmallLoc = kSmallTri + 18 + 1 + 2;  // padded to a multiple of 4 doubles
 struct SmallOut {
-  double H[18 * 18];
-  double g[18];
-  double c;
-  double pad;
+  double v[kSmallLoc];
 };
 
 // Scalars and small vectors of the solver; lives in global memory between launches and in LDS
@@ -115,6 +114,14 @@ struct LmHead {
   int vcol[kMaxPoses];
   int num_small;
   int bw;  // half bandwidth of J^T J (max column distance coupled by any block)
+  // Block-tridiagonal partition of the columns (0 groups = not of that shape): group k = the free
+  // columns of one control point (6 pose and / or 3 velocity columns, contiguous), and every block
+  // couples a group with itself or with a NEIGHBOURING group -- the shape of every sliding window
+  // (SURVEY 8a16). The factorisation then runs block by block in registers (cholesky_solve_btd).
+  int btd_groups;
+  int btd_uniform;  // 6 or 9: every group has that many columns and the band holds the full coupling of neighbours
+  int btd_start[kMaxPoses + 1];
+  int btd_size[kMaxPoses + 1];
   SmallBlockDev small[kMaxSmall];
   double scale[kMaxCols], diagonal[kMaxCols], g[kMaxCols], step[kMaxCols], delta[kMaxCols];
   double gc[kMaxCols];
@@ -128,10 +135,27 @@ struct LmHead {
 #endif
 };
 
+// Index tables of a problem's structure, built once per solve (k_lm MODE_PREPARE) and staged into LDS by
+// every LM step.
+constexpr int kPairMax = 8;
+struct LmTables {
+  int colcp[kMaxCols];    // global column -> control point * 16 + slot (0..5 pose, 6..8 velocity)
+  int desc[kMaxBlocks + kMaxSmall];  // per block: active << 16 | (pose_b & 255) << 8 | pose_a (TSDF blocks, then small)
+  // per pair of control points (p >= q): the blocks that cover both, in block order (TSDF blocks, then
+  // small): block | small << 8 | local offset of p's columns << 12 | of q's << 20. A pair that more
+  // than kPairMax blocks cover (per-point unwarping: dozens of blocks between two control points) sets
+  // pair_overflow and the assembly scans all blocks per entry instead.
+  int pair_list[kMaxPoses][kMaxPoses][kPairMax];
+  int pair_count[kMaxPoses][kMaxPoses];
+  int pair_overflow;
+  int pad;
+};
+
 struct LmState {
   LmHead h;
   double H[kHCap];   // J^T J at x (unscaled), band storage n x (bw + 1)
   double Hc[kHCap];  // J^T J at the candidate
+  LmTables T;
 };
 
 struct PinBox {
@@ -957,7 +981,7 @@ __device__ __forceinline__ void window_body_plain(const EvalBlock& eb, const Blo
     double sum = 0.0;
 #pragma unroll
     for (int wv = 0; wv < kWaves; ++wv) sum += cs[wv][a * 8 + b];
-    partials[static_cast<size_t>(wg) * kAcc + threadIdx.x] = sum;
+    store_partial(&partials[static_cast<size_t>(wg) * kAcc + threadIdx.x], sum);
   }
 }
 
@@ -1056,7 +1080,96 @@ __device__ __forceinline__ void window_body_unwarp(const EvalBlock& eb, const do
     double sum = 0.0;
 #pragma unroll
     for (int wv = 0; wv < kWaves; ++wv) sum += cs[wv][a * 16 + b];
-    partials[static_cast<size_t>(wg) * kAccU + threadIdx.x] = sum;
+    store_partial(&partials[static_cast<size_t>(wg) * kAccU + threadIdx.x], sum);
+  }
+}
+
+// Tail of a block's LAST workgroup (a ticket per block counts them): sums the block's workgroup
+// partials and maps them to the block's local normal equations over [pose_a 6 | pose_b 6] --
+// J^T J = M^T A7 M, J^T r = M^T b7 with M = d(t, q) / d(local parameters) of the block's transform
+// (prepare_block) for per-scan blocks; blocks with a ratio per return already are in that form. The
+// blocks of a window finish at about the same time, so these tails run side by side, and k_lm reads 91
+// numbers per block instead of a thousand partials. Hand-over of the partials as in single_eval: sc1
+// stores drained by every storing wavefront, one counted arrival per workgroup behind the barrier, sc1
+// loads by the workgroup whose arrival was the last.
+template <bool UNWARP>
+__device__ __forceinline__ void window_block_tail(const EvalBlock& eb, const double* __restrict__ partials,
+                                                  unsigned* ticket, const BlockXform* __restrict__ xf,
+                                                  double* __restrict__ loc_out, double* lds) {
+  constexpr int ACC = UNWARP ? kAccU : kAcc;
+  constexpr int STRIPES = kBatchThreads / ACC;
+  __shared__ int s_last;
+  const int t = threadIdx.x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left
+  __syncthreads();
+  if (t == 0) {
+    const unsigned arrived = atomicAdd(ticket, 1u);
+    s_last = (arrived == eb.num_wg - 1u) ? 1 : 0;
+    if (s_last) *ticket = 0u;  // ready for the next launch
+  }
+  __syncthreads();  // the arrival count has returned to wave 0 before any wave loads a partial
+  if (!s_last) return;
+  {
+    const int j = t / ACC, k = t - j * ACC;
+    if (j < STRIPES) {
+      double acc = 0.0;
+      const double* p = partials + k;
+      for (unsigned w = j; w < eb.num_wg; w += 16 * STRIPES) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const unsigned idx = w + u * STRIPES;
+          v[u] = idx < eb.num_wg ? load_partial(&p[static_cast<size_t>(idx) * ACC]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+      }
+      lds[j * ACC + k] = acc;
+    }
+  }
+  __syncthreads();
+  double* sm = lds + STRIPES * ACC;
+  if (t < ACC) {
+    double sum = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < STRIPES; ++jj) sum += lds[jj * ACC + t];
+    sm[t] = sum;
+  }
+  __syncthreads();
+  if (UNWARP) {
+    if (t < kAccU) loc_out[t] = sm[t];
+    return;
+  }
+  const double* M = xf->M;
+  if (t < 78) {
+    // entry (lo, hi) of the upper triangle; evaluated as the lower-triangle entry (c1 = hi, c2 = lo):
+    // column c1 of M contracted with A7, then with column c2
+    int lo = 0, e = t;
+    while (e >= 12 - lo) { e -= 12 - lo; ++lo; }
+    const int c1 = lo + e, c2 = lo;
+    double m1[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) m1[k] = M[k * 12 + c1];
+    double v = 0.0;
+#pragma unroll
+    for (int l = 0; l < 7; ++l) {
+      double tt = 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int a = k < l ? k : l, b = k < l ? l : k;
+        tt += m1[k] * sm[a * 7 - (a * (a - 1)) / 2 + (b - a)];
+      }
+      v += tt * M[l * 12 + c2];
+    }
+    loc_out[t] = v;
+  } else if (t < 90) {
+    const int c1 = t - 78;
+    double gs = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) gs += M[k * 12 + c1] * sm[28 + k];
+    loc_out[t] = gs;
+  } else if (t == 90) {
+    loc_out[90] = sm[35];
   }
 }
 
@@ -1068,20 +1181,21 @@ __device__ __forceinline__ void window_body_unwarp(const EvalBlock& eb, const do
 #define HG_STAMP(S, i) do {} while (0)
 #endif
 
+constexpr int kLoc = kAccU + 1;   // per TSDF block: 78 (upper triangle of its 12 x 12 local system) + 12 + 1, padded
+
 struct LmShared {
-  double stripe[2][kMaxStripes * kAcc];  // double-buffered: block b + 1 is summed while b is combined
   LmHead h;
   double H[kHCap];
   double Hc[kHCap];
-  double A[kHCap];
+  double A[kHCap + 1];    // + a dump slot for predicated-off stores of the block solver
   double rhs[kMaxCols], y[kMaxCols];
   double invd[kMaxCols];  // reciprocals of the Cholesky diagonal
-  int colmap[18];         // local -> global column of the odometry / IMU block being assembled
-  double sums[kMaxBlocks * kAccU];
-  BlockXform xfs[kMaxBlocks];  // transform + d(t,q)/d(local) of every block
-  double red[kLmThreads];
+  double loc[kMaxBlocks][kLoc];         // local normal equations of the TSDF blocks (k_window_residuals tail)
+  double small[kMaxSmall][kSmallLoc];   // the same of the odometry / IMU blocks (lower triangle, row-major)
+  LmTables T;
+  double red[16];         // per-pose partial results
+  int solve_ok;           // wavefront 0's factorisation succeeded
 };
-
 
 __device__ inline double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -1093,10 +1207,11 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
+// Candidate = Plus(x, delta): thread p handles control point p. Workgroup-wide (ends with a barrier).
 __device__ __forceinline__ void pose_plus(const LmHead& h, const double (*x)[kState], const double* delta,
-                                 double (*out)[kState], int lane) {
-  if (lane < h.num_poses) {
-    const int p = lane;
+                                 double (*out)[kState]) {
+  if (static_cast<int>(threadIdx.x) < h.num_poses) {
+    const int p = threadIdx.x;
     for (int k = 0; k < kState; ++k) out[p][k] = x[p][k];
     if (!h.constant[p]) {
       const double* d = delta + h.col[p];
@@ -1110,7 +1225,7 @@ __device__ __forceinline__ void pose_plus(const LmHead& h, const double (*x)[kSt
       for (int k = 0; k < 3; ++k) out[p][7 + k] = x[p][7 + k] + d[k];
     }
   }
-  wave_sync();
+  __syncthreads();
 }
 
 // Right-looking band Cholesky + column-oriented substitutions on an LDS band matrix (W = bw + 1).
@@ -1286,6 +1401,329 @@ __device__ __attribute__((noinline)) bool cholesky_solve_wave(int n, int W, lds_
   return ok;
 }
 
+// Block-tridiagonal systems (LmHead::btd_*): groups of up to 9 columns, every coupling inside a group
+// or between neighbouring groups. One wavefront, block by block, the band matrix in LDS updated in
+// place (L over A, as the band path leaves it):
+//   1. the diagonal block is loaded by every lane (uniform LDS addresses) and factorised in registers,
+//      redundantly -- no cross-lane traffic inside the serial chain of its columns;
+//   2. lane r solves row r of the sub-diagonal block against it;
+//   3. lane e = (r, c) subtracts row r . row c from the next diagonal block (the Schur complement).
+// The band path spends ~900 cycles per COLUMN on LDS round trips (81 columns of a ten-control-point
+// window: 30 us, 49 us with its substitutions); here a BLOCK costs ~2000 cycles. Groups smaller than 9
+// are padded with identity rows in registers. Entries outside the band are structural zeros: they are
+// read as 0 and never written (fill-in stays inside the band).
+typedef __attribute__((address_space(3))) int lds_i32;
+// Entry (i, j), j <= i, of the band matrix when `on`, else 0 -- as an unconditional load from an address
+// that is always valid plus a select, so that a run of reads stays straight-line code with all of its
+// LDS loads in flight (as conditional loads every entry became a branch with its own wait).
+__device__ inline double band_read(const lds_f64* A, int i, int j, int W, bool on = true) {
+  const bool in = on && (i - j < W);
+  const double v = A[in ? band_index(i, j, W) : 0];
+  return in ? v : 0.0;
+}
+__device__ __attribute__((noinline)) bool cholesky_solve_btd(int W, lds_f64* A, const lds_f64* b, lds_f64* x,
+                                                            lds_f64* y, lds_f64* invd, const lds_i32* start,
+                                                            const lds_i32* size, int groups, int lane) {
+  constexpr int MB = 9;
+  // lane -> entry (er, ec), ec <= er, of the lower triangle of a 9 x 9 block
+  int er = static_cast<int>((sqrtf(8.0f * static_cast<float>(lane) + 1.0f) - 1.0f) * 0.5f);
+  while (er * (er + 1) / 2 > lane) --er;
+  while ((er + 1) * (er + 2) / 2 <= lane) ++er;
+  const int ec = lane - er * (er + 1) / 2;
+  auto load_diag = [&](int s0, int m, double (*L)[MB]) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j)
+      {
+        const bool in = i < m && j < m;
+        const double v = band_read(A, s0 + i, s0 + j, W, in);
+        L[i][j] = in ? v : (i == j ? 1.0 : 0.0);
+      }
+  };
+  bool ok = true;
+  for (int g = 0; g < groups; ++g) {
+    const int s0 = start[g], m = size[g];
+    const bool has_next = g + 1 < groups;
+    const int s1 = has_next ? start[g + 1] : 0, m1 = has_next ? size[g + 1] : 0;
+    double L[MB][MB], inv[MB];
+    load_diag(s0, m, L);
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      double d = L[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+      ok = ok && (d > 0.0) && isfinite(d);
+      inv[j] = rsqrt(d);
+      L[j][j] = d * inv[j];
+#pragma unroll
+      for (int i = j + 1; i < MB; ++i) {
+        double v = L[i][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+        L[i][j] = v * inv[j];
+      }
+    }
+    if (!ok) return false;  // uniform: every lane holds the same block
+    if (lane == 0) {
+      // stores that do not apply go to the dump slot A[kHCap]: straight-line code instead of 54 branches
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+          A[(i < m && j < m && i - j < W) ? band_index(s0 + i, s0 + j, W) : kHCap] = L[i][j];
+        if (i < m) invd[s0 + i] = inv[i];
+      }
+    }
+    if (has_next) {
+      // row `lane` of the sub-diagonal block: X L^T = B
+      double X[MB];
+#pragma unroll
+      for (int c = 0; c < MB; ++c) X[c] = band_read(A, s1 + lane, s0 + c, W, lane < m1 && c < m);
+#pragma unroll
+      for (int k = 0; k < MB; ++k) {
+        double v = X[k];
+#pragma unroll
+        for (int j = 0; j < k; ++j) v -= X[j] * L[k][j];
+        X[k] = v * inv[k];
+      }
+#pragma unroll
+      for (int c = 0; c < MB; ++c)
+        A[(lane < m1 && c < m && (s1 + lane) - (s0 + c) < W) ? band_index(s1 + lane, s0 + c, W) : kHCap] = X[c];
+      wave_sync();
+      if (lane < MB * (MB + 1) / 2 && er < m1 && er - ec < W) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < MB; ++k)
+          sum += band_read(A, s1 + er, s0 + k, W, k < m) * band_read(A, s1 + ec, s0 + k, W, k < m);
+        A[band_index(s1 + er, s1 + ec, W)] -= sum;
+      }
+    }
+    wave_sync();
+  }
+  // forward substitution L y = b, block by block: lane r forms its row's right-hand side, then every
+  // lane solves the diagonal block in registers
+  for (int g = 0; g < groups; ++g) {
+    const int s0 = start[g], m = size[g];
+    const int sp = g > 0 ? start[g - 1] : 0, mp = g > 0 ? size[g - 1] : 0;
+    if (lane < m) {
+      double t = b[s0 + lane];
+#pragma unroll
+      for (int c = 0; c < MB; ++c) t -= band_read(A, s0 + lane, sp + c, W, c < mp) * y[sp + (c < mp ? c : 0)];
+      y[s0 + lane] = t;
+    }
+    wave_sync();
+    double L[MB][MB], yy[MB];
+    load_diag(s0, m, L);
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      const double v = y[s0 + (k < m ? k : 0)];
+      yy[k] = k < m ? v : 0.0;
+    }
+    double dinv[MB];
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      const double v = invd[s0 + (k < m ? k : 0)];
+      dinv[k] = k < m ? v : 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      double v = yy[k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) v -= L[k][j] * yy[j];
+      yy[k] = v * dinv[k];
+    }
+    wave_sync();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < MB; ++k)
+        if (k < m) y[s0 + k] = yy[k];
+    }
+    wave_sync();
+  }
+  // backward substitution L^T x = y
+  for (int g = groups - 1; g >= 0; --g) {
+    const int s0 = start[g], m = size[g];
+    const bool has_next = g + 1 < groups;
+    const int sn = has_next ? start[g + 1] : 0, mn = has_next ? size[g + 1] : 0;
+    if (lane < m) {
+      double t = y[s0 + lane];
+#pragma unroll
+      for (int r = 0; r < MB; ++r) t -= band_read(A, sn + r, s0 + lane, W, r < mn) * x[sn + (r < mn ? r : 0)];
+      x[s0 + lane] = t;
+    }
+    wave_sync();
+    double L[MB][MB], xx[MB];
+    load_diag(s0, m, L);
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      const double v = x[s0 + (k < m ? k : 0)];
+      xx[k] = k < m ? v : 0.0;
+    }
+    double dinv[MB];
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      const double v = invd[s0 + (k < m ? k : 0)];
+      dinv[k] = k < m ? v : 1.0;
+    }
+#pragma unroll
+    for (int k = MB - 1; k >= 0; --k) {
+      double v = xx[k];
+#pragma unroll
+      for (int j = k + 1; j < MB; ++j) v -= L[j][k] * xx[j];
+      xx[k] = v * dinv[k];
+      ok = ok && isfinite(xx[k]);
+    }
+    wave_sync();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < MB; ++k)
+        if (k < m) x[s0 + k] = xx[k];
+    }
+    wave_sync();
+  }
+  return ok;
+}
+
+// The same for the usual window: every group has MB columns (6 pose, or 6 pose + 3 velocity) and the band
+// holds the whole 2 MB x 2 MB coupling of neighbouring groups (bw >= 2 MB - 1), so nothing is padded or
+// predicated and entry (i, j) sits at i * (W - 1) + (W - 1) + j. The forward substitution rides along
+// with the factorisation: the right-hand side is treated as one more row below each sub-diagonal block
+// (its Schur update by spare lanes, its triangular solve in registers next to the block's), which
+// leaves only the backward pass as a second sweep over the blocks.
+template <int MB>
+__device__ __attribute__((noinline)) bool cholesky_solve_btd_full(int W, lds_f64* A, const lds_f64* b, lds_f64* x,
+                                                                 lds_f64* y, lds_f64* invd, int groups, int lane) {
+  const int Wm = W - 1;
+  constexpr int kTri = MB * (MB + 1) / 2;
+  int er = static_cast<int>((sqrtf(8.0f * static_cast<float>(lane) + 1.0f) - 1.0f) * 0.5f);
+  while (er * (er + 1) / 2 > lane) --er;
+  while ((er + 1) * (er + 2) / 2 <= lane) ++er;
+  const int ec = lane - er * (er + 1) / 2;
+  const int rl = lane - 48;  // lanes 48 .. 48 + MB - 1 carry the right-hand side of the next group
+  if (lane < MB) y[lane] = b[lane];
+  wave_sync();
+  bool ok = true;
+  for (int g = 0; g < groups; ++g) {
+    const int s0 = g * MB, s1 = s0 + MB;
+    const bool has_next = g + 1 < groups;
+    const int base = s0 * Wm + Wm + s0;  // entry (s0, s0)
+    double L[MB][MB], inv[MB], yy[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) L[i][j] = A[base + i * Wm + j];
+#pragma unroll
+    for (int k = 0; k < MB; ++k) yy[k] = y[s0 + k];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      double d = L[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+      ok = ok && (d > 0.0) && isfinite(d);
+      inv[j] = rsqrt(d);
+      L[j][j] = d * inv[j];
+#pragma unroll
+      for (int i = j + 1; i < MB; ++i) {
+        double v = L[i][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+        L[i][j] = v * inv[j];
+      }
+    }
+    if (!ok) return false;  // uniform
+    // y_g = L^-1 (b_g - L_{g,g-1} y_{g-1}): the bracket was left in y[] by the previous group
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      double v = yy[k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) v -= L[k][j] * yy[j];
+      yy[k] = v * inv[k];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) A[base + i * Wm + j] = L[i][j];
+        invd[s0 + i] = inv[i];
+        y[s0 + i] = yy[i];
+      }
+    }
+    if (has_next) {
+      const int row = (s1 + (lane < MB ? lane : 0)) * Wm + Wm + s0;  // entry (s1 + lane, s0)
+      double X[MB];
+#pragma unroll
+      for (int c = 0; c < MB; ++c) X[c] = A[row + c];
+#pragma unroll
+      for (int k = 0; k < MB; ++k) {
+        double v = X[k];
+#pragma unroll
+        for (int j = 0; j < k; ++j) v -= X[j] * L[k][j];
+        X[k] = v * inv[k];
+      }
+      if (lane < MB) {
+#pragma unroll
+        for (int c = 0; c < MB; ++c) A[row + c] = X[c];
+      }
+      wave_sync();
+      if (lane < kTri) {
+        const int ra = (s1 + er) * Wm + Wm + s0, rb = (s1 + ec) * Wm + Wm + s0;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) sum += A[ra + k] * A[rb + k];
+        A[(s1 + er) * Wm + Wm + s1 + ec] -= sum;
+      } else if (rl >= 0 && rl < MB) {
+        const int ra = (s1 + rl) * Wm + Wm + s0;
+        double t = b[s1 + rl];
+#pragma unroll
+        for (int k = 0; k < MB; ++k) t -= A[ra + k] * yy[k];
+        y[s1 + rl] = t;
+      }
+    }
+    wave_sync();
+  }
+  // backward substitution L^T x = y
+  for (int g = groups - 1; g >= 0; --g) {
+    const int s0 = g * MB, sn = s0 + MB;
+    const bool has_next = g + 1 < groups;
+    if (lane < MB) {
+      double t = y[s0 + lane];
+      if (has_next) {
+#pragma unroll
+        for (int r = 0; r < MB; ++r) t -= A[(sn + r) * Wm + Wm + s0 + lane] * x[sn + r];
+      }
+      x[s0 + lane] = t;
+    }
+    wave_sync();
+    const int base = s0 * Wm + Wm + s0;
+    double L[MB][MB], xx[MB], dinv[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) L[i][j] = A[base + i * Wm + j];
+#pragma unroll
+    for (int k = 0; k < MB; ++k) {
+      xx[k] = x[s0 + k];
+      dinv[k] = invd[s0 + k];
+    }
+#pragma unroll
+    for (int k = MB - 1; k >= 0; --k) {
+      double v = xx[k];
+#pragma unroll
+      for (int j = k + 1; j < MB; ++j) v -= L[j][k] * xx[j];
+      xx[k] = v * dinv[k];
+      ok = ok && isfinite(xx[k]);
+    }
+    wave_sync();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < MB; ++k) x[s0 + k] = xx[k];
+    }
+    wave_sync();
+  }
+  return ok;
+}
+
 // Small systems: every lane factorises its own register copy (no LDS round trips, no barriers);
 // left-looking term order; one reciprocal per column instead of a division per entry.
 template <int N>
@@ -1345,10 +1783,13 @@ __device__ inline void finish(LmHead& h, int type, int reason) {
   h.termination_reason = reason;
 }
 
-// |x - Plus(x, -g)|_inf in the ambient space (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-__device__ __forceinline__ double gradient_max_norm(const LmHead& h) {
-  double m = 0.0;
-  for (int p = 0; p < h.num_poses; ++p) {
+// |x - Plus(x, -g)|_inf in the ambient space (TrustRegionMinimizer::EvaluateGradientAndJacobian):
+// thread p takes control point p, every thread returns the maximum. Workgroup-wide.
+__device__ __forceinline__ double gradient_max_norm(LmShared& S) {
+  const LmHead& h = S.h;
+  if (static_cast<int>(threadIdx.x) < h.num_poses) {
+    const int p = threadIdx.x;
+    double m = 0.0;
     if (!h.constant[p]) {
       const double* g = h.g + h.col[p];
       const double neg[6] = {-g[0], -g[1], -g[2], -g[3], -g[4], -g[5]};
@@ -1361,24 +1802,33 @@ __device__ __forceinline__ double gradient_max_norm(const LmHead& h) {
       const double* g = h.g + h.vcol[p];
       for (int k = 0; k < 3; ++k) m = fmax(m, fabs(h.x[p][7 + k] - (h.x[p][7 + k] - g[k])));
     }
+    S.red[p] = m;
   }
+  __syncthreads();
+  double m = 0.0;
+  for (int p = 0; p < h.num_poses; ++p) m = fmax(m, S.red[p]);
+  __syncthreads();  // S.red may be rewritten
   return m;
 }
 
 // LevenbergMarquardtStrategy::ComputeStep + TrustRegionMinimizer::ComputeTrustRegionStep,
 // looping over invalid steps (each one is an iteration). Leaves the next candidate in h.cand
-// or terminates. Scalar updates of `h` are done by lane 0 between syncs; every lane reads them.
-__device__ __forceinline__ void compute_next_candidate(LmShared& S, int lane) {
+// or terminates. Workgroup-wide: every thread evaluates the (uniform) predicates from the head in
+// LDS, thread 0 updates its scalars between barriers, the loops over the matrix are spread over all
+// threads; the factorisation itself runs in wavefront 0.
+__device__ __forceinline__ void compute_next_candidate(LmShared& S) {
   LmHead& h = S.h;
   const int n = h.ncols, W = h.bw + 1;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
   while (true) {
-    wave_sync();
-    // FinalizeIterationAndCheckIfMinimizerCanContinue (all lanes evaluate the same predicates)
+    __syncthreads();
+    // FinalizeIterationAndCheckIfMinimizerCanContinue (all threads evaluate the same predicates)
     const bool stop_iter = h.iteration >= h.opt.max_num_iterations;
     const bool stop_grad = h.step_is_successful && h.gradient_max_norm <= h.opt.gradient_tolerance;
     const bool stop_rad = h.radius <= h.opt.min_trust_region_radius;
-    wave_sync();
-    if (lane == 0) {
+    const bool reuse = h.reuse_diagonal != 0;
+    __syncthreads();
+    if (tid == 0) {
       if (h.step_is_successful) ++h.num_successful; else ++h.num_unsuccessful;
       if (stop_iter) finish(h, 1, 4);
       else if (stop_grad) finish(h, 0, 1);
@@ -1389,62 +1839,97 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S, int lane) {
         h.step_is_successful = 0;
       }
     }
-    wave_sync();
-    if (stop_iter || stop_grad || stop_rad) return;
-    if (!h.reuse_diagonal) {
-      for (int k = lane; k < n; k += kLmThreads) {
-        const double s = S.H[band_index(k, k, W)] * h.scale[k] * h.scale[k];
-        h.diagonal[k] = fmin(fmax(s, h.opt.min_lm_diagonal), h.opt.max_lm_diagonal);
+    if (stop_iter || stop_grad || stop_rad) {
+      __syncthreads();
+      return;
+    }
+    if (!reuse) {
+      for (int k = tid; k < n; k += nthreads) {
+        const double sd = S.H[band_index(k, k, W)] * h.scale[k] * h.scale[k];
+        h.diagonal[k] = fmin(fmax(sd, h.opt.min_lm_diagonal), h.opt.max_lm_diagonal);
       }
     }
-    wave_sync();
-    for (int idx = lane; idx < n * W; idx += kLmThreads) {
-      const int a = idx / W, b = a - (W - 1) + idx % W;
-      double v = 0.0;
-      if (b >= 0) {
-        v = S.H[idx] * h.scale[a] * h.scale[b];
-        if (a == b) {
-          const double lm = sqrt(h.diagonal[a] / h.radius);
-          v += lm * lm;
+    __syncthreads();
+    {
+      // A = scaled H + LM diagonal; rows walked without an integer division per entry
+      const double radius = h.radius;
+      int a = tid / W, c = tid - a * W;
+      const int da = nthreads / W, dc = nthreads - da * W;
+      for (int idx = tid; idx < n * W; idx += nthreads) {
+        const int b = a - (W - 1) + c;
+        double v = 0.0;
+        if (b >= 0) {
+          v = S.H[idx] * h.scale[a] * h.scale[b];
+          if (a == b) {
+            const double lm = sqrt(h.diagonal[a] / radius);
+            v += lm * lm;
+          }
         }
+        S.A[idx] = v;
+        a += da;
+        c += dc;
+        if (c >= W) { c -= W; ++a; }
       }
-      S.A[idx] = v;
     }
-    for (int a = lane; a < n; a += kLmThreads) S.rhs[a] = h.g[a] * h.scale[a];
-    wave_sync();
+    for (int a = tid; a < n; a += nthreads) S.rhs[a] = h.g[a] * h.scale[a];
+    __syncthreads();
     HG_STAMP(S, 4);
-    bool valid = (n == 6)    ? cholesky_solve_regs<6>((const lds_f64*)S.A, W, (const lds_f64*)S.rhs, (lds_f64*)h.step, lane)
-                 : (n == 12) ? cholesky_solve_regs<12>((const lds_f64*)S.A, W, (const lds_f64*)S.rhs, (lds_f64*)h.step, lane)
+    if (tid < kLmThreads) {
+      const int lane = tid;
+      bool valid = (n == 6)    ? cholesky_solve_regs<6>((const lds_f64*)S.A, W, (const lds_f64*)S.rhs, (lds_f64*)h.step, lane)
+                   : (n == 12) ? cholesky_solve_regs<12>((const lds_f64*)S.A, W, (const lds_f64*)S.rhs, (lds_f64*)h.step, lane)
+                   : (h.btd_groups >= 2 && h.btd_uniform == 9)
+                       ? cholesky_solve_btd_full<9>(W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step,
+                                                    (lds_f64*)S.y, (lds_f64*)S.invd, h.btd_groups, lane)
+                   : (h.btd_groups >= 2 && h.btd_uniform == 6)
+                       ? cholesky_solve_btd_full<6>(W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step,
+                                                    (lds_f64*)S.y, (lds_f64*)S.invd, h.btd_groups, lane)
+                   : (h.btd_groups >= 2)
+                       ? cholesky_solve_btd(W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step, (lds_f64*)S.y,
+                                            (lds_f64*)S.invd, (const lds_i32*)h.btd_start, (const lds_i32*)h.btd_size,
+                                            h.btd_groups, lane)
 #ifdef HG_LM_STAMPS
-                             : cholesky_solve_wave(n, W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step,
-                                                   (lds_f64*)S.y, (lds_f64*)S.invd, lane,
-                                                   h.stamps[15] ? h.stamps : nullptr);
+                               : cholesky_solve_wave(n, W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step,
+                                                     (lds_f64*)S.y, (lds_f64*)S.invd, lane,
+                                                     h.stamps[15] ? h.stamps : nullptr);
 #else
-                             : cholesky_solve_wave(n, W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step,
-                                                   (lds_f64*)S.y, (lds_f64*)S.invd, lane);
+                               : cholesky_solve_wave(n, W, (lds_f64*)S.A, (const lds_f64*)S.rhs, (lds_f64*)h.step,
+                                                     (lds_f64*)S.y, (lds_f64*)S.invd, lane);
 #endif
+      if (lane == 0) S.solve_ok = valid ? 1 : 0;
+    }
     HG_STAMP(S, 5);
-    wave_sync();
+    __syncthreads();
+    bool valid = S.solve_ok != 0;
     double mcc = 0.0;
     if (valid) {
-      for (int k = lane; k < n; k += kLmThreads) h.step[k] = -h.step[k];
-      wave_sync();
-      // model_cost_change = -(step.J^T r + step^T J^T J step / 2) on the scaled system
-      double part = 0.0;
-      for (int a = lane; a < n; a += kLmThreads) {
+      __syncthreads();
+      for (int k = tid; k < n; k += nthreads) h.step[k] = -h.step[k];
+      __syncthreads();
+      // model_cost_change = -(step.J^T r + step^T J^T J step / 2) on the scaled system: thread a forms
+      // term a, wavefront 0 adds the terms (lane-strided partial sums, then a butterfly)
+      for (int a = tid; a < n; a += nthreads) {
         double row = 0.0;
         const int b0 = max(0, a - (W - 1)), b1 = min(n - 1, a + (W - 1));
         for (int b = b0; b <= b1; ++b) row += band_get(S.H, a, b, W) * h.scale[a] * h.scale[b] * h.step[b];
-        part += h.step[a] * (h.g[a] * h.scale[a]) + 0.5 * (h.step[a] * row);
+        S.y[a] = h.step[a] * (h.g[a] * h.scale[a]) + 0.5 * (h.step[a] * row);
       }
-      mcc = -wave_sum(part);
+      __syncthreads();
+      if (tid < kLmThreads) {
+        double part = 0.0;
+        for (int a = tid; a < n; a += kLmThreads) part += S.y[a];
+        const double m = -wave_sum(part);
+        if (tid == 0) S.red[15] = m;
+      }
+      __syncthreads();
+      mcc = S.red[15];
       valid = mcc > 0.0;
     }
-    wave_sync();
+    __syncthreads();
     if (!valid) {
       const bool fail = (h.invalid_steps + 1) >= 5;  // max_num_consecutive_invalid_steps
-      wave_sync();
-      if (lane == 0) {
+      __syncthreads();
+      if (tid == 0) {
         ++h.invalid_steps;
         h.reuse_diagonal = 1;
         if (fail) finish(h, 2, 6);
@@ -1453,250 +1938,206 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S, int lane) {
           h.decrease_factor *= 2.0;
         }
       }
-      wave_sync();
+      __syncthreads();
       if (fail) return;
       continue;
     }
-    if (lane == 0) {
+    if (tid == 0) {
       h.reuse_diagonal = 1;
       h.invalid_steps = 0;
       h.model_cost_change = mcc;
     }
-    for (int k = lane; k < n; k += kLmThreads) h.delta[k] = h.step[k] * h.scale[k];
-    wave_sync();
-    pose_plus(h, h.x, h.delta, h.cand, lane);
+    for (int k = tid; k < n; k += nthreads) h.delta[k] = h.step[k] * h.scale[k];
+    __syncthreads();
+    pose_plus(h, h.x, h.delta, h.cand);
     return;
   }
 }
 
-// All threads of the workgroup: thread (stripe j, column k) sums every stripes-th workgroup
-// partial of column k with up to 8 loads in flight; the stripes are then added in a fixed order.
-__device__ __forceinline__ void reduce_partials(LmShared& S, const double* partials) {
-  const LmHead& h = S.h;
-  const int t = threadIdx.x;
-  // Thread (stripe j, column k) of block b sums the partials of workgroups j, j + stripes, ...
-  // The raw loads of block b + 1 are issued before block b is combined (they are only added one
-  // iteration later), so one memory round trip is exposed for the whole window, not one per block.
-  // Blocks with more than 16 * stripes workgroups add the remaining rounds in place.
-  auto issue = [&](int b, double* v) {
-    const BlockInfo& bi = h.blocks[b];
-    const int acc_n = bi.acc;
-    const int stripes = min(static_cast<int>(blockDim.x) / acc_n, kMaxStripes);
-    const int j = t / acc_n, k = t % acc_n;
-    const bool on = j < stripes && bi.active;
-    const double* p = partials + bi.partial_offset + k;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const unsigned idx = j + u * stripes;
-      v[u] = (on && idx < bi.num_wg) ? p[static_cast<size_t>(idx) * acc_n] : 0.0;
-    }
-  };
-  double cur[16], nxt[16];
-  if (h.num_blocks > 0) issue(0, cur);
-  for (int b = 0; b < h.num_blocks; ++b) {
-    if (b + 1 < h.num_blocks) issue(b + 1, nxt);
-    const BlockInfo& bi = h.blocks[b];
-    const int acc_n = bi.acc;
-    const int stripes = min(static_cast<int>(blockDim.x) / acc_n, kMaxStripes);
-    const int j = t / acc_n, k = t % acc_n;
-    double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc += cur[u];
-    if (j < stripes && bi.active) {
-      const double* p = partials + bi.partial_offset + k;
-      for (unsigned w = j + 16 * stripes; w < bi.num_wg; w += 16 * stripes) {
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const unsigned idx = w + u * stripes;
-          v[u] = idx < bi.num_wg ? p[static_cast<size_t>(idx) * acc_n] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc += v[u];
+// Local column of global column `col` in a block over control points (pa, pb), or -1. TSDF blocks:
+// [pose_a 6 | pose_b 6]; odometry / IMU blocks: [pose_a 6 | vel_a 3 | pose_b 6 | vel_b 3].
+__device__ inline int local_col_tsdf(int cp, int pa, int pb) {
+  const int p = cp >> 4, sl = cp & 15;
+  const int l = p == pa ? sl : (p == pb ? 6 + sl : -1);
+  return sl >= 6 ? -1 : l;
+}
+__device__ inline int local_col_small(int cp, int pa, int pb) {
+  const int p = cp >> 4, sl = cp & 15;
+  return p == pa ? sl : (p == pb ? 9 + sl : -1);
+}
+
+// Normal equations at the candidate from the blocks' local systems: every thread GATHERS its band
+// entries (for each entry the blocks that cover both of its columns, in block order), so no entry is
+// written twice and there is nothing to synchronise. The loops over the blocks are branch-free (a
+// block that does not cover the entry adds 0.0 read from a valid address), so their LDS reads are
+// independent of each other and pipeline. Workgroup-wide.
+__device__ __forceinline__ void assemble(LmShared& S) {
+  LmHead& h = S.h;
+  const int n = h.ncols, W = h.bw + 1;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int nb = h.num_blocks, ns = h.num_small;
+  int a = tid / W, c = tid - a * W;
+  const int da = nthreads / W, dc = nthreads - da * W;
+  const bool by_pairs = S.T.pair_overflow == 0;
+  for (int idx = tid; idx < n * W; idx += nthreads) {
+    const int b = a - (W - 1) + c;  // entry (a, b), b <= a
+    double v = 0.0;
+    if (b >= 0 && by_pairs) {
+      // the blocks that cover both columns' control points, from the pair's list
+      const int cpa = S.T.colcp[a], cpb = S.T.colcp[b];
+      const int p = cpa >> 4, q = cpb >> 4, sa = cpa & 15, sb = cpb & 15;
+      const bool sw = p < q;  // the list is kept for (larger, smaller) control point
+      const int hi_p = sw ? q : p, lo_p = sw ? p : q;
+      const int* list = S.T.pair_list[hi_p][lo_p];
+      const int cnt = S.T.pair_count[hi_p][lo_p];
+      for (int k = 0; k < cnt; ++k) {
+        const int e = list[k];
+        const int blk = e & 255, small = (e >> 8) & 1;
+        const int o_hi = (e >> 12) & 255, o_lo = (e >> 20) & 255;
+        const int l1 = sa + (sw ? o_lo : o_hi), l2 = sb + (sw ? o_hi : o_lo);
+        const int lo = l1 < l2 ? l1 : l2, hi = l1 < l2 ? l2 : l1;
+        const bool on = small || (sa < 6 && sb < 6);
+        const double* src = small ? S.small[blk] : S.loc[blk];
+        const int at = small ? hi * (hi + 1) / 2 + lo : lo * 12 - (lo * (lo - 1)) / 2 + (hi - lo);
+        const double t = src[on ? at : 0];
+        v += on ? t : 0.0;
+      }
+    } else if (b >= 0) {
+      const int cpa = S.T.colcp[a], cpb = S.T.colcp[b];
+#pragma unroll 4
+      for (int k = 0; k < nb; ++k) {
+        const int d = S.T.desc[k];
+        const int pa = d & 255, pb = (d >> 8) & 255;
+        const int l1 = local_col_tsdf(cpa, pa, pb), l2 = local_col_tsdf(cpb, pa, pb);
+        const bool on = (d >> 16) && l1 >= 0 && l2 >= 0;
+        const int lo = l1 < l2 ? l1 : l2, hi = l1 < l2 ? l2 : l1;
+        const double t = S.loc[k][on ? lo * 12 - (lo * (lo - 1)) / 2 + (hi - lo) : 0];
+        v += on ? t : 0.0;
+      }
+#pragma unroll 4
+      for (int k = 0; k < ns; ++k) {
+        const int d = S.T.desc[kMaxBlocks + k];
+        const int pa = d & 255, pb = (d >> 8) & 255;
+        const int l1 = local_col_small(cpa, pa, pb), l2 = local_col_small(cpb, pa, pb);
+        const bool on = (d >> 16) && l1 >= 0 && l2 >= 0;
+        const int lo = l1 < l2 ? l1 : l2, hi = l1 < l2 ? l2 : l1;
+        const double t = S.small[k][on ? hi * (hi + 1) / 2 + lo : 0];
+        v += on ? t : 0.0;
       }
     }
-    double* buf = S.stripe[b & 1];
-    if (j < stripes) buf[t] = acc;  // t = j * acc_n + k
-    __syncthreads();
-    if (t < acc_n) {
-      double part[kMaxStripes];
-#pragma unroll
-      for (int jj = 0; jj < kMaxStripes; ++jj)  // all LDS reads in flight; missing stripes add 0
-        part[jj] = jj < stripes ? buf[jj * acc_n + t] : 0.0;
-      double sum = 0.0;
-#pragma unroll
-      for (int jj = 0; jj < kMaxStripes; ++jj) sum += part[jj];
-      S.sums[b * kAccU + t] = sum;
+    S.Hc[idx] = v;
+    a += da;
+    c += dc;
+    if (c >= W) { c -= W; ++a; }
+  }
+  for (int i = tid; i < n; i += nthreads) {
+    const int cp = S.T.colcp[i];
+    double v = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < nb; ++k) {
+      const int d = S.T.desc[k];
+      const int l = local_col_tsdf(cp, d & 255, (d >> 8) & 255);
+      const bool on = (d >> 16) && l >= 0;
+      const double t = S.loc[k][on ? 78 + l : 0];
+      v += on ? t : 0.0;
     }
-    // no second barrier: the next block writes the other buffer, and the barrier of that block
-    // orders this block's reads before the buffer is written again
-#pragma unroll
-    for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
+#pragma unroll 4
+    for (int k = 0; k < ns; ++k) {
+      const int d = S.T.desc[kMaxBlocks + k];
+      const int l = local_col_small(cp, d & 255, (d >> 8) & 255);
+      const bool on = (d >> 16) && l >= 0;
+      const double t = S.small[k][on ? kSmallTri + l : 0];
+      v += on ? t : 0.0;
+    }
+    h.gc[i] = v;
+  }
+  if (tid == 0) {
+    double cost = 0.0;
+    for (int k = 0; k < nb; ++k)
+      if (h.blocks[k].active) cost += S.loc[k][90];
+    for (int k = 0; k < ns; ++k)
+      if (h.small[k].active) cost += S.small[k][kSmallTri + 18];
+    h.cand_cost = 0.5 * cost;
   }
   __syncthreads();
 }
 
-// Maps the per-block 7x7 sums through M into Hc / gc / cand_cost.
-__device__ __forceinline__ void assemble(LmShared& S, const BlockXform* xf, const double* partials,
-                         const SmallOut* small_out, int lane) {
-  LmHead& h = S.h;
-  const int n = h.ncols, W = h.bw + 1;
-  // S.sums was filled by reduce_partials (all 256 threads) before the other waves retired
-  for (int i = lane; i < n * W; i += kLmThreads) S.Hc[i] = 0.0;
-  for (int i = lane; i < n; i += kLmThreads) h.gc[i] = 0.0;
-  wave_sync();
-  double cost = 0.0;
-  for (int b = 0; b < h.num_blocks; ++b) {
-    const BlockInfo& bi = h.blocks[b];
-    if (!bi.active) continue;
-    const double* sm = S.sums + b * kAccU;
-    const int ca = h.constant[bi.pose_a] ? -1 : h.col[bi.pose_a];
-    const int cb = (bi.pose_b >= 0 && !h.constant[bi.pose_b]) ? h.col[bi.pose_b] : -1;
-    if (bi.acc == kAccU) {  // already over the 12 local columns
-      cost += sm[90];
-      for (int idx = lane; idx < 12 * 12; idx += kLmThreads) {
-        const int c1 = idx / 12, c2 = idx % 12;
-        const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
-        const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
-        if (g1 < 0 || g2 < 0 || g2 > g1 || g1 - g2 >= W) continue;  // lower band only
-        const int lo = c1 < c2 ? c1 : c2, hi = c1 < c2 ? c2 : c1;
-        S.Hc[band_index(g1, g2, W)] += sm[lo * 12 - (lo * (lo - 1)) / 2 + (hi - lo)];
-      }
-      if (lane < 12) {
-        const int g1 = lane < 6 ? (ca < 0 ? -1 : ca + lane) : (cb < 0 ? -1 : cb + lane - 6);
-        if (g1 >= 0) h.gc[g1] += sm[78 + lane];
-      }
-      wave_sync();
-      continue;
-    }
-    cost += sm[35];
-    // J^T J = M^T A7 M over the block's local columns: one lane per lower-triangle entry keeps
-    // column c1 of M in registers, forms t = M[:,c1]^T A7 and contracts it with column c2
-    const double* M = S.xfs[b].M;
-    const int nc = bi.pose_b >= 0 ? 12 : 6;
-    const int ne = nc * (nc + 1) / 2;
-    for (int it = lane; it < ne + nc; it += kLmThreads) {
-      if (it < ne) {
-        int c1 = 0, e = it;
-        while (e > c1) { e -= c1 + 1; ++c1; }
-        const int c2 = e;  // c2 <= c1
-        const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
-        const int g2 = c2 < 6 ? (ca < 0 ? -1 : ca + c2) : (cb < 0 ? -1 : cb + c2 - 6);
-        if (g1 < 0 || g2 < 0) continue;
-        double m1[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) m1[k] = M[k * 12 + c1];
-        double v = 0.0;
-#pragma unroll
-        for (int l = 0; l < 7; ++l) {
-          double t = 0.0;
-#pragma unroll
-          for (int k = 0; k < 7; ++k) {
-            const int lo = k < l ? k : l, hi = k < l ? l : k;
-            t += m1[k] * sm[lo * 7 - (lo * (lo - 1)) / 2 + (hi - lo)];
-          }
-          v += t * M[l * 12 + c2];
-        }
-        const int hi_g = g1 > g2 ? g1 : g2, lo_g = g1 > g2 ? g2 : g1;
-        if (hi_g - lo_g < W) S.Hc[band_index(hi_g, lo_g, W)] += v;  // unique per lane within this block
-      } else {
-        const int c1 = it - ne;
-        const int g1 = c1 < 6 ? (ca < 0 ? -1 : ca + c1) : (cb < 0 ? -1 : cb + c1 - 6);
-        if (g1 >= 0) {
-          double gs = 0.0;
-#pragma unroll
-          for (int k = 0; k < 7; ++k) gs += M[k * 12 + c1] * sm[28 + k];
-          h.gc[g1] += gs;
-        }
-      }
-    }
-    wave_sync();
+// Transforms of every block at the candidate (thread b: block b), written straight to device memory
+// for the next residual launch. Only the structural non-zeros of M are filled by prepare_block.
+__device__ __forceinline__ void prepare_all(const LmHead& h, BlockXform* xf) {
+  if (static_cast<int>(threadIdx.x) < h.num_blocks) {
+    BlockXform* dst = xf + threadIdx.x;
+    double* d = reinterpret_cast<double*>(dst);
+    for (int i = 0; i < static_cast<int>(sizeof(BlockXform) / sizeof(double)); ++i) d[i] = 0.0;
+    prepare_block(h.blocks[threadIdx.x], h.cand, dst);
   }
-  // odometry / IMU blocks: their 18 x 18 local systems were computed by k_small_blocks. Each lane
-  // owns entries lane, lane + 64, ... of the block; the next block's entries are loaded while the
-  // current block is added (the loads come from global memory).
-  {
-    auto fetch = [&](int b, double* v, double& gv, double& cv) {
-      const SmallOut& so = small_out[b];
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int idx = lane + u * kLmThreads;
-        v[u] = idx < 18 * 18 ? so.H[idx] : 0.0;
-      }
-      gv = lane < 18 ? so.g[lane] : 0.0;
-      cv = so.c;
-    };
-    int b = 0;
-    while (b < h.num_small && !h.small[b].active) ++b;
-    double cur[6], cg = 0.0, cc = 0.0;
-    if (b < h.num_small) fetch(b, cur, cg, cc);
-    while (b < h.num_small) {
-      int nb = b + 1;
-      while (nb < h.num_small && !h.small[nb].active) ++nb;
-      double nxt[6], ng = 0.0, nc = 0.0;
-      if (nb < h.num_small) fetch(nb, nxt, ng, nc);
-      const SmallBlockDev& sb = h.small[b];
-      // local column -> global column: [pose_a 6 | vel_a 3 | pose_b 6 | vel_b 3]
-      if (lane < 18) {
-        const int c = lane;
-        int gcol;
-        if (c < 6) gcol = h.constant[sb.a] ? -1 : h.col[sb.a] + c;
-        else if (c < 9) gcol = h.vfree[sb.a] ? h.vcol[sb.a] + (c - 6) : -1;
-        else if (c < 15) gcol = h.constant[sb.b] ? -1 : h.col[sb.b] + (c - 9);
-        else gcol = h.vfree[sb.b] ? h.vcol[sb.b] + (c - 15) : -1;
-        S.colmap[c] = gcol;
-      }
-      wave_sync();
-      cost += cc;
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int idx = lane + u * kLmThreads;
-        if (idx < 18 * 18) {
-          const int g1 = S.colmap[idx / 18], g2 = S.colmap[idx % 18];
-          // entries beyond the band are structural zeros (an odometry block has no velocity
-          // columns); their band address would alias another entry, so they must be skipped
-          if (g1 >= 0 && g2 >= 0 && g2 <= g1 && g1 - g2 < W) S.Hc[band_index(g1, g2, W)] += cur[u];
-        }
-      }
-      if (lane < 18) {
-        const int g1 = S.colmap[lane];
-        if (g1 >= 0) h.gc[g1] += cg;
-      }
-      wave_sync();
-#pragma unroll
-      for (int u = 0; u < 6; ++u) cur[u] = nxt[u];
-      cg = ng;
-      cc = nc;
-      b = nb;
-    }
-  }
-  if (lane == 0) h.cand_cost = 0.5 * cost;
-  wave_sync();
 }
 
-// Transforms of every block at the candidate: built in LDS (M zeroed cooperatively, one lane per
-// block fills the non-zeros), then copied out coalesced. Runs in wavefront 0.
-__device__ __forceinline__ void prepare_all(LmShared& S, BlockXform* xf) {
+// Builds the index tables of the problem in LDS (head already there) and stores them for the LM steps.
+// Workgroup-wide, at least 192 + kMaxPoses^2 threads.
+__device__ __forceinline__ void build_tables(LmShared& S, LmState* G) {
   const LmHead& h = S.h;
-  const int lane = threadIdx.x;
-  if (lane >= kLmThreads) return;
-  const int per = static_cast<int>(sizeof(BlockXform) / sizeof(double));
-  double* buf = reinterpret_cast<double*>(S.xfs);
-  for (int i = lane; i < h.num_blocks * per; i += kLmThreads) buf[i] = 0.0;
-  wave_sync();
-  if (lane < h.num_blocks) prepare_block(h.blocks[lane], h.cand, &S.xfs[lane]);
-  wave_sync();
-  double* dst = reinterpret_cast<double*>(xf);
-  for (int i = lane; i < h.num_blocks * per; i += kLmThreads) dst[i] = buf[i];
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  if (tid == 0) S.T.pair_overflow = 0;
+  __syncthreads();
+  if (tid < h.num_poses) {
+    const int p = tid;
+    if (!h.constant[p])
+      for (int k = 0; k < 6; ++k) S.T.colcp[h.col[p] + k] = p * 16 + k;
+    if (h.vfree[p])
+      for (int k = 0; k < 3; ++k) S.T.colcp[h.vcol[p] + k] = p * 16 + 6 + k;
+  }
+  if (tid >= 64 && tid < 64 + h.num_blocks) {
+    const BlockInfo& bi = h.blocks[tid - 64];
+    S.T.desc[tid - 64] = (bi.active ? 1 << 16 : 0) | ((bi.pose_b & 255) << 8) | (bi.pose_a & 255);
+  }
+  if (tid >= 128 && tid < 128 + h.num_small) {
+    const SmallBlockDev& sb = h.small[tid - 128];
+    S.T.desc[kMaxBlocks + tid - 128] = (sb.active ? 1 << 16 : 0) | ((sb.b & 255) << 8) | (sb.a & 255);
+  }
+  if (tid >= 192 && tid < 192 + kMaxPoses * kMaxPoses) {
+    // thread (p, q), q <= p: the blocks covering both control points, in block order
+    const int p = (tid - 192) / kMaxPoses, q = (tid - 192) % kMaxPoses;
+    if (q <= p && p < h.num_poses) {
+      int cnt = 0;
+      bool over = false;
+      for (int k = 0; k < h.num_blocks; ++k) {
+        const BlockInfo& bi = h.blocks[k];
+        const bool hp = bi.pose_a == p || bi.pose_b == p, hq = bi.pose_a == q || bi.pose_b == q;
+        if (!bi.active || !hp || !hq) continue;
+        if (cnt < kPairMax)
+          S.T.pair_list[p][q][cnt] = k | ((bi.pose_a == p ? 0 : 6) << 12) | ((bi.pose_a == q ? 0 : 6) << 20);
+        else over = true;
+        ++cnt;
+      }
+      for (int k = 0; k < h.num_small; ++k) {
+        const SmallBlockDev& sb = h.small[k];
+        const bool hp = sb.a == p || sb.b == p, hq = sb.a == q || sb.b == q;
+        if (!sb.active || !hp || !hq) continue;
+        if (cnt < kPairMax)
+          S.T.pair_list[p][q][cnt] = k | (1 << 8) | ((sb.a == p ? 0 : 9) << 12) | ((sb.a == q ? 0 : 9) << 20);
+        else over = true;
+        ++cnt;
+      }
+      S.T.pair_count[p][q] = cnt < kPairMax ? cnt : kPairMax;
+      if (over) S.T.pair_overflow = 1;
+    }
+  }
+  __syncthreads();
+  {
+    const int* src = reinterpret_cast<const int*>(&S.T);
+    int* td = reinterpret_cast<int*>(&G->T);
+    for (int i = tid; i < static_cast<int>(sizeof(LmTables) / sizeof(int)); i += nthreads) td[i] = src[i];
+  }
 }
 
-// One LM iteration by the calling workgroup (any size >= 64): loads the solver head, sums the
-// partials, and lets wavefront 0 advance the state machine. Called from k_lm and from the tail of
-// the last k_tsdf_residuals workgroup of an iteration.
-__device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* partials,
+// One LM iteration by the calling workgroup: loads the solver head, the blocks' local systems
+// (written by the tails of k_window_residuals and by the odometry / IMU wavefronts) and advances the
+// state machine.
+__device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* loc_sums,
                         const SmallOut* small_out, int mode, const PinBox* host_up = nullptr,
                         unsigned up_words = 0) {
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
 #ifdef HG_LM_STAMPS
   const long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -1737,42 +2178,49 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
       unsigned long long* dst = reinterpret_cast<unsigned long long*>(&G->h);
       for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
     }
-    prepare_all(S, xf);
+    prepare_all(h, xf);
+    build_tables(S, G);
     return;
   }
   HG_STAMP(S, 0);
-  // stage M (all blocks) and H into LDS; these loads and the first partial loads overlap
+  // stage the local systems and H; build the column table
   {
-    const double* src = reinterpret_cast<const double*>(xf);
-    double* dst = reinterpret_cast<double*>(S.xfs);
-    const int cnt = h.num_blocks * static_cast<int>(sizeof(BlockXform) / sizeof(double));
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
+    double* dst = &S.loc[0][0];
+    for (int i = tid; i < h.num_blocks * kLoc; i += nthreads) dst[i] = loc_sums[i];
+    {
+      // (inactive blocks keep whatever an earlier solve left there: the descriptors mask them out)
+      const double* src = reinterpret_cast<const double*>(small_out);
+      double* sd = &S.small[0][0];
+      for (int i = tid; i < h.num_small * kSmallLoc; i += nthreads) sd[i] = src[i];
+    }
+    if (h.phase != PHASE_INIT)
+      for (int i = tid; i < nW; i += nthreads) S.H[i] = G->H[i];
+    {
+      const int* src = reinterpret_cast<const int*>(&G->T);
+      int* td = reinterpret_cast<int*>(&S.T);
+      for (int i = tid; i < static_cast<int>(sizeof(LmTables) / sizeof(int)); i += nthreads) td[i] = src[i];
+    }
   }
-  if (h.phase != PHASE_INIT)
-    for (int i = threadIdx.x; i < nW; i += blockDim.x) S.H[i] = G->H[i];
-  reduce_partials(S, partials);
-  if (threadIdx.x >= kLmThreads) return;  // retired waves no longer take part in barriers
+  __syncthreads();
   HG_STAMP(S, 1);
-  assemble(S, xf, partials, small_out, lane);
+  assemble(S);
   HG_STAMP(S, 2);
   if (mode == MODE_ASSEMBLE) {
-    for (int i = lane; i < nW; i += kLmThreads) G->Hc[i] = S.Hc[i];
-    for (int i = lane; i < n; i += kLmThreads) G->h.gc[i] = h.gc[i];
-    if (lane == 0) G->h.cand_cost = h.cand_cost;
+    for (int i = tid; i < nW; i += nthreads) G->Hc[i] = S.Hc[i];
+    for (int i = tid; i < n; i += nthreads) G->h.gc[i] = h.gc[i];
+    if (tid == 0) G->h.cand_cost = h.cand_cost;
     return;
   }
   bool h_changed = false;
   if (h.phase == PHASE_INIT) {
     // IterationZero: EvaluateGradientAndJacobian at x (= cand)
-    for (int i = lane; i < nW; i += kLmThreads) S.H[i] = S.Hc[i];
-    for (int i = lane; i < n; i += kLmThreads) h.g[i] = h.gc[i];
-    wave_sync();
-    for (int k = lane; k < n; k += kLmThreads)
+    for (int i = tid; i < nW; i += nthreads) S.H[i] = S.Hc[i];
+    for (int i = tid; i < n; i += nthreads) h.g[i] = h.gc[i];
+    __syncthreads();
+    for (int k = tid; k < n; k += nthreads)
       h.scale[k] = h.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(S.H[band_index(k, k, h.bw + 1)])) : 1.0;
-    wave_sync();
-    const double gmn = gradient_max_norm(h);
-    wave_sync();
-    if (lane == 0) {
+    const double gmn = gradient_max_norm(S);  // barriers inside
+    if (tid == 0) {
       ++h.num_cost_evals;
       ++h.num_jac_evals;
       h.x_cost = h.cand_cost;
@@ -1783,17 +2231,31 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
       h.phase = PHASE_CANDIDATE;
     }
     h_changed = true;
-    compute_next_candidate(S, lane);
+    compute_next_candidate(S);
   } else {
     // candidate evaluated: ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful
-    double sn = 0.0, xn = 0.0;
-    for (int p = 0; p < h.num_poses; ++p) {
+    // (every thread evaluates the same scalars from the head in LDS)
+    if (tid < h.num_poses) {  // thread p: the squared norms of control point p's free parameters
+      const int p = tid;
       const int k0 = h.constant[p] ? 7 : 0, k1 = h.vfree[p] ? kState : 7;
-      for (int k = k0; k < k1; ++k) {
-        const double d = h.x[p][k] - h.cand[p][k];
-        sn += d * d;
-        xn += h.x[p][k] * h.x[p][k];
+      double dn = 0.0, pn = 0.0;
+#pragma unroll
+      for (int k = 0; k < kState; ++k) {
+        const bool on = k >= k0 && k < k1;
+        const double xv = h.x[p][k], d = xv - h.cand[p][k];
+        dn += on ? d * d : 0.0;
+        pn += on ? xv * xv : 0.0;
       }
+      S.red[p] = dn;
+      S.A[p] = pn;  // (A is free until the next solve)
+    }
+    __syncthreads();
+    double sn = 0.0, xn = 0.0;
+#pragma unroll
+    for (int p = 0; p < kMaxPoses; ++p) {
+      const double dn = S.red[p], pn = S.A[p];
+      sn += p < h.num_poses ? dn : 0.0;
+      xn += p < h.num_poses ? pn : 0.0;
     }
     sn = sqrt(sn);
     xn = sqrt(xn);
@@ -1802,25 +2264,24 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
     const bool ftol = fabs(cost_change) <= h.opt.function_tolerance * h.x_cost;
     const double relative_decrease = cost_change / h.model_cost_change;
     const bool accept = relative_decrease > h.opt.min_relative_decrease;
-    wave_sync();
+    __syncthreads();
     HG_STAMP(S, 3);
-    if (lane == 0) ++h.num_cost_evals;
+    if (tid == 0) ++h.num_cost_evals;
     if (ptol) {
-      if (lane == 0) finish(h, 0, 2);
+      if (tid == 0) finish(h, 0, 2);
     } else if (ftol) {
-      if (lane == 0) finish(h, 0, 3);
+      if (tid == 0) finish(h, 0, 3);
     } else {
       if (accept) {
         // HandleSuccessfulStep: the candidate's normal equations become x's
-        for (int i = lane; i < nW; i += kLmThreads) S.H[i] = S.Hc[i];
-        for (int i = lane; i < n; i += kLmThreads) h.g[i] = h.gc[i];
-        if (lane < h.num_poses)
-          for (int k = 0; k < kState; ++k) h.x[lane][k] = h.cand[lane][k];
+        for (int i = tid; i < nW; i += nthreads) S.H[i] = S.Hc[i];
+        for (int i = tid; i < n; i += nthreads) h.g[i] = h.gc[i];
+        if (tid < h.num_poses)
+          for (int k = 0; k < kState; ++k) h.x[tid][k] = h.cand[tid][k];
         h_changed = true;
-        wave_sync();
-        const double gmn = gradient_max_norm(h);
-        wave_sync();
-        if (lane == 0) {
+        __syncthreads();
+        const double gmn = gradient_max_norm(S);
+        if (tid == 0) {
           h.x_cost = h.cand_cost;
           ++h.num_jac_evals;
           h.gradient_max_norm = gmn;
@@ -1834,35 +2295,34 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
           h.reuse_diagonal = 0;
         }
       } else {
-        if (lane == 0) {
+        if (tid == 0) {
           h.radius = h.radius / h.decrease_factor;
           h.decrease_factor *= 2.0;
           h.reuse_diagonal = 1;
         }
       }
-      compute_next_candidate(S, lane);
+      compute_next_candidate(S);
     }
   }
-  wave_sync();
+  __syncthreads();
   HG_STAMP(S, 6);
-  if (!h.done) prepare_all(S, xf);
+  if (!h.done) prepare_all(h, xf);
   HG_STAMP(S, 7);
-  wave_sync();
   // store the head and (if it changed) H
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&G->h);
-    for (unsigned i = lane; i < sizeof(LmHead) / 8; i += kLmThreads) dst[i] = src[i];
+    for (unsigned i = tid; i < sizeof(LmHead) / 8; i += nthreads) dst[i] = src[i];
   }
   if (h_changed)
-    for (int i = lane; i < nW; i += kLmThreads) G->H[i] = S.H[i];
+    for (int i = tid; i < nW; i += nthreads) G->H[i] = S.H[i];
   if (h.done && h.box) {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&h.box->h);
-    for (unsigned i = lane; i < sizeof(LmHead) / 8; i += kLmThreads) dst[i] = src[i];
+    for (unsigned i = tid; i < sizeof(LmHead) / 8; i += nthreads) dst[i] = src[i];
     __threadfence_system();
-    wave_sync();
-    if (lane == 0) {
+    __syncthreads();
+    if (tid == 0) {
       *reinterpret_cast<volatile unsigned long long*>(&h.box->flag) = h.seq;
       __threadfence_system();
     }
@@ -2429,21 +2889,26 @@ __device__ __forceinline__ void small_block_eval(const LmState* G, int b, SmallO
   }
   wave_sync();
   SmallOut& o = out[b];
-  for (int idx = lane; idx < 18 * 18; idx += kWave) {
-    const int c1 = idx / 18, c2 = idx % 18;
-    double s = 0.0;
-    for (int i = 0; i < 9; ++i) s += Jl[i][c1] * Jl[i][c2];
-    o.H[idx] = s;
+  {
+    int c1 = 0, c2 = lane;  // entry `lane` of the lower triangle; 64 entries further is at most 11 rows down
+    while (c2 > c1) { c2 -= c1 + 1; ++c1; }
+    for (int idx = lane; idx < kSmallTri; idx += kWave) {
+      double s = 0.0;
+      for (int i = 0; i < 9; ++i) s += Jl[i][c1] * Jl[i][c2];
+      o.v[idx] = s;
+      c2 += kWave;
+      while (c2 > c1) { c2 -= c1 + 1; ++c1; }
+    }
   }
   if (lane < 18) {
     double s = 0.0;
     for (int i = 0; i < 9; ++i) s += Jl[i][lane] * rs[i];
-    o.g[lane] = s;
+    o.v[kSmallTri + lane] = s;
   }
   if (lane == 0) {
     double s = 0.0;
     for (int i = 0; i < 9; ++i) s += rs[i] * rs[i];
-    o.c = s;
+    o.v[kSmallTri + 18] = s;
     if (residuals)
       for (int i = 0; i < rows; ++i) residuals[sb.row_offset + i] = rs[i];
   }
@@ -2596,7 +3061,7 @@ template <bool UNWARP>
 __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals(
     const EvalBlock* __restrict__ blocks, int num_eval, unsigned tiles, double* __restrict__ residuals,
     LmState* G, const BlockXform* __restrict__ xf_all, double* __restrict__ partials_all, SmallOut* small_out,
-    unsigned tsdf_wg) {
+    unsigned tsdf_wg, unsigned* tickets, double* __restrict__ loc_all) {
   if (G->h.done) return;
   if (blockIdx.x >= tsdf_wg) {
 #ifndef HG_NO_SMALL_FOLD
@@ -2622,6 +3087,9 @@ __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k
                        tiles, smem);
   else
     window_body_plain(eb, xf_all + eb.index, partials_all + eb.partial_offset, res, wg, tiles, smem);
+  // (the barrier at the head of the tail also ends this workgroup's use of the tiles in smem)
+  window_block_tail<UNWARP>(eb, partials_all + eb.partial_offset, tickets + 8 + eb.index, xf_all + eb.index,
+                            loc_all + static_cast<size_t>(eb.index) * kLoc, reinterpret_cast<double*>(smem));
 }
 
 __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
@@ -2657,6 +3125,7 @@ struct hg_problem {
   std::vector<int> vfree;  // 1: velocity set and not constant
   std::vector<SmallBlockDev> small;
   SmallOut* d_small = nullptr;
+  double* d_loc = nullptr;  // per TSDF block: its local normal equations (kLoc doubles), k_window_residuals -> k_lm
   // device state
   LmState* d_state = nullptr;
   unsigned* d_ticket = nullptr;
@@ -2789,6 +3258,43 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   for (int b = 0; b < S.num_small; ++b)
     if (S.small[b].active) couple({S.small[b].a, S.small[b].b}, S.small[b].type == 2);
   S.bw = bw;
+  {
+    // block-tridiagonal partition: one group per control point with free columns (its pose and / or
+    // velocity columns are contiguous by construction); usable when every active block couples a
+    // group with itself or its neighbour. HG_LM_BAND=1 keeps the band factorisation (diagnostics).
+    int group_of[kMaxPoses];
+    int groups = 0;
+    for (int i = 0; i < S.num_poses; ++i) {
+      group_of[i] = -1;
+      const int first = !S.constant[i] ? S.col[i] : (S.vfree[i] ? S.vcol[i] : -1);
+      if (first < 0) continue;
+      group_of[i] = groups;
+      S.btd_start[groups] = first;
+      S.btd_size[groups] = (!S.constant[i] ? 6 : 0) + (S.vfree[i] ? 3 : 0);
+      ++groups;
+    }
+    bool ok = groups >= 2 && std::getenv("HG_LM_BAND") == nullptr;
+    auto near = [&](int a, int b) {
+      if (a < 0 || b < 0 || group_of[a] < 0 || group_of[b] < 0) return true;  // a constant end couples nothing
+      return std::abs(group_of[a] - group_of[b]) <= 1;
+    };
+    for (int b = 0; b < S.num_blocks && ok; ++b)
+      if (S.blocks[b].active) ok = near(S.blocks[b].pose_a, S.blocks[b].pose_b);
+    for (int b = 0; b < S.num_small && ok; ++b)
+      if (S.small[b].active) ok = near(S.small[b].a, S.small[b].b);
+    S.btd_groups = ok ? groups : 0;
+    S.btd_uniform = 0;
+    if (ok && S.btd_start[0] == 0) {
+      const int mb = S.btd_size[0];
+      bool uni = (mb == 6 || mb == 9) && bw >= 2 * mb - 1;
+      for (int g = 1; g < groups; ++g) uni = uni && S.btd_size[g] == mb;
+      if (uni && std::getenv("HG_LM_BTD_GENERIC") == nullptr) S.btd_uniform = mb;
+    }
+    if (!ok) {
+      std::memset(S.btd_start, 0, sizeof(S.btd_start));
+      std::memset(S.btd_size, 0, sizeof(S.btd_size));
+    }
+  }
   if (static_cast<long long>(S.ncols) * (bw + 1) > kHCap) {
     set_last_error("normal equations exceed the band capacity (n * (bandwidth + 1) > " +
                    std::to_string(kHCap) + "): blocks must couple nearby control points");
@@ -2909,7 +3415,8 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
     ProfScope ps(p->ctx, HG_K_RESIDUALS, units_plain);
     hipLaunchKernelGGL(k_window_residuals<false>, dim3(p->wg_plain + small_left), dim3(kBatchThreads), 0, s,
                        static_cast<const EvalBlock*>(p->d_eval), p->num_plain, p->tiles, d_residuals, p->d_state,
-                       static_cast<const BlockXform*>(p->d_xf), p->partials.as<double>(), p->d_small, p->wg_plain);
+                       static_cast<const BlockXform*>(p->d_xf), p->partials.as<double>(), p->d_small, p->wg_plain,
+                       p->d_ticket, p->d_loc);
     HG_HIP_CHECK(hipGetLastError());
     small_left = 0;
   }
@@ -2918,7 +3425,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
     hipLaunchKernelGGL(k_window_residuals<true>, dim3(p->wg_unwarp + small_left), dim3(kBatchThreads), 0, s,
                        static_cast<const EvalBlock*>(p->d_eval + p->num_plain), p->num_unwarp, p->tiles, d_residuals,
                        p->d_state, static_cast<const BlockXform*>(p->d_xf), p->partials.as<double>(), p->d_small,
-                       p->wg_unwarp);
+                       p->wg_unwarp, p->d_ticket, p->d_loc);
     HG_HIP_CHECK(hipGetLastError());
     small_left = 0;
   }
@@ -2928,8 +3435,8 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
   }
   if (with_lm) {
     ProfScope ps(p->ctx, HG_K_LM, 1);
-    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small,
-                       MODE_STEP, static_cast<const PinBox*>(nullptr), 0u);
+    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc),
+                       p->d_small, MODE_STEP, static_cast<const PinBox*>(nullptr), 0u);
     HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
@@ -2965,6 +3472,8 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_xf), sizeof(BlockXform) * kMaxBlocks);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 256);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_small), sizeof(SmallOut) * kMaxSmall);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_loc), sizeof(double) * kLoc * kMaxBlocks);
+  if (e == hipSuccess) e = hipMemset(p->d_loc, 0, sizeof(double) * kLoc * kMaxBlocks);
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void**>(&p->h_box), sizeof(PinBox), hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) {
@@ -2996,6 +3505,7 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->d_xf) (void)hipFree(p->d_xf);
   if (p->d_ticket) (void)hipFree(p->d_ticket);
   if (p->d_small) (void)hipFree(p->d_small);
+  if (p->d_loc) (void)hipFree(p->d_loc);
   if (p->h_box) (void)hipHostFree(p->h_box);
   if (p->d_eval) (void)hipFree(p->d_eval);
   if (p->d_pv) (void)hipFree(p->d_pv);
@@ -3206,11 +3716,11 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
     if (rc != HG_OK) return rc;
     d_res = p->residuals.as<double>();
   }
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
   HG_HIP_CHECK(hipGetLastError());
   rc = launch_eval(p, d_res, false);
   if (rc != HG_OK) return rc;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_ASSEMBLE, static_cast<const PinBox*>(nullptr), 0u);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_ASSEMBLE, static_cast<const PinBox*>(nullptr), 0u);
   HG_HIP_CHECK(hipGetLastError());
   HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmState), hipMemcpyDeviceToHost, s));
   if (d_res) HG_HIP_CHECK(hipMemcpyAsync(residuals, d_res, sizeof(double) * nres, hipMemcpyDeviceToHost, s));
@@ -3244,7 +3754,7 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
                              S0.blocks[0].active && S0.num_small == 0 && p->num_eval < 2 &&
                              !std::getenv("HG_PREPARE_KERNEL");
   if (!first_uploads) {
-    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, p->partials.as<double>(), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
+    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
     HG_HIP_CHECK(hipGetLastError());
   }
   // the launches of the single-pose registration step are back-to-back: one event pair brackets all
