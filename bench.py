@@ -78,9 +78,11 @@ def make_scans(rings, cols, first, count, stream_base):
 
 def cpu_baseline(args, map_scans, query_scans, gpu_steps):
     """Oracle (CPU restatement of the reference, 1 thread) on a bounded sample of the workload: the
-    FIRST `--cpu-scans` registration steps of this very run (same map scans, same guesses, scans
-    inserted at the solved poses), so its poses are also the parity gate of the timed GPU steps:
-    gpu_steps[i] = (pose, num_iterations, termination_type, termination_reason) of GPU step i."""
+    first `--cpu-scans` TIMED registration steps of this very run (same map: the map scans plus the
+    warm-up scans inserted where the GPU inserted them; same guesses; scans inserted at the solved
+    poses), so its poses are also the parity gate of the timed GPU steps:
+    gpu_steps[i] = (pose, num_iterations, termination_type, termination_reason) of GPU step i
+    (warm-up steps first)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     from hectorgrapher_amd import synth
@@ -89,13 +91,18 @@ def cpu_baseline(args, map_scans, query_scans, gpu_steps):
         loc = synth.transform_points(pose, pts)
         for g in grids:
             g.insert(pose[:3], loc)
+    for k in range(args.warmup):  # untimed: bring the oracle's map to the state the timed steps start from
+        at = gpu_steps[k][0]
+        loc = synth.transform_points(at, query_scans[k][1])
+        for g in grids:
+            g.insert(at[:3].astype(np.float32), loc)
     t_match = t_insert = 0.0
     n = 0
     probed = lookups = 0
     u_total = nin_total = 0
     max_dt = max_dr = 0.0
     same_flow = True
-    for k, (pose, pts) in enumerate(query_scans[:args.cpu_scans]):
+    for k, (pose, pts) in enumerate(query_scans[args.warmup:args.warmup + args.cpu_scans], start=args.warmup):
         guess = synth.pose_mul(pose, synth.perturbation())
         t0 = time.perf_counter()
         pr = po.Problem()
@@ -127,12 +134,13 @@ def cpu_baseline(args, map_scans, query_scans, gpu_steps):
     total = t_match + t_insert
     return {
         "value": n / total, "unit": "scans/s", "cores": 1, "kind": "port",
-        "sample": "the first %d registration steps of this run (match + 3-level insert), oracle -O3 1 thread; "
+        "sample": "the first %d timed registration steps of this run (match + 3-level insert), oracle -O3 1 thread; "
                   "match %.3f s/scan, insert %.3f s/scan" % (n, t_match / n, t_insert / n),
         "mean_levels_probed": probed / max(1, lookups),
         "updates_per_scan": u_total / n, "hits_per_scan": nin_total / n,
         "parity": {"max_dt_m": max_dt, "max_dr_rad": max_dr, "scans": n, "tolerance": 1e-4,
-                   "same_iterations_and_termination": bool(same_flow)},
+                   "same_iterations_and_termination": bool(same_flow),
+                   "steps": "timed steps %d..%d" % (0, n - 1)},
     }
 
 
@@ -367,22 +375,37 @@ def run_insert_stream(args):
     }
 
 
-def window_problem(pr, synth, first, n_cp, clouds, pyramid, n_pts):
-    """OptimizingLocalTrajectoryBuilder-shaped problem: n_cp control points (first constant,
-    oltb.cc:1268-1275) with velocities, IMU pre-integration + odometry blocks between neighbours
-    (:928-1074), one multi-resolution scan block per free control point (:343-364)."""
-    for i in range(n_cp):
-        k = first + i
-        tq = synth.pose_k(k) if i == 0 else synth.pose_mul(synth.pose_k(k), synth.perturbation())
-        pr.add_pose(tq, i == 0)
-        pr.set_velocity(i, np.array([0.5, 0.2, 0.0]), i == 0)
+def window_spec(synth, first, n_cp):
+    """Numbers of one OptimizingLocalTrajectoryBuilder-shaped window (control points first .. first +
+    n_cp - 1): initial poses (the first one at ground truth, the others perturbed), odometry deltas and
+    IMU delta rotations between neighbours. Pure host arithmetic, prepared outside the timed loop."""
+    poses = [synth.pose_k(first) if i == 0 else synth.pose_mul(synth.pose_k(first + i), synth.perturbation())
+             for i in range(n_cp)]
+    deltas, dqs = [], []
     for i in range(1, n_cp):
         k = first + i
-        delta = synth.pose_mul(synth.pose_inverse(synth.pose_k(k)), synth.pose_k(k - 1))
-        dq = synth.pose_mul(synth.pose_inverse(synth.pose_k(k - 1)), synth.pose_k(k))[3:]
-        pr.add_odometry_block(i - 1, i, 12.0, 30.0, delta)
-        pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, dq)
-        pr.add_block(clouds[i - 1], pyramid, 1.0 / np.sqrt(float(n_pts)), i, multi_res=True)
+        deltas.append(synth.pose_mul(synth.pose_inverse(synth.pose_k(k)), synth.pose_k(k - 1)))
+        dqs.append(synth.pose_mul(synth.pose_inverse(synth.pose_k(k - 1)), synth.pose_k(k))[3:])
+    return {"poses": poses, "deltas": deltas, "dqs": dqs, "velocity": np.array([0.5, 0.2, 0.0])}
+
+
+def window_build(pr, spec, clouds, pyramid, n_pts):
+    """The problem of a window: n_cp control points (first constant, oltb.cc:1268-1275) with velocities,
+    IMU pre-integration + odometry blocks between neighbours (:928-1074), one multi-resolution scan block
+    per free control point (:343-364)."""
+    n_cp = len(spec["poses"])
+    for i in range(n_cp):
+        pr.add_pose(spec["poses"][i], i == 0)
+        pr.set_velocity(i, spec["velocity"], i == 0)
+    scale = 1.0 / np.sqrt(float(n_pts))
+    for i in range(1, n_cp):
+        pr.add_odometry_block(i - 1, i, 12.0, 30.0, spec["deltas"][i - 1])
+        pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, spec["dqs"][i - 1])
+        pr.add_block(clouds[i - 1], pyramid, scale, i, multi_res=True)
+
+
+def window_problem(pr, synth, first, n_cp, clouds, pyramid, n_pts):
+    window_build(pr, window_spec(synth, first, n_cp), clouds, pyramid, n_pts)
 
 
 def run_window(args):
@@ -411,10 +434,12 @@ def run_window(args):
     problem = api.Problem(ctx)
     its, evals, inserted_at, solved = [], [], [], []
 
+    # control point 0 of window s sits on the last inserted scan
+    specs = [window_spec(synth, args.map_scans - 1 + s, n_cp) for s in range(total)]
+
     def step(s, sample=False):
         problem.reset()
-        first = args.map_scans - 1 + s  # control point 0 sits on the last inserted scan
-        window_problem(problem, synth, first, n_cp, d_scans[s:s + n_cp - 1], grids, n_pts)
+        window_build(problem, specs[s], d_scans[s:s + n_cp - 1], grids, n_pts)
         summ = problem.solve()
         its.append(summ.num_iterations)
         if sample:
@@ -630,6 +655,7 @@ def run_match_batch(args):
             p.add_block(d, grids, scale, i, multi_res=True)
         summ = api.solve_batch(problems)
         stats["its"].append(np.mean([s_.num_iterations for s_ in summ]))
+        stats["last"] = summ
         if sample:
             stats["evals"] += sum(s_.num_cost_evaluations for s_ in summ)
 
@@ -648,7 +674,9 @@ def run_match_batch(args):
     prof = ctx.prof_read()
     ctx.prof_enable(False)
     errs = [float(np.linalg.norm(p.get_pose(0)[:3] - q[0][:3])) for p, q in zip(problems, queries)]
+    last = stats["last"]  # every step solves the same matches: the last timed step's results are the gate's
     base = None
+    parity = None
     lbar = 4.0 / 3.0
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -661,17 +689,29 @@ def run_match_batch(args):
         t1 = time.perf_counter()
         n_cpu = min(B, args.cpu_scans)
         lk = pb = 0
-        for pose, pts, _, guess in queries[:n_cpu]:
+        max_dt = max_dr = 0.0
+        same_flow = True
+        for j, (pose, pts, _, guess) in enumerate(queries[:n_cpu]):
             pr = po.Problem()
             i = pr.add_pose(guess)
             pr.add_block(pts, og, scale, i, multi_res=True)
-            pr.solve()
+            so = pr.solve()
             a, b = pr.lookup_stats()
             lk += a
             pb += b
+            o, g = pr.get_pose(i), problems[j].get_pose(0)
+            max_dt = max(max_dt, float(np.linalg.norm(o[:3] - g[:3])))
+            max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(np.dot(o[3:], g[3:])))))))
+            same_flow = same_flow and (so.num_iterations, so.termination_type, so.termination_reason) == (
+                last[j].num_iterations, last[j].termination_type, last[j].termination_reason)
         lbar = pb / max(1, lk)
         base = {"value": n_cpu / (time.perf_counter() - t1), "unit": "matches/s", "cores": 1, "kind": "port",
                 "sample": "%d matches of the same workload, oracle -O3 1 thread" % n_cpu}
+        parity = {"max_dt_m": max_dt, "max_dr_rad": max_dr, "matches": n_cpu, "tolerance": 1e-4,
+                  "same_iterations_and_termination": bool(same_flow),
+                  "step": "matches 0..%d of the last timed step (batch of %d, %d-pt scans)" % (n_cpu - 1, B, n_pts)}
+        if not (max_dt <= 1e-4 and max_dr <= 1e-4):
+            raise SystemExit("bench.py: parity gate failed, GPU and oracle poses of the batch differ: %r" % (parity,))
     n_launch = max(1, prof["residuals"][0])
     avg_ms = prof["residuals"][1] / n_launch
     # launches after a problem's termination move no data for it: scale by the share that evaluated
@@ -691,7 +731,7 @@ def run_match_batch(args):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_tsdf_residuals_single_batch",
                      "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                      "problems_evaluating_per_launch": evals_per_launch, "sampled_steps": sampled_steps},
-        "cpu_baseline": base,
+        "parity": parity, "cpu_baseline": base,
         "gpu_over_cpu": (args.steps * B / elapsed) / base["value"] if base else None,
     }
 
@@ -732,6 +772,8 @@ def run_register_batch(args):
 
         def step(self, i, sample):
             n = len(self.problems)
+            if not hasattr(self, "steps0"):
+                self.steps0 = {}  # step -> (pose, iterations, termination) of submap 0 of this group
             for j in range(n):
                 p = self.problems[j]
                 p.reset()
@@ -740,6 +782,7 @@ def run_register_batch(args):
             poses, summ = api.register_scan_batch(self.problems, [0] * n, self.ins,
                                                   [api.RangeData([0, 0, 0], self.queries[j][i][1]) for j in range(n)],
                                                   self.pyramids)
+            self.steps0[i] = (poses[0].copy(), summ[0].num_iterations, summ[0].termination_type, summ[0].termination_reason)
             for j in range(n):
                 self.errs.append(float(np.linalg.norm(poses[j][:3] - self.queries[j][i][0][:3])))
                 self.its.append(summ[j].num_iterations)
@@ -793,6 +836,54 @@ def run_register_batch(args):
     bytes_per_launch = n_pts * (12.0 + 32.0 * lbar) * (evals / n_launch)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     ins_ms = sum(prof[k][1] for k in ("ray_count", "scan", "ray_expand", "apply")) / max(1, prof["apply"][0])
+    base = None
+    parity = None
+    if not args.no_cpu_baseline:
+        # the oracle replays submap 0: map scans, the warm-up scans where the GPU inserted them, then the
+        # first --cpu-scans TIMED steps (match + insert) -> parity gate and CPU rate of the same work
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        sb0 = 100000
+        og = [po.Grid(r) for r in RESOLUTIONS]
+        for pose, pts in make_scans(args.rings, args.cols, 0, args.map_scans, sb0):
+            loc = synth.transform_points(pose, pts)
+            for g in og:
+                g.insert(pose[:3], loc)
+        q0 = make_scans(args.rings, args.cols, args.map_scans, total, sb0)
+        g0 = groups[0]
+        for i in range(args.warmup):
+            at = g0.steps0[i][0]
+            loc = synth.transform_points(at, q0[i][1])
+            for g in og:
+                g.insert(at[:3].astype(np.float32), loc)
+        max_dt = max_dr = 0.0
+        same_flow = True
+        n_cpu = min(args.steps, args.cpu_scans)
+        t1 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + n_cpu):
+            pose, pts = q0[i]
+            pr = po.Problem()
+            pi = pr.add_pose(synth.pose_mul(pose, synth.perturbation()))
+            pr.add_block(pts, og, scale, pi, multi_res=True)
+            so = pr.solve()
+            o = pr.get_pose(pi)
+            g_pose, g_it, g_tt, g_tr = g0.steps0[i]
+            max_dt = max(max_dt, float(np.linalg.norm(o[:3] - g_pose[:3])))
+            max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(np.dot(o[3:], g_pose[3:])))))))
+            same_flow = same_flow and (so.num_iterations, so.termination_type, so.termination_reason) == (g_it, g_tt, g_tr)
+            at = o if np.array_equal(o.astype(np.float32), g_pose.astype(np.float32)) else g_pose
+            loc = synth.transform_points(at, pts)
+            for g in og:
+                g.insert(at[:3].astype(np.float32), loc)
+        cpu_s = time.perf_counter() - t1
+        parity = {"max_dt_m": max_dt, "max_dr_rad": max_dr, "scans": n_cpu, "tolerance": 1e-4,
+                  "same_iterations_and_termination": bool(same_flow),
+                  "steps": "submap 0, the first %d timed steps of the batch of %d" % (n_cpu, S)}
+        if not (max_dt <= 1e-4 and max_dr <= 1e-4):
+            raise SystemExit("bench.py: parity gate failed, GPU and oracle poses of submap 0 differ: %r" % (parity,))
+        base = {"value": n_cpu / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
+                "sample": "%d registration steps of one submap (match + 3-level insert), oracle -O3 1 thread" % n_cpu}
+    resident_gib = S * len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30
     return {
         "metric": "scans/s (%d independent submaps mapped together on one GPU, 100k-pt scans, 3-res TSDF registration)" % S,
         "value": args.steps * S / elapsed, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
@@ -802,14 +893,16 @@ def run_register_batch(args):
                                "for each of %d independent submaps (hg_register_scan_batch, %d host thread(s) / stream(s))"
                                % (n_pts, S, T),
                    "submaps": S, "host_threads": T, "mean_lm_iterations": float(np.mean(its)),
-                   "mean_pose_error_m": float(np.mean(errs)), "insert_ms_per_call": ins_ms},
+                   "mean_pose_error_m": float(np.mean(errs)), "insert_ms_per_call": ins_ms,
+                   "resident_voxel_gib": resident_gib},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_tsdf_residuals_single_batch",
                      "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                      "problems_evaluating_per_launch": evals / n_launch,
                      "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
                      "per_kernel_launches": {k: v[0] for k, v in prof.items()}},
-        "cpu_baseline": None,
+        "parity": parity, "cpu_baseline": base,
+        "gpu_over_cpu": (args.steps * S / elapsed) / base["value"] if base else None,
     }
 
 

@@ -45,7 +45,8 @@ def build_map(po_or_none, hg_ctx_and_api, resolutions, rings, cols, num_scans, m
     inserter = None
     if hg_ctx_and_api:
         c, api = hg_ctx_and_api
-        ggrids = [api.HybridGridTSDF(c, r, max_blocks=max_blocks) for r in resolutions]
+        per_level = max_blocks if isinstance(max_blocks, (list, tuple)) else [max_blocks] * len(resolutions)
+        ggrids = [api.HybridGridTSDF(c, r, max_blocks=m) for r, m in zip(resolutions, per_level)]
         inserter = api.TSDFRangeDataInserter3D(api.InsertOpts(**opts_kw))
     for k in range(num_scans):
         pose = synth.pose_k(k)

@@ -129,3 +129,90 @@ def test_stream_of_small_scans_shares_passes(po, hg, ctx):
     for o, g in zip(og, gg):
         for x, y in zip(o.export(), g.export()):
             assert np.array_equal(x, y)
+
+
+def test_window_of_nine_100k_point_scans_against_oracle(po, hg, ctx):
+    """The OptimizingLocalTrajectoryBuilder shape at the size bench.py --workload window quotes: ten
+    control points (81 free columns), nine 100 000-point multi-resolution scan blocks, IMU + odometry
+    blocks -- k_window_residuals (lean tiles, per-block tails) + k_lm (block-tridiagonal solve) against the
+    oracle: every control point within 1e-4 m / 1e-4 rad, same iterations and termination."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n_cp = 10
+    og = [po.Grid(r) for r in bench.RESOLUTIONS]
+    gg = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 18) for r in bench.RESOLUTIONS]
+    ins = [hg.TSDFRangeDataInserter3D() for _ in gg]
+    for pose, pts in bench.make_scans(RINGS, COLS, 0, MAP_SCANS, 0):
+        loc = synth.transform_points(pose, pts)
+        for g in og:
+            g.insert(pose[:3], loc)
+        hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), gg,
+                          pose_tq=pose.astype(np.float32))
+    for g in gg:
+        assert g.window_status()["direct"]
+    scans = [synth.generate_scan(synth.pose_k(MAP_SCANS + j), RINGS, COLS, stream=MAP_SCANS + j) for j in range(n_cp - 1)]
+    spec = bench.window_spec(synth, MAP_SCANS - 1, n_cp)
+    op, gp = po.Problem(), hg.Problem(ctx)
+    bench.window_build(op, spec, scans, og, RINGS * COLS)
+    bench.window_build(gp, spec, [torch.from_numpy(s).to(dev) for s in scans], gg, RINGS * COLS)
+    assert gp.num_columns() == 81
+    so, sg = op.solve(), gp.solve()
+    assert (sg.num_iterations, sg.num_successful_steps, sg.termination_type, sg.termination_reason) == \
+           (so.num_iterations, so.num_successful_steps, so.termination_type, so.termination_reason)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-9 * max(1.0, abs(so.final_cost))
+    for i in range(n_cp):
+        a, b = op.get_pose(i), gp.get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+        assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+        np.testing.assert_allclose(gp.get_velocity(i), op.get_velocity(i), atol=1e-6)
+
+
+def test_register_scan_batch_of_100k_point_scans_against_oracle(po, hg, ctx):
+    """hg_register_scan_batch at full size: four independent submaps, one 100 000-point registration step
+    each (batched matcher + job-table insert kernels); submaps 0 and 3 replayed by the oracle: pose
+    within 1e-4 m / 1e-4 rad, same iterations, and every voxel code of their three grids."""
+    import torch
+    dev = torch.device("cuda", 0)
+    S, map_scans = 4, 3
+    ins = [hg.TSDFRangeDataInserter3D() for _ in bench.RESOLUTIONS]
+    pyramids, oracles, queries, guesses = [], {}, [], []
+    for j in range(S):
+        sb = 100000 * (j + 1)
+        grids = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in bench.RESOLUTIONS]
+        if j in (0, 3):
+            oracles[j] = [po.Grid(r) for r in bench.RESOLUTIONS]
+        for pose, pts in bench.make_scans(RINGS, COLS, 0, map_scans, sb):
+            hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                              pose_tq=pose.astype(np.float32))
+            if j in oracles:
+                loc = synth.transform_points(pose, pts)
+                for g in oracles[j]:
+                    g.insert(pose[:3], loc)
+        pose, pts = bench.make_scans(RINGS, COLS, map_scans, 1, sb)[0]
+        pyramids.append(grids)
+        queries.append((pts, torch.from_numpy(pts).to(dev)))
+        guesses.append(synth.pose_mul(pose, synth.perturbation()))
+    scale = 1.0 / np.sqrt(float(RINGS * COLS))
+    problems = [hg.Problem(ctx) for _ in range(S)]
+    for j in range(S):
+        problems[j].add_pose(guesses[j])
+        problems[j].add_block(queries[j][1], pyramids[j], scale, 0, multi_res=True)
+    poses, summ = hg.register_scan_batch(problems, [0] * S, ins, [hg.RangeData([0, 0, 0], d) for _, d in queries], pyramids)
+    ctx.synchronize()
+    for j, og in oracles.items():
+        op = po.Problem()
+        op.add_pose(guesses[j])
+        op.add_block(queries[j][0], og, scale, 0, multi_res=True)
+        so = op.solve()
+        ref = op.get_pose(0)
+        assert np.linalg.norm(ref[:3] - poses[j][:3]) < POSE_TOL_M
+        assert rot_angle(ref[3:], poses[j][3:]) < POSE_TOL_RAD
+        assert (so.num_iterations, so.termination_type, so.termination_reason) == \
+               (summ[j].num_iterations, summ[j].termination_type, summ[j].termination_reason)
+        at = ref if np.array_equal(ref.astype(np.float32), poses[j].astype(np.float32)) else poses[j]
+        loc = synth.transform_points(at, queries[j][0])
+        for o, g in zip(og, pyramids[j]):
+            o.insert(at[:3].astype(np.float32), loc)
+            g.status()
+            for x, y in zip(o.export(), g.export()):
+                assert np.array_equal(x, y)

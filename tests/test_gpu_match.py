@@ -21,6 +21,38 @@ def maps(po, hg, ctx):
     return build_map(po, (ctx, hg), [0.05, 0.10, 0.20], 16, 625, 10, max_blocks=1 << 16)
 
 
+# The matcher reads voxels either by DIRECT address (all blocks in their window slot, bounding box inside
+# the window: pyramid_tsd_direct) or through the hash table (pyramid_tsd_general). Which one a test
+# exercised must not be luck: these fixtures pin the path per level and assert it.
+@pytest.fixture(scope="module")
+def maps_direct(po, hg, ctx):
+    """Windows of 2^18 blocks (25.6 m at 0.05 m): the 10 x 20 x 10 m room fits at every level."""
+    from conftest import build_map
+    m = build_map(po, (ctx, hg), [0.05, 0.10, 0.20], 16, 625, 10, max_blocks=1 << 18)
+    for g in m[1]:
+        st = g.window_status()
+        assert st["direct"] and st["overflow_blocks"] == 0, st
+    return m
+
+
+@pytest.fixture(scope="module")
+def maps_overflowed(po, hg, ctx):
+    """Pools whose windows (12.8 m along y at every level) are narrower than the 20 m room: blocks
+    spill into the overflow area and every lookup of every level goes through the hash table."""
+    from conftest import build_map
+    m = build_map(po, (ctx, hg), [0.05, 0.10, 0.20], 16, 625, 10, max_blocks=[1 << 14, 1 << 12, 1 << 10])
+    for g in m[1]:
+        st = g.window_status()
+        assert not st["direct"], st
+        assert st["overflow_blocks"] > 0 or any(e > w for e, w in zip(st["extent"], st["window"])), st
+    return m
+
+
+@pytest.fixture(params=["direct", "overflowed"])
+def maps_by_path(request, maps_direct, maps_overflowed):
+    return maps_direct if request.param == "direct" else maps_overflowed
+
+
 def query(K=10, rings=16, cols=625):
     pose = synth.pose_k(K)
     pts = synth.generate_scan(pose, rings, cols, stream=K)
@@ -50,10 +82,25 @@ def compare_evaluate(op, gp):
 
 
 @pytest.mark.parametrize("levels,multi", [([1], False), ([0], False), ([0, 1, 2], True)])
-def test_evaluate_single_pose(po, hg, ctx, maps, levels, multi):
+def test_evaluate_single_pose(po, hg, ctx, maps_by_path, levels, multi):
+    """Residuals, cost, gradient and J^T J through BOTH voxel-lookup paths (asserted by the fixtures)."""
     _, pts, guess = query()
-    op, gp = both_problems(po, hg, ctx, maps, levels, multi, pts, [guess], [False])
+    op, gp = both_problems(po, hg, ctx, maps_by_path, levels, multi, pts, [guess], [False])
     compare_evaluate(op, gp)
+
+
+def test_lookup_paths_agree_bit_for_bit(hg, ctx, maps_direct, maps_overflowed):
+    """The same map in a direct and in an overflowed pool: identical residuals (the two lookups return
+    the same voxels, the arithmetic behind them is shared)."""
+    _, pts, guess = query()
+    out = []
+    for m in (maps_direct, maps_overflowed):
+        gp = hg.Problem(ctx)
+        gp.add_pose(guess)
+        gp.add_block(pts, m[1], 1.0 / np.sqrt(len(pts)), 0, multi_res=True)
+        out.append(gp.evaluate())
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert out[0][0] == out[1][0]
 
 
 def test_evaluate_interpolated_two_poses(po, hg, ctx, maps):
@@ -67,12 +114,13 @@ def test_evaluate_interpolated_two_poses(po, hg, ctx, maps):
 
 @pytest.mark.parametrize("general_lm", [False, True])
 @pytest.mark.parametrize("levels,multi", [([1], False), ([0, 1, 2], True)])
-def test_solve_single_pose(po, hg, ctx, maps, levels, multi, general_lm, monkeypatch):
-    """Both LM tails: the register-resident single-pose step and (HG_LM_GENERAL=1) the general one."""
+def test_solve_single_pose(po, hg, ctx, maps_by_path, levels, multi, general_lm, monkeypatch):
+    """Both LM tails: the register-resident single-pose step and (HG_LM_GENERAL=1) the general one;
+    both voxel-lookup paths."""
     if general_lm:
         monkeypatch.setenv("HG_LM_GENERAL", "1")
     truth, pts, guess = query()
-    op, gp = both_problems(po, hg, ctx, maps, levels, multi, pts, [guess], [False])
+    op, gp = both_problems(po, hg, ctx, maps_by_path, levels, multi, pts, [guess], [False])
     so, sg = op.solve(), gp.solve()
     a, b = op.get_pose(0), gp.get_pose(0)
     assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
@@ -374,6 +422,44 @@ def test_window_of_ten_control_points(po, hg, ctx, maps):
     so, sg = op.solve(), gp.solve()
     assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
     assert abs(so.final_cost - sg.final_cost) <= 1e-8 * max(1e-12, so.final_cost) + 1e-15
+    for i in range(n_cp):
+        a, b = op.get_pose(i), gp.get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
+        assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+        np.testing.assert_allclose(gp.get_velocity(i), op.get_velocity(i), atol=1e-6)
+
+
+@pytest.mark.parametrize("path", ["btd_uniform", "btd_padded", "band"])
+def test_window_linear_solver_paths(po, hg, ctx, maps, path, monkeypatch):
+    """The three factorisations of the window's normal equations -- block-tridiagonal with uniform
+    9-column groups (registers, forward pass folded in), the padded block form, the band Cholesky -- give
+    the oracle's solve: same iterations, poses within tolerance. (The environment switches are read at
+    every solve.)"""
+    if path == "btd_padded":
+        monkeypatch.setenv("HG_LM_BTD_GENERIC", "1")
+    elif path == "band":
+        monkeypatch.setenv("HG_LM_BAND", "1")
+    og, gg = maps
+    n_cp = 6
+    poses = [synth.pose_k(3 + i) if i == 0 else synth.pose_mul(synth.pose_k(3 + i), synth.perturbation())
+             for i in range(n_cp)]
+    op, gp = po.Problem(), hg.Problem(ctx)
+    for i in range(n_cp):
+        for pr in (op, gp):
+            pr.add_pose(poses[i], i == 0)
+            pr.set_velocity(i, np.array([0.4, 0.1, 0.0]), i == 0)
+    for i in range(1, n_cp):
+        delta = synth.pose_mul(synth.pose_inverse(synth.pose_k(3 + i)), synth.pose_k(2 + i))
+        dq = synth.pose_mul(synth.pose_inverse(synth.pose_k(2 + i)), synth.pose_k(3 + i))[3:]
+        pts = synth.generate_scan(synth.pose_k(3 + i), 16, 100, stream=300 + i)
+        s = 1.0 / np.sqrt(len(pts))
+        for pr, g in ((op, og), (gp, gg)):
+            pr.add_odometry_block(i - 1, i, 12.0, 30.0, delta)
+            pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, dq)
+            pr.add_block(pts, [g[0], g[1], g[2]], s, i, -1, 0.0, True)
+    so, sg = op.solve(), gp.solve()
+    assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
+    assert so.num_successful_steps == sg.num_successful_steps
     for i in range(n_cp):
         a, b = op.get_pose(i), gp.get_pose(i)
         assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
