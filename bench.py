@@ -55,6 +55,14 @@ def parse_args():
                          "(hg_register_scan_batch: shared launches), BASELINE configs[3] at G = 1")
     ap.add_argument("--batch-threads", type=int, default=1,
                     help="--workload register_batch: host threads, each with its own context (stream) and an equal share of the submaps")
+    ap.add_argument("--total-submaps", type=int, default=0,
+                    help="BASELINE configs[3] (offline batch mapping): this many independent submaps farmed to the "
+                         "--gpus ranks (rank r owns submaps r, r + G, ...; must divide), every rank registering one "
+                         "scan of each of its submaps per step through hg_register_scan_batch, then ONE gather of "
+                         "the finished TSDF blocks to rank 0 (RCCL), checked by import + export digests. Strong "
+                         "scaling: the work is fixed as G grows")
+    ap.add_argument("--scans-per-submap", type=int, default=0,
+                    help="--total-submaps: timed scans per submap (overrides --steps; configs[3] names 500)")
     ap.add_argument("--submap-index", type=int, default=-1, help=argparse.SUPPRESS)  # child of --submaps
     ap.add_argument("--prof-every", type=int, default=4,
                     help="HIP-event kernel timing on every N-th timed step (each event pair costs "
@@ -188,10 +196,12 @@ def run_rank_processes(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()  # counts devices without creating a HIP context
-    if have < args.gpus:
+    share = os.environ.get("HG_RANKS_SHARE_GPU") == "1"  # tests on a one-GPU box: every rank on GPU 0, gloo
+    if have < args.gpus and not (share and have >= 1):
         raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (args.gpus, have))
-    if args.workload != "register":
-        raise SystemExit("bench.py: --gpus N > 1 runs the register workload (independent submap per rank)")
+    if args.workload != "register" and args.total_submaps <= 0:
+        raise SystemExit("bench.py: --gpus N > 1 runs the register workload (independent submap per rank) "
+                         "or --total-submaps (offline batch mapping)")
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -199,9 +209,11 @@ def run_rank_processes(args):
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if share:
+            env["HG_DIST_BACKEND"] = "gloo"  # RCCL refuses two ranks on one device
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
@@ -736,6 +748,204 @@ def run_match_batch(args):
     }
 
 
+def oracle_replay_submap(args, stream_base, steps0, scale, total):
+    """Parity gate + CPU rate of a batched mapping run: the oracle replays ONE submap (PRNG streams
+    `stream_base`): map scans, the warm-up scans where the GPU inserted them, then the first --cpu-scans
+    TIMED steps (match + insert). steps0[i] = (pose, iterations, termination type, reason) of the GPU's
+    step i of that submap. Returns (cpu_baseline, parity); aborts above the 1e-4 tolerance."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from hectorgrapher_amd import synth
+    og = [po.Grid(r) for r in RESOLUTIONS]
+    for pose, pts in make_scans(args.rings, args.cols, 0, args.map_scans, stream_base):
+        loc = synth.transform_points(pose, pts)
+        for g in og:
+            g.insert(pose[:3], loc)
+    n_cpu = min(args.steps, args.cpu_scans)
+    q0 = make_scans(args.rings, args.cols, args.map_scans, args.warmup + n_cpu, stream_base)
+    for i in range(args.warmup):
+        at = steps0[i][0]
+        loc = synth.transform_points(at, q0[i][1])
+        for g in og:
+            g.insert(at[:3].astype(np.float32), loc)
+    max_dt = max_dr = 0.0
+    same_flow = True
+    t1 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + n_cpu):
+        pose, pts = q0[i]
+        pr = po.Problem()
+        pi = pr.add_pose(synth.pose_mul(pose, synth.perturbation()))
+        pr.add_block(pts, og, scale, pi, multi_res=True)
+        so = pr.solve()
+        o = pr.get_pose(pi)
+        g_pose, g_it, g_tt, g_tr = steps0[i]
+        max_dt = max(max_dt, float(np.linalg.norm(o[:3] - g_pose[:3])))
+        max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(np.dot(o[3:], g_pose[3:])))))))
+        same_flow = same_flow and (so.num_iterations, so.termination_type, so.termination_reason) == (g_it, g_tt, g_tr)
+        at = o if np.array_equal(o.astype(np.float32), g_pose.astype(np.float32)) else g_pose
+        loc = synth.transform_points(at, pts)
+        for g in og:
+            g.insert(at[:3].astype(np.float32), loc)
+    cpu_s = time.perf_counter() - t1
+    parity = {"max_dt_m": max_dt, "max_dr_rad": max_dr, "scans": n_cpu, "tolerance": 1e-4,
+              "same_iterations_and_termination": bool(same_flow),
+              "steps": "one submap of the batch, its first %d timed steps" % n_cpu}
+    if not (max_dt <= 1e-4 and max_dr <= 1e-4):
+        raise SystemExit("bench.py: parity gate failed, GPU and oracle poses of the replayed submap differ: %r" % (parity,))
+    base = {"value": n_cpu / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
+            "sample": "%d registration steps of one submap (match + 3-level insert), oracle -O3 1 thread" % n_cpu}
+    return base, parity
+
+
+def init_dist(args):
+    """(dist or None, rank, local_rank, world): one process per GPU, RCCL (backend "nccl") unless
+    HG_DIST_BACKEND=gloo. A single rank started by torch.distributed.run still gets a process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or launched or os.environ.get("HG_FORCE_DIST") == "1":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        # RCCL pins the calling thread to the GPU's NUMA-local cores at communicator creation, next to its
+        # own proxy threads; the thread that feeds the registration chain loses 2 % to that
+        os.environ.setdefault("NCCL_IGNORE_CPU_AFFINITY", "1")
+        torch.cuda.set_device(local_rank)
+        try:
+            if os.environ.get("HG_DIST_BACKEND") == "gloo":
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+        except Exception as e:
+            if world > 1:
+                raise
+            sys.stderr.write("process group of one rank not initialised (%r): running without it\n" % (e,))
+            dist = None
+    return dist, rank, local_rank, world
+
+
+def run_offline_batch(args, out_fd=None):
+    """BASELINE configs[3], one command: --total-submaps S independent submaps x K scans each farmed to
+    the --gpus ranks (hectorgrapher_amd.distributed.map_sharded), every rank registering its S / G
+    submaps together per step (hg_register_scan_batch; a single owned submap takes the single chain), then
+    the one exchange: gather of all finished TSDF blocks to rank 0 (RCCL over xGMI; one count round, then
+    point to point) and its end-to-end check (import into fresh grids, export digests)."""
+    import torch
+    from hectorgrapher_amd import api, synth
+    from hectorgrapher_amd import distributed as hgd
+    dist, rank, local_rank, world = init_dist(args)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    S = args.total_submaps
+    steps = args.scans_per_submap if args.scans_per_submap > 0 else args.steps
+    n_pts = args.rings * args.cols
+    scale = 1.0 / np.sqrt(float(n_pts))
+    total = args.warmup + steps
+    distinct = min(total, 120)  # the bench trajectory folds back after 120 poses: longer runs revisit them
+
+    class Engine:
+        def open(self, owned):
+            self.ctx = api.Context(local_rank)
+            self.ins = [api.TSDFRangeDataInserter3D() for _ in RESOLUTIONS]
+            self.owned = owned
+            self.pyramids, self.queries, self.guesses, self.problems = [], [], [], []
+            self.steps0, self.errs, self.its = {}, [], []
+            for j in owned:
+                sb = 100000 * (j + 1)  # PRNG streams of submap j (the same submaps whatever G is)
+                grids = [api.HybridGridTSDF(self.ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+                for pose, pts in make_scans(args.rings, args.cols, 0, args.map_scans, sb):
+                    api.insert_pyramid(self.ins, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                                       pose_tq=pose.astype(np.float32))
+                q = make_scans(args.rings, args.cols, args.map_scans, distinct, sb)
+                self.pyramids.append(grids)
+                self.queries.append([(pose, torch.from_numpy(pts).to(dev)) for pose, pts in q])
+                self.guesses.append([synth.pose_mul(pose, synth.perturbation()) for pose, _ in q])
+                self.problems.append(api.Problem(self.ctx))
+            torch.cuda.synchronize()
+
+        def step(self, i):
+            n, k = len(self.problems), i % distinct
+            for j in range(n):
+                p = self.problems[j]
+                p.reset()
+                p.add_pose(self.guesses[j][k])
+                p.add_block(self.queries[j][k][1], self.pyramids[j], scale, 0, multi_res=True)
+            poses, summ = api.register_scan_batch(self.problems, [0] * n, self.ins,
+                                                  [api.RangeData([0, 0, 0], self.queries[j][k][1]) for j in range(n)],
+                                                  self.pyramids)
+            self.steps0[i] = (poses[0].copy(), summ[0].num_iterations, summ[0].termination_type, summ[0].termination_reason)
+            if i >= args.warmup:
+                for j in range(n):
+                    self.errs.append(float(np.linalg.norm(poses[j][:3] - self.queries[j][k][0][:3])))
+                    self.its.append(summ[j].num_iterations)
+
+        def sync(self):
+            self.ctx.synchronize()
+            torch.cuda.synchronize()
+
+        def grids(self):
+            return [g for pyr in self.pyramids for g in pyr]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    eng = Engine()
+    res = hgd.map_sharded(S, rank, world, eng, steps, args.warmup, barrier, dist)
+    for g in eng.grids():
+        g.status()  # raises on sticky capacity / range flags
+    gather_ms = gather_check = None
+    if dist is not None:
+        eng.sync()
+        barrier()
+        tg = time.perf_counter()
+        gathered = hgd.gather_grids(eng.grids(), dist, rank, world, dev, host=dist.get_backend() != "nccl")
+        eng.sync()
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        gather_check = hgd.verify_gather(api, eng.ctx, eng.grids(), gathered, dist, rank, world)
+        del gathered
+    # statistics over ALL submaps (every rank holds those of its own)
+    acc = torch.tensor([float(np.sum(eng.errs)), float(np.sum(eng.its)), float(len(eng.errs))], dtype=torch.float64)
+    if dist is not None:
+        if dist.get_backend() == "nccl":
+            acc = acc.to(dev)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    mean_err, mean_its = float(acc[0] / acc[2]), float(acc[1] / acc[2])
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return None
+    value = res["scans"] / res["elapsed"]
+    base = parity = None
+    if not args.no_cpu_baseline and world == 1:
+        base, parity = oracle_replay_submap(args, 100000 * (res["owned"][0] + 1), eng.steps0, scale, total)
+    per_rank = len(res["owned"])
+    out = {
+        "metric": "scans/s (offline batch mapping: %d independent submaps x %d scans, 100k-pt scans, 3-res TSDF registration)" % (S, steps),
+        "value": value, "unit": "scans/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": res["elapsed"] / steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "offline_batch: %d submaps x %d scans of %d points farmed to %d rank(s); a step registers one scan "
+                               "(multi-res LM match + exact insert x3) of each of a rank's %d submaps together (hg_register_scan_batch)"
+                               % (S, steps, n_pts, world, per_rank),
+                   "total_submaps": S, "submaps_per_gpu": per_rank, "scans_per_submap": steps,
+                   "parallelism": "submap s on rank s mod %d, no data-path collective; one gather at the end" % world,
+                   "mean_lm_iterations": mean_its, "mean_pose_error_m": mean_err,
+                   "resident_voxel_gib_per_gpu": per_rank * len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30,
+                   "gather_ms": gather_ms, "gather_check": gather_check},
+        "roofline": None, "parity": parity, "cpu_baseline": base,
+        "gpu_over_cpu": value / base["value"] if base else None,
+    }
+    if dist is not None:
+        dist.destroy_process_group()
+    return out
+
+
 def run_register_batch(args):
     """BASELINE configs[3] on one GPU: S independent submaps mapped together in one process. One step
     = one registration (multi-res LM match + exact 3-level insert of a 100k-point scan) for EVERY
@@ -839,50 +1049,7 @@ def run_register_batch(args):
     base = None
     parity = None
     if not args.no_cpu_baseline:
-        # the oracle replays submap 0: map scans, the warm-up scans where the GPU inserted them, then the
-        # first --cpu-scans TIMED steps (match + insert) -> parity gate and CPU rate of the same work
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import pyoracle as po
-        sb0 = 100000
-        og = [po.Grid(r) for r in RESOLUTIONS]
-        for pose, pts in make_scans(args.rings, args.cols, 0, args.map_scans, sb0):
-            loc = synth.transform_points(pose, pts)
-            for g in og:
-                g.insert(pose[:3], loc)
-        q0 = make_scans(args.rings, args.cols, args.map_scans, total, sb0)
-        g0 = groups[0]
-        for i in range(args.warmup):
-            at = g0.steps0[i][0]
-            loc = synth.transform_points(at, q0[i][1])
-            for g in og:
-                g.insert(at[:3].astype(np.float32), loc)
-        max_dt = max_dr = 0.0
-        same_flow = True
-        n_cpu = min(args.steps, args.cpu_scans)
-        t1 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + n_cpu):
-            pose, pts = q0[i]
-            pr = po.Problem()
-            pi = pr.add_pose(synth.pose_mul(pose, synth.perturbation()))
-            pr.add_block(pts, og, scale, pi, multi_res=True)
-            so = pr.solve()
-            o = pr.get_pose(pi)
-            g_pose, g_it, g_tt, g_tr = g0.steps0[i]
-            max_dt = max(max_dt, float(np.linalg.norm(o[:3] - g_pose[:3])))
-            max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(np.dot(o[3:], g_pose[3:])))))))
-            same_flow = same_flow and (so.num_iterations, so.termination_type, so.termination_reason) == (g_it, g_tt, g_tr)
-            at = o if np.array_equal(o.astype(np.float32), g_pose.astype(np.float32)) else g_pose
-            loc = synth.transform_points(at, pts)
-            for g in og:
-                g.insert(at[:3].astype(np.float32), loc)
-        cpu_s = time.perf_counter() - t1
-        parity = {"max_dt_m": max_dt, "max_dr_rad": max_dr, "scans": n_cpu, "tolerance": 1e-4,
-                  "same_iterations_and_termination": bool(same_flow),
-                  "steps": "submap 0, the first %d timed steps of the batch of %d" % (n_cpu, S)}
-        if not (max_dt <= 1e-4 and max_dr <= 1e-4):
-            raise SystemExit("bench.py: parity gate failed, GPU and oracle poses of submap 0 differ: %r" % (parity,))
-        base = {"value": n_cpu / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
-                "sample": "%d registration steps of one submap (match + 3-level insert), oracle -O3 1 thread" % n_cpu}
+        base, parity = oracle_replay_submap(args, 100000, groups[0].steps0, scale, total)
     resident_gib = S * len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30
     return {
         "metric": "scans/s (%d independent submaps mapped together on one GPU, 100k-pt scans, 3-res TSDF registration)" % S,
@@ -907,6 +1074,8 @@ def run_register_batch(args):
 
 
 def run(args, out_fd=None):
+    if args.total_submaps > 0:
+        return run_offline_batch(args, out_fd)
     if args.workload == "register_batch":
         return run_register_batch(args)
     if args.workload == "match_batch":
@@ -917,33 +1086,8 @@ def run(args, out_fd=None):
         return run_register_filtered(args)
     if args.workload == "window":
         return run_window(args)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    dist = None
-    # one rank launched by torch.distributed.run (RANK / MASTER_ADDR set) still goes through RCCL: the
-    # gather and its import / export check then run at N = 1 too
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
-    if world > 1 or launched or os.environ.get("HG_FORCE_DIST") == "1":
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        # RCCL pins the calling thread to the GPU's NUMA-local cores at communicator creation, next to its
-        # own proxy threads; the thread that feeds the registration chain loses 2 % to that
-        os.environ.setdefault("NCCL_IGNORE_CPU_AFFINITY", "1")
-        torch.cuda.set_device(local_rank)
-        try:
-            if os.environ.get("HG_DIST_BACKEND") == "gloo":
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-            else:
-                dist.init_process_group("nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank))
-        except Exception as e:
-            if world > 1:
-                raise
-            sys.stderr.write("process group of one rank not initialised (%r): running without it\n" % (e,))
-            dist = None
+    dist, rank, local_rank, world = init_dist(args)
     from hectorgrapher_amd import api, synth
     from hectorgrapher_amd import distributed as hgd
 

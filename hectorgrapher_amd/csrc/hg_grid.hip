@@ -267,6 +267,11 @@ int hg_ctx_destroy(hg_ctx* c) {
   if (!c) return HG_ERR_INVALID;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  // children that outlive the context keep their device memory and lose the context (see live_grids)
+  for (hg_grid* g : c->live_grids) g->ctx = nullptr;
+  for (hg_problem* p : c->live_problems) orphan_problem(p);
+  c->live_grids.clear();
+  c->live_problems.clear();
   for (DeviceBuffer* b : {&c->ws_points, &c->ws_scan_table, &c->ws_gate, &c->ws_counts,
                           &c->ws_offsets, &c->ws_keys_a, &c->ws_keys_b, &c->ws_vals_a,
                           &c->ws_vals_b, &c->ws_temp, &c->ws_misc, &c->ws_filter, &c->ws_jobs,
@@ -339,6 +344,7 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
   hg_grid* g = new hg_grid();
   g->ctx = ctx;
   g->relative_truncation_distance = relative_truncation_distance;
+  ctx->live_grids.push_back(g);
   if (!ctx->flag_free.empty()) {
     g->flag_slot = ctx->flag_free.back();
     ctx->flag_free.pop_back();
@@ -346,6 +352,7 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
     g->flag_slot = ctx->flag_next++;
   } else {
     set_last_error("too many grids on one context (4096 sticky-error words)");
+    ctx->live_grids.pop_back();
     delete g;
     return HG_ERR_CAPACITY;
   }
@@ -412,8 +419,10 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
 
 int hg_grid_destroy(hg_grid* g) {
   if (!g) return HG_ERR_INVALID;
-  (void)hipSetDevice(g->ctx->device);
-  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->ctx) {
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+  }
   if (g->view.table) (void)hipFree(g->view.table);
   if (g->view.voxels) (void)hipFree(g->view.voxels);
   if (g->view.block_keys) (void)hipFree(g->view.block_keys);
@@ -421,9 +430,13 @@ int hg_grid_destroy(hg_grid* g) {
   if (g->view.bin_count) (void)hipFree(g->view.bin_count);
   if (g->view.accum) (void)hipFree(g->view.accum);
   g->pack.release();
-  if (g->flag_slot < hg_ctx::kFlagSlots) {  // the stream has drained: nothing writes the word any more
-    g->ctx->flag_words[g->flag_slot] = 0u;
-    g->ctx->flag_free.push_back(static_cast<uint16_t>(g->flag_slot));
+  if (g->ctx) {
+    if (g->flag_slot < hg_ctx::kFlagSlots) {  // the stream has drained: nothing writes the word any more
+      g->ctx->flag_words[g->flag_slot] = 0u;
+      g->ctx->flag_free.push_back(static_cast<uint16_t>(g->flag_slot));
+    }
+    auto& live = g->ctx->live_grids;
+    live.erase(std::remove(live.begin(), live.end(), g), live.end());
   }
   delete g;
   return HG_OK;

@@ -69,6 +69,7 @@ inline uint64_t export_order_key(unsigned long long key) {
 }
 }  // namespace hg
 
+struct hg_problem;
 struct hg_ctx {
   int device = 0;
   int prof_on = 0;  // 0 off, 1 every kernel family, 2 the residual family only
@@ -116,6 +117,11 @@ struct hg_ctx {
   uint32_t* async_flags = nullptr;          // their device address
   uint32_t flag_next = 0;                   // slots [0, flag_next) have been handed out at some time
   std::vector<uint16_t> flag_free;          // released slots
+  // Live grids and problems of the context. hg_ctx_destroy ORPHANS what is still alive (child->ctx =
+  // nullptr) instead of leaving dangling pointers behind: a garbage-collected host (Python finalisers
+  // run in any order) may destroy a grid after its context; that then only frees the grid's memory.
+  std::vector<hg_grid*> live_grids;
+  std::vector<hg_problem*> live_problems;
 };
 
 namespace hg {
@@ -180,6 +186,7 @@ int pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, int l
 
 namespace hg {
 int grid_block_order(hg_grid* g, std::vector<uint32_t>* order);
+void orphan_problem(hg_problem* p);  // hg_match.hip: the problem's context is going away
 }
 
 struct hg_grid {

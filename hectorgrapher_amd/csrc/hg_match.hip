@@ -3444,6 +3444,8 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
 
 }  // namespace
 
+void hg::orphan_problem(hg_problem* p) { p->ctx = nullptr; }
+
 extern "C" {
 
 int hg_solver_default_opts(hg_solver_opts* o) {
@@ -3468,6 +3470,7 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
   HG_HIP_CHECK(hipSetDevice(ctx->device));
   hg_problem* p = new hg_problem();
   p->ctx = ctx;
+  ctx->live_problems.push_back(p);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(LmState));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_xf), sizeof(BlockXform) * kMaxBlocks);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 256);
@@ -3497,8 +3500,12 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
 
 int hg_problem_destroy(hg_problem* p) {
   if (!p) return HG_ERR_INVALID;
-  (void)hipSetDevice(p->ctx->device);
-  (void)hipStreamSynchronize(p->ctx->stream);
+  if (p->ctx) {
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    auto& live = p->ctx->live_problems;
+    live.erase(std::remove(live.begin(), live.end(), p), live.end());
+  }
   for (auto& b : p->blocks)
     if (b.owned) (void)hipFree(b.owned);
   if (p->d_state) (void)hipFree(p->d_state);

@@ -69,16 +69,88 @@ def gather_block_arrays(keys, vox, dist, rank, world, dst=0):
 
 
 def gather_grids(grids, dist, rank, world, dev, dst=0, host=False):
-    """Gathers every pyramid level's blocks to `dst`. Returns [level][src_rank] -> (keys, vox).
+    """Gathers the blocks of every grid of `grids` (the levels of one pyramid, or of all the submaps a
+    rank owns: every rank must pass the same number of grids) to `dst`: ONE all_gather of the block
+    counts of all grids, then point-to-point transfers of the non-empty ones, all in flight together.
+    Returns [grid][src_rank] -> (keys, vox) on dst, a list of None elsewhere.
     host=True stages the block arrays through host memory (gloo, or ranks that share one GPU)."""
-    out = []
+    ctxs = []
     for g in grids:
-        g.ctx.synchronize()
-        keys, vox = grid_block_tensors(g, dev)
+        if g.ctx not in ctxs:
+            ctxs.append(g.ctx)
+    for c in ctxs:
+        c.synchronize()
+    arrays = []
+    for g in grids:
+        # (a grid type may hand its block arrays over itself: host stand-ins of the CPU tests)
+        keys, vox = g.block_tensors(dev) if hasattr(g, "block_tensors") else grid_block_tensors(g, dev)
         if host:
             keys, vox = keys.cpu(), vox.cpu()
-        out.append(gather_block_arrays(keys, vox, dist, rank, world, dst))
-    return out
+        arrays.append((keys, vox))
+    if not arrays:
+        return []
+    tdev = arrays[0][0].device
+    mine = torch.tensor([a[0].shape[0] for a in arrays], dtype=torch.int64, device=tdev)
+    allc = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    counts = [c.tolist() for c in allc]  # [src][grid]
+    reqs = []
+    if rank == dst:
+        out = []
+        for gi, (keys, vox) in enumerate(arrays):
+            row = []
+            for src in range(world):
+                if src == dst:
+                    row.append((keys.clone(), vox.clone()))
+                    continue
+                k = torch.empty(counts[src][gi], dtype=torch.int64, device=tdev)
+                v = torch.empty((counts[src][gi], 512), dtype=torch.int32, device=tdev)
+                row.append((k, v))
+                if counts[src][gi] > 0:
+                    reqs.append(dist.irecv(k, src=src))
+                    reqs.append(dist.irecv(v, src=src))
+            out.append(row)
+        for r in reqs:
+            r.wait()
+        return out
+    for keys, vox in arrays:
+        if keys.shape[0] > 0:
+            reqs.append(dist.isend(keys.contiguous(), dst=dst))
+            reqs.append(dist.isend(vox.contiguous(), dst=dst))
+    for r in reqs:
+        r.wait()
+    return [None] * len(arrays)
+
+
+def map_sharded(total_submaps, rank, world, engine, steps, warmup, barrier, dist=None):
+    """BASELINE configs[3]: `total_submaps` independent submaps farmed to `world` ranks, rank r owning
+    shard(total_submaps, r, world) -- no data-path collective while mapping. `engine` maps the owned
+    submaps: engine.open(owned) builds them, engine.step(i) registers scan i of EVERY owned submap (the
+    batched registration step), engine.sync() drains the device. Times `steps` steps behind `warmup`
+    untimed ones, bracketed by `barrier()`; returns {"owned", "elapsed": max over ranks, "scans": all
+    ranks' scans in the timed region}."""
+    import time
+    if total_submaps % world != 0:
+        raise ValueError("map_sharded: %d submaps do not divide over %d ranks" % (total_submaps, world))
+    owned = shard(total_submaps, rank, world)
+    engine.open(owned)
+    for i in range(warmup):
+        engine.step(i)
+    engine.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        engine.step(i)
+    engine.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {"owned": owned, "elapsed": elapsed, "scans": total_submaps * steps}
 
 
 def export_digest(grid):

@@ -149,6 +149,99 @@ def test_gather_blocks_gloo_world2():
     assert owned == [0, 1, 2, 3, 4]           # every submap has exactly one owner
 
 
+class _FakeCtx:
+    def synchronize(self):
+        pass
+
+
+class _FakeEngine:
+    """Host stand-in of bench.py's offline-batch engine: every owned submap is a pyramid of two fake
+    grids; a step adds one block per level whose content depends only on (submap, step, level)."""
+
+    def __init__(self):
+        self.ctx = _FakeCtx()
+
+    def open(self, owned):
+        self.owned = owned
+        self.pyramids = []
+        for _ in owned:
+            pyr = [_FakeGrid(resolution=0.05 * (l + 1)) for l in range(2)]
+            for g in pyr:
+                g.ctx = self.ctx
+                g.block_tensors = (lambda dev, g=g: _fake_tensors(g))
+            self.pyramids.append(pyr)
+        self.steps = []
+
+    def step(self, i):
+        self.steps.append(i)
+        for j, pyr in zip(self.owned, self.pyramids):
+            for l, g in enumerate(pyr):
+                row = np.full((1, 512), 1 + 1000 * j + 10 * i + l, np.uint32)
+                g.import_blocks(np.array([100 * j + i], np.uint64), row)
+
+    def sync(self):
+        pass
+
+    def grids(self):
+        return [g for pyr in self.pyramids for g in pyr]
+
+
+def _fake_tensors(g):
+    import torch
+    keys = np.array(sorted(g.blocks), np.uint64)
+    vox = np.stack([g.blocks[int(k)] for k in keys]) if len(keys) else np.zeros((0, 512), np.uint32)
+    return torch.from_numpy(keys.view(np.int64).copy()), torch.from_numpy(vox.astype(np.uint32).view(np.int32).copy())
+
+
+def _sharded_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from hectorgrapher_amd import distributed as hgd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _FakeEngine()
+    res = hgd.map_sharded(8, rank, world, eng, steps=5, warmup=2, barrier=dist.barrier, dist=dist)
+    gathered = hgd.gather_grids(eng.grids(), dist, rank, world, None, host=True)
+    chk = hgd.verify_gather(_FakeApi, None, eng.grids(), gathered, dist, rank, world)
+    out.put((rank, res["owned"], eng.steps, res["scans"], res["elapsed"], chk,
+             None if rank else [[int(k.shape[0]) for k, _ in row] for row in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_offline_batch_driver_gloo_world2():
+    """BASELINE configs[3] driver logic on CPU: 8 submaps over 2 ranks (4 each, all of them stepped
+    together per step), warm-up + timed steps, ONE gather of all owned grids (8 grids per rank) to rank 0
+    and its import / export check."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {g[0]: g for g in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][1] == [0, 2, 4, 6] and got[1][1] == [1, 3, 5, 7]
+    for r in (0, 1):
+        assert got[r][2] == list(range(7))          # 2 warm-up + 5 timed steps, every owned submap each time
+        assert got[r][3] == 40 and got[r][4] > 0    # whole-job scans of the timed region, max-over-ranks time
+    assert got[1][5] is None
+    chk = got[0][5]
+    assert chk["ok"] and chk["ranks"] == 2 and chk["levels"] == 8
+    assert chk["blocks"] == 2 * 8 * 7               # every (rank, grid) contributed its 7 blocks
+    assert got[0][6] == [[7, 7]] * 8
+
+
+def test_map_sharded_refuses_uneven_split():
+    from hectorgrapher_amd import distributed as hgd
+    with pytest.raises(ValueError):
+        hgd.map_sharded(8, 0, 3, _FakeEngine(), 1, 0, lambda: None)
+
+
 def test_shard_partitions():
     from hectorgrapher_amd import distributed as hgd
     for world in (1, 2, 4, 8):

@@ -95,3 +95,24 @@ def test_cpp_gather_rccl_transport_single_rank():
     out = subprocess.run([_build_gather(), "rccl"], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert re.search(r"^gather ok: ranks 1 levels 3", out.stdout, re.M), out.stdout
+
+
+def test_cpp_gather_rccl_transport_two_ranks():
+    """RcclTransport with a real peer: two rank processes, one GPU each (ncclSend / ncclRecv of the block
+    payload over xGMI, counts and digests by ncclAllGather). Needs two GPUs: skipped on a one-GPU box (the
+    driver's multi-GPU node runs it)."""
+    import tempfile
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    exe = _build_gather()
+    with tempfile.TemporaryDirectory() as d:
+        id_file = os.path.join(d, "nccl_id")
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), HG_NCCL_ID_FILE=id_file,
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([exe, "rccl"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+        outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert re.search(r"^gather ok: ranks 2 levels 3 blocks (\d+) voxels (\d+)", outs[0][0], re.M), outs[0][0]

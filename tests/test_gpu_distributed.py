@@ -79,3 +79,38 @@ def test_gather_import_export_two_ranks_one_gpu():
     assert chk["blocks"] == sum(got["rank0"][2]) + sum(got["peer"][2])
     assert chk["voxels"] > 10000
     assert got["rank0"][3] == got["peer"][3]  # device-memory import of rank 1's level 0
+
+
+def _offline_batch(gpus, extra_env):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--total-submaps", "4",
+                        "--steps", "3", "--warmup", "1", "--rings", "16", "--cols", "625", "--map-scans", "3",
+                        "--max-blocks", str(1 << 15), "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_offline_batch_command_two_ranks_equal_one_rank():
+    """BASELINE configs[3] as ONE command: `bench.py --gpus G --total-submaps 4`. Two rank processes
+    (sharing the one GPU of the test box, so gloo instead of RCCL) map two submaps each through
+    hg_register_scan_batch, the finished blocks of all 12 grids are gathered to rank 0 in one exchange and
+    pass the import / export check; the same four submaps mapped by ONE rank (four per step) end with the
+    same number of blocks and voxels: sharding changes who maps a submap, not the map."""
+    two = _offline_batch(2, {"HG_RANKS_SHARE_GPU": "1"})
+    one = _offline_batch(1, {"HG_FORCE_DIST": "1", "HG_DIST_BACKEND": "gloo", "MASTER_PORT": str(_free_port())})
+    for out, g in ((two, 2), (one, 1)):
+        assert out["n_gpus"] == g and out["scaling"] == "strong" and out["value"] > 0
+        cfg = out["config"]
+        assert cfg["total_submaps"] == 4 and cfg["submaps_per_gpu"] == 4 // g
+        chk = cfg["gather_check"]
+        assert chk and chk["ok"] and chk["ranks"] == g and chk["levels"] == 3 * (4 // g)
+        assert cfg["gather_ms"] > 0
+    assert two["config"]["gather_check"]["blocks"] == one["config"]["gather_check"]["blocks"]
+    assert two["config"]["gather_check"]["voxels"] == one["config"]["gather_check"]["voxels"]
+    assert abs(two["config"]["mean_pose_error_m"] - one["config"]["mean_pose_error_m"]) < 1e-9

@@ -469,3 +469,20 @@ def test_async_insert_errors_are_per_grid(hg):
         fine.close()
     finally:
         c.close()
+
+
+def test_children_may_outlive_their_context(hg):
+    """A garbage-collected host destroys handles in any order: a context destroyed before its grids and
+    problems orphans them (hg_ctx_destroy), and destroying them afterwards only frees their memory."""
+    from hectorgrapher_amd import _lib
+    import ctypes as C
+    L = _lib.load()
+    c = hg.Context(0)
+    g = hg.HybridGridTSDF(c, 0.1, max_blocks=256)
+    p = hg.Problem(c)
+    gh, ph = g._h, p._h
+    g._h = p._h = None           # keep the Python wrappers from closing them first
+    c._children = set()
+    c.close()
+    assert L.hg_grid_destroy(gh) == 0
+    assert L.hg_problem_destroy(ph) == 0
