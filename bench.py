@@ -55,6 +55,12 @@ def parse_args():
                          "(hg_register_scan_batch: shared launches), BASELINE configs[3] at G = 1")
     ap.add_argument("--batch-threads", type=int, default=1,
                     help="--workload register_batch: host threads, each with its own context (stream) and an equal share of the submaps")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default workload: skip the bounded runs of the secondary workloads (match_batch 64, "
+                         "register_batch 8, insert_stream 32, window) that fill the `secondary` object")
+    ap.add_argument("--host-steps", type=int, default=20,
+                    help="default workload: extra registration steps with the scans handed over in HOST memory "
+                         "(what a drop-in receives), reported as `host_inclusive`; 0 disables")
     ap.add_argument("--total-submaps", type=int, default=0,
                     help="BASELINE configs[3] (offline batch mapping): this many independent submaps farmed to the "
                          "--gpus ranks (rank r owns submaps r, r + G, ...; must divide), every rank registering one "
@@ -362,6 +368,30 @@ def run_insert_stream(args):
                 "sample": "%d scans x 3 levels into fresh grids, oracle -O3 1 thread" % len(sample),
                 "all_cores": {"value": allc, "cores": cores,
                               "sample": "one independent submap per thread, %d scans each" % len(sample)}}
+    parity = None
+    if not args.no_cpu_baseline:
+        # gate: the first --cpu-scans scans of the stream, ONE batched call into fresh grids, against the
+        # oracle inserting them one after the other: every cell, code and the order of the export
+        n_chk = min(B, args.cpu_scans)
+        fresh = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+        farr = (C.c_void_p * 3)(*[g._h for g in fresh])
+        offs_chk = np.arange(n_chk + 1, dtype=np.uint64) * n_pts
+        api.check(L.hg_pyramid_insert_batch(farr, opts, 3, origins.ctypes.data_as(C.c_void_p), xyz.data_ptr(),
+                                            offs_chk.ctypes.data_as(C.c_void_p), n_chk, 0,
+                                            poses.ctypes.data_as(C.c_void_p), mode, 1, st), "hg_pyramid_insert_batch")
+        og = [po.Grid(r) for r in RESOLUTIONS]
+        for pose, pts in scans[:n_chk]:
+            loc = synth.transform_points(pose, pts)
+            for g in og:
+                g.insert(pose[:3], loc)
+        same = all(np.array_equal(x, y) for o, g in zip(og, fresh) for x, y in zip(o.export(), g.export()))
+        voxels = int(sum(len(g.export()[1]) for g in fresh))
+        parity = {"bit_exact": bool(same), "scans": n_chk, "voxels": voxels,
+                  "check": "cells, order, tsd and weight codes of the three grids after one batched call"}
+        for g in fresh:
+            g.close()
+        if args.insert_mode == "exact" and not same:
+            raise SystemExit("bench.py: parity gate failed, the streamed insertion differs from the oracle: %r" % (parity,))
     t_fam = sum(prof[k][1] for k in ("ray_count", "scan", "ray_expand", "sort", "alloc", "apply"))
     avg_ms = t_fam / max(1, prof["apply"][0])
     bytes_per = 12.0 * N_in + 8.0 * U
@@ -382,7 +412,7 @@ def run_insert_stream(args):
                      "hip_event_sampling": "every %d-th of the %d timed steps" % (max(1, args.prof_every), args.steps),
                      "per_kernel_ms_total": {k: round(v[1], 3) for k, v in prof.items()},
                      "per_kernel_launches": {k: v[0] for k, v in prof.items()}},
-        "cpu_baseline": base,
+        "parity": parity, "cpu_baseline": base,
         "gpu_over_cpu": (args.steps * B / elapsed) / base["value"] if base else None,
     }
 
@@ -1073,6 +1103,40 @@ def run_register_batch(args):
     }
 
 
+def secondary_workloads(args):
+    """Bounded runs of the other workloads inside the default command, so that the driver's record holds
+    them too: each {value, unit, ms_per_step, frac (algorithmic bytes / HBM peak of its dominant kernel),
+    parity_ok (its in-run oracle gate)}. Every run builds its own context and maps and frees them."""
+    import copy
+    out = {}
+    plan = [
+        ("match_batch_64", run_match_batch, {"workload": "match_batch", "batch": 64, "steps": 3, "warmup": 1, "prof_every": 1, "cpu_scans": 2}),
+        ("register_batch_8", run_register_batch, {"workload": "register_batch", "batch_submaps": 8, "batch_threads": 1, "steps": 6, "warmup": 2, "prof_every": 2, "cpu_scans": 2}),
+        ("insert_stream_32", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "steps": 4, "warmup": 1, "prof_every": 2, "cpu_scans": 2}),
+        ("window_10", run_window, {"workload": "window", "window": 10, "steps": 6, "warmup": 2, "prof_every": 2}),
+    ]
+    for name, fn, kw in plan:
+        a = copy.copy(args)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            r = fn(a)
+            par = r.get("parity") or {}
+            ok = par.get("bit_exact") if "bit_exact" in par else (
+                par.get("max_dt_m", 1.0) <= 1e-4 and par.get("max_dr_rad", 1.0) <= 1e-4) if par else None
+            roof = r.get("roofline") or {}
+            out[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                         "frac": roof.get("frac"), "kernel": roof.get("kernel"), "avg_launch_ms": roof.get("avg_launch_ms"),
+                         "parity_ok": None if ok is None else bool(ok), "parity": par or None,
+                         "wall_s": round(time.perf_counter() - t0, 2)}
+        except SystemExit as e:  # a failed parity gate of a secondary run is reported, the headline stands
+            out[name] = {"error": str(e), "parity_ok": False}
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    return out
+
+
 def run(args, out_fd=None):
     if args.total_submaps > 0:
         return run_offline_batch(args, out_fd)
@@ -1099,7 +1163,10 @@ def run(args, out_fd=None):
     # independent submap per rank: rank r uses PRNG streams offset by 1000*r
     sb = 1000 * rank + (100000 * (args.submap_index + 1) if args.submap_index >= 0 else 0)
     map_scans = make_scans(args.rings, args.cols, 0, args.map_scans, sb)
-    query = make_scans(args.rings, args.cols, args.map_scans, args.warmup + args.steps, sb)
+    lead = rank == 0 and world == 1 and args.submap_index < 0  # the one process that reports extras
+    host_steps = args.host_steps if lead else 0
+    host_warm = 2 if host_steps > 0 else 0  # the first host-memory call creates the copy stream and the staging slots
+    query = make_scans(args.rings, args.cols, args.map_scans, args.warmup + args.steps + host_warm + host_steps, sb)
 
     grids = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
     ins_mode = api._lib.HG_INSERT_FAST if args.insert_mode == "fast" else api._lib.HG_INSERT_EXACT
@@ -1109,7 +1176,7 @@ def run(args, out_fd=None):
         torch.cuda.synchronize()
         api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d), grids,
                            pose_tq=pose.astype(np.float32))
-    d_scans = [torch.from_numpy(pts).to(dev) for _, pts in query]
+    d_scans = [torch.from_numpy(pts).to(dev) for _, pts in query[:args.warmup + args.steps]]
     guesses = [synth.pose_mul(pose, synth.perturbation()) for pose, _ in query]
     torch.cuda.synchronize()
     problem = api.Problem(ctx)
@@ -1187,6 +1254,27 @@ def run(args, out_fd=None):
         timed_collect(timed_result)
     prof = ctx.prof_read()
     ctx.prof_enable(False)
+    # host-inclusive leg (untimed for `value`): the same step with the scans handed over in HOST memory,
+    # as INTEGRATION.md binds Insert / Match (sensor::RangeData lives in host vectors). Scan k + 1 travels
+    # to the device while step k runs (hg_register_scan_sequence); continues the same trajectory.
+    host_inclusive = None
+    if host_steps > 0:
+        lo = args.warmup + args.steps
+        w_scans = [api.RangeData([0, 0, 0], np.ascontiguousarray(query[i][1], np.float32)) for i in range(lo, lo + host_warm)]
+        api.register_scan_sequence(problem, inserters, w_scans, guesses[lo:lo + host_warm], grids, scale, multi_res=True)
+        lo += host_warm
+        h_scans = [api.RangeData([0, 0, 0], np.ascontiguousarray(query[i][1], np.float32)) for i in range(lo, lo + host_steps)]
+        h_call = api.register_scan_sequence(problem, inserters, h_scans, guesses[lo:lo + host_steps], grids, scale,
+                                            multi_res=True, prof_every=0, prepare_only=True)
+        barrier()
+        th = time.perf_counter()
+        h_res = h_call()
+        barrier()
+        th = time.perf_counter() - th
+        h_err = [float(np.linalg.norm(h_res[0][k][:3] - query[lo + k][0][:3])) for k in range(host_steps)]
+        host_inclusive = {"value": host_steps / th, "unit": "scans/s", "steps": host_steps, "ms_per_step": th / host_steps * 1e3,
+                          "mean_pose_error_m": float(np.mean(h_err)),
+                          "handover": "scans in pageable host memory (HG_HOST), 1.2 MB each; copy of scan k + 1 overlapped with step k"}
     # accounting pass (untimed): N_in and U of one more scan of the same workload
     last = args.warmup + args.steps - 1
     acc = api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d_scans[last]), grids,
@@ -1298,6 +1386,15 @@ def run(args, out_fd=None):
                    "gather_ms": gather_ms, "gather_check": gather_check},
         "roofline": roofline,
     }
+    if host_inclusive:
+        out["host_inclusive"] = host_inclusive
+    if lead and not args.no_secondary and args.insert_mode == "exact":
+        # free this run's maps first: the secondary runs build their own
+        del problem
+        for g in grids:
+            g.close()
+        ctx.close()
+        out["secondary"] = secondary_workloads(args)
     if base:
         out["parity"] = parity
         out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}

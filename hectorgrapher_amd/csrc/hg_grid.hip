@@ -277,6 +277,16 @@ int hg_ctx_destroy(hg_ctx* c) {
                           &c->ws_vals_b, &c->ws_temp, &c->ws_misc, &c->ws_filter, &c->ws_jobs,
                           &c->ws_keys_c, &c->ws_vals_c, &c->ws_offsets_b, &c->ws_sjobs, &c->ws_shadow})
     b->release();
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
+    for (int i = 0; i < 2; ++i) {
+      if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
+      if (c->ev_used[i]) (void)hipEventDestroy(c->ev_used[i]);
+      c->ws_seq[i].release();
+      if (c->pin_seq[i]) (void)hipHostFree(c->pin_seq[i]);
+    }
+  }
   if (c->apply_stream) {
     (void)hipStreamSynchronize(c->apply_stream);
     (void)hipStreamDestroy(c->apply_stream);

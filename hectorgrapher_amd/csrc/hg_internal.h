@@ -97,6 +97,13 @@ struct hg_ctx {
   size_t sjobs_capacity = 0;
   hipEvent_t ev_sjobs = nullptr;
   bool sjobs_pending = false;
+  // hg_register_scan_sequence with scans in host memory: scan k + 1 travels to one of two device slots on
+  // a copy stream while step k runs (ev_up: slot filled; ev_used: the step that read the slot is enqueued)
+  hg::DeviceBuffer ws_seq[2];
+  void* pin_seq[2] = {nullptr, nullptr};  // pinned staging of the two slots (the caller's memory is pageable)
+  size_t pin_seq_bytes[2] = {0, 0};
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
   hipStream_t apply_stream = nullptr;
   hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr};
   const uint32_t* filter_idx = nullptr;  // results of the last voxel-filter call (device)

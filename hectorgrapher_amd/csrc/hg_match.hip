@@ -3970,6 +3970,12 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
 }
 }  // namespace
 
+static int register_scan_step(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
+                              hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
+                              const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
+                              int insert_mode, double pose_out[7], hg_solver_summary* summary,
+                              int (*between)(void*), void* between_arg);
+
 extern "C" {
 
 int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solver_opts* opts,
@@ -4073,16 +4079,109 @@ int hg_register_scan_sequence(hg_problem* p, const hg_solver_opts* sopts, hg_gri
     int saved;
     ~ProfRestore() { c->prof_on = saved; }
   } restore{p->ctx, p->ctx->prof_on};
+  // Scans in HOST memory (what a drop-in receives from sensor::RangeData): scan k + 1 is copied to one of
+  // two device slots on a copy stream while step k runs on the GPU, started by the host between the
+  // enqueue of step k and the wait for its pose; the step itself then works on device pointers. Matching
+  // and insertion read the same upload.
+  struct Uploader {
+    hg_ctx* c;
+    const float* const* xyz;
+    const size_t* n;
+    int count, next;
+    static int run(void* self) { return static_cast<Uploader*>(self)->upload(); }
+    int upload() {  // scan `next` into slot next & 1
+      if (next >= count) return HG_OK;
+      const int slot = next & 1;
+      const size_t bytes = n[next] * 3 * sizeof(float);
+      if (c->ws_seq[slot].bytes < bytes) {
+        // (growing a slot frees it: the step that last read it must be done)
+        HG_HIP_CHECK(hipStreamSynchronize(c->stream));
+        const int rc = c->ws_seq[slot].reserve(bytes);
+        if (rc != HG_OK) return rc;
+      }
+      // through pinned staging: a copy from pageable memory blocks the host for the whole transfer
+      // (~330 us per 1.2 MB scan, measured), a memcpy into pinned memory takes a third of that and the
+      // DMA behind it is asynchronous. The staging slot's previous DMA (two steps ago) has long finished.
+      if (c->pin_seq_bytes[slot] < bytes) {
+        HG_HIP_CHECK(hipEventSynchronize(c->ev_up[slot]));
+        if (c->pin_seq[slot]) (void)hipHostFree(c->pin_seq[slot]);
+        c->pin_seq[slot] = nullptr;
+        c->pin_seq_bytes[slot] = 0;
+        HG_HIP_CHECK(hipHostMalloc(&c->pin_seq[slot], bytes + bytes / 4 + 256));
+        c->pin_seq_bytes[slot] = bytes + bytes / 4 + 256;
+      } else {
+        HG_HIP_CHECK(hipEventSynchronize(c->ev_up[slot]));
+      }
+      if (bytes) std::memcpy(c->pin_seq[slot], xyz[next], bytes);
+      HG_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_used[slot], 0));  // step next - 2 is through with the slot
+      if (bytes) HG_HIP_CHECK(hipMemcpyAsync(c->ws_seq[slot].ptr, c->pin_seq[slot], bytes, hipMemcpyHostToDevice, c->copy_stream));
+      HG_HIP_CHECK(hipEventRecord(c->ev_up[slot], c->copy_stream));
+      ++next;
+      return HG_OK;
+    }
+  } up{p->ctx, xyz, n, count, 0};
+  const bool staged = memspace == HG_HOST && count > 0;
+  if (staged) {
+    hg_ctx* c = p->ctx;
+    HG_HIP_CHECK(hipSetDevice(c->device));
+    if (!c->copy_stream) {
+      HG_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
+        HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_used[i], hipEventDisableTiming));
+      }
+    }
+    for (int i = 0; i < 2; ++i) {
+      HG_HIP_CHECK(hipEventRecord(c->ev_used[i], c->stream));  // both slots free once the stream gets here
+      HG_HIP_CHECK(hipEventRecord(c->ev_up[i], c->copy_stream));  // (nothing in flight on the staging slots)
+    }
+    const int rc = up.upload();
+    if (rc != HG_OK) return rc;
+  }
   for (int k = 0; k < count; ++k) {
+#ifdef HG_HOST_STAMPS
+    const auto q0 = std::chrono::steady_clock::now();
+#endif
     int rc = hg_problem_reset(p);
     if (rc != HG_OK) return rc;
     const int pi = hg_problem_add_pose(p, guesses + 7 * k, 0);
     if (pi < 0) return pi;
-    rc = hg_problem_add_block(p, xyz[k], n[k], memspace, grids, levels, multi_res, scaling[k], pi, -1, 0.0);
+    const float* pts = xyz[k];
+    int space = memspace;
+#ifdef HG_HOST_STAMPS
+    const auto q1 = std::chrono::steady_clock::now();
+#endif
+    if (staged) {
+      HG_HIP_CHECK(hipStreamWaitEvent(p->ctx->stream, p->ctx->ev_up[k & 1], 0));
+      pts = static_cast<const float*>(p->ctx->ws_seq[k & 1].ptr);
+      space = HG_DEVICE;
+    }
+#ifdef HG_HOST_STAMPS
+    const auto q2 = std::chrono::steady_clock::now();
+#endif
+    rc = hg_problem_add_block(p, pts, n[k], space, grids, levels, multi_res, scaling[k], pi, -1, 0.0);
     if (rc != HG_OK) return rc;
+#ifdef HG_HOST_STAMPS
+    {
+      const auto q3 = std::chrono::steady_clock::now();
+      auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      if (k % 10 == 5) fprintf(stderr, "sequence loop (us): reset+pose %.1f, wait event %.1f, add block %.1f\n", us(q0, q1), us(q1, q2), us(q2, q3));
+    }
+#endif
     if (prof_every > 0) p->ctx->prof_on = (k % prof_every) ? 0 : ((k % (5 * prof_every)) ? 2 : 1);
-    rc = hg_register_scan_mode(p, sopts, pi, grids, iopts, levels, origins + 3 * k, xyz[k], n[k], width, memspace,
-                               insert_mode, poses_out ? poses_out + 7 * k : nullptr, summaries ? summaries + k : nullptr);
+    struct Between {
+      Uploader* up;
+      hg_ctx* c;
+      int slot;
+      static int run(void* self) {
+        Between* b = static_cast<Between*>(self);
+        HG_HIP_CHECK(hipEventRecord(b->c->ev_used[b->slot], b->c->stream));  // solve + insertion of this step are enqueued
+        return b->up->upload();
+      }
+    } between{&up, p->ctx, k & 1};
+    rc = register_scan_step(p, sopts, pi, grids, iopts, levels, origins + 3 * k, pts, n[k], width, space, insert_mode,
+                            poses_out ? poses_out + 7 * k : nullptr, summaries ? summaries + k : nullptr,
+                            staged ? &Between::run : nullptr, &between);
     if (rc != HG_OK) return rc;
   }
   return HG_OK;
@@ -4100,6 +4199,19 @@ int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_i
                           hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
                           const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
                           int insert_mode, double pose_out[7], hg_solver_summary* summary) {
+  return register_scan_step(p, sopts, pose_index, grids, iopts, levels, origin, xyz, n, width, memspace, insert_mode,
+                            pose_out, summary, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+// One registration step; `between` (if any) runs on the host after solve and insertion have been enqueued
+// and before the wait for the pose: the place to start work for the NEXT step.
+static int register_scan_step(hg_problem* p, const hg_solver_opts* sopts, int pose_index,
+                              hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
+                              const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
+                              int insert_mode, double pose_out[7], hg_solver_summary* summary,
+                              int (*between)(void*), void* between_arg) {
   if (!p || !grids || !iopts || !origin || pose_index < 0 ||
       pose_index >= static_cast<int>(p->poses.size()))
     return HG_ERR_INVALID;
@@ -4130,6 +4242,7 @@ int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_i
 #ifdef HG_HOST_STAMPS
   const auto h2 = std::chrono::steady_clock::now();
 #endif
+  if (rc == HG_OK && between) rc = between(between_arg);
   const int rc2 = hg_problem_fetch(p, summary);
   if (rc == HG_OK) rc = rc2;
   if (rc == HG_OK && pose_out) std::memcpy(pose_out, p->poses[pose_index].data(), sizeof(double) * 7);
@@ -4149,6 +4262,8 @@ int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_i
 #endif
   return rc;
 }
+
+extern "C" {
 
 int hg_match_evaluate(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_res,
                       const float* xyz, size_t n, int memspace, double scaling_factor,

@@ -673,3 +673,38 @@ def test_register_scan_sequence_equals_step_by_step(hg, ctx):
         a.status()
         for x, y in zip(a.export(), b.export()):
             assert np.array_equal(x, y)
+
+
+def test_register_scan_sequence_with_host_scans_equals_device_scans(hg, ctx):
+    """Scans handed over in HOST memory (what a drop-in receives from sensor::RangeData) travel through two
+    device slots on a copy stream, scan k + 1 while step k runs: same poses bit for bit, same maps as the
+    sequence over device-resident scans -- also for scans of different sizes (a slot grows) and more steps
+    than slots."""
+    import torch
+    dev = torch.device("cuda", 0)
+    res = [0.05, 0.10, 0.20]
+    sets = {name: [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 15) for r in res] for name in ("host", "device")}
+    ins = [hg.TSDFRangeDataInserter3D() for _ in res]
+    for k in range(3):
+        pose = synth.pose_k(k)
+        pts = synth.generate_scan(pose, 16, 625, stream=k)
+        for grids in sets.values():
+            hg.insert_pyramid(ins, hg.RangeData([0, 0, 0], pts), grids, pose_tq=pose.astype(np.float32))
+    sizes = [(16, 400), (16, 625), (12, 500), (16, 700), (16, 625), (8, 300), (16, 625)]
+    host, device, guesses, scale = [], [], [], []
+    for j, (rings, cols) in enumerate(sizes):
+        pose = synth.pose_k(3 + j)
+        pts = synth.generate_scan(pose, rings, cols, stream=3 + j)
+        host.append(hg.RangeData([0, 0, 0], pts))
+        device.append(hg.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)))
+        guesses.append(synth.pose_mul(pose, synth.perturbation()))
+        scale.append(1.0 / np.sqrt(float(len(pts))))
+    ph, pd = hg.Problem(ctx), hg.Problem(ctx)
+    poses_h, summ_h = hg.register_scan_sequence(ph, ins, host, guesses, sets["host"], scale, multi_res=True)
+    poses_d, summ_d = hg.register_scan_sequence(pd, ins, device, guesses, sets["device"], scale, multi_res=True)
+    assert np.array_equal(poses_h, poses_d)
+    assert [s.num_iterations for s in summ_h] == [s.num_iterations for s in summ_d]
+    for a, b in zip(sets["host"], sets["device"]):
+        a.status()
+        for x, y in zip(a.export(), b.export()):
+            assert np.array_equal(x, y)
