@@ -42,6 +42,10 @@ def parse_args():
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
+    ap.add_argument("--stream-tiles", type=int, default=1,
+                    help="--workload insert_stream: scan i is shifted to copy (i mod T) of the room (copies 30 m apart "
+                         "on a 4-wide lattice), so that the blocks the stream touches outgrow the 256 MB Infinity Cache "
+                         "(SURVEY 8d: B = 500 with an HBM-resident working set); 1 = the single room")
     ap.add_argument("--batch", type=int, default=8, help="--workload match_batch: independent matches per call")
     ap.add_argument("--insert-mode", default="exact", choices=["exact", "fast"],
                     help="exact = voxel codes bit-identical to the reference (default, headline); fast = "
@@ -297,6 +301,15 @@ def run_insert_stream(args):
     n_pts = args.rings * args.cols
     B = args.stream_scans
     scans = make_scans(args.rings, args.cols, 0, B, 0)
+    if args.stream_tiles > 1:
+        shifted = []
+        for i, (pose, pts) in enumerate(scans):
+            t = i % args.stream_tiles
+            pose = pose.copy()
+            pose[0] += 30.0 * (t % 4)
+            pose[1] += 30.0 * (t // 4)
+            shifted.append((pose, pts))
+        scans = shifted
     xyz = torch.from_numpy(np.concatenate([p for _, p in scans])).to(dev)
     poses = np.array([pose for pose, _ in scans], np.float32)
     origins = np.zeros((B, 3), np.float32)
@@ -392,6 +405,7 @@ def run_insert_stream(args):
             g.close()
         if args.insert_mode == "exact" and not same:
             raise SystemExit("bench.py: parity gate failed, the streamed insertion differs from the oracle: %r" % (parity,))
+    blocks = [g.num_blocks() for g in grids]
     t_fam = sum(prof[k][1] for k in ("ray_count", "scan", "ray_expand", "sort", "alloc", "apply"))
     avg_ms = t_fam / max(1, prof["apply"][0])
     bytes_per = 12.0 * N_in + 8.0 * U
@@ -404,7 +418,8 @@ def run_insert_stream(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32/u16", "data": "synthetic",
         "config": {"workload": "insert_stream: %d scans x %d pts per batched call, 3-res TSDF, %s mode"
                                % (B, n_pts, args.insert_mode), "updates_per_step": U, "hits_per_step": N_in,
-                   "insert_mode": args.insert_mode},
+                   "insert_mode": args.insert_mode, "room_copies": args.stream_tiles, "blocks_per_level": blocks,
+                   "voxel_working_set_mib": sum(blocks) * 2048 / 2.0 ** 20},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "insert family (expand+sort+alloc+apply) per chunk launch",

@@ -3055,7 +3055,10 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm_single_batch(const SingleJo
 // each): their 15 us of serial Jet arithmetic run in the shadow of the TSDF blocks instead of in a
 // launch of their own. No solver tail: k_lm follows as its own launch.
 #ifndef HG_WINDOW_WAVES
-#define HG_WINDOW_WAVES 4  // workgroups per CU the per-scan body is compiled for (register budget 512 / waves)
+// Workgroups per CU the per-scan body is compiled for (register budget 512 / waves). Measured on the
+// window of nine 100k-point scans: 4 (128 VGPRs, 31 of them spilled) 34.9 us per launch and 14.9 MB of
+// scratch writes; 3 (no spills) 35.5 us and 0.2 MB of writes -- the spill traffic buys 2 %, not taken.
+#define HG_WINDOW_WAVES 3
 #endif
 template <bool UNWARP>
 __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals(

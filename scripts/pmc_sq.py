@@ -23,7 +23,7 @@ def main():
         waves = d.get("SQ_WAVES") or 1.0
         d["per_wave"] = {k: round(v / waves, 1) for k, v in d.items() if k.startswith("SQ_") and k != "SQ_WAVES"}
         out[name] = d
-    json.dump({"command": COMMAND,
+    json.dump({"command": COMMAND if len(sys.argv) < 4 else COMMAND.split(" -- ")[0] + " -- python3 " + sys.argv[3] + " --no-cpu-baseline",
                "unit": "counter totals per launch, averaged over the launches of the run (early-exit launches of "
                        "the residual kernel included); per_wave = total / SQ_WAVES",
                "kernels": out}, open(sys.argv[2], "w"), indent=1)

@@ -24,7 +24,7 @@ def per_kernel(path, counter):
         launches[name].append(float(r["Counter_Value"]) * 1024.0)  # counter unit: KiB
     out = {}
     for name, vals in launches.items():
-        if "k_tsdf_residuals" in name:
+        if "k_tsdf_residuals" in name or "k_window_residuals" in name or name.endswith("k_lm"):
             # launches enqueued after the solver terminated exit at once and move (almost) nothing
             vals = [v for v in vals if v > 0.25 * max(vals)]
         out[name] = (sum(vals) / len(vals), len(vals))
@@ -42,8 +42,9 @@ def main():
         ws, _ = w.get(name, (0.0, 0))
         kernels[name] = {"FETCH_SIZE": fs, "WRITE_SIZE": ws, "launches_sampled": n, "traffic_bytes": fs + ws}
     doc = {
-        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py "
-                   "--steps 3 --warmup 1 --no-cpu-baseline; aggregated by scripts/pmc_traffic.py",
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 "
+                   + (sys.argv[4] if len(sys.argv) > 4 else "bench.py --steps 3 --warmup 1") +
+                   " --no-cpu-baseline; aggregated by scripts/pmc_traffic.py",
         "unit": "bytes per launch (counter value x 1024); FETCH_SIZE NOT doubled: the gfx950 x2 correction is "
                 "calibrated only for wide 16-B/lane streams, these kernels issue 4/8-byte gathers "
                 "(MI355X_MICROARCH.md HBM section: other widths uncalibrated); early-exit launches of the residual "
