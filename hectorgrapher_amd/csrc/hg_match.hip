@@ -151,11 +151,20 @@ struct LmTables {
   int pad;
 };
 
+// Static gather lists of the assembly (built once per solve next to the tables): for every band entry and
+// every column the positions of its <= kGatherMax contributions in the concatenation of the blocks' local
+// systems [TSDF blocks: kMaxBlocks x kLoc | small blocks: kMaxSmall x kSmallLoc], in block order; 0xFFFF =
+// none. An LM step then assembles the normal equations with independent loads straight from device
+// memory -- no staging of the local systems, no per-entry search through the blocks.
+constexpr int kGatherMax = 8;
+constexpr unsigned kGatherSmallBase = kMaxBlocks * (kAccU + 1);
 struct LmState {
   LmHead h;
   double H[kHCap];   // J^T J at x (unscaled), band storage n x (bw + 1)
   double Hc[kHCap];  // J^T J at the candidate
   LmTables T;
+  alignas(16) unsigned short gather_h[kHCap][kGatherMax];
+  alignas(16) unsigned short gather_g[kMaxCols][kGatherMax];
 };
 
 struct PinBox {
@@ -1908,10 +1917,24 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
       __syncthreads();
       // model_cost_change = -(step.J^T r + step^T J^T J step / 2) on the scaled system: thread a forms
       // term a, wavefront 0 adds the terms (lane-strided partial sums, then a butterfly)
+      // (row a of the band is cut into kSplit runs of columns summed by different threads and added in run
+      // order: the 81 rows of a window alone would leave 430 of the 512 threads idle behind 35 dependent
+      // LDS round trips each. A holds the consumed factor by now and serves as scratch.)
+      constexpr int kSplit = 4;
+      for (int t = tid; t < n * kSplit; t += nthreads) {
+        const int a = t / kSplit, part = t - a * kSplit;
+        const int b0 = max(0, a - (W - 1)), b1 = min(n - 1, a + (W - 1));
+        const int len = b1 - b0 + 1, per = (len + kSplit - 1) / kSplit;
+        const int lo = b0 + part * per, hi = min(b1, lo + per - 1);
+        double row = 0.0;
+        for (int b = lo; b <= hi; ++b) row += band_get(S.H, a, b, W) * h.scale[a] * h.scale[b] * h.step[b];
+        S.A[t] = row;
+      }
+      __syncthreads();
       for (int a = tid; a < n; a += nthreads) {
         double row = 0.0;
-        const int b0 = max(0, a - (W - 1)), b1 = min(n - 1, a + (W - 1));
-        for (int b = b0; b <= b1; ++b) row += band_get(S.H, a, b, W) * h.scale[a] * h.scale[b] * h.step[b];
+#pragma unroll
+        for (int part = 0; part < kSplit; ++part) row += S.A[a * kSplit + part];
         S.y[a] = h.step[a] * (h.g[a] * h.scale[a]) + 0.5 * (h.step[a] * row);
       }
       __syncthreads();
@@ -2062,6 +2085,58 @@ __device__ __forceinline__ void assemble(LmShared& S) {
   __syncthreads();
 }
 
+// The same from the static gather lists (LmState::gather_*): every contribution is an independent load from
+// device memory (the local systems were written by the previous launch), summed in list order = block order.
+__device__ __forceinline__ void assemble_gathered(LmShared& S, const LmState* G, const double* loc_sums,
+                                                  const SmallOut* small_out) {
+  LmHead& h = S.h;
+  const int n = h.ncols, W = h.bw + 1;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const double* small = reinterpret_cast<const double*>(small_out);
+  auto fetch = [&](unsigned short at) {
+    const bool on = at != 0xFFFFu;
+    const bool sm = at >= kGatherSmallBase;
+    const double* src = sm ? small : loc_sums;
+    const unsigned o = on ? (sm ? at - kGatherSmallBase : at) : 0u;
+    const double v = src[o];
+    return on ? v : 0.0;
+  };
+  for (int idx = tid; idx < n * W; idx += nthreads) {
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    const us8 at = *reinterpret_cast<const us8*>(&G->gather_h[idx][0]);
+    double t[kGatherMax];
+#pragma unroll
+    for (int k = 0; k < kGatherMax; ++k) t[k] = fetch(at[k]);
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < kGatherMax; ++k) v += t[k];
+    S.Hc[idx] = v;
+  }
+  for (int i = tid; i < n; i += nthreads) {
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    const us8 at = *reinterpret_cast<const us8*>(&G->gather_g[i][0]);
+    double t[kGatherMax];
+#pragma unroll
+    for (int k = 0; k < kGatherMax; ++k) t[k] = fetch(at[k]);
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < kGatherMax; ++k) v += t[k];
+    h.gc[i] = v;
+  }
+  // cost: the blocks' r^T r, added in block order by thread 0 (loads by one thread each)
+  const int nb = h.num_blocks, ns = h.num_small;
+  if (tid < nb) S.A[tid] = h.blocks[tid].active ? loc_sums[tid * kLoc + 90] : 0.0;  // (A is free until the next solve)
+  if (tid >= 64 && tid < 64 + ns) S.A[kMaxBlocks + tid - 64] = h.small[tid - 64].active ? small[(tid - 64) * kSmallLoc + kSmallTri + 18] : 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    double cost = 0.0;
+    for (int k = 0; k < nb; ++k) cost += S.A[k];
+    for (int k = 0; k < ns; ++k) cost += S.A[kMaxBlocks + k];
+    h.cand_cost = 0.5 * cost;
+  }
+  __syncthreads();
+}
+
 // Transforms of every block at the candidate (thread b: block b), written straight to device memory
 // for the next residual launch. Only the structural non-zeros of M are filled by prepare_block.
 __device__ __forceinline__ void prepare_all(const LmHead& h, BlockXform* xf) {
@@ -2129,6 +2204,46 @@ __device__ __forceinline__ void build_tables(LmShared& S, LmState* G) {
     int* td = reinterpret_cast<int*>(&G->T);
     for (int i = tid; i < static_cast<int>(sizeof(LmTables) / sizeof(int)); i += nthreads) td[i] = src[i];
   }
+  if (S.T.pair_overflow) return;  // uniform: the step scans the blocks per entry instead
+  // gather lists from the pair lists (same contributions, same order as assemble's by-pairs loop)
+  const int n = h.ncols, W = h.bw + 1;
+  for (int idx = tid; idx < n * W; idx += nthreads) {
+    const int a = idx / W, b = a - (W - 1) + (idx - a * W);
+    int k_out = 0;
+    if (b >= 0) {
+      const int cpa = S.T.colcp[a], cpb = S.T.colcp[b];
+      const int p = cpa >> 4, q = cpb >> 4, sa = cpa & 15, sb = cpb & 15;
+      const bool sw = p < q;
+      const int hi_p = sw ? q : p, lo_p = sw ? p : q;
+      const int cnt = S.T.pair_count[hi_p][lo_p];
+      for (int k = 0; k < cnt; ++k) {
+        const int e = S.T.pair_list[hi_p][lo_p][k];
+        const int blk = e & 255, small = (e >> 8) & 1;
+        const int o_hi = (e >> 12) & 255, o_lo = (e >> 20) & 255;
+        const int l1 = sa + (sw ? o_lo : o_hi), l2 = sb + (sw ? o_hi : o_lo);
+        const int lo = l1 < l2 ? l1 : l2, hi = l1 < l2 ? l2 : l1;
+        if (!(small || (sa < 6 && sb < 6))) continue;
+        const unsigned at = small ? kGatherSmallBase + blk * kSmallLoc + hi * (hi + 1) / 2 + lo
+                                  : blk * kLoc + lo * 12 - (lo * (lo - 1)) / 2 + (hi - lo);
+        G->gather_h[idx][k_out++] = static_cast<unsigned short>(at);
+      }
+    }
+    for (; k_out < kGatherMax; ++k_out) G->gather_h[idx][k_out] = 0xFFFFu;
+  }
+  for (int i = tid; i < n; i += nthreads) {
+    const int cp = S.T.colcp[i];
+    const int p = cp >> 4, sl = cp & 15;
+    const int cnt = S.T.pair_count[p][p];
+    int k_out = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const int e = S.T.pair_list[p][p][k];
+      const int blk = e & 255, small = (e >> 8) & 1, off = (e >> 12) & 255;
+      if (!small && sl >= 6) continue;
+      const unsigned at = small ? kGatherSmallBase + blk * kSmallLoc + kSmallTri + off + sl : blk * kLoc + 78 + off + sl;
+      G->gather_g[i][k_out++] = static_cast<unsigned short>(at);
+    }
+    for (; k_out < kGatherMax; ++k_out) G->gather_g[i][k_out] = 0xFFFFu;
+  }
 }
 
 // One LM iteration by the calling workgroup: loads the solver head, the blocks' local systems
@@ -2183,8 +2298,15 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
     return;
   }
   HG_STAMP(S, 0);
-  // stage the local systems and H; build the column table
-  {
+  // H at x; the assembly gathers from device memory through the static lists, or -- more than kPairMax
+  // blocks on a pair of control points -- stages the local systems and the tables and searches per entry
+  const bool gathered = G->T.pair_overflow == 0;  // uniform
+  if (h.phase != PHASE_INIT)
+    for (int i = tid; i < nW; i += nthreads) S.H[i] = G->H[i];
+  if (gathered) {
+    HG_STAMP(S, 1);
+    assemble_gathered(S, G, loc_sums, small_out);
+  } else {
     double* dst = &S.loc[0][0];
     for (int i = tid; i < h.num_blocks * kLoc; i += nthreads) dst[i] = loc_sums[i];
     {
@@ -2193,17 +2315,15 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
       double* sd = &S.small[0][0];
       for (int i = tid; i < h.num_small * kSmallLoc; i += nthreads) sd[i] = src[i];
     }
-    if (h.phase != PHASE_INIT)
-      for (int i = tid; i < nW; i += nthreads) S.H[i] = G->H[i];
     {
       const int* src = reinterpret_cast<const int*>(&G->T);
       int* td = reinterpret_cast<int*>(&S.T);
       for (int i = tid; i < static_cast<int>(sizeof(LmTables) / sizeof(int)); i += nthreads) td[i] = src[i];
     }
+    __syncthreads();
+    HG_STAMP(S, 1);
+    assemble(S);
   }
-  __syncthreads();
-  HG_STAMP(S, 1);
-  assemble(S);
   HG_STAMP(S, 2);
   if (mode == MODE_ASSEMBLE) {
     for (int i = tid; i < nW; i += nthreads) G->Hc[i] = S.Hc[i];
