@@ -120,6 +120,7 @@ struct LmHead {
   // (SURVEY 8a16). The factorisation then runs block by block in registers (cholesky_solve_btd).
   int btd_groups;
   int btd_uniform;  // 6 or 9: every group has that many columns and the band holds the full coupling of neighbours
+  int btd_cr;       // 1: uniform groups are factorised by cyclic reduction over the workgroup (0: HG_LM_BTD_CHAIN=1)
   int btd_start[kMaxPoses + 1];
   int btd_size[kMaxPoses + 1];
   SmallBlockDev small[kMaxSmall];
@@ -1733,6 +1734,225 @@ __device__ __attribute__((noinline)) bool cholesky_solve_btd_full(int W, lds_f64
   return ok;
 }
 
+// The same system by block CYCLIC REDUCTION over the whole workgroup. cholesky_solve_btd_full is a chain of
+// `groups` block steps in one wavefront (81 columns: nine steps of ~7k cycles); the groups at the even
+// positions of the chain do not touch each other, so they are eliminated AT THE SAME TIME by different
+// wavefronts, the odd ones form a chain of half the length, and so on: 9 -> 4 -> 2 -> 1 -> 0, four levels.
+// Per level, wavefront w takes the group p at position 2w with its kept neighbours l (before) and r (after):
+//   phase 1  L_p = chol(D_p) in registers (every lane), y_p = L_p^-1 b_p; lanes 0.. solve the rows of
+//            X_l = A_lp L_p^-T, lanes 16.. those of X_r = A_rp L_p^-T; the new coupling of r with l is
+//            -X_r X_l^T (fill);
+//   phase 2  every kept group q (wavefront per group) subtracts X X^T of its eliminated neighbours from
+//            D_q and X y from b_q;
+// then the levels are unwound: x_p = L_p^-T (y_p - X_l^T x_l - X_r^T x_r). Same factorisation up to the
+// elimination order (a symmetric permutation of the system), hence the same solution to rounding.
+// Workspace: dense blocks in LDS (`ws`, kCrStride doubles per group).
+constexpr int kCrStride = 5 * 81 + 3 * 9 + 5;  // D/L, E, Xl, Xr, fill scratch | b/y, x, inv
+template <int MB>
+__device__ __forceinline__ bool cholesky_solve_cr(int W, const double* A, const double* b, double* x, double* ws,
+                                                  int groups, int* ok_flag) {
+  constexpr int MM = MB * MB;
+  constexpr int oD = 0, oE = 81, oXl = 162, oXr = 243, oB = 405, oX = 414, oI = 423;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int wave = tid / kWave, lane = tid % kWave;
+  const int Wm = W - 1;
+  // dense copies of the diagonal blocks (lower triangle), the couplings with the next group, the rhs
+  for (int i = tid; i < groups * MM; i += nthreads) {
+    const int g = i / MM, e = i - g * MM, r = e / MB, c = e - r * MB;
+    const int s0 = g * MB;
+    if (c <= r) ws[g * kCrStride + oD + e] = A[(s0 + r) * Wm + Wm + s0 + c];
+    if (g + 1 < groups) ws[g * kCrStride + oE + e] = A[(s0 + MB + r) * Wm + Wm + s0 + c];  // rows: next group, cols: g
+  }
+  for (int i = tid; i < groups * MB; i += nthreads) ws[(i / MB) * kCrStride + oB + i % MB] = b[i];
+  if (tid == 0) *ok_flag = 1;
+  __syncthreads();
+  // The chain of level v holds the groups (k + 1) 2^v - 1, k = 0 .. (groups >> v) - 1: the kept (odd)
+  // positions of the level before.
+  auto chain_at = [](int v, int k) { return ((k + 1) << v) - 1; };
+  auto chain_len = [groups](int v) { return groups >> v; };
+  int levels = 0;
+  while (chain_len(levels) > 0) ++levels;
+  int er = static_cast<int>((sqrtf(8.0f * static_cast<float>(lane) + 1.0f) - 1.0f) * 0.5f);
+  while (er * (er + 1) / 2 > lane) --er;
+  while ((er + 1) * (er + 2) / 2 <= lane) ++er;
+  const int ec = lane - er * (er + 1) / 2;
+  for (int v = 0; v < levels; ++v) {
+    const int len_v = chain_len(v);
+    const int n_el = (len_v + 1) / 2, n_keep = len_v / 2;
+    if (wave < n_el) {  // ---- phase 1: eliminate the group at position 2 * wave
+      const int p = chain_at(v, 2 * wave);
+      const int l = 2 * wave - 1 >= 0 ? chain_at(v, 2 * wave - 1) : -1;
+      const int r = 2 * wave + 1 < len_v ? chain_at(v, 2 * wave + 1) : -1;
+      double* wp = ws + p * kCrStride;
+      double L[MB][MB], inv[MB], yy[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[i][j] = wp[oD + i * MB + j];
+#pragma unroll
+      for (int k = 0; k < MB; ++k) yy[k] = wp[oB + k];
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        double d = L[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        ok = ok && (d > 0.0) && isfinite(d);
+        inv[j] = rsqrt(d);
+        L[j][j] = d * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < MB; ++i) {
+          double t = L[i][j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+          L[i][j] = t * inv[j];
+        }
+      }
+      if (!ok && lane == 0) *ok_flag = 0;
+#pragma unroll
+      for (int k = 0; k < MB; ++k) {
+        double t = yy[k];
+#pragma unroll
+        for (int j = 0; j < k; ++j) t -= L[k][j] * yy[j];
+        yy[k] = t * inv[k];
+      }
+      // rows of X_l (lanes 0 .. MB - 1: row i of A_lp = column i of the coupling block of l, whose rows are
+      // p's) and of X_r (lanes 16 .. 16 + MB - 1: row i of the coupling block of p, whose rows are r's)
+      {
+        const bool right = lane >= 16;
+        const int i = lane & 15;
+        const bool on = i < MB && lane < 32 && (right ? r >= 0 : l >= 0);
+        const double* src = right ? wp + oE : ws + (l >= 0 ? l : 0) * kCrStride + oE;
+        const int base0 = on ? (right ? i * MB : i) : 0, stride = right ? 1 : MB;
+        double X[MB];
+#pragma unroll
+        for (int k = 0; k < MB; ++k) X[k] = src[base0 + k * stride];
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+          double t = X[k];
+#pragma unroll
+          for (int j = 0; j < k; ++j) t -= X[j] * L[k][j];
+          X[k] = t * inv[k];
+        }
+        if (on) {
+          double* dst = wp + (right ? oXr : oXl) + i * MB;
+#pragma unroll
+          for (int k = 0; k < MB; ++k) dst[k] = X[k];
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) wp[oD + i * MB + j] = L[i][j];
+          wp[oI + i] = inv[i];
+          wp[oB + i] = yy[i];
+        }
+      }
+      wave_sync();
+      if (l >= 0 && r >= 0) {  // fill: coupling of r (rows) with l (columns), replaces l's coupling with p
+        double* fe = ws + l * kCrStride + oE;
+        for (int e = lane; e < MM; e += kWave) {
+          const int i = e / MB, j = e - i * MB;
+          double sum = 0.0;
+#pragma unroll
+          for (int k = 0; k < MB; ++k) sum += wp[oXr + i * MB + k] * wp[oXl + j * MB + k];
+          fe[e] = -sum;
+        }
+      }
+    }
+    __syncthreads();
+    if (wave < n_keep) {  // ---- phase 2: the kept group at position 2 * wave + 1 takes its neighbours' updates
+      const int q = chain_at(v, 2 * wave + 1);
+      const int pp = chain_at(v, 2 * wave);
+      const int pn = 2 * wave + 2 < len_v ? chain_at(v, 2 * wave + 2) : -1;
+      double* wq = ws + q * kCrStride;
+      const double* xa = ws + pp * kCrStride + oXr;                       // q is pp's right neighbour
+      const double* xb = ws + (pn >= 0 ? pn : pp) * kCrStride + oXl;      // and pn's left neighbour
+      const double* ya = ws + pp * kCrStride + oB;
+      const double* yb = ws + (pn >= 0 ? pn : pp) * kCrStride + oB;
+      if (lane < MB * (MB + 1) / 2) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) sum += xa[er * MB + k] * xa[ec * MB + k];
+        if (pn >= 0) {
+#pragma unroll
+          for (int k = 0; k < MB; ++k) sum += xb[er * MB + k] * xb[ec * MB + k];
+        }
+        wq[oD + er * MB + ec] -= sum;
+      } else if (lane >= 48 && lane < 48 + MB) {
+        const int i = lane - 48;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) sum += xa[i * MB + k] * ya[k];
+        if (pn >= 0) {
+#pragma unroll
+          for (int k = 0; k < MB; ++k) sum += xb[i * MB + k] * yb[k];
+        }
+        wq[oB + i] -= sum;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- unwind: x_p = L_p^-T (y_p - X_l^T x_l - X_r^T x_r), last level first
+  for (int v = levels - 1; v >= 0; --v) {
+    const int len_v = chain_len(v);
+    const int n_el = (len_v + 1) / 2;
+    if (wave < n_el) {
+      const int p = chain_at(v, 2 * wave);
+      const int l = 2 * wave - 1 >= 0 ? chain_at(v, 2 * wave - 1) : -1;
+      const int r = 2 * wave + 1 < len_v ? chain_at(v, 2 * wave + 1) : -1;
+      double* wp = ws + p * kCrStride;
+      if (lane < MB) {
+        double t = wp[oB + lane];
+        if (l >= 0) {
+          const double* xl = ws + l * kCrStride + oX;
+#pragma unroll
+          for (int i = 0; i < MB; ++i) t -= wp[oXl + i * MB + lane] * xl[i];
+        }
+        if (r >= 0) {
+          const double* xr = ws + r * kCrStride + oX;
+#pragma unroll
+          for (int i = 0; i < MB; ++i) t -= wp[oXr + i * MB + lane] * xr[i];
+        }
+        wp[oX + lane] = t;
+      }
+      wave_sync();
+      double L[MB][MB], xx[MB], dinv[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[i][j] = wp[oD + i * MB + j];
+#pragma unroll
+      for (int k = 0; k < MB; ++k) {
+        xx[k] = wp[oX + k];
+        dinv[k] = wp[oI + k];
+      }
+#pragma unroll
+      for (int k = MB - 1; k >= 0; --k) {
+        double t = xx[k];
+#pragma unroll
+        for (int j = k + 1; j < MB; ++j) t -= L[j][k] * xx[j];
+        xx[k] = t * dinv[k];
+      }
+      wave_sync();
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MB; ++k) wp[oX + k] = xx[k];
+      }
+    }
+    __syncthreads();
+  }
+  bool ok = *ok_flag != 0;
+  for (int i = tid; i < groups * MB; i += nthreads) {
+    const double v = ws[(i / MB) * kCrStride + oX + i % MB];
+    x[i] = v;
+    if (!isfinite(v)) *ok_flag = 0;  // benign race: same value
+  }
+  __syncthreads();
+  return ok && *ok_flag != 0;
+}
+
 // Small systems: every lane factorises its own register copy (no LDS round trips, no barriers);
 // left-looking term order; one reciprocal per column instead of a division per entry.
 template <int N>
@@ -1883,7 +2103,15 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
     for (int a = tid; a < n; a += nthreads) S.rhs[a] = h.g[a] * h.scale[a];
     __syncthreads();
     HG_STAMP(S, 4);
-    if (tid < kLmThreads) {
+    // uniform 6 / 9-column groups, three or more of them: cyclic reduction over all wavefronts
+    const bool use_cr = h.btd_groups >= 3 && (h.btd_uniform == 9 || h.btd_uniform == 6) && h.btd_cr != 0 &&
+                        (h.btd_groups + 1) / 2 <= static_cast<int>(blockDim.x) / kWave;
+    if (use_cr) {
+      double* ws = &S.loc[0][0];  // (the local systems were consumed by the assembly)
+      static_assert(sizeof(S.loc) + sizeof(S.small) >= sizeof(double) * kCrStride * kMaxPoses, "cyclic-reduction workspace");
+      if (h.btd_uniform == 9) cholesky_solve_cr<9>(W, S.A, S.rhs, h.step, ws, h.btd_groups, &S.solve_ok);
+      else cholesky_solve_cr<6>(W, S.A, S.rhs, h.step, ws, h.btd_groups, &S.solve_ok);
+    } else if (tid < kLmThreads) {
       const int lane = tid;
       bool valid = (n == 6)    ? cholesky_solve_regs<6>((const lds_f64*)S.A, W, (const lds_f64*)S.rhs, (lds_f64*)h.step, lane)
                    : (n == 12) ? cholesky_solve_regs<12>((const lds_f64*)S.A, W, (const lds_f64*)S.rhs, (lds_f64*)h.step, lane)
@@ -3412,6 +3640,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       bool uni = (mb == 6 || mb == 9) && bw >= 2 * mb - 1;
       for (int g = 1; g < groups; ++g) uni = uni && S.btd_size[g] == mb;
       if (uni && std::getenv("HG_LM_BTD_GENERIC") == nullptr) S.btd_uniform = mb;
+      S.btd_cr = std::getenv("HG_LM_BTD_CHAIN") == nullptr ? 1 : 0;
     }
     if (!ok) {
       std::memset(S.btd_start, 0, sizeof(S.btd_start));

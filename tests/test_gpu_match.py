@@ -429,25 +429,30 @@ def test_window_of_ten_control_points(po, hg, ctx, maps):
         np.testing.assert_allclose(gp.get_velocity(i), op.get_velocity(i), atol=1e-6)
 
 
-@pytest.mark.parametrize("path", ["btd_uniform", "btd_padded", "band"])
-def test_window_linear_solver_paths(po, hg, ctx, maps, path, monkeypatch):
-    """The three factorisations of the window's normal equations -- block-tridiagonal with uniform
-    9-column groups (registers, forward pass folded in), the padded block form, the band Cholesky -- give
-    the oracle's solve: same iterations, poses within tolerance. (The environment switches are read at
-    every solve.)"""
-    if path == "btd_padded":
+@pytest.mark.parametrize("velocities", [True, False])
+@pytest.mark.parametrize("path", ["cyclic_reduction", "btd_chain", "btd_padded", "band"])
+def test_window_linear_solver_paths(po, hg, ctx, maps, path, velocities, monkeypatch):
+    """The factorisations of the window's normal equations -- block cyclic reduction over the workgroup
+    (uniform 9- or 6-column groups), the block chain in one wavefront (registers, forward pass folded in),
+    the padded block form, the band Cholesky -- give the oracle's solve: same iterations, poses within
+    tolerance. With velocities: 9-column groups (pose + velocity, IMU blocks); without: 6-column groups
+    coupled by two-pose scan blocks. (The environment switches are read at every solve.)"""
+    if path == "btd_chain":
+        monkeypatch.setenv("HG_LM_BTD_CHAIN", "1")
+    elif path == "btd_padded":
         monkeypatch.setenv("HG_LM_BTD_GENERIC", "1")
     elif path == "band":
         monkeypatch.setenv("HG_LM_BAND", "1")
     og, gg = maps
-    n_cp = 6
+    n_cp = 7
     poses = [synth.pose_k(3 + i) if i == 0 else synth.pose_mul(synth.pose_k(3 + i), synth.perturbation())
              for i in range(n_cp)]
     op, gp = po.Problem(), hg.Problem(ctx)
     for i in range(n_cp):
         for pr in (op, gp):
             pr.add_pose(poses[i], i == 0)
-            pr.set_velocity(i, np.array([0.4, 0.1, 0.0]), i == 0)
+            if velocities:
+                pr.set_velocity(i, np.array([0.4, 0.1, 0.0]), i == 0)
     for i in range(1, n_cp):
         delta = synth.pose_mul(synth.pose_inverse(synth.pose_k(3 + i)), synth.pose_k(2 + i))
         dq = synth.pose_mul(synth.pose_inverse(synth.pose_k(2 + i)), synth.pose_k(3 + i))[3:]
@@ -455,8 +460,12 @@ def test_window_linear_solver_paths(po, hg, ctx, maps, path, monkeypatch):
         s = 1.0 / np.sqrt(len(pts))
         for pr, g in ((op, og), (gp, gg)):
             pr.add_odometry_block(i - 1, i, 12.0, 30.0, delta)
-            pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, dq)
-            pr.add_block(pts, [g[0], g[1], g[2]], s, i, -1, 0.0, True)
+            if velocities:
+                pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, dq)
+                pr.add_block(pts, [g[0], g[1], g[2]], s, i, -1, 0.0, True)
+            else:
+                pr.add_block(pts, [g[0], g[1], g[2]], s, i - 1, i, 0.6, True)   # couples the two poses: band of 11
+    assert gp.num_columns() == (9 if velocities else 6) * (n_cp - 1)
     so, sg = op.solve(), gp.solve()
     assert so.num_iterations == sg.num_iterations and so.termination_reason == sg.termination_reason
     assert so.num_successful_steps == sg.num_successful_steps
@@ -464,7 +473,8 @@ def test_window_linear_solver_paths(po, hg, ctx, maps, path, monkeypatch):
         a, b = op.get_pose(i), gp.get_pose(i)
         assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
         assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
-        np.testing.assert_allclose(gp.get_velocity(i), op.get_velocity(i), atol=1e-6)
+        if velocities:
+            np.testing.assert_allclose(gp.get_velocity(i), op.get_velocity(i), atol=1e-6)
 
 
 def test_band_capacity_is_reported(hg, ctx, maps):
