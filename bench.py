@@ -1397,11 +1397,12 @@ def run(args, out_fd=None):
     }
     dom = max(fam, key=lambda k: fam[k][2])
     avg_ms, bytes_per, _ = fam[dom]
-    # HBM traffic of the dominant kernel from the committed PMC passes of this same command
-    # (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs)
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected by the timed run itself (separate
+    # rocprofv3 --pmc passes, MI355X guide), so the figure comes from the committed passes of this same
+    # command (scripts/r03_profile.sh -> profiles/r03_bench_pmc_traffic.json) and is labelled as such
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_bench_pmc_traffic.json")) as f:
             pmc = json.load(f)["kernels"]
         if dom == "k_tsdf_residuals":
             # the single-pose registration step runs the k_tsdf_residuals_single<512> instantiation
@@ -1418,7 +1419,7 @@ def run(args, out_fd=None):
         families[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved": gbs,
                           "frac": gbs / HBM_PEAK_GBS}
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/r02_profile.sh), not collected by this run", "kernel": dom,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "from_profile: profiles/r03_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scripts/r03_profile.sh), not collected by this run", "kernel": dom,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per,
                 "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
                 "per_kernel_launches": {k: v[0] for k, v in prof.items()},
@@ -1440,6 +1441,7 @@ def run(args, out_fd=None):
                    "points_per_scan": n_pts, "map_scans": args.map_scans,
                    "parallelism": "independent submap per GPU x%d" % world,
                    "insert_mode": args.insert_mode, "mean_pose_error_m": float(np.mean(errs)),
+                   "resident_voxel_gib": len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30,
                    "gather_ms": gather_ms, "gather_check": gather_check},
         "roofline": roofline,
     }

@@ -215,11 +215,14 @@ __device__ inline void interpolate_linear(double both_invalid, const D3& q1, con
     q = q1;
     w = w1;
   } else {
+    // fused multiply-adds, nested so that the terms that are structurally zero (a derivative slot no
+    // stage has touched yet, or the slot of another axis) drop out exactly: the same bits as
+    // interp_all_valid, which leaves those terms out
     const double da = q2.a - q1.a;
-    q.a = da * r.a + q1.a;
-    q.d0 = (da * r.d0 + (q2.d0 - q1.d0) * r.a) + q1.d0;
-    q.d1 = (da * r.d1 + (q2.d1 - q1.d1) * r.a) + q1.d1;
-    q.d2 = (da * r.d2 + (q2.d2 - q1.d2) * r.a) + q1.d2;
+    q.a = fma(da, r.a, q1.a);
+    q.d0 = fma(q2.d0 - q1.d0, r.a, fma(da, r.d0, q1.d0));
+    q.d1 = fma(q2.d1 - q1.d1, r.a, fma(da, r.d1, q1.d1));
+    q.d2 = fma(q2.d2 - q1.d2, r.a, fma(da, r.d2, q1.d2));
     w = w1 + w2;
   }
 }
@@ -409,13 +412,17 @@ __device__ inline void direct_load(const GridView& g, DirectFetch& f) {
 }
 // Inside the window anchored at the bounding-box minimum (which implies inside the index range)?
 // Outside it no block exists: the voxels read as unknown.
-__device__ inline void direct_accept(const GridView& g, const uint32_t* wmin, bool usable, DirectFetch& f) {
+__device__ inline bool direct_inside(const GridView& g, const uint32_t* wmin, bool usable, const DirectFetch& f) {
   bool in = usable;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const uint32_t mask = (1u << g.dir_bits[a]) - 1u;
     in = in && ((f.s0[a] >> 3) - wmin[a]) <= mask && (((f.s0[a] + 1u) >> 3) - wmin[a]) <= mask;
   }
+  return in;
+}
+__device__ inline void direct_accept(const GridView& g, const uint32_t* wmin, bool usable, DirectFetch& f) {
+  const bool in = direct_inside(g, wmin, usable, f);
 #pragma unroll
   for (int c = 0; c < 8; ++c) f.code[c] = in ? f.code[c] : 0u;
 }
@@ -426,23 +433,28 @@ __device__ inline void direct_accept(const GridView& g, const uint32_t* wmin, bo
 // derivative slots no stage has touched yet) are left out, which can only change the sign of a zero.
 __device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offset, float min_tsd,
                                       const float* c3, const uint32_t* code, double x, double y, double z) {
+  (void)min_tsd;
   double q[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
+    // decode as the LUT does (float multiply, then float add: never fused). A voxel with a non-zero weight
+    // code has a non-zero tsd code (SetCell writes both), so the unknown-code case cannot occur on a level
+    // that is all valid; callers discard the result otherwise.
     const uint32_t v = code[c] & 0x7FFFu;
-    q[c] = static_cast<double>(v == 0 ? min_tsd : static_cast<float>(v) * tsd_scale + tsd_offset);
+    q[c] = static_cast<double>(static_cast<float>(v) * tsd_scale + tsd_offset);
   }
   const double x1 = c3[0], y1 = c3[1], z1 = c3[2];
   const double x2 = c3[0] + res, y2 = c3[1] + res, z2 = c3[2] + res;  // float adds, as the reference
   // Jet / double: Ceres multiplies by the inverse (jet.h operator/(Jet, T))
   const double ix = 1.0 / (x2 - x1), iy = 1.0 / (y2 - y1), iz = 1.0 / (z2 - z1);
   const double nx = (x - x1) * ix, ny = (y - y1) * iy, nz = (z - z1) * iz;
+  // the lerps as fused multiply-adds (continuous outputs only: agreement with the reference to rounding)
   // along z: value and d/dz
   double a1[4], dz1[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const double da = q[2 * k + 1] - q[2 * k];
-    a1[k] = da * nz + q[2 * k];
+    a1[k] = fma(da, nz, q[2 * k]);
     dz1[k] = da * iz;
   }
   // along y
@@ -450,17 +462,17 @@ __device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offs
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const double da = a1[2 * k + 1] - a1[2 * k];
-    a2[k] = da * ny + a1[2 * k];
+    a2[k] = fma(da, ny, a1[2 * k]);
     dy2[k] = da * iy;
-    dz2[k] = (dz1[2 * k + 1] - dz1[2 * k]) * ny + dz1[2 * k];
+    dz2[k] = fma(dz1[2 * k + 1] - dz1[2 * k], ny, dz1[2 * k]);
   }
   // along x
   const double da = a2[1] - a2[0];
   D3 r;
-  r.a = da * nx + a2[0];
+  r.a = fma(da, nx, a2[0]);
   r.d0 = da * ix;
-  r.d1 = (dy2[1] - dy2[0]) * nx + dy2[0];
-  r.d2 = (dz2[1] - dz2[0]) * nx + dz2[0];
+  r.d1 = fma(dy2[1] - dy2[0], nx, dy2[0]);
+  r.d2 = fma(dz2[1] - dz2[0], nx, dz2[0]);
   return r;
 }
 
@@ -479,10 +491,9 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   const DirectPyramid dp = direct_resolve(pv, raw);  // the counters have long arrived
   *ok = dp.ok;
   if (!dp.ok) return {0.0, 0.0, 0.0, 0.0};  // wave-uniform: the caller takes the general path
-#pragma unroll
-  for (int l = 0; l < LEVELS; ++l) direct_accept(pv.level[l], dp.min_b[l], usable, f[l]);
   BODY_STAMP(3);
   if (!pv.multi_res) {
+    direct_accept(pv.level[0], dp.min_b[0], usable, f[0]);
     const GridView& g = pv.level[0];
     LevelSel s;
     s.x1 = f[0].c[0]; s.y1 = f[0].c[1]; s.z1 = f[0].c[2];
@@ -513,7 +524,9 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   bool found = false;
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) {
-    bool valid = true;
+    // valid: inside the window (outside it no block exists: the voxels read as unknown, whatever the
+    // toroidal slot holds) and all 8 weights non-zero
+    bool valid = direct_inside(pv.level[l], dp.min_b[l], usable, f[l]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) valid = valid && ((f[l].code[c] >> 16) & 0x7FFFu) > 1u;
     if (l > 0) {
@@ -656,20 +669,37 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRa
   const D3 tsd = pyramid_tsd(pv, dp, wx, wy, wz);
   const double r = scaling * tsd.a;
   const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
-  // d world / d q = [uv | w*duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v)
+  // d world / d q = [uv | qw duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v). Written out per k with
+  // the structural zeros of e_k x . dropped and the sums as fused multiply-adds: nothing downstream of
+  // the world point takes a discrete decision, and the row only has to agree with the reference's Jet
+  // evaluation to rounding (tests: 1e-9 relative on J^T J); the world point itself keeps Eigen's
+  // operation order, because cell indices and validity branches are derived from it.
   row8[0] = g[0]; row8[1] = g[1]; row8[2] = g[2];
-  row8[3] = g[0] * uv[0] + g[1] * uv[1] + g[2] * uv[2];
-  const double ekv[3][3] = {{0.0, -v[2], v[1]}, {v[2], 0.0, -v[0]}, {-v[1], v[0], 0.0}};
-  const double eku[3][3] = {{0.0, -uv[2], uv[1]}, {uv[2], 0.0, -uv[0]}, {-uv[1], uv[0], 0.0}};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double duv[3] = {2.0 * ekv[k][0], 2.0 * ekv[k][1], 2.0 * ekv[k][2]};
-    double ud[3];
-    cross3(u, duv, ud);
-    const double c0 = qw * duv[0] + eku[k][0] + ud[0];
-    const double c1 = qw * duv[1] + eku[k][1] + ud[1];
-    const double c2k = qw * duv[2] + eku[k][2] + ud[2];
-    row8[4 + k] = g[0] * c0 + g[1] * c1 + g[2] * c2k;
+  row8[3] = fma(g[2], uv[2], fma(g[1], uv[1], g[0] * uv[0]));
+  const double v2[3] = {v[0] + v[0], v[1] + v[1], v[2] + v[2]};
+  {
+    // k = 0: duv = (0, -2 v2, 2 v1); e0 x uv = (0, -uv2, uv1); u x duv = (u1 duv2 - u2 duv1, -u0 duv2, u0 duv1)
+    const double d1 = -v2[2], d2 = v2[1];
+    const double c0 = fma(u[1], d2, -(u[2] * d1));
+    const double c1 = fma(qw, d1, -uv[2]) - u[0] * d2;
+    const double c2k = fma(qw, d2, uv[1]) + u[0] * d1;
+    row8[4] = fma(g[2], c2k, fma(g[1], c1, g[0] * c0));
+  }
+  {
+    // k = 1: duv = (2 v2, 0, -2 v0); e1 x uv = (uv2, 0, -uv0); u x duv = (u1 duv2, u2 duv0 - u0 duv2, -u1 duv0)
+    const double d0 = v2[2], d2 = -v2[0];
+    const double c0 = fma(qw, d0, uv[2]) + u[1] * d2;
+    const double c1 = fma(u[2], d0, -(u[0] * d2));
+    const double c2k = fma(qw, d2, -uv[0]) - u[1] * d0;
+    row8[5] = fma(g[2], c2k, fma(g[1], c1, g[0] * c0));
+  }
+  {
+    // k = 2: duv = (-2 v1, 2 v0, 0); e2 x uv = (-uv1, uv0, 0); u x duv = (-u2 duv1, u2 duv0, u0 duv1 - u1 duv0)
+    const double d0 = -v2[1], d1 = v2[0];
+    const double c0 = fma(qw, d0, -uv[1]) - u[2] * d1;
+    const double c1 = fma(qw, d1, uv[0]) + u[2] * d0;
+    const double c2k = fma(u[0], d1, -(u[1] * d0));
+    row8[6] = fma(g[2], c2k, fma(g[1], c1, g[0] * c0));
   }
   row8[7] = r;
 }
