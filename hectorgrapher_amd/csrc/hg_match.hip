@@ -3398,8 +3398,10 @@ struct SingleJob {
 // is right for one latency-bound chain and wrong for a batch that has to hide memory latency with
 // occupancy), followed by one launch in which workgroup b runs problem b's LM step. Partials cross a
 // kernel boundary here, so no hand-over protocol is needed.
+// (compiled for four workgroups per CU: 128 VGPRs instead of 134, 212 against 230 us per launch of 64 matches;
+// five -- 102 VGPRs, 75 of them spilled -- 326 us)
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
+__global__ __launch_bounds__(THREADS, 4) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
   const SingleJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.num_wg) return;
   if (J.G->h.done) return;
