@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--stream-scans", type=int, default=64)
     ap.add_argument("--stream-tiles", type=int, default=1,
                     help="--workload insert_stream: scan i is shifted to copy (i mod T) of the room (copies 30 m apart "
-                         "on a 4-wide lattice), so that the blocks the stream touches outgrow the 256 MB Infinity Cache "
+                         "on a centred square lattice), so that the blocks the stream touches outgrow the 256 MB Infinity Cache "
                          "(SURVEY 8d: B = 500 with an HBM-resident working set); 1 = the single room")
     ap.add_argument("--batch", type=int, default=8, help="--workload match_batch: independent matches per call")
     ap.add_argument("--insert-mode", default="exact", choices=["exact", "fast"],
@@ -303,11 +303,12 @@ def run_insert_stream(args):
     scans = make_scans(args.rings, args.cols, 0, B, 0)
     if args.stream_tiles > 1:
         shifted = []
+        lattice = int(np.ceil(np.sqrt(args.stream_tiles)))  # centred square lattice: +-8192 cells of 0.05 m reach +-409 m
         for i, (pose, pts) in enumerate(scans):
             t = i % args.stream_tiles
             pose = pose.copy()
-            pose[0] += 30.0 * (t % 4)
-            pose[1] += 30.0 * (t // 4)
+            pose[0] += 30.0 * (t % lattice - lattice // 2)
+            pose[1] += 30.0 * (t // lattice - lattice // 2)
             shifted.append((pose, pts))
         scans = shifted
     xyz = torch.from_numpy(np.concatenate([p for _, p in scans])).to(dev)
@@ -537,17 +538,20 @@ def run_window(args):
     specs = [window_spec(synth, args.map_scans - 1 + s, n_cp) for s in range(total)]
     builds = [window_prepare(problem, specs[s], d_scans[s:s + n_cp - 1], grids, n_pts) for s in range(total)]
 
+    leaving = [api.RangeData([0, 0, 0], d_scans[s]) for s in range(total)]
+
     def step(s, sample=False):
         builds[s]()
-        summ = problem.solve()
+        # solve the window, then insert the scan that leaves it at control point 1's solved pose, handed
+        # over in device memory (hg_register_scan_mode works on any problem shape): the insertion is
+        # enqueued behind the solve before the host has seen its result
+        at, summ = api.register_scan(problem, 1, inserters, leaving[s], grids)
         its.append(summ.num_iterations)
         if sample:
             evals.append(summ.num_cost_evaluations)
         solved.append((np.array([problem.get_pose(i) for i in range(n_cp)]), summ.num_iterations,
                        summ.termination_type, summ.termination_reason))
-        at = problem.get_pose(1).astype(np.float32)
-        inserted_at.append(at)
-        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d_scans[s]), grids, pose_tq=at, want_stats=False)
+        inserted_at.append(at.astype(np.float32))
 
     for s_ in range(args.warmup):
         step(s_)
