@@ -1330,6 +1330,8 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
   // one wavefront per small bin: inside k_bin_apply (eight per workgroup, LDS for 256 records each) or,
   // batched registration, in k_bin_apply_small_jobs (512 records)
   const unsigned small_cap = P.slice_records == 0 ? kSmallBinInKernel : kSmallBin;
+  // bits of the call's seq values (seq < records_per_level): the apply pass cuts a voxel's records into seq buckets
+  const unsigned seq_bits = 32u - static_cast<unsigned>(__builtin_clz((records_per_level > 2u ? records_per_level : 2u) - 1u));
   __shared__ unsigned s_scan[16];
   __shared__ unsigned s_base, s_work, s_large;
   const unsigned nt = L.g.call[0];
@@ -1380,7 +1382,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
           if (w0 + k < L.g.work_capacity)
-            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 16), cnt, bin_off);
+            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 10) | (seq_bits << 20), cnt, bin_off);
           else
             atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
@@ -1416,7 +1418,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
         const unsigned step = 512u / slices;
         for (unsigned k = 0; k < slices; ++k) {
           if (w0 + k < L.g.work_capacity)
-            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 16), cnt, bin_off);
+            L.g.work[w0 + k] = make_uint4(slot, (k * step) | (((k + 1) * step) << 10) | (seq_bits << 20), cnt, bin_off);
           else
             atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
@@ -1718,19 +1720,33 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
   for (unsigned wi = bx; wi < nwork; wi += gstride) {
     const uint4 item = g.work[wi];
     const uint32_t slot = item.x;
-    const unsigned v_lo = item.y & 0xFFFFu;
-    const unsigned v_hi = item.y >> 16;
     const unsigned n = item.z;  // all 32 bits: a bin may hold every record of the scan
     // The slices of a bin interleave its voxels (voxel v belongs to slice v mod S): the heavy voxels
     // of a block are spatial neighbours, contiguous slices would queue their chains in one workgroup.
-    // Inside the kernel a voxel is addressed by pv = (v mod S) * (512 / S) + v / S, which makes every
-    // slice a contiguous range [v_lo, v_hi) of pv.
-    const unsigned per_slice = v_hi - v_lo;                 // 512 / S, a power of two
+    // A slice has 512 / S voxels, so the 512 counters of the item are spent on S seq BUCKETS per voxel:
+    // a record is filed under l = (v / S) * S + bucket, bucket = (seq - first seq of the voxel) >> shift of the
+    // voxel (monotone in seq). Order by (l, seq) is order by (voxel, seq), and the rank step -- quadratic in the
+    // group size -- works on groups up to S times smaller: the few voxels of a heavy slice hold hundreds of
+    // records each (a slice of a 15k-record bin spent 12.6 of its 45 us ranking before). Items that cannot
+    // keep their records in LDS (below) use bucket 0 only.
+    const unsigned per_slice = ((item.y >> 10) & 1023u) - (item.y & 1023u);  // 512 / S, a power of two
     const unsigned s_bits = 9u - (31u - __builtin_clz(per_slice));  // log2(S)
     const unsigned s_mask = (1u << s_bits) - 1u;
-    auto to_pv = [&](unsigned v) { return (v & s_mask) * per_slice + (v >> s_bits); };
-    auto from_pv = [&](unsigned pv) { return ((pv & (per_slice - 1u)) << s_bits) | (pv / per_slice); };
+    const unsigned slice = (item.y & 1023u) >> (9u - s_bits);  // this item's voxels: slice_of(v) == slice
     const uint32_t seq_mask_all = (1u << kSeqBits) - 1u;
+    // slice of voxel v = x | y << 3 | z << 6: the low log2(S) bits of v ^ v >> 3 ^ v >> 6 (low three bits:
+    // x ^ y ^ z). Plain v mod S put a wall square to the x axis -- one x for the whole block -- into ONE slice
+    // whenever S <= 8, whose records then no longer fitted one pass. (v >> log2 S, slice) still names the voxel.
+    auto slice_of = [&](uint32_t v) { return (v ^ (v >> 3) ^ (v >> 6)) & s_mask; };
+    auto is_mine = [&](uint32_t k) { return k != 0xFFFFFFFFu && slice_of(k >> kSeqBits) == slice; };
+    auto to_l = [&](uint32_t k) { return ((k >> kSeqBits) >> s_bits) << s_bits; };  // bucket 0 of the record's voxel
+    auto voxel_of_l = [&](unsigned l) {
+      unsigned v = (l >> s_bits) << s_bits;
+      for (int i = static_cast<int>(s_bits) - 1; i >= 0; --i)  // bit i of v from the slice and v's higher bits
+        v |= (((slice >> i) ^ (v >> (i + 3)) ^ (v >> (i + 6))) & 1u) << i;
+      return v;
+    };
+    constexpr unsigned v_lo = 0u, v_hi = 512u;  // the item's counters: all 512 values of l
     const uint32_t* bk = rec_keys + item.w;
     const uint32_t* bv = rec_vals + item.w;
     BIN_STAMP(0);
@@ -1739,44 +1755,112 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
 #endif
     hist[tid] = 0;
     cursor[tid] = 0;  // (the first pass of the item finds it zero; later passes clear it again)
-    if (tid == 0) { s_m = 0; s_big = 0; }
+    base[tid] = tid < 256u ? 0xFFFFFFFFu : 0u;  // first / last seq per voxel of a compact slice (<= 256 voxels)
+    if (tid == 0) { s_big = 0; s_m = 0; }
     __syncthreads();
     const bool single = n <= static_cast<unsigned>(kBinCap);  // whole bin in registers: one read
     uint32_t rk4[4], rv4[4];
-    // A slice of a larger bin scans the WHOLE bin for its voxels' records: that scan, not the chain,
-    // was most of a heavy slice's time when it ran twice (histogram, then grouping). The records of
-    // the slice are therefore copied to LDS (tk / tv) during the histogram pass; when they fit one
-    // pass (they do unless a voxel holds thousands of records) the grouping reads them from there.
-    for (unsigned i0 = 0; i0 < n; i0 += 4 * kBinThreads) {  // 4 records (8 loads) in flight per thread
-      uint32_t k4[4], v4[4];
+    bool compact = false;
+    if (single) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const unsigned i = i0 + u * kBinThreads + tid;
-        k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
-        v4[u] = i < n ? bv[i] : 0u;
+        const unsigned i = u * kBinThreads + tid;
+        rk4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+        rv4[u] = i < n ? bv[i] : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (single) { rk4[u] = k4[u]; rv4[u] = v4[u]; }
-        const unsigned v = to_pv(k4[u] >> kSeqBits);
-        const bool mine = k4[u] != 0xFFFFFFFFu && v >= v_lo && v < v_hi;
-        if (mine) atomicAdd(&hist[v], 1u);
-        if (!single) {  // append to the slice's compact list: one LDS atomic per wavefront
-          const unsigned long long mb = __ballot(mine);
-          if (mb) {
-            const int first = __builtin_ctzll(mb);
-            unsigned p0 = 0;
-            if (static_cast<int>(tid & (kWave - 1)) == first) p0 = atomicAdd(&s_m, static_cast<unsigned>(__popcll(mb)));
-            p0 = __shfl(p0, first);
-            const unsigned p = p0 + static_cast<unsigned>(__popcll(mb & ((1ull << (tid & (kWave - 1))) - 1ull)));
-            if (mine && p < static_cast<unsigned>(kBinCap)) { tk[p] = k4[u]; tv[p] = v4[u]; }
+      for (int u = 0; u < 4; ++u)
+        if (is_mine(rk4[u])) atomicAdd(&hist[to_l(rk4[u])], 1u);
+      __syncthreads();
+    } else {
+      // A slice of a larger bin scans the WHOLE bin for its voxels' records; with S slices per bin that scan
+      // is most of the pass's instructions, so it does nothing but filter: keys only, eight in flight, the
+      // slice's records appended to a list in LDS (tk: key, tv: record index) by ballots, with one LDS atomic
+      // per wavefront and eight rows of keys. Everything else -- values, buckets, histogram, grouping -- then
+      // works on the list.
+      const unsigned lane = tid & (kWave - 1);
+      for (unsigned i0 = 0; i0 < n; i0 += 8 * kBinThreads) {
+        uint32_t k8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned i = i0 + u * kBinThreads + tid;
+          k8[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+        }
+        unsigned long long mb[8];
+        unsigned tot = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned i = i0 + u * kBinThreads + tid;
+          mb[u] = __ballot(i < n && slice_of(k8[u] >> kSeqBits) == slice);
+          tot += static_cast<unsigned>(__popcll(mb[u]));
+        }
+        if (tot) {  // wave-uniform
+          unsigned p0 = 0;
+          if (lane == 0) p0 = atomicAdd(&s_m, tot);
+          p0 = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(p0)));
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const unsigned p = p0 + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mb[u] >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mb[u]), 0u));
+            if (((mb[u] >> lane) & 1ull) && p < static_cast<unsigned>(kBinCap)) { tk[p] = k8[u]; tv[p] = i0 + u * kBinThreads + tid; }
+            p0 += static_cast<unsigned>(__popcll(mb[u]));
           }
         }
       }
+      __syncthreads();
+      const unsigned m_slice = s_m;
+      compact = m_slice <= static_cast<unsigned>(kBinCap);
+      if (compact) {
+        // slots of this thread: j = tid + 512 u, u < 4
+        uint32_t kk[4], vv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned j = tid + u * kBinThreads;
+          ok[u] = j < m_slice;
+          kk[u] = ok[u] ? tk[j] : 0u;
+          vv[u] = ok[u] ? bv[tv[j]] : 0u;  // the values of the slice's records only
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (ok[u]) {
+            const unsigned vl = (kk[u] >> kSeqBits) >> s_bits, sq = kk[u] & seq_mask_all;
+            atomicMin(&base[vl], sq);
+            atomicMax(&base[256u + vl], sq);
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned j = tid + u * kBinThreads;
+          if (ok[u]) {
+            const unsigned vl = (kk[u] >> kSeqBits) >> s_bits, sq = kk[u] & seq_mask_all;
+            const unsigned first = base[vl], range = base[256u + vl] - first;
+            const unsigned bits = range ? 32u - static_cast<unsigned>(__builtin_clz(range)) : 0u;
+            const unsigned sh = bits > s_bits ? bits - s_bits : 0u;  // (range >> sh) < S
+            const unsigned l = (vl << s_bits) | ((sq - first) >> sh);
+            atomicAdd(&hist[l], 1u);
+            tk[j] = (l << kSeqBits) | sq;  // keyed by l from here on
+            tv[j] = vv[u];
+          }
+        }
+        __syncthreads();
+      } else {
+        // the slice's records do not fit the list (thousands of records on its voxels): histogram per
+        // voxel by a second scan, the grouping passes read the bin again
+        for (unsigned i0 = 0; i0 < n; i0 += 4 * kBinThreads) {
+          uint32_t k4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * kBinThreads + tid;
+            k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (is_mine(k4[u])) atomicAdd(&hist[to_l(k4[u])], 1u);
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
-    const unsigned m_slice = s_m;
-    const bool compact = !single && m_slice <= static_cast<unsigned>(kBinCap);
     BIN_STAMP(1);
     // exclusive prefix of hist over the 512 voxels -> base
     {
@@ -1814,11 +1898,11 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
         const unsigned total_v = hist[lo];
         unsigned done_v = 0;
         const uint32_t seq_mask = (1u << kSeqBits) - 1u;
-        uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + from_pv(lo);
-        const unsigned lo_v = from_pv(lo);  // the voxel id as the records carry it
+        const unsigned lo_v = voxel_of_l(lo);  // the voxel id as the records carry it
+        uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + lo_v;
         UnitChain chain;
         if (tid == 0) chain.begin(g, *cell);
-        uint32_t cur_lo = 0;  // records with seq < cur_lo are applied
+        uint32_t cur_lo = 0;  // records with seq < cur_lo are applied (this form files a voxel under ONE l)
         unsigned* bucket = sv;            // 512 counters (sv is free until a round is sorted)
         unsigned* bucket_pre = sv + 512;  // their exclusive prefix
         while (done_v < total_v) {
@@ -1892,13 +1976,17 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
       }
       if (cnt) {
         // group by voxel (arbitrary order inside a group)
-        for (unsigned i = tid; compact && i < m_slice; i += kBinThreads) {
-          const uint32_t k = tk[i];
-          const unsigned v = to_pv(k >> kSeqBits);
-          if (v >= lo && v < hi) {
-            const unsigned p = base[v] - b_lo + atomicAdd(&cursor[v], 1u);
-            gk[p] = (v << kSeqBits) | (k & seq_mask_all);
-            gv[p] = tv[i];
+        if (compact) {  // (one pass: lo = 0, hi = 512; the list is keyed by l already)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned j = tid + u * kBinThreads;
+            if (j < s_m) {
+              const uint32_t k = tk[j];
+              const unsigned l = k >> kSeqBits;
+              const unsigned p = base[l] + atomicAdd(&cursor[l], 1u);
+              gk[p] = k;
+              gv[p] = tv[j];
+            }
           }
         }
         for (unsigned i0 = 0; !compact && i0 < n; i0 += 4 * kBinThreads) {
@@ -1916,10 +2004,10 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const unsigned v = to_pv(k4[u] >> kSeqBits);
-            if (k4[u] != 0xFFFFFFFFu && v >= lo && v < hi) {
+            const unsigned v = to_l(k4[u]);
+            if (is_mine(k4[u]) && v >= lo && v < hi) {
               const unsigned p = base[v] - b_lo + atomicAdd(&cursor[v], 1u);
-              gk[p] = (v << kSeqBits) | (k4[u] & seq_mask_all);  // keyed by pv from here on
+              gk[p] = (v << kSeqBits) | (k4[u] & seq_mask_all);  // keyed by l from here on
               gv[p] = v4[u];
             }
           }
@@ -1955,15 +2043,18 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
         // one thread per voxel applies its updates in reference order; a wavefront that holds a
         // long chain is the critical path of the whole insert: give it issue priority
         {
-          const unsigned mine = (tid >= lo && tid < hi) ? hist[tid] : 0u;
+          // thread t < 512 / S owns voxel t of the slice: its buckets [t S, (t + 1) S) inside this pass
+          const unsigned l0 = max(lo, tid << s_bits), l1 = min(hi, (tid + 1u) << s_bits);
+          unsigned b0 = 0, mine = 0;
+          if (tid < per_slice && l0 < l1) {
+            b0 = base[l0] - b_lo;
+            mine = base[l1 - 1u] + hist[l1 - 1u] - b_lo - b0;
+          }
           if (__ballot(mine > 48u)) __builtin_amdgcn_s_setprio(3);
-        }
-        if (tid >= lo && tid < hi && hist[tid]) {
-          uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + from_pv(tid);
-          uint32_t code = *cell;
-          const unsigned b0 = base[tid] - b_lo, b1 = b0 + hist[tid];
-          code = update_chain_unit(g, L.p.maximum_weight, code, sv + b0, b1 - b0);
-          *cell = code;
+          if (mine) {
+            uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + voxel_of_l(l0);
+            *cell = update_chain_unit(g, L.p.maximum_weight, *cell, sv + b0, mine);
+          }
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
