@@ -785,6 +785,19 @@ constexpr int kBinCap = 2048;       // records per LDS pass of k_bin_apply (4 pe
 constexpr int kBinThreads = 512;    // one thread per voxel of a block
 constexpr unsigned kSmallBin = 512; // a bin of at most this many records is one wavefront's work (k_bin_apply_small)
 constexpr unsigned kSmallBinInKernel = 256;  // the same inside k_bin_apply
+#ifndef HG_SLICE_THRESH  // (tuning switches of the single-chain slice sizes)
+#define HG_SLICE_THRESH 4096u
+#endif
+#ifndef HG_SLICE_BELOW
+#define HG_SLICE_BELOW 2048u
+#endif
+#ifndef HG_SLICE_ABOVE
+#define HG_SLICE_ABOVE 512u
+#endif
+#ifndef HG_HEAVY_BIN
+#define HG_HEAVY_BIN 8192u
+#endif
+constexpr unsigned kHeavyBin = HG_HEAVY_BIN;  // bins from this size on head the work list (their slices carry the long chains)
 constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
 
 enum : uint32_t { kFlagBinOverflow = 8u, kFlagWorkOverflow = 16u };
@@ -1329,7 +1342,9 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
   const unsigned slice_records = P.slice_records > 0 ? static_cast<unsigned>(P.slice_records) : 512u;
   // one wavefront per small bin: inside k_bin_apply (eight per workgroup, LDS for 256 records each) or,
   // batched registration, in k_bin_apply_small_jobs (512 records)
-  const unsigned small_cap = P.slice_records == 0 ? kSmallBinInKernel : kSmallBin;
+  const unsigned small_cap = P.slice_records <= 0 ? kSmallBinInKernel : kSmallBin;
+  // slice_records < 0: sizes by bin as for 0, large bins in slices of -slice_records records (scan stream)
+  const unsigned slice_above = P.slice_records < 0 ? static_cast<unsigned>(-P.slice_records) : HG_SLICE_ABOVE;
   // bits of the call's seq values (seq < records_per_level): the apply pass cuts a voxel's records into seq buckets
   const unsigned seq_bits = 32u - static_cast<unsigned>(__builtin_clz((records_per_level > 2u ? records_per_level : 2u) - 1u));
   __shared__ unsigned s_scan[16];
@@ -1356,7 +1371,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       r_cnt[c] = i < nt ? L.g.bin_count[r_slot[c]] : 0u;
     }
   }
-  for (int round = 0; round < 2; ++round) {
+  for (int round = 0; round < 3; ++round) {
 #pragma unroll
     for (int c = 0; c < kRegChunks; ++c) {
       const unsigned c0 = c * 1024u;
@@ -1372,10 +1387,11 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       } else if (i < nt) {
         bin_off = L.g.bin_offset[slot];  // written by this thread in round 0
       }
-      const bool large = cnt > small_cap;  // smaller bins are whole-bin items for one wavefront each
-      const bool emit = i < nt && ((round == 0) == large);
+      // smaller bins are whole-bin items for one wavefront each; the heaviest bins go first
+      const int tier = cnt > small_cap ? (cnt >= kHeavyBin ? 0 : 1) : 2;
+      const bool emit = i < nt && round == tier;
       unsigned slices = emit ? 1u : 0u;
-      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < 4096u ? 2048u : 512u);
+      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above);
       while (emit && slices < 128 && cnt > slices * per_slice) slices <<= 1;  // 1 slice while cnt <= per_slice
       const unsigned w0 = reserve_items(&s_work, slices);
       if (emit) {
@@ -1387,7 +1403,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
             atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
       }
-      if (round == 1 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
+      if (round == 2 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
       if (round == 0) {
         __syncthreads();
         if (threadIdx.x == 0) s_base += chunk_total;
@@ -1408,10 +1424,11 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       } else if (i < nt) {
         bin_off = L.g.bin_offset[slot];  // written by this thread in round 0
       }
-      const bool large = cnt > small_cap;  // smaller bins are whole-bin items for one wavefront each
-      const bool emit = i < nt && ((round == 0) == large);
+      // smaller bins are whole-bin items for one wavefront each; the heaviest bins go first
+      const int tier = cnt > small_cap ? (cnt >= kHeavyBin ? 0 : 1) : 2;
+      const bool emit = i < nt && round == tier;
       unsigned slices = emit ? 1u : 0u;
-      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < 4096u ? 2048u : 512u);
+      const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above);
       while (emit && slices < 128 && cnt > slices * per_slice) slices <<= 1;  // 1 slice while cnt <= per_slice
       const unsigned w0 = reserve_items(&s_work, slices);
       if (emit) {
@@ -1423,19 +1440,19 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
             atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
       }
-      if (round == 1 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
+      if (round == 2 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
       __syncthreads();
       if (round == 0 && threadIdx.x == 0) s_base += chunk_total;
       __syncthreads();
     }
     __syncthreads();
-    if (round == 0 && threadIdx.x == 0) s_large = s_work;  // items [0, s_large): slices of large bins
-    __syncthreads();  // snapshot taken before any wavefront reserves round-1 items
+    if (round == 1 && threadIdx.x == 0) s_large = s_work;  // items [0, s_large): slices of large bins
+    __syncthreads();  // snapshot taken before any wavefront reserves round-2 items
   }
   if (threadIdx.x == 0) {
     // items [call[2], call[1]) are whole bins for k_bin_apply_small (batched inserts); one
     // registration chain keeps them in k_bin_apply: a second kernel behind it costs more than it saves
-    L.g.call[2] = min((P.slice_records >= 2048 || P.slice_records == 0) ? s_large : s_work, L.g.work_capacity);
+    L.g.call[2] = min((P.slice_records >= 2048 || P.slice_records <= 0) ? s_large : s_work, L.g.work_capacity);
     L.g.call[1] = min(s_work, L.g.work_capacity);  // consumed by k_bin_apply
     L.g.call[0] = 0;                               // next call collects from scratch
     unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
@@ -2089,10 +2106,16 @@ __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply(PyramidIns P, cons
                                                           , long long* stamps
 #endif
                                                           ) {
-  // workgroups are dispatched in index order: the last (coarsest) level has the longest per-voxel
-  // chains, so it goes first
-  bin_apply_body(P.lv[P.levels - 1 - blockIdx.y], blockIdx.y, blockIdx.x, gridDim.x, rec_keys, rec_vals,
-                 P.slice_records == 0
+  // Workgroups are dispatched in index order and a third of the grid is resident at a time. Grid (G, levels):
+  // the last (coarsest) level has the longest per-voxel chains, so it goes first. Grid (G * levels): the levels
+  // take turns, workgroup b works on level b mod levels -- every level's work list starts with its heaviest
+  // bins, so the heads of all lists start at once and no level waits for the one before it to drain.
+  const bool turns = gridDim.y == 1u && P.levels > 1;
+  const unsigned order = turns ? blockIdx.x % static_cast<unsigned>(P.levels) : blockIdx.y;
+  const unsigned bx = turns ? blockIdx.x / static_cast<unsigned>(P.levels) : blockIdx.x;
+  const unsigned gs = turns ? gridDim.x / static_cast<unsigned>(P.levels) : gridDim.x;
+  bin_apply_body(P.lv[P.levels - 1 - order], order, bx, gs, rec_keys, rec_vals,
+                 P.slice_records <= 0
 #ifdef HG_BIN_STAMPS
                  , stamps
 #endif
@@ -2104,7 +2127,7 @@ __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply_jobs(const InsertJ
   const InsertJob& J = jobs[blockIdx.y % njobs];
   const unsigned order = blockIdx.y / njobs;
   const LevelIns L = J.P.lv[J.P.levels - 1 - order];  // a copy, see k_bin_apply_small_jobs
-  bin_apply_body(L, order, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals, J.P.slice_records == 0);
+  bin_apply_body(L, order, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals, J.P.slice_records <= 0);
 }
 #endif
 
@@ -2113,6 +2136,20 @@ __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply_jobs(const InsertJ
 using namespace hg;
 
 namespace {
+
+// Launch shape of k_bin_apply (see there). HG_APPLY_TURNS=0: one grid row per level.
+dim3 apply_grid(int levels) {
+  static const int turns = [] { const char* e = getenv("HG_APPLY_TURNS"); return e ? atoi(e) : 0; }();
+  return turns ? dim3(1024u * static_cast<unsigned>(levels), 1u) : dim3(1024u, static_cast<unsigned>(levels));
+}
+// Slice size of the large bins of a scan stream (PyramidIns::slice_records < 0). HG_STREAM_SLICE overrides.
+int stream_slice_records() {
+  // 1024: measured 16.4k scans/s at B = 32 against 14.9k with the single chain's 512 (768: 16.0k, 1280: 15.9k,
+  // 1536: 15.7k) -- applies of consecutive scans queue behind each other, so total work counts for more than
+  // the latency of the heaviest slice
+  static const int v = [] { const char* e = getenv("HG_STREAM_SLICE"); return e ? atoi(e) : 1024; }();
+  return v > 0 ? -v : 0;
+}
 
 // Sequential decimation of Insert (:703-710): depends only on the index and the ratio.
 void build_gate(double ratio, size_t n, uint8_t* out) {
@@ -2380,7 +2417,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
     static long long* d_st = nullptr;
     if (!d_st) hipMalloc(reinterpret_cast<void**>(&d_st), 3 * 4096 * 8 * sizeof(long long));
     hipMemsetAsync(d_st, 0, 3 * 4096 * 8 * sizeof(long long), s);
-    hipLaunchKernelGGL(k_bin_apply, dim3(1024, P.levels), dim3(kBinThreads), 0, s, P, rk, rv, d_st);
+    hipLaunchKernelGGL(k_bin_apply, apply_grid(P.levels), dim3(kBinThreads), 0, s, P, rk, rv, d_st);
     {
       std::vector<long long> h(3 * 4096 * 8);
       hipMemcpy(h.data(), d_st, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
@@ -2434,7 +2471,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
       }
     }
 #else
-    hipLaunchKernelGGL(k_bin_apply, dim3(1024, P.levels), dim3(kBinThreads), 0, sa, P, rk, rv);
+    hipLaunchKernelGGL(k_bin_apply, apply_grid(P.levels), dim3(kBinThreads), 0, sa, P, rk, rv);
 #endif
   }
   HG_HIP_CHECK(hipGetLastError());
@@ -2798,7 +2835,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
     P.d_pose = nullptr;
     P.accumulate = 1;
     P.shared = 1;
-    P.slice_records = 0;
+    P.slice_records = stream_slice_records();
     P.scan0.begin = 0;
     P.scan0.count = nj;
     std::memcpy(P.scan0.origin, origins + 3 * i, sizeof(P.scan0.origin));
@@ -2853,7 +2890,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
       ProfScope ps(c, HG_K_APPLY, units * kSlots, static_cast<unsigned>(gn));
 #ifndef HG_BIN_STAMPS
       for (int j = g0; j < g0 + gn; ++j)  // pyramid as kernel argument (scalar registers), as scan by scan
-        hipLaunchKernelGGL(k_bin_apply, dim3(1024, levels), dim3(kBinThreads), 0, s, jobs[j].P, jobs[j].rec_keys,
+        hipLaunchKernelGGL(k_bin_apply, apply_grid(levels), dim3(kBinThreads), 0, s, jobs[j].P, jobs[j].rec_keys,
                            jobs[j].rec_vals);
 #endif
     }
