@@ -794,10 +794,7 @@ constexpr unsigned kSmallBinInKernel = 256;  // the same inside k_bin_apply
 #ifndef HG_SLICE_ABOVE
 #define HG_SLICE_ABOVE 512u
 #endif
-#ifndef HG_HEAVY_BIN
-#define HG_HEAVY_BIN 8192u
-#endif
-constexpr unsigned kHeavyBin = HG_HEAVY_BIN;  // bins from this size on head the work list (their slices carry the long chains)
+  // bins from this size on head the work list (their slices carry the long chains)
 constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
 
 enum : uint32_t { kFlagBinOverflow = 8u, kFlagWorkOverflow = 16u };
@@ -1358,7 +1355,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
   // round trips for the whole list instead of two per 1024-block chunk and round).
   constexpr int kRegChunks = 4;
   const bool in_regs = nt <= 1024u * kRegChunks;
-  unsigned r_slot[kRegChunks], r_cnt[kRegChunks];
+  unsigned r_slot[kRegChunks], r_cnt[kRegChunks], r_off[kRegChunks];
   if (in_regs) {
 #pragma unroll
     for (int c = 0; c < kRegChunks; ++c) {
@@ -1371,7 +1368,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       r_cnt[c] = i < nt ? L.g.bin_count[r_slot[c]] : 0u;
     }
   }
-  for (int round = 0; round < 3; ++round) {
+  for (int round = 0; round < 2; ++round) {
 #pragma unroll
     for (int c = 0; c < kRegChunks; ++c) {
       const unsigned c0 = c * 1024u;
@@ -1384,11 +1381,13 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
         const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
         bin_off = static_cast<unsigned>(level) * records_per_level + s_base + excl;
         if (i < nt) L.g.bin_offset[slot] = bin_off;
-      } else if (i < nt) {
-        bin_off = L.g.bin_offset[slot];  // written by this thread in round 0
+        r_off[c] = bin_off;
+      } else {
+        bin_off = r_off[c];
       }
-      // smaller bins are whole-bin items for one wavefront each; the heaviest bins go first
-      const int tier = cnt > small_cap ? (cnt >= kHeavyBin ? 0 : 1) : 2;
+      // smaller bins are whole-bin items for one wavefront each. (The heaviest bins in a round of their own, ahead
+      // of the other large ones, start their slices 13 us earlier and leave the launch as long as it was.)
+      const int tier = cnt > small_cap ? 0 : 1;
       const bool emit = i < nt && round == tier;
       unsigned slices = emit ? 1u : 0u;
       const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above);
@@ -1403,7 +1402,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
             atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
       }
-      if (round == 2 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
+      if (round == 0 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
       if (round == 0) {
         __syncthreads();
         if (threadIdx.x == 0) s_base += chunk_total;
@@ -1424,8 +1423,9 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
       } else if (i < nt) {
         bin_off = L.g.bin_offset[slot];  // written by this thread in round 0
       }
-      // smaller bins are whole-bin items for one wavefront each; the heaviest bins go first
-      const int tier = cnt > small_cap ? (cnt >= kHeavyBin ? 0 : 1) : 2;
+      // smaller bins are whole-bin items for one wavefront each. (The heaviest bins in a round of their own, ahead
+      // of the other large ones, start their slices 13 us earlier and leave the launch as long as it was.)
+      const int tier = cnt > small_cap ? 0 : 1;
       const bool emit = i < nt && round == tier;
       unsigned slices = emit ? 1u : 0u;
       const unsigned per_slice = P.slice_records > 0 ? slice_records : (cnt < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above);
@@ -1440,14 +1440,14 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
             atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes the list from the records
         }
       }
-      if (round == 2 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
+      if (round == 1 && i < nt) L.g.bin_count[slot] = 0;  // ready for the next call (items carry n)
       __syncthreads();
       if (round == 0 && threadIdx.x == 0) s_base += chunk_total;
       __syncthreads();
     }
     __syncthreads();
-    if (round == 1 && threadIdx.x == 0) s_large = s_work;  // items [0, s_large): slices of large bins
-    __syncthreads();  // snapshot taken before any wavefront reserves round-2 items
+    if (round == 0 && threadIdx.x == 0) s_large = s_work;  // items [0, s_large): slices of large bins
+    __syncthreads();  // snapshot taken before any wavefront reserves round-1 items
   }
   if (threadIdx.x == 0) {
     // items [call[2], call[1]) are whole bins for k_bin_apply_small (batched inserts); one
