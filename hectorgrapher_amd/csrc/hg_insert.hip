@@ -785,6 +785,9 @@ constexpr int kBinCap = 2048;       // records per LDS pass of k_bin_apply (4 pe
 constexpr int kBinThreads = 512;    // one thread per voxel of a block
 constexpr unsigned kSmallBin = 512; // a bin of at most this many records is one wavefront's work (k_bin_apply_small)
 constexpr unsigned kSmallBinInKernel = 256;  // the same inside k_bin_apply
+#ifndef HG_APPLY_WAVES
+#define HG_APPLY_WAVES 8
+#endif
 #ifndef HG_SLICE_THRESH  // (tuning switches of the single-chain slice sizes)
 #define HG_SLICE_THRESH 4096u
 #endif
@@ -1731,7 +1734,13 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
   uint32_t* sv = gv + kBinCap;        // values in (voxel, seq) order
   uint32_t* tk = sv + kBinCap;        // keys of the slice's records as read (compact list)
   uint32_t* tv = sv;                  // their values: sv is free until the rank step
-  __shared__ unsigned s_hi, s_m, s_big, s_scan16[16];
+  // (the item path's few scalars live behind its arrays inside the pool, which the small-bin layout sizes:
+  // 40 KiB in all, four workgroups per CU as far as LDS goes)
+  static_assert(kItemWords + 19u <= kPoolWords, "pool");
+  unsigned& s_hi = pool[kItemWords];
+  unsigned& s_m = pool[kItemWords + 1];
+  unsigned& s_big = pool[kItemWords + 2];
+  unsigned* s_scan16 = pool + kItemWords + 3;
   const unsigned nwork = min(g.call[2], g.call[1]);  // the slices of large bins; whole bins: k_bin_apply_small
   const unsigned tid = threadIdx.x;
   for (unsigned wi = bx; wi < nwork; wi += gstride) {
@@ -2100,7 +2109,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
   }
 }
 
-__global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
+__global__ __launch_bounds__(kBinThreads, HG_APPLY_WAVES) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
                                                           const uint32_t* __restrict__ rec_vals
 #ifdef HG_BIN_STAMPS
                                                           , long long* stamps
