@@ -113,6 +113,26 @@ __device__ inline void transform_point(const float* pose, float& x, float& y, fl
 
 __device__ inline int cell_index_1d(float p, float resolution) { return round_to_int(p / resolution); }
 
+// 1 / den refined as the IEEE division sequence refines it (see div_in_range in hg_insert.hip).
+__device__ inline float refined_rcp(float den) {
+  const float r0 = __builtin_amdgcn_rcpf(den);
+  const float e0 = __builtin_fmaf(-den, r0, 1.0f);
+  return __builtin_fmaf(e0, r0, r0);
+}
+// lround(p / res) with the division spelled out: the Newton-Raphson sequence the compiler emits for
+// an IEEE fdiv, without the v_div_scale / v_div_fixup wrappers (same FMAs on the same operands, hence
+// the same bits) -- those only act on operands with extreme exponents, where the index is 0 or out
+// of range whichever way the last bits fall (callers reject |p| >= 1e30 beforehand). res and r are
+// uniform, so the reciprocal is refined once per wavefront instead of once per division.
+__device__ inline int cell_index_fast(float p, float res, float r) {
+  const float q0 = p * r;
+  const float rem0 = __builtin_fmaf(-res, q0, p);
+  const float q1 = __builtin_fmaf(rem0, r, q0);
+  const float rem1 = __builtin_fmaf(-res, q1, p);
+  return round_to_int(__builtin_fmaf(rem1, r, q1));
+}
+
+
 // Block key of a cell index: 11 bits per axis of (index + 8192) >> 3.
 __device__ inline bool cell_in_range(int x, int y, int z) {
   return (static_cast<unsigned>(x + kIndexOffset) < 16384u) &&

@@ -155,12 +155,27 @@ __device__ inline Ray ray_setup(const GridView& g, const InsertParams& p, const 
     const float e = 1.0f + ratio;
     e_x = ox + e * rx; e_y = oy + e * ry; e_z = oz + e * rz;
   }
-  r.bx = cell_index_1d(b_x, g.resolution);
-  r.by = cell_index_1d(b_y, g.resolution);
-  r.bz = cell_index_1d(b_z, g.resolution);
-  r.dx = cell_index_1d(e_x, g.resolution) - r.bx;
-  r.dy = cell_index_1d(e_y, g.resolution) - r.by;
-  r.dz = cell_index_1d(e_z, g.resolution) - r.bz;
+  // GetCellIndex of both ends (:311-312): six divisions by the resolution, spelled out with one refined
+  // reciprocal (cell_index_fast: the bits of the IEEE division) unless a coordinate of the wavefront is
+  // beyond anything a grid can index
+  const bool tame = fabsf(b_x) < 1e30f && fabsf(b_y) < 1e30f && fabsf(b_z) < 1e30f &&
+                    fabsf(e_x) < 1e30f && fabsf(e_y) < 1e30f && fabsf(e_z) < 1e30f;
+  if (__ballot(!tame) == 0ull) {
+    const float rr = refined_rcp(g.resolution);
+    r.bx = cell_index_fast(b_x, g.resolution, rr);
+    r.by = cell_index_fast(b_y, g.resolution, rr);
+    r.bz = cell_index_fast(b_z, g.resolution, rr);
+    r.dx = cell_index_fast(e_x, g.resolution, rr) - r.bx;
+    r.dy = cell_index_fast(e_y, g.resolution, rr) - r.by;
+    r.dz = cell_index_fast(e_z, g.resolution, rr) - r.bz;
+  } else {
+    r.bx = cell_index_1d(b_x, g.resolution);
+    r.by = cell_index_1d(b_y, g.resolution);
+    r.bz = cell_index_1d(b_z, g.resolution);
+    r.dx = cell_index_1d(e_x, g.resolution) - r.bx;
+    r.dy = cell_index_1d(e_y, g.resolution) - r.by;
+    r.dz = cell_index_1d(e_z, g.resolution) - r.bz;
+  }
   r.n = max(abs(r.dx), max(abs(r.dy), abs(r.dz)));
   r.range = range;
   r.ox = ox; r.oy = oy; r.oz = oz;
@@ -168,12 +183,19 @@ __device__ inline Ray ray_setup(const GridView& g, const InsertParams& p, const 
   return r;
 }
 
+// tsd and weight of the update of cell (cx, cy, cz) along ray r (:318-342).
+__device__ inline void ray_sample_cell(const GridView& g, const InsertParams& p, const Ray& r,
+                                       int cx, int cy, int cz, float& tsd, float& weight);
 __device__ inline void ray_sample(const GridView& g, const InsertParams& p, const Ray& r, int pos,
                                   int& cx, int& cy, int& cz, float& tsd, float& weight) {
   const float fp = static_cast<float>(pos), fn = static_cast<float>(r.n);
   cx = r.bx + static_cast<int>(roundf(static_cast<float>(r.dx) * fp / fn));
   cy = r.by + static_cast<int>(roundf(static_cast<float>(r.dy) * fp / fn));
   cz = r.bz + static_cast<int>(roundf(static_cast<float>(r.dz) * fp / fn));
+  ray_sample_cell(g, p, r, cx, cy, cz, tsd, weight);
+}
+__device__ inline void ray_sample_cell(const GridView& g, const InsertParams& p, const Ray& r,
+                                       int cx, int cy, int cz, float& tsd, float& weight) {
   const float ccx = static_cast<float>(cx) * g.resolution;
   const float ccy = static_cast<float>(cy) * g.resolution;
   const float ccz = static_cast<float>(cz) * g.resolution;
@@ -802,13 +824,6 @@ constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call
 
 enum : uint32_t { kFlagBinOverflow = 8u, kFlagWorkOverflow = 16u };
 
-__device__ inline void ray_cell(const Ray& r, int pos, int& cx, int& cy, int& cz) {
-  const float fp = static_cast<float>(pos), fn = static_cast<float>(r.n);
-  cx = r.bx + static_cast<int>(roundf(static_cast<float>(r.dx) * fp / fn));
-  cy = r.by + static_cast<int>(roundf(static_cast<float>(r.dy) * fp / fn));
-  cz = r.bz + static_cast<int>(roundf(static_cast<float>(r.dz) * fp / fn));
-}
-
 __device__ inline ScanTable scan_of(const PyramidIns& P) {
   ScanTable sc = P.scan0;
   if (P.d_pose) {
@@ -820,29 +835,122 @@ __device__ inline ScanTable scan_of(const PyramidIns& P) {
 
 constexpr int kMaxRuns = 4;  // a straight 8-sample walk visits at most 4 blocks (monotone per axis)
 
+// The sample cells of a SHORT ray (n <= 7: the binned path) without floating point. The reference rounds
+// fl(fl(d * pos) / n) half away from zero (:318-320; ray_sample). For |d| <= n <= 7, pos <= 7 the
+// product is a small integer, exact in fp32, and the quotient of two such integers is either exactly k + 1/2
+// -- representable, so the division returns it and the tie goes away from zero -- or at least 1/(2n) >= 1/14
+// from any tie, which no rounding of the division can bridge. Hence the offset is sign(d) * floor((2 |d| pos
+// + n) / (2 n)) in exact integer arithmetic, and along pos = 0, 1, ... it is a digital differential: the
+// remainder grows by 2 |d| <= 2 n per step and carries at most once. Twelve integer operations per sample
+// instead of three fp32 divisions and three roundf (~ 57): the front end of a scan stream and of batched
+// registration is bound by instruction issue.
+struct RayWalk {
+  int c[3];    // cell of the current position
+  int rem[3];  // (2 |d| pos + n) mod 2 n
+  int a[3];    // 2 |d|
+  int s[3];    // sign(d)
+  int n2;
+  __device__ inline void begin(const Ray& r) {
+    const int d[3] = {r.dx, r.dy, r.dz};
+    c[0] = r.bx; c[1] = r.by; c[2] = r.bz;
+    n2 = 2 * r.n;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      rem[k] = r.n;
+      a[k] = 2 * abs(d[k]);
+      s[k] = d[k] < 0 ? -1 : 1;
+    }
+  }
+  __device__ inline void step() {  // pos -> pos + 1
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      rem[k] += a[k];
+      const bool carry = rem[k] >= n2;
+      rem[k] -= carry ? n2 : 0;
+      c[k] += carry ? s[k] : 0;
+    }
+  }
+};
+
 // Splits the samples of a ray into runs that stay inside one block. Returns the number of runs.
-__device__ inline int ray_block_runs(const Ray& r, unsigned long long* run_key, int* run_begin,
-                                     int* run_len, bool* range_err) {
+// (Sample by sample: the form for rays that leave the index range; ray_block_runs below.)
+__device__ inline int ray_block_runs_walk(const Ray& r, unsigned long long* run_key, int* run_begin,
+                                                             int* run_len, bool* range_err) {
   int nr = 0;
-  unsigned long long cur = ~0ull;
+  RayWalk w;
+  w.begin(r);
+  bool open = false;   // the previous sample lies in range (its run can be continued)
+  int pbx = 0, pby = 0, pbz = 0;  // block coordinates of the previous sample
   for (int pos = 0; pos <= r.n; ++pos) {
-    int cx, cy, cz;
-    ray_cell(r, pos, cx, cy, cz);
+    const int cx = w.c[0], cy = w.c[1], cz = w.c[2];
+    w.step();
     if (!cell_in_range(cx, cy, cz)) {
       *range_err = true;
-      cur = ~0ull;
+      open = false;
       continue;
     }
-    const unsigned long long key = block_key(cx, cy, cz);
-    if (key != cur) {
+    const int bx = (cx + kIndexOffset) >> 3, by = (cy + kIndexOffset) >> 3, bz = (cz + kIndexOffset) >> 3;
+    if (!open || bx != pbx || by != pby || bz != pbz) {
       if (nr == kMaxRuns) break;  // cannot happen for a straight walk; guards the arrays
-      run_key[nr] = key;
+      run_key[nr] = block_key(cx, cy, cz);
       run_begin[nr] = pos;
       run_len[nr] = 0;
       ++nr;
-      cur = key;
+      open = true;
+      pbx = bx; pby = by; pbz = bz;
     }
     ++run_len[nr - 1];
+  }
+  return nr;
+}
+
+// The same without walking the samples, for a SHORT ray (n <= 7) whose two ends lie in the index range (then
+// every sample does): a coordinate moves |d| <= 7 cells monotonically, so it crosses at most ONE block face,
+// at the first position whose offset floor((2 |d| pos + n) / 2 n) reaches t = cells up to the face:
+// pos = ceil(n (2 t - 1) / 2 |d|). The runs start at position 0 and at the distinct crossing positions; a
+// run's block key is the previous one stepped along the axes that cross there (~ 130 operations instead of
+// ~ 50 per sample: k_bin_count of a scan stream is bound by instruction issue).
+__device__ inline int ray_block_runs(const Ray& r, unsigned long long* run_key, int* run_begin,
+                                     int* run_len, bool* range_err) {
+  const bool inside = cell_in_range(r.bx, r.by, r.bz) && cell_in_range(r.bx + r.dx, r.by + r.dy, r.bz + r.dz);
+  if (__ballot(!inside) != 0ull) return ray_block_runs_walk(r, run_key, run_begin, run_len, range_err);
+  const int b[3] = {r.bx, r.by, r.bz}, d[3] = {r.dx, r.dy, r.dz};
+  int cross[3];  // position of the axis' block crossing, 8 = none
+  unsigned chg = 1u;  // bit pos: a run starts at pos
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ad = abs(d[k]);
+    const int u = (b[k] + kIndexOffset) & 7;
+    const int t = d[k] > 0 ? 8 - u : u + 1;  // cells to move until the coordinate leaves its block
+    // ceil(x / y), x = n (2 t - 1) <= 105, y = 2 |d| <= 14, by a 16-bit reciprocal: floor(32768 / |d|) + 1
+    // (the truncated product with v_rcp is that floor: exact for powers of two, far from an integer otherwise)
+    const unsigned y = 2u * static_cast<unsigned>(ad);
+    const unsigned x = static_cast<unsigned>(r.n * (2 * t - 1)) + y - 1u;
+    const unsigned m = static_cast<unsigned>(32768.0f * __builtin_amdgcn_rcpf(static_cast<float>(ad))) + 1u;
+    const int pos = static_cast<int>((x * m) >> 16);
+    cross[k] = (ad >= t) ? pos : 8;
+    chg |= (ad >= t) ? (1u << pos) : 0u;
+  }
+  // the (up to three) later run starts, in position order
+  const unsigned m1 = chg & ~1u, m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
+  const int q1 = m1 ? __builtin_ctz(m1) : 8, q2 = m2 ? __builtin_ctz(m2) : 8, q3 = m3 ? __builtin_ctz(m3) : 8;
+  const int nr = 1 + (m1 ? 1 : 0) + (m2 ? 1 : 0) + (m3 ? 1 : 0);
+  const int last = r.n + 1;
+  run_begin[0] = 0;  run_len[0] = min(q1, last);
+  run_begin[1] = q1; run_len[1] = min(q2, last) - q1;
+  run_begin[2] = q2; run_len[2] = min(q3, last) - q2;
+  run_begin[3] = q3; run_len[3] = last - q3;
+  unsigned long long key = block_key(r.bx, r.by, r.bz);
+  run_key[0] = key;
+  const int q[3] = {q1, q2, q3};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // (a block coordinate in range stays inside its 11 bits)
+      const long long step = static_cast<long long>(d[k] > 0 ? 1 : -1) << (11 * k);
+      key += (cross[k] == q[j]) ? static_cast<unsigned long long>(step) : 0ull;
+    }
+    run_key[j + 1] = key;
   }
   return nr;
 }
@@ -1097,16 +1205,19 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_accumulate(PyramidIns P, 
   // of neighbouring lanes with the same (block, voxel) are summed in registers (segmented prefix
   // sum) and only the last lane of a run issues the atomic — the hot voxels next to the sensor
   // would otherwise serialise thousands of same-address atomics.
+  RayWalk walk;  // (hit: n <= 7, the integer walk is exact)
+  if (hit) walk.begin(r);
   for (int pos = 0; pos < kSlots; ++pos) {
     bool valid = hit && pos <= r.n;
     uint32_t key = 0xFFFFFFFFu;
     unsigned units = 0;
     if (valid) {
-      int cx, cy, cz;
+      const int cx = walk.c[0], cy = walk.c[1], cz = walk.c[2];
+      walk.step();
       float tsd, w;
-      ray_sample(L.g, L.p, r, pos, cx, cy, cz, tsd, w);
       valid = cell_in_range(cx, cy, cz);
       if (valid) {
+        ray_sample_cell(L.g, L.p, r, cx, cy, cz, tsd, w);
         const unsigned long long bk = block_key(cx, cy, cz);
         uint32_t sl = 0xFFFFFFFFu;
 #pragma unroll
@@ -1489,32 +1600,36 @@ __device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, const Leve
   // every run as long as its longest lane: ~10-12 sample evaluations where 8 suffice). The runs of a ray
   // are consecutive stretches of in-range samples inside one block, in position order, so a lane only
   // tracks which run it is in and how many of that run's samples it has written.
-  unsigned dst[kMaxRuns];
-  int len[kMaxRuns];
+  // Run k holds the samples [begin_k, begin_k + len_k) and writes them to consecutive records from dst_k on:
+  // sample pos of run k goes to (dst_k - begin_k) + pos. Samples outside every run (beyond the ray's end,
+  // outside the index range, in a block that could not be allocated) are not written.
+  unsigned base[kMaxRuns], len[kMaxRuns];
+  int beg[kMaxRuns];
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {  // the four bin offsets in flight together
-    len[k] = static_cast<int>(info.slot[k] >> 28);
-    dst[k] = len[k] ? L.g.bin_offset[info.slot[k] & 0xFFFFFFu] + info.off[k] : 0u;
+    len[k] = info.slot[k] >> 28;
+    beg[k] = static_cast<int>((info.slot[k] >> 24) & 15u);
+    base[k] = len[k] ? L.g.bin_offset[info.slot[k] & 0xFFFFFFu] + info.off[k] - static_cast<unsigned>(beg[k]) : 0u;
   }
-  int k = 0, q = 0;
-  while (k < kMaxRuns && len[k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 2 : 3))] == 0) ++k;  // leading empty entries (none in practice)
+  RayWalk walk;  // (every ray that left run info has n <= 7: the integer walk is exact)
+  walk.begin(r);
+#pragma unroll
   for (int pos = 0; pos < kSlots; ++pos) {
-    if (pos > r.n || k >= kMaxRuns) continue;
-    int cx, cy, cz;
-    float tsd, w;
-    ray_sample(L.g, L.p, r, pos, cx, cy, cz, tsd, w);
-    if (!cell_in_range(cx, cy, cz)) continue;  // breaks a run (ray_block_runs), never inside one
-    const int lk = k == 0 ? len[0] : (k == 1 ? len[1] : (k == 2 ? len[2] : len[3]));
-    const unsigned dk = k == 0 ? dst[0] : (k == 1 ? dst[1] : (k == 2 ? dst[2] : dst[3]));
-    const int bk = static_cast<int>(((k == 0 ? info.slot[0] : (k == 1 ? info.slot[1] : (k == 2 ? info.slot[2] : info.slot[3]))) >> 24) & 15u);
-    if (pos < bk) continue;  // a run whose block could not be allocated left no entry: its samples are skipped
-    rec_keys[dk + q] = (voxel_in_block(cx, cy, cz) << kSeqBits) | (i * kSlots + pos);
-    rec_vals[dk + q] = __float_as_uint(tsd);
-    if (++q == lk) {
-      q = 0;
-      ++k;
-      while (k < kMaxRuns && (k == 1 ? len[1] : (k == 2 ? len[2] : (k == 3 ? len[3] : 0))) == 0) ++k;
+    const int cx = walk.c[0], cy = walk.c[1], cz = walk.c[2];
+    walk.step();
+    bool in = false;
+    unsigned at = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxRuns; ++k) {
+      const bool ink = static_cast<unsigned>(pos - beg[k]) < len[k];
+      in = in || ink;
+      at = ink ? base[k] : at;
     }
+    if (!in) continue;
+    float tsd, w;
+    ray_sample_cell(L.g, L.p, r, cx, cy, cz, tsd, w);
+    rec_keys[at + pos] = (voxel_in_block(cx, cy, cz) << kSeqBits) | (i * kSlots + pos);
+    rec_vals[at + pos] = __float_as_uint(tsd);
   }
 }
 
