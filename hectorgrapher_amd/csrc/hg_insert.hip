@@ -1896,22 +1896,38 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
 #endif
     hist[tid] = 0;
     cursor[tid] = 0;  // (the first pass of the item finds it zero; later passes clear it again)
-    base[tid] = tid < 256u ? 0xFFFFFFFFu : 0u;  // first / last seq per voxel of a compact slice (<= 256 voxels)
+    {
+      // first / last seq per voxel of a compact slice (<= 256 voxels): all ones / zero. Computed from a copy of
+      // tid the optimiser cannot see through: hoisted out of the item loop the value was spilled to scratch
+      // memory in the prologue of EVERY wavefront (6 MB of writes per launch for one select).
+      unsigned t2 = tid;
+      asm volatile("" : "+v"(t2));
+      base[tid] = t2 < 256u ? 0xFFFFFFFFu : 0u;
+    }
     if (tid == 0) { s_big = 0; s_m = 0; }
     __syncthreads();
-    const bool single = n <= static_cast<unsigned>(kBinCap);  // whole bin in registers: one read
-    uint32_t rk4[4], rv4[4];
+    // a whole bin that fits one pass: its records go straight into the LDS list (no filter, no buckets)
+    const bool single = n <= static_cast<unsigned>(kBinCap) && s_bits == 0u;
     bool compact = false;
     if (single) {
+      uint32_t k4[4], v4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const unsigned i = u * kBinThreads + tid;
-        rk4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
-        rv4[u] = i < n ? bv[i] : 0u;
+        k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+        v4[u] = i < n ? bv[i] : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (is_mine(rk4[u])) atomicAdd(&hist[to_l(rk4[u])], 1u);
+      for (int u = 0; u < 4; ++u) {
+        const unsigned i = u * kBinThreads + tid;
+        if (i < n) {
+          tk[i] = k4[u];  // (one slice: l is the voxel, the key is keyed by l as it stands)
+          tv[i] = v4[u];
+          atomicAdd(&hist[k4[u] >> kSeqBits], 1u);
+        }
+      }
+      if (tid == 0) s_m = n;
+      compact = true;
       __syncthreads();
     } else {
       // A slice of a larger bin scans the WHOLE bin for its voxels' records; with S slices per bin that scan
@@ -2016,7 +2032,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
       // voxel range [lo, hi): the longest prefix of voxels whose records fit one LDS pass
       const unsigned b_lo = base[lo];
       unsigned hi = v_hi;
-      if (!(single || compact)) {  // (a whole small bin, or a slice whose records fit one pass, is ONE range)
+      if (!compact) {  // (a whole small bin, or a slice whose records fit one pass, is ONE range)
         if (tid == 0) s_hi = 1024;
         __syncthreads();
         {
@@ -2135,13 +2151,8 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const unsigned i = i0 + u * kBinThreads + tid;
-            if (single) {
-              k4[u] = rk4[u];
-              v4[u] = rv4[u];
-            } else {
-              k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
-              v4[u] = i < n ? bv[i] : 0u;
-            }
+            k4[u] = i < n ? bk[i] : 0xFFFFFFFFu;
+            v4[u] = i < n ? bv[i] : 0u;
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
