@@ -1424,7 +1424,7 @@ __device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* s_wave /*[
 // grid (levels), 1024 threads: bin offsets by an exclusive scan over the touched list, and the
 // apply work list: a bin larger than one LDS pass is split into voxel slices handled by
 // different workgroups (voxels are independent of each other); slice k takes the voxels
-// v with v mod slices == k (see k_bin_apply).
+// v whose mixed low bits (slice_of in k_bin_apply) equal k.
 // Reserves `mine` consecutive work items for every lane with ONE LDS atomic per wavefront (a prefix
 // sum over the lanes): thousands of same-address atomics of a level's touched blocks serialised.
 __device__ inline unsigned reserve_items(unsigned* counter, unsigned mine) {
@@ -1862,7 +1862,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
     const uint4 item = g.work[wi];
     const uint32_t slot = item.x;
     const unsigned n = item.z;  // all 32 bits: a bin may hold every record of the scan
-    // The slices of a bin interleave its voxels (voxel v belongs to slice v mod S): the heavy voxels
+    // The slices of a bin interleave its voxels (slice_of below): the heavy voxels
     // of a block are spatial neighbours, contiguous slices would queue their chains in one workgroup.
     // A slice has 512 / S voxels, so the 512 counters of the item are spent on S seq BUCKETS per voxel:
     // a record is filed under l = (v / S) * S + bucket, bucket = (seq - first seq of the voxel) >> shift of the
@@ -2272,7 +2272,8 @@ using namespace hg;
 
 namespace {
 
-// Launch shape of k_bin_apply (see there). HG_APPLY_TURNS=0: one grid row per level.
+// Launch shape of k_bin_apply (see there): one grid row per level; HG_APPLY_TURNS=1 lets the levels take turns
+// (measured: slower, kept as a switch for the diagnostics).
 dim3 apply_grid(int levels) {
   static const int turns = [] { const char* e = getenv("HG_APPLY_TURNS"); return e ? atoi(e) : 0; }();
   return turns ? dim3(1024u * static_cast<unsigned>(levels), 1u) : dim3(1024u, static_cast<unsigned>(levels));
