@@ -1,4 +1,5 @@
 """GPU parity: HIP TSDF inserter vs the CPU oracle, bit-exact on the uint16 voxel codes."""
+import os
 import numpy as np
 import pytest
 
@@ -486,3 +487,19 @@ def test_children_may_outlive_their_context(hg):
     c.close()
     assert L.hg_grid_destroy(gh) == 0
     assert L.hg_problem_destroy(ph) == 0
+
+
+@pytest.mark.parametrize("env", [{"HG_STREAM_SLICE": "512"}, {"HG_STREAM_SLICE": "2048"}, {"HG_APPLY_TURNS": "1"}])
+def test_apply_schedules_are_all_bit_exact(env):
+    """The slice size of a scan stream's large bins and the dispatch order of k_bin_apply are schedules, not
+    semantics: the tests that compare grouped streams, giant voxels and dense pools with the oracle pass under the
+    alternative settings too (the switches are read once per process, hence a child process)."""
+    import subprocess
+    import sys
+    child_env = dict(os.environ)
+    child_env.update(env)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                          "grouped_stream or thousands_of_rays or giant_voxel or small_block_pool or batch_equals or 2_pow_20"],
+                         env=child_env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
