@@ -38,6 +38,9 @@ def parse_args():
     ap.add_argument("--cpu-scans", type=int, default=3)
     ap.add_argument("--max-blocks", type=int, default=1 << 18)
     ap.add_argument("--window", type=int, default=10, help="control points of --workload window")
+    ap.add_argument("--no-window-unwarp", action="store_true",
+                    help="--workload window: insert the leaving scan at control point 1's pose instead of unwarping it "
+                         "per point between control points 0 and 1 (hg_register_scan_unwarped)")
     ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "register_filtered", "match_batch", "register_batch"],
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
@@ -539,18 +542,41 @@ def run_window(args):
     builds = [window_prepare(problem, specs[s], d_scans[s:s + n_cp - 1], grids, n_pts) for s in range(total)]
 
     leaving = [api.RangeData([0, 0, 0], d_scans[s]) for s in range(total)]
+    # Per-point unwarping of the scan that leaves the window (use_per_point_unwarping, oltb.cc:1331-1379):
+    # control point i of window s sits at time (first + i) * 0.1 s; the leaving scan belongs to control
+    # point 1 and its returns carry per-point times (all 0 here: the synthetic scans are taken from a
+    # standing sensor, so any spread would smear the map; every return still runs the whole fp64
+    # interpolation chain between control points 0 and 1). --no-window-unwarp inserts at control point 1's pose.
+    unwarp = not args.no_window_unwarp
+    cp_dt = 1_000_000  # 0.1 s in ticks, the delta_time of the IMU blocks
+    d_timed = None
+    if unwarp:
+        d_timed = [torch.cat([d, torch.zeros((d.shape[0], 1), dtype=d.dtype, device=dev)], 1).contiguous() for d in d_scans[:total]]
+    torch.cuda.synchronize()
+
+    def control_times(s):
+        first = args.map_scans - 1 + s
+        return np.array([(first + i) * cp_dt for i in range(n_cp)], np.int64)
 
     def step(s, sample=False):
         builds[s]()
-        # solve the window, then insert the scan that leaves it at control point 1's solved pose, handed
-        # over in device memory (hg_register_scan_mode works on any problem shape): the insertion is
-        # enqueued behind the solve before the host has seen its result
-        at, summ = api.register_scan(problem, 1, inserters, leaving[s], grids)
+        if unwarp:
+            # solve the window, then unwarp + insert the leaving scan with the SOLVED control poses read from
+            # device memory (hg_register_scan_unwarped): no host round trip between solve and insertion
+            ct = control_times(s)
+            poses, summ = api.register_scan_unwarped(problem, inserters, [(int(ct[1]), [0, 0, 0], d_timed[s])], args.rings,
+                                                     list(range(n_cp)), ct, grids)
+            at = poses[1]
+        else:
+            # solve the window, then insert the scan that leaves it at control point 1's solved pose, handed
+            # over in device memory (hg_register_scan_mode works on any problem shape): the insertion is
+            # enqueued behind the solve before the host has seen its result
+            at, summ = api.register_scan(problem, 1, inserters, leaving[s], grids)
+            poses = np.array([problem.get_pose(i) for i in range(n_cp)])
         its.append(summ.num_iterations)
         if sample:
             evals.append(summ.num_cost_evaluations)
-        solved.append((np.array([problem.get_pose(i) for i in range(n_cp)]), summ.num_iterations,
-                       summ.termination_type, summ.termination_reason))
+        solved.append((poses.copy(), summ.num_iterations, summ.termination_type, summ.termination_reason))
         inserted_at.append(at.astype(np.float32))
 
     for s_ in range(args.warmup):
@@ -580,19 +606,32 @@ def run_window(args):
             loc = synth.transform_points(pose, pts)
             for g in og:
                 g.insert(pose[:3], loc)
+        def oracle_insert(w, poses):
+            """Insertion of the scan leaving window w at the window's `poses`, as the GPU step does it."""
+            if unwarp:
+                ct = control_times(w)
+                timed = np.concatenate([scans[w], np.zeros((len(scans[w]), 1), np.float32)], 1)
+                xyz, origin, ok = po.unwarp_range_data(ct, poses, [(int(ct[1]), [0, 0, 0], timed)])
+                assert ok
+                opt = np.asarray(poses[0], np.float64).astype(np.float32)  # optimized_pose.cast<float>() (:1437-1440)
+                xyz = po.transform_points(opt, xyz)
+                origin = po.transform_points(opt, origin[None])[0]
+                for g in og:
+                    g.insert(origin, xyz, width=args.rings)
+            else:
+                at = np.asarray(poses[1])
+                loc = synth.transform_points(at, scans[w])
+                for g in og:
+                    g.insert(at[:3].astype(np.float32), loc)
+
         for w in range(args.warmup):
-            loc = synth.transform_points(inserted_at[w], scans[w])
-            for g in og:
-                g.insert(inserted_at[w][:3], loc)
+            oracle_insert(w, solved[w][0])
         s0 = args.warmup
         t1 = time.perf_counter()
         pr = po.Problem()
         window_problem(pr, synth, args.map_scans - 1 + s0, n_cp, scans[s0:s0 + n_cp - 1], og, n_pts)
         so = pr.solve()
-        est = pr.get_pose(1)
-        loc = synth.transform_points(est, scans[s0])
-        for g in og:
-            g.insert(est[:3].astype(np.float32), loc)
+        oracle_insert(s0, np.array([pr.get_pose(i) for i in range(n_cp)]))
         cpu_s = time.perf_counter() - t1
         lk, pb = pr.lookup_stats()
         lbar = pb / max(1, lk)
@@ -622,8 +661,11 @@ def run_window(args):
         "value": args.steps / elapsed, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "window: %d control points (81 free columns at 10), %d multi-res scan blocks + IMU/odometry blocks per solve, exact insert of the scan leaving the window"
-                               % (n_cp, n_cp - 1), "mean_lm_iterations": float(np.mean(its))},
+        "config": {"workload": "window: %d control points (81 free columns at 10), %d multi-res scan blocks + IMU/odometry blocks per solve, exact insert of the scan leaving the window%s"
+                               % (n_cp, n_cp - 1, " after per-point unwarping on the device (hg_register_scan_unwarped)" if unwarp else ""),
+                   "mean_lm_iterations": float(np.mean(its)),
+                   "problem_build": "pre-marshalled C-ABI calls per window (window_prepare); initial guesses from the synthetic ground truth + a fixed perturbation, not from the previous solve",
+                   "unwarp_ms_per_call": (prof["unwarp"][1] / max(1, prof["unwarp"][0])) if unwarp else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_window_residuals<false>",
                      "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -1175,12 +1217,28 @@ def secondary_workloads(args):
         ("register_batch_8", run_register_batch, {"workload": "register_batch", "batch_submaps": 8, "batch_threads": 1, "steps": 6, "warmup": 2, "prof_every": 2, "cpu_scans": 2}),
         ("insert_stream_32", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "steps": 4, "warmup": 1, "prof_every": 2, "cpu_scans": 2}),
         ("window_10", run_window, {"workload": "window", "window": 10, "steps": 6, "warmup": 2, "prof_every": 2}),
+        # BASELINE configs[2] with the voxels in HBM: 64 scans over 64 copies of the room (~0.4 GB of voxel
+        # blocks touched per call, beyond the 256 MB Infinity Cache); insert_stream_32 above stays in cache
+        ("insert_stream_64_hbm", run_insert_stream, {"workload": "insert_stream", "stream_scans": 64, "stream_tiles": 64,
+                                                     "steps": 3, "warmup": 1, "prof_every": 1, "cpu_scans": 2}),
+        # BASELINE configs[3] bounded: 8 submaps x 10 scans on this GPU, then the gather of all finished blocks
+        # through a one-rank process group and its import / export-digest check (the full 8 x 500 run is
+        # `bench.py --total-submaps 8 --scans-per-submap 500`, profiles/r04_bench_offline8x500.json)
+        ("offline8", run_offline_batch, {"total_submaps": 8, "scans_per_submap": 10, "steps": 10, "warmup": 2, "cpu_scans": 2,
+                                         "_force_dist": True}),
     ]
     for name, fn, kw in plan:
         a = copy.copy(args)
         for k, v in kw.items():
             setattr(a, k, v)
         t0 = time.perf_counter()
+        forced = bool(kw.get("_force_dist"))
+        if forced and "RANK" in os.environ:
+            # this process already belongs to a process group (torch.distributed.run with one rank)
+            out[name] = {"skipped": "needs a process group of its own: run bench.py bare"}
+            continue
+        if forced:
+            os.environ["HG_FORCE_DIST"] = "1"
         try:
             r = fn(a)
             par = r.get("parity") or {}
@@ -1191,10 +1249,17 @@ def secondary_workloads(args):
                          "frac": roof.get("frac"), "kernel": roof.get("kernel"), "avg_launch_ms": roof.get("avg_launch_ms"),
                          "parity_ok": None if ok is None else bool(ok), "parity": par or None,
                          "wall_s": round(time.perf_counter() - t0, 2)}
+            cfg = r.get("config") or {}
+            for k in ("gather_ms", "gather_check", "voxel_working_set_mib", "room_copies"):
+                if cfg.get(k) is not None:
+                    out[name][k] = cfg[k]
         except SystemExit as e:  # a failed parity gate of a secondary run is reported, the headline stands
             out[name] = {"error": str(e), "parity_ok": False}
         except Exception as e:
             out[name] = {"error": repr(e)}
+        finally:
+            if forced:
+                os.environ.pop("HG_FORCE_DIST", None)
     return out
 
 

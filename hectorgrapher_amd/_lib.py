@@ -15,10 +15,10 @@ HG_HOST, HG_DEVICE = 0, 1
 HG_INSERT_EXACT = 0
 HG_INSERT_FAST = 1
 KERNELS = {"ray_count": 0, "ray_expand": 1, "sort": 2, "alloc": 3, "apply": 4, "residuals": 5,
-           "lm": 6, "scan": 7}
+           "lm": 6, "scan": 7, "unwarp": 8}
 
 ERRORS = {-1: "HG_ERR_INVALID", -2: "HG_ERR_NO_DEVICE", -3: "HG_ERR_HIP", -4: "HG_ERR_CAPACITY",
-          -5: "HG_ERR_UNSUPPORTED", -6: "HG_ERR_RANGE"}
+          -5: "HG_ERR_UNSUPPORTED", -6: "HG_ERR_RANGE", -7: "HG_ERR_TIME"}
 
 # Every symbol include/hg_mi355x.h declares.
 SYMBOLS = [
@@ -35,6 +35,7 @@ SYMBOLS = [
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
     "hg_solver_default_opts", "hg_problem_solve", "hg_problem_solve_batch", "hg_problem_solve_async", "hg_problem_fetch",
     "hg_register_scan", "hg_register_scan_mode", "hg_register_scan_batch", "hg_register_scan_sequence", "hg_match_evaluate", "hg_match_solve",
+    "hg_pyramid_insert_unwarped", "hg_unwarp_range_data", "hg_unwarp_last_device", "hg_register_scan_unwarped",
 ]
 
 
@@ -70,6 +71,12 @@ class InsertOpts(C.Structure):
         self.normal_computation_vertical_stride = 1
         for k, v in kw.items():
             setattr(self, k, v)
+
+
+class TimedCloud(C.Structure):
+    """hg_timed_cloud: one sensor::TimedPointCloudData of the accumulation."""
+    _fields_ = [("time", C.c_int64), ("begin", C.c_uint64), ("count", C.c_uint64),
+                ("origin", C.c_float * 3), ("reserved", C.c_float)]
 
 
 class InsertStats(C.Structure):
@@ -188,6 +195,11 @@ def load():
     L.hg_match_evaluate.argtypes = [vp, vp, i32, i32, vp, sz, i32, f64, vp, vp, f64, vp, vp, vp, vp]
     L.hg_match_solve.argtypes = [vp, vp, i32, i32, vp, sz, i32, f64, vp, vp, i32, f64,
                                  P(SolverOpts), P(SolverSummary)]
+    L.hg_pyramid_insert_unwarped.argtypes = [vp, vp, i32, vp, sz, sz, i32, vp, i32, vp, vp, i32, vp, i32, vp]
+    L.hg_unwarp_range_data.argtypes = [vp, vp, sz, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.hg_unwarp_last_device.argtypes = [vp, P(vp), P(vp), P(sz)]
+    L.hg_register_scan_unwarped.argtypes = [vp, P(SolverOpts), vp, vp, i32, vp, sz, sz, i32, vp, i32, vp, vp, i32,
+                                            vp, i32, vp, P(SolverSummary)]
     for name in SYMBOLS:
         getattr(L, name)  # raises AttributeError if the ABI is incomplete
     _lib = L

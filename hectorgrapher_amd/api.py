@@ -393,6 +393,88 @@ def insert_pyramid(inserters, range_data, grids, pose_tq=None, want_stats=True):
     return list(st) if want_stats else None
 
 
+def _timed_clouds(clouds):
+    """[(time_ticks, origin[3], points[n, 4])] -> (hg_timed_cloud array, concatenated points, n, memspace).
+    A single cloud may hold a CUDA tensor (passed as a device pointer); several clouds are concatenated on
+    the host."""
+    arr = (_lib.TimedCloud * len(clouds))()
+    begin = 0
+    for k, (t, origin, pts) in enumerate(clouds):
+        arr[k].time = int(t)
+        arr[k].begin = begin
+        arr[k].count = int(pts.shape[0])
+        o = np.asarray(origin, np.float32).reshape(3)
+        arr[k].origin[0], arr[k].origin[1], arr[k].origin[2] = float(o[0]), float(o[1]), float(o[2])
+        begin += int(pts.shape[0])
+    if len(clouds) == 1 and _is_device(clouds[0][2]):
+        p = clouds[0][2]
+        return arr, p, p.data_ptr(), begin, _lib.HG_DEVICE
+    allp = np.ascontiguousarray(np.concatenate([_host(c[2], np.float32, 4) for c in clouds], 0))
+    return arr, allp, allp.ctypes.data, begin, _lib.HG_HOST
+
+
+def insert_pyramid_unwarped(inserters, clouds, width, control_times, control_poses, grids, pose_tq=None,
+                            want_stats=True):
+    """hg_pyramid_insert_unwarped: per-point unwarping of the accumulated range data
+    (optimizing_local_trajectory_builder.cc:1331-1379), the frame changes of AddAccumulatedRangeData /
+    Submap3D::InsertData and the insertion, all on the device. clouds: [(time_ticks, origin[3],
+    points[n, 4] = x y z time)]; control_poses[0] is optimized_pose."""
+    L = _lib.load()
+    n_l = len(grids)
+    opts = (InsertOpts * n_l)(*[i.options for i in inserters])
+    garr = (C.c_void_p * n_l)(*[g._h for g in grids])
+    arr, keep, ptr, n, space = _timed_clouds(clouds)
+    ct = np.ascontiguousarray(control_times, np.int64)
+    cp = np.ascontiguousarray(control_poses, np.float64).reshape(-1, 7)
+    pose = None if pose_tq is None else np.ascontiguousarray(pose_tq, np.float32)
+    st = (InsertStats * n_l)() if want_stats else None
+    check(L.hg_pyramid_insert_unwarped(garr, opts, n_l, ptr, n, int(width), space, arr, len(clouds), _p(cp), _p(ct),
+                                       len(ct), _p(pose), inserters[0].mode, st), "hg_pyramid_insert_unwarped")
+    del keep
+    return list(st) if want_stats else None
+
+
+def unwarp_range_data(ctx, clouds, control_times, control_poses, frame=0, pose_tq=None):
+    """hg_unwarp_range_data: (xyz [n, 3], origin [3]) of the accumulated range data in the tracking frame
+    (frame 0) or moved on by control_poses[0].cast<float>() and pose_tq (frame 1)."""
+    L = _lib.load()
+    arr, keep, ptr, n, space = _timed_clouds(clouds)
+    ct = np.ascontiguousarray(control_times, np.int64)
+    cp = np.ascontiguousarray(control_poses, np.float64).reshape(-1, 7)
+    pose = None if pose_tq is None else np.ascontiguousarray(pose_tq, np.float32)
+    xyz = np.empty((n, 3), np.float32)
+    origin = np.empty(3, np.float32)
+    check(L.hg_unwarp_range_data(ctx._h, ptr, n, space, arr, len(clouds), _p(cp), _p(ct), len(ct), int(frame),
+                                 _p(pose), _p(xyz), _p(origin)), "hg_unwarp_range_data")
+    del keep
+    return xyz, origin
+
+
+def register_scan_unwarped(problem, inserters, clouds, width, pose_index, control_times, grids, pose_tq=None,
+                           **solver_kw):
+    """hg_register_scan_unwarped: solve the window, then insert `clouds` unwarped with the SOLVED control poses
+    (problem pose pose_index[k] at control_times[k]) without a host round trip. Returns (poses [K, 7], summary)."""
+    L = _lib.load()
+    o = SolverOpts()
+    L.hg_solver_default_opts(C.byref(o))
+    for k, v in solver_kw.items():
+        setattr(o, k, v)
+    n_l = len(grids)
+    opts = (InsertOpts * n_l)(*[i.options for i in inserters])
+    garr = (C.c_void_p * n_l)(*[g._h for g in grids])
+    arr, keep, ptr, n, space = _timed_clouds(clouds)
+    ct = np.ascontiguousarray(control_times, np.int64)
+    idx = np.ascontiguousarray(pose_index, np.int32)
+    pose = None if pose_tq is None else np.ascontiguousarray(pose_tq, np.float32)
+    poses = np.empty((len(ct), 7), np.float64)
+    summ = SolverSummary()
+    check(L.hg_register_scan_unwarped(problem._h, C.byref(o), garr, opts, n_l, ptr, n, int(width), space, arr,
+                                      len(clouds), _p(idx), _p(ct), len(ct), _p(pose), inserters[0].mode, _p(poses),
+                                      C.byref(summ)), "hg_register_scan_unwarped")
+    del keep
+    return poses, summ
+
+
 class Problem:
     """ceres::Problem restricted to TSDF space cost functions over pose blocks."""
 

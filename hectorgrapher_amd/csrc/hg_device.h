@@ -55,7 +55,7 @@ struct GridView {
   float weight_scale, weight_offset;
 };
 
-enum : uint32_t { kFlagCapacity = 1u, kFlagRange = 2u };
+enum : uint32_t { kFlagCapacity = 1u, kFlagRange = 2u, kFlagTime = 32u };  // (4, 8, 16: hg_insert.hip)
 
 // Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8), and each
 // XCD has its own L2. Consecutive returns of a scan touch the same voxel blocks, so workgroup b is

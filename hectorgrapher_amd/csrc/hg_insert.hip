@@ -512,6 +512,8 @@ struct PyramidIns {
   ScanTable scan0;  // the scan when a call carries exactly one (no table upload needed)
   const double* d_pose;  // optional: pose (t xyz, q wxyz, fp64) in device memory, e.g. the pose a
                          // solve left there; cast to float as Rigid3d::cast<float>() does
+  const float* d_origin; // optional: origin of the scan in device memory (the per-point unwarping leaves it
+                         // there, hg_unwarp.hip), read instead of scan0.origin
   int accumulate;        // not the first chunk of a call: hit / update counters add up
   uint32_t* host_flags;  // the context's mapped pinned flag words: sticky error flags of calls that do not
                          // read their stats back (written only when a flag is set), one word per grid
@@ -602,6 +604,7 @@ __global__ __launch_bounds__(256) void k_expand_fixed(PyramidIns P, const ScanTa
   bool hit = false;
   if (i < n) {
     ScanTable sc = (n_scans == 1) ? P.scan0 : scans[find_scan(scans, n_scans, i)];
+    if (P.d_origin) { sc.origin[0] = P.d_origin[0]; sc.origin[1] = P.d_origin[1]; sc.origin[2] = P.d_origin[2]; }
     if (P.d_pose) {
 #pragma unroll
       for (int k = 0; k < 7; ++k) sc.pose[k] = static_cast<float>(P.d_pose[k]);
@@ -826,6 +829,7 @@ enum : uint32_t { kFlagBinOverflow = 8u, kFlagWorkOverflow = 16u };
 
 __device__ inline ScanTable scan_of(const PyramidIns& P) {
   ScanTable sc = P.scan0;
+  if (P.d_origin) { sc.origin[0] = P.d_origin[0]; sc.origin[1] = P.d_origin[1]; sc.origin[2] = P.d_origin[2]; }
   if (P.d_pose) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) sc.pose[k] = static_cast<float>(P.d_pose[k]);
@@ -2696,6 +2700,10 @@ int hg::flags_to_status(uint32_t flags) {
     set_last_error("apply work list overflow (internal sizing error)");
     return HG_ERR_CAPACITY;
   }
+  if (flags & kFlagTime) {
+    set_last_error("per-point unwarping: a return's time lies outside the control points");
+    return HG_ERR_TIME;
+  }
   return HG_OK;
 }
 namespace {
@@ -3055,8 +3063,10 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
 int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                             const float* origins, const float* xyz, const uint64_t* scan_offsets,
                             size_t n_scans, size_t width, const float* poses_tq,
-                            const double* d_pose_tq, int mode, int memspace, hg_insert_stats* stats) {
+                            const double* d_pose_tq, int mode, int memspace, hg_insert_stats* stats,
+                            const float* d_origin) {
   if (d_pose_tq && (n_scans != 1 || !poses_tq)) return HG_ERR_INVALID;
+  if (d_origin && (n_scans != 1 || d_pose_tq)) return HG_ERR_INVALID;
   if (!grids || !opts || levels < 1 || levels > kMaxInsLevels || !origins || !scan_offsets || n_scans == 0)
     return HG_ERR_INVALID;
   if (mode != HG_INSERT_EXACT && mode != HG_INSERT_FAST) return HG_ERR_INVALID;
@@ -3142,7 +3152,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     if (d_pose_tq) return HG_ERR_UNSUPPORTED;
     for (int l = 0; l < levels && rc == HG_OK; ++l)
       rc = pyramid_insert_impl(grids + l, opts + l, 1, origins, xyz, scan_offsets, n_scans, width,
-                               poses_tq, nullptr, mode, memspace, stats ? stats + l : nullptr);
+                               poses_tq, nullptr, mode, memspace, stats ? stats + l : nullptr, d_origin);
     return rc;
   }
 
@@ -3157,6 +3167,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
   std::memset(&P, 0, sizeof(P));
   P.levels = levels;
   P.d_pose = d_pose_tq;
+  P.d_origin = d_origin;
   P.host_flags = stats ? nullptr : c->async_flags;
   if (d_pose_tq && !fixed_ok) return HG_ERR_UNSUPPORTED;
   for (int l = 0; l < levels; ++l) {
@@ -3175,7 +3186,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     for (size_t i = 0; i < n_scans; ++i)
       for (int a = 0; a < 3; ++a)
         reach = std::max(reach, static_cast<double>(std::fabs(go[3 * i + a] - go[a])));
-    reach += opts[l].max_range + L.p.truncation_distance + 2.0 * res + (d_pose_tq ? 2.0 : 0.0);
+    reach += opts[l].max_range + L.p.truncation_distance + 2.0 * res + ((d_pose_tq || d_origin) ? 2.0 : 0.0);
     if (!(reach / (8.0 * res) < 62.0)) key32 = false;
   }
 
@@ -3239,6 +3250,9 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
                                     hipMemcpyHostToDevice, s));
         HG_HIP_CHECK(hipStreamSynchronize(s));  // `table` is reused by the next chunk
         d_scans = c->ws_scan_table.as<ScanTable>();
+        if (d_origin)  // the origin the unwarping left in device memory replaces the host's guess
+          HG_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(c->ws_scan_table.ptr) + offsetof(ScanTable, origin), d_origin,
+                                      3 * sizeof(float), hipMemcpyDeviceToDevice, s));
       }
       const unsigned long long first = scan_offsets[s0] - scan_offsets[0];
       PyramidIns Pc = P;

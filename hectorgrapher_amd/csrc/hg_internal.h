@@ -83,6 +83,12 @@ struct hg_ctx {
   // insertion workspace
   hg::DeviceBuffer ws_points, ws_scan_table, ws_gate, ws_counts, ws_offsets, ws_keys_a, ws_keys_b,
       ws_vals_a, ws_vals_b, ws_temp, ws_misc, ws_filter, ws_jobs;
+  // per-point unwarping (hg_unwarp.hip): the unwarped cloud, its small tables (+ first-valid word and
+  // origin slot), the upload of host-resident timed points
+  hg::DeviceBuffer ws_unwarp, ws_unwarp_tab, ws_unwarp_in;
+  const float* unwarp_xyz = nullptr;     // results of the last unwarp call (device)
+  const float* unwarp_origin = nullptr;
+  size_t unwarp_count = 0;
   // second set of record / work-list buffers and the apply stream of the pipelined scan stream
   // (insert_chunk_binned with `pipe`): the front end of scan k + 1 runs next to the apply pass of scan k
   hg::DeviceBuffer ws_keys_c, ws_vals_c, ws_offsets_b;
@@ -188,7 +194,19 @@ int pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const hg_in
 int pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                         const float* origins, const float* xyz, const uint64_t* scan_offsets,
                         size_t n_scans, size_t width, const float* poses_tq,
-                        const double* d_pose_tq, int mode, int memspace, hg_insert_stats* stats);
+                        const double* d_pose_tq, int mode, int memspace, hg_insert_stats* stats,
+                        const float* d_origin = nullptr);
+// hg_unwarp.hip
+int unwarp_enqueue(hg_ctx* c, hg_grid* const* grids, int levels, const float* points, size_t n, int memspace,
+                   const hg_timed_cloud* clouds, int n_clouds, const double* control_poses,
+                   const double* d_poses, const int* pose_index, int pose_stride,
+                   const int64_t* control_times, int n_control, int optimized, int to_local,
+                   const float* post_tq);
+int unwarp_insert(hg_grid* const* grids, const hg_insert_opts* opts, int levels, const float* points, size_t n,
+                  size_t width, int memspace, const hg_timed_cloud* clouds, int n_clouds,
+                  const double* control_poses, const double* d_poses, const int* pose_index, int pose_stride,
+                  const int64_t* control_times, int n_control, const float* pose_tq, int mode,
+                  hg_insert_stats* stats);
 }
 
 namespace hg {

@@ -4621,6 +4621,34 @@ int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_i
                             pose_out, summary, nullptr, nullptr);
 }
 
+int hg_register_scan_unwarped(hg_problem* p, const hg_solver_opts* sopts, hg_grid* const* grids,
+                              const hg_insert_opts* iopts, int levels, const float* points, size_t n,
+                              size_t width, int memspace, const hg_timed_cloud* clouds, int n_clouds,
+                              const int* pose_index, const int64_t* control_times, int n_control,
+                              const float* pose_tq, int insert_mode, double* poses_out,
+                              hg_solver_summary* summary) {
+  if (!p || !p->ctx || !grids || !iopts || levels < 1 || !pose_index || n_control < 2) return HG_ERR_INVALID;
+  for (int k = 0; k < n_control; ++k)
+    if (pose_index[k] < 0 || pose_index[k] >= static_cast<int>(p->poses.size())) return HG_ERR_INVALID;
+  int rc = async_status_grids(grids, levels);
+  if (rc != HG_OK) return rc;
+  rc = hg_problem_solve_async(p, sopts);
+  if (rc != HG_OK) return rc;
+  // the unwarping reads the solved control poses where the solve leaves them (LmHead::x, kState doubles per
+  // control point); the host's copy (the initial guesses) only sizes the key window. A problem without free
+  // parameters launches nothing: its poses are the host's.
+  std::vector<double> guess(static_cast<size_t>(n_control) * 7);
+  for (int k = 0; k < n_control; ++k) std::memcpy(&guess[7 * k], p->poses[pose_index[k]].data(), sizeof(double) * 7);
+  const double* d_poses = (p->h_state.h.ncols == 0) ? nullptr : &p->d_state->h.x[0][0];
+  rc = unwarp_insert(grids, iopts, levels, points, n, width, memspace, clouds, n_clouds, guess.data(), d_poses,
+                     d_poses ? pose_index : nullptr, kState, control_times, n_control, pose_tq, insert_mode, nullptr);
+  const int rc2 = hg_problem_fetch(p, summary);
+  if (rc == HG_OK) rc = rc2;
+  if (rc == HG_OK && poses_out)
+    for (int k = 0; k < n_control; ++k) std::memcpy(poses_out + 7 * k, p->poses[pose_index[k]].data(), sizeof(double) * 7);
+  return rc;
+}
+
 }  // extern "C"
 
 // One registration step; `between` (if any) runs on the host after solve and insertion have been enqueued

@@ -45,7 +45,9 @@ enum {
   HG_ERR_HIP = -3,         /* HIP runtime error, see hg_last_error */
   HG_ERR_CAPACITY = -4,    /* block pool or hash table full */
   HG_ERR_UNSUPPORTED = -5, /* option not implemented on the device path */
-  HG_ERR_RANGE = -6        /* cell index outside +-8192 (reference: CHECK_LE(new_bits, 8)) */
+  HG_ERR_RANGE = -6,       /* cell index outside +-8192 (reference: CHECK_LE(new_bits, 8)) */
+  HG_ERR_TIME = -7         /* a return's time lies outside the control points (reference: CHECK_LE / CHECK_GE,
+                              optimizing_local_trajectory_builder.cc:1358-1359) */
 };
 
 enum { HG_HOST = 0, HG_DEVICE = 1 };
@@ -127,7 +129,7 @@ const char* hg_version(void);
 /* ---- per-kernel timing (HIP events on the context's stream) ------------------------------ */
 enum {
   HG_K_RAY_COUNT = 0, HG_K_RAY_EXPAND = 1, HG_K_SORT = 2, HG_K_ALLOC = 3, HG_K_APPLY = 4,
-  HG_K_RESIDUALS = 5, HG_K_LM = 6, HG_K_SCAN = 7, HG_K_COUNT = 8
+  HG_K_RESIDUALS = 5, HG_K_LM = 6, HG_K_SCAN = 7, HG_K_UNWARP = 8, HG_K_COUNT = 9
 };
 /* on = 1: bracket every launch of the kernels above with hipEvents (costs ~2 event records per
  * launch); on = 2: only the residual family (HG_K_RESIDUALS); 0: off. hg_prof_read synchronises the stream and returns launches / summed milliseconds since
@@ -228,6 +230,43 @@ int hg_pyramid_insert_batch(hg_grid* const* grids, const hg_insert_opts* opts, i
                             const float* origins, const float* xyz, const uint64_t* scan_offsets,
                             size_t n_scans, size_t width, const float* poses_tq, int mode,
                             int memspace, hg_insert_stats* stats);
+/* ---- per-point unwarping before insertion ------------------------------------------------ */
+/* One sensor::TimedPointCloudData of the accumulation (point_cloud_data_ entries that leave the window). */
+typedef struct hg_timed_cloud {
+  int64_t time;    /* common::Time of the cloud in universal 100 ns ticks */
+  uint64_t begin;  /* its returns are points[begin .. begin + count); the clouds tile [0, n) in order */
+  uint64_t count;
+  float origin[3]; /* sensor origin in the tracking frame (TimedPointCloudData::origin) */
+  float reserved;
+} hg_timed_cloud;
+/* use_per_point_unwarping branch of OptimizingLocalTrajectoryBuilder::MaybeOptimize
+ * (mapping/internal/3d/optimizing_local_trajectory_builder.cc:1331-1379), then the frame changes of
+ * AddAccumulatedRangeData (:1437-1440) and Submap3D::InsertData (mapping/3d/submap_3d.cc:436-437), then
+ * TSDFRangeDataInserter3D::Insert -- all on the device, no host pass over the returns:
+ *   points: n x 4 floats (x y z time), sensor::TimedRangefinderPoint in the tracking frame at its own time,
+ *   time in seconds relative to its cloud; every return is moved with
+ *   (control_poses[0].inverse() * InterpolateTransform(prev, next, t_prev, t_next, cloud.time +
+ *   FromSeconds(time))).cast<float>() for the control points bracketing it (transform/
+ *   timestamped_transform.h:41-65), NaN returns are kept as they are (:1342-1345), the origin is the first
+ *   unwarped return's transform applied to its cloud's origin (:1370-1374); then
+ *   control_poses[0].cast<float>() (optimized_pose = the front control point, :1294-1295) and, when
+ *   pose_tq != NULL, pose_tq (float[7] = local_pose().inverse().cast<float>()).
+ * control_poses: n_control x 7 doubles (host), control_times: ascending ticks (host). A return whose time
+ * lies outside [control_times[0], control_times[n_control - 1]] raises HG_ERR_TIME (the reference
+ * CHECK-fails), reported like the other sticky insert errors. width / mode / stats as hg_pyramid_insert. */
+int hg_pyramid_insert_unwarped(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
+                               const float* points, size_t n, size_t width, int memspace,
+                               const hg_timed_cloud* clouds, int n_clouds, const double* control_poses,
+                               const int64_t* control_times, int n_control, const float* pose_tq, int mode,
+                               hg_insert_stats* stats);
+/* The unwarping alone. frame 0: accumulated_range_data_in_tracking (:1331-1379); frame 1: additionally
+ * moved by control_poses[0].cast<float>() (range_data_in_local) and, if given, pose_tq. xyz_out (n x 3)
+ * and origin_out are host arrays or NULL; the device copies stay valid until the context's next unwarp
+ * call (hg_unwarp_last_device), e.g. as input of hg_voxel_filter / hg_pyramid_insert with HG_DEVICE. */
+int hg_unwarp_range_data(hg_ctx* ctx, const float* points, size_t n, int memspace, const hg_timed_cloud* clouds,
+                         int n_clouds, const double* control_poses, const int64_t* control_times, int n_control,
+                         int frame, const float* pose_tq, float* xyz_out, float origin_out[3]);
+int hg_unwarp_last_device(hg_ctx* ctx, const float** xyz_dev, const float** origin_dev, size_t* count);
 /* Synchronises and returns the counters of the last insert call + sticky error flags. */
 int hg_grid_status(hg_grid* grid, hg_insert_stats* stats);
 
@@ -341,6 +380,20 @@ int hg_register_scan_mode(hg_problem* p, const hg_solver_opts* sopts, int pose_i
                           hg_grid* const* grids, const hg_insert_opts* iopts, int levels,
                           const float origin[3], const float* xyz, size_t n, size_t width, int memspace,
                           int insert_mode, double pose_out[7], hg_solver_summary* summary);
+
+/* The window step with per-point unwarping (MaybeOptimize with use_per_point_unwarping: ceres::Solve
+ * :1283, unwarp :1331-1379, AddAccumulatedRangeData :1437-1440, insertion): solve the prepared window
+ * problem, then hg_pyramid_insert_unwarped of `points` with the SOLVED control poses taken from device
+ * memory -- control point k of the unwarping is pose pose_index[k] of the problem (pose_index[0] = the
+ * front of the window = optimized_pose), control_times[k] its time. No host round trip between the solve
+ * and the insertion; returns when the poses have arrived (insertion errors as hg_register_scan).
+ * poses_out: n_control x 7 or NULL. */
+int hg_register_scan_unwarped(hg_problem* p, const hg_solver_opts* sopts, hg_grid* const* grids,
+                              const hg_insert_opts* iopts, int levels, const float* points, size_t n,
+                              size_t width, int memspace, const hg_timed_cloud* clouds, int n_clouds,
+                              const int* pose_index, const int64_t* control_times, int n_control,
+                              const float* pose_tq, int insert_mode, double* poses_out,
+                              hg_solver_summary* summary);
 
 /* The registration step of `count` INDEPENDENT submaps with shared launches (offline batch mapping puts
  * several submaps on one GPU: one registration chain is latency-bound and fills a fraction of the

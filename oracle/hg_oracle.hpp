@@ -938,6 +938,89 @@ template <typename T> inline Rigid3<T> RigidInverse(const Rigid3<T>& r) {
 template <typename T> inline Rigid3<T> RigidMul(const Rigid3<T>& a, const Rigid3<T>& b) {
   return {Rotate(a.q, b.t) + a.t, QuatNormalized(QuatMul(a.q, b.q))};
 }
+// ---------------------------------------------------------------------------
+// Per-point unwarping of the accumulated range data.
+// ref: mapping/internal/3d/optimizing_local_trajectory_builder.cc:1331-1379 (use_per_point_unwarping
+// branch of MaybeOptimize), common/time.cc:30-38, transform/timestamped_transform.h:53-65.
+// ---------------------------------------------------------------------------
+using int64 = std::int64_t;
+struct TimedCloud {      // sensor::TimedPointCloudData
+  int64 time;            // common::Time in universal ticks (100 ns)
+  Vec3f origin;
+  const float* points;   // n x 4: position xyz + time [s relative to `time`] (sensor::TimedRangefinderPoint)
+  size_t n;
+};
+struct ControlPoint {
+  int64 time;
+  Rigid3<double> pose;   // state.ToRigid()
+};
+struct UnwarpedRangeData {  // accumulated_range_data_in_tracking
+  Vec3f origin{0.f, 0.f, 0.f};  // Eigen::Vector3f::Zero() (:1298-1299)
+  std::vector<float> returns;   // n x 3
+  bool time_in_range = true;    // false where the reference would CHECK-fail (:1355-1359)
+};
+// common::FromSeconds (time.cc:30-33): duration_cast<Duration>(duration<double>(s)) = (int64)(s * 1e7).
+inline int64 FromSeconds(const double seconds) { return static_cast<int64>(seconds * 1e7); }
+// common::ToSeconds (time.cc:35-38): duration_cast<duration<double>>(ticks) = ticks / 1e7.
+inline double ToSeconds(const int64 ticks) { return static_cast<double>(ticks) / 1e7; }
+// transform/timestamped_transform.h:53-65
+inline Rigid3<double> InterpolateTransformTimed(const Rigid3<double>& start, const Rigid3<double>& end,
+                                                const int64 time_start, const int64 time_end, const int64 time) {
+  const double duration = ToSeconds(time_end - time_start);
+  const double factor = ToSeconds(time - time_start) / duration;
+  return InterpolateTransform(start, end, factor);
+}
+// The while loop of :1337-1378 over the clouds that leave the window (the caller decides which: the loop
+// condition compares window times only). `control_points` are the window's control points after the solve;
+// optimized_pose = control_points.front() (:1294-1295).
+inline UnwarpedRangeData UnwarpAccumulatedRangeData(const std::vector<ControlPoint>& control_points,
+                                                    const std::vector<TimedCloud>& clouds) {
+  UnwarpedRangeData out;
+  const Rigid3<double> optimized_pose = control_points.front().pose;
+  size_t next_control_point = 0;  // iterator into control_points (:1335)
+  bool first_point = true;
+  const size_t last = control_points.size() - 1;
+  for (const TimedCloud& cloud : clouds) {
+    for (size_t i = 0; i < cloud.n; ++i) {
+      const Vec3f position{cloud.points[4 * i], cloud.points[4 * i + 1], cloud.points[4 * i + 2]};
+      const float time = cloud.points[4 * i + 3];
+      if (HasNaN(position)) {  // :1342-1345
+        out.returns.insert(out.returns.end(), {position.x, position.y, position.z});
+        continue;
+      }
+      const int64 point_time = cloud.time + FromSeconds(time);  // :1345-1346
+      while (control_points[next_control_point].time <= point_time) {  // :1347-1350
+        if (next_control_point == last) break;
+        ++next_control_point;
+      }
+      while (next_control_point > 0 && control_points[next_control_point - 1].time > point_time) {  // :1351-1354
+        if (next_control_point - 1 == 0) break;
+        --next_control_point;
+      }
+      if (next_control_point == 0) {  // CHECK(next_control_point != control_points_.begin()) (:1355)
+        out.time_in_range = false;
+        next_control_point = 1;
+      }
+      const ControlPoint& prev = control_points[next_control_point - 1];
+      const ControlPoint& next = control_points[next_control_point];
+      if (!(prev.time <= point_time && next.time >= point_time)) out.time_in_range = false;  // :1358-1359
+      const Rigid3<double> transform_cloud =
+          InterpolateTransformTimed(prev.pose, next.pose, prev.time, next.time, point_time);  // :1361-1365
+      const Rigid3<double> rel = RigidMul(RigidInverse(optimized_pose), transform_cloud);
+      const Rigid3<float> transform{{static_cast<float>(rel.t.x), static_cast<float>(rel.t.y), static_cast<float>(rel.t.z)},
+                                    {static_cast<float>(rel.q.w), static_cast<float>(rel.q.x),
+                                     static_cast<float>(rel.q.y), static_cast<float>(rel.q.z)}};  // :1366-1367
+      const Vec3f p = transform * position;  // :1368-1369
+      out.returns.insert(out.returns.end(), {p.x, p.y, p.z});
+      if (first_point) {  // :1370-1374
+        out.origin = transform * cloud.origin;
+        first_point = false;
+      }
+    }
+  }
+  return out;
+}
+
 template <typename T> inline T GetRoll(const Quat<T>& q) {
   const T sinr_cosp = T(2.0) * (q.w * q.x + q.y * q.z);
   const T cosr_cosp = T(1.0) - T(2.0) * (q.x * q.x + q.y * q.y);

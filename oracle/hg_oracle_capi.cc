@@ -230,6 +230,39 @@ void hgo_interpolate_transform(const double* a, const double* b, double factor, 
   out[3] = r.q.w; out[4] = r.q.x; out[5] = r.q.y; out[6] = r.q.z;
 }
 
+// Per-point unwarping (oltb.cc:1331-1379). control: K x (time in `control_times`, tq in `control_poses`);
+// clouds: times, begin offsets (n_clouds + 1) into `points` (n x 4), origins (n_clouds x 3). Writes the
+// accumulated range data in the tracking frame: xyz_out (n x 3), origin_out[3]. Returns 1 when every return's
+// time lies inside the control points, else 0 (the reference CHECK-fails).
+int hgo_unwarp_range_data(const long long* control_times, const double* control_poses, int n_control,
+                          const long long* cloud_times, const unsigned long long* cloud_offsets,
+                          const float* cloud_origins, int n_clouds, const float* points, float* xyz_out,
+                          float* origin_out) {
+  std::vector<ControlPoint> cps(n_control);
+  for (int k = 0; k < n_control; ++k) {
+    const double* a = control_poses + 7 * k;
+    cps[k].time = control_times[k];
+    cps[k].pose = Rigid3<double>{{a[0], a[1], a[2]}, {a[3], a[4], a[5], a[6]}};
+  }
+  std::vector<TimedCloud> clouds(n_clouds);
+  for (int c = 0; c < n_clouds; ++c) {
+    clouds[c].time = cloud_times[c];
+    clouds[c].origin = Vec3f{cloud_origins[3 * c], cloud_origins[3 * c + 1], cloud_origins[3 * c + 2]};
+    clouds[c].points = points + 4 * cloud_offsets[c];
+    clouds[c].n = static_cast<size_t>(cloud_offsets[c + 1] - cloud_offsets[c]);
+  }
+  const UnwarpedRangeData r = UnwarpAccumulatedRangeData(cps, clouds);
+  std::memcpy(xyz_out, r.returns.data(), r.returns.size() * sizeof(float));
+  origin_out[0] = r.origin.x; origin_out[1] = r.origin.y; origin_out[2] = r.origin.z;
+  return r.time_in_range ? 1 : 0;
+}
+
+// sensor::TransformRangeData / TransformTimedRangeData on the returns (range_data.cc:25-39): float Rigid3f.
+void hgo_transform_points(const float* tq, const float* in, size_t n, float* out) {
+  const Rigid3<float> T{{tq[0], tq[1], tq[2]}, {tq[3], tq[4], tq[5], tq[6]}};
+  TransformPointsF(T, in, n, out);
+}
+
 void hgo_quaternion_plus(const double* q, const double* delta, double* out) {
   QuaternionPlus(q, delta, out);
 }

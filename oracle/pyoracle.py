@@ -126,6 +126,9 @@ def lib():
     L.hgo_interp_tsd.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, vp]
     L.hgo_interpolate_transform.argtypes = [vp, vp, f64, vp]
     L.hgo_quaternion_plus.argtypes = [vp, vp, vp]
+    L.hgo_unwarp_range_data.restype = C.c_int
+    L.hgo_unwarp_range_data.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.hgo_transform_points.argtypes = [vp, vp, sz, vp]
     L.hgo_problem_create.restype = vp
     L.hgo_problem_destroy.argtypes = [vp]
     L.hgo_problem_add_pose.restype = C.c_int
@@ -298,6 +301,33 @@ def interpolate_transform(a, b, factor):
     b = np.ascontiguousarray(b, np.float64)
     out = np.empty(7, np.float64)
     lib().hgo_interpolate_transform(_ptr(a), _ptr(b), float(factor), _ptr(out))
+    return out
+
+
+def unwarp_range_data(control_times, control_poses, clouds):
+    """UnwarpAccumulatedRangeData (oltb.cc:1331-1379). clouds: [(time_ticks, origin[3], points[n, 4])].
+    Returns (xyz [n, 3] float32, origin [3] float32, time_in_range)."""
+    ct = np.ascontiguousarray(control_times, np.int64)
+    cp = np.ascontiguousarray(control_poses, np.float64).reshape(-1, 7)
+    times = np.ascontiguousarray([c[0] for c in clouds], np.int64)
+    origins = np.ascontiguousarray([c[1] for c in clouds], np.float32).reshape(-1, 3)
+    pts = [np.ascontiguousarray(c[2], np.float32).reshape(-1, 4) for c in clouds]
+    offs = np.zeros(len(clouds) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(p) for p in pts])
+    allp = np.ascontiguousarray(np.concatenate(pts, 0)) if pts else np.zeros((0, 4), np.float32)
+    xyz = np.empty((len(allp), 3), np.float32)
+    origin = np.zeros(3, np.float32)
+    ok = lib().hgo_unwarp_range_data(_ptr(ct), _ptr(cp), len(ct), _ptr(times), _ptr(offs), _ptr(origins),
+                                     len(clouds), _ptr(allp), _ptr(xyz), _ptr(origin))
+    return xyz, origin, bool(ok)
+
+
+def transform_points(tq, xyz):
+    """Rigid3f * point for every row (sensor::TransformRangeData, range_data.cc:25-39)."""
+    tq = np.ascontiguousarray(tq, np.float32)
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    lib().hgo_transform_points(_ptr(tq), _ptr(xyz), len(xyz), _ptr(out))
     return out
 
 

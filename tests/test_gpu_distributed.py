@@ -81,14 +81,15 @@ def test_gather_import_export_two_ranks_one_gpu():
     assert got["rank0"][3] == got["peer"][3]  # device-memory import of rank 1's level 0
 
 
-def _offline_batch(gpus, extra_env):
+def _offline_batch(gpus, extra_env, submaps=4, size=("--rings", "16", "--cols", "625", "--map-scans", "3"), steps=3,
+                   cpu=False):
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--total-submaps", "4",
-                        "--steps", "3", "--warmup", "1", "--rings", "16", "--cols", "625", "--map-scans", "3",
-                        "--max-blocks", str(1 << 15), "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--total-submaps", str(submaps),
+                        "--steps", str(steps), "--warmup", "1", *size,
+                        "--max-blocks", str(1 << 15)] + ([] if cpu else ["--no-cpu-baseline"]),
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -114,3 +115,26 @@ def test_offline_batch_command_two_ranks_equal_one_rank():
     assert two["config"]["gather_check"]["blocks"] == one["config"]["gather_check"]["blocks"]
     assert two["config"]["gather_check"]["voxels"] == one["config"]["gather_check"]["voxels"]
     assert abs(two["config"]["mean_pose_error_m"] - one["config"]["mean_pose_error_m"]) < 1e-9
+
+
+def test_offline_batch_command_full_size_two_ranks():
+    """The sharded command at BASELINE's scan size (100 000 returns, 50 x 2000): two rank processes on the
+    one GPU, one submap each (the single registration chain per rank -- what an 8-GPU run of 8 submaps
+    does), two timed steps, gather + import / export check; the same two submaps mapped by one rank
+    (batched registration, with the oracle replaying its submap 0 inside the run) end with the same
+    blocks and voxels."""
+    size = ("--rings", "50", "--cols", "2000", "--map-scans", "3")
+    two = _offline_batch(2, {"HG_RANKS_SHARE_GPU": "1"}, submaps=2, size=size, steps=2)
+    one = _offline_batch(1, {"HG_FORCE_DIST": "1", "HG_DIST_BACKEND": "gloo", "MASTER_PORT": str(_free_port())},
+                         submaps=2, size=size, steps=2)
+    for out, g in ((two, 2), (one, 1)):
+        assert out["n_gpus"] == g and out["value"] > 0
+        chk = out["config"]["gather_check"]
+        assert chk and chk["ok"] and chk["ranks"] == g and chk["levels"] == 3 * (2 // g)
+    assert two["config"]["gather_check"]["blocks"] == one["config"]["gather_check"]["blocks"]
+    assert two["config"]["gather_check"]["voxels"] == one["config"]["gather_check"]["voxels"]
+    assert abs(two["config"]["mean_pose_error_m"] - one["config"]["mean_pose_error_m"]) < 1e-9
+    # one rank, no process group: the in-run oracle replay of submap 0 at full size
+    solo = _offline_batch(1, {}, submaps=2, size=size, steps=2, cpu=True)
+    par = solo["parity"]
+    assert par and par["max_dt_m"] <= 1e-4 and par["max_dr_rad"] <= 1e-4 and par["same_iterations_and_termination"]
