@@ -17,6 +17,20 @@
 //                     and runs one step of the Ceres-1.13 trust-region LM state machine
 //                     (Jacobi scaling, LM diagonal, Cholesky, step quality, radius update,
 //                     tolerances) entirely on the device.
+//
+// This file is compiled TWICE (csrc/Makefile). The plain build holds every entry point of the C ABI and a
+// solver whose whole working set lives in LDS: windows of up to 10 control points, 32 TSDF blocks and 20
+// odometry / IMU blocks -- the sliding window of trajectory_builder_3d.lua's ct_window_horizon /
+// ct_window_rate, and the single-pose registration step. The second build (-DHG_BIG, hg_match_big.o) is the
+// same solver with larger limits -- 48 control points (432 columns), 160 TSDF blocks, 96 odometry / IMU
+// blocks: the ADAPTIVE / SYNCED_WITH_RANGE_DATA control-point sampling (oltb.cc:1162-1232) and the two
+// blocks per scan of use_multi_resolution_matching = false (oltb.cc:392-502) reach ~36 control points and
+// ~70 blocks -- whose band matrices, local systems and index tables live in device memory (they no longer
+// fit 160 KB of LDS) behind the same code. A problem that outgrows the plain limits is handed to the big
+// build by the entry points below (promote()); nothing changes for the problems that fit.
+#ifdef HG_BIG
+#include "hg_match_big_names.h"  // every global name this file defines gets a _big twin
+#endif
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -27,19 +41,50 @@
 #include <vector>
 
 #include "hg_internal.h"
+#ifndef HG_BIG
+#include "hg_match_big.h"  // the big build's entry points (same signatures on hg_problem_big)
+#endif
 
+#ifdef HG_BIG
+struct hg_problem;  // (= hg_problem_big here)
 namespace hg {
+const double* big_device_poses(hg_problem* p, int* stride);
+void big_orphan(hg_problem* p);
+}
+#define HG_CAP_NS_OPEN namespace hg { inline namespace big {
+#define HG_CAP_NS_CLOSE } }
+#else
+#define HG_CAP_NS_OPEN namespace hg {
+#define HG_CAP_NS_CLOSE }
+#endif
+
+HG_CAP_NS_OPEN
 
 constexpr int kMaxLevels = 4;
-constexpr int kMaxPoses = 10;           // ct_window_horizon / ct_window_rate ~ 9 control points
 constexpr int kState = 10;              // per control point: t(3) q(4) v(3)
-constexpr int kMaxCols = 9 * kMaxPoses;  // 6 pose + 3 velocity columns per control point
+#ifdef HG_BIG
+constexpr int kMaxPoses = 48;
+constexpr int kMaxSmall = 96;
+constexpr int kMaxBlocks = 160;
+#else
+constexpr int kMaxPoses = 10;           // ct_window_horizon / ct_window_rate ~ 9 control points
 constexpr int kMaxSmall = 20;           // odometry / IMU blocks
 constexpr int kMaxBlocks = 32;
+#endif
+constexpr int kMaxCols = 9 * kMaxPoses;  // 6 pose + 3 velocity columns per control point
 // The normal equations are stored as a symmetric band (lower part, row i holds columns
 // i-bw..i): blocks couple neighbouring control points only, so the system is block-tridiagonal
-// (SURVEY 8a16). n * (bw + 1) <= kHCap: a 90-column window with bw <= 35, or dense up to 56 x 56.
+// (SURVEY 8a16). n * (bw + 1) <= kHCap: a 90-column window with bw <= 35, or dense up to 56 x 56
+// (big build: 432 columns with bw <= 35).
+#ifdef HG_BIG
+constexpr int kHCap = kMaxCols * 36;
+#else
 constexpr int kHCap = 3240;
+#endif
+#ifndef HG_BIG
+// Limits of the big build (the plain build checks the caller's adds against them and promotes beyond its own).
+constexpr int kBigMaxPoses = 48, kBigMaxSmall = 96, kBigMaxBlocks = 160;
+#endif
 constexpr int kAcc = 36;  // 28 (upper triangle of 7x7) + 7 + 1
 constexpr int kAccU = 91;  // unwarped blocks: 78 (upper triangle of 12x12) + 12 + 1
 constexpr int kEvalThreads = 512;
@@ -138,7 +183,11 @@ struct LmHead {
 
 // Index tables of a problem's structure, built once per solve (k_lm MODE_PREPARE) and staged into LDS by
 // every LM step.
+#ifdef HG_BIG
+constexpr int kPairMax = 16;  // two blocks per scan (use_multi_resolution_matching = false) double the blocks of a pair
+#else
 constexpr int kPairMax = 8;
+#endif
 struct LmTables {
   int colcp[kMaxCols];    // global column -> control point * 16 + slot (0..5 pose, 6..8 velocity)
   int desc[kMaxBlocks + kMaxSmall];  // per block: active << 16 | (pose_b & 255) << 8 | pose_a (TSDF blocks, then small)
@@ -157,8 +206,9 @@ struct LmTables {
 // systems [TSDF blocks: kMaxBlocks x kLoc | small blocks: kMaxSmall x kSmallLoc], in block order; 0xFFFF =
 // none. An LM step then assembles the normal equations with independent loads straight from device
 // memory -- no staging of the local systems, no per-entry search through the blocks.
-constexpr int kGatherMax = 8;
+constexpr int kGatherMax = kPairMax;
 constexpr unsigned kGatherSmallBase = kMaxBlocks * (kAccU + 1);
+constexpr int kCrStride = 5 * 81 + 3 * 9 + 5;  // cyclic-reduction workspace per group (cholesky_solve_cr)
 struct LmState {
   LmHead h;
   double H[kHCap];   // J^T J at x (unscaled), band storage n x (bw + 1)
@@ -166,6 +216,10 @@ struct LmState {
   LmTables T;
   alignas(16) unsigned short gather_h[kHCap][kGatherMax];
   alignas(16) unsigned short gather_g[kMaxCols][kGatherMax];
+#ifdef HG_BIG
+  double A[kHCap + 1];                 // the scaled system / its factor (LDS in the plain build)
+  double cr_ws[kCrStride * kMaxPoses];  // cyclic-reduction workspace
+#endif
 };
 
 struct PinBox {
@@ -178,7 +232,9 @@ struct PinBox {
   unsigned up_idx[sizeof(LmHead) / 8];
 };
 
+#ifndef HG_BIG
 typedef __attribute__((address_space(3))) double lds_f64;
+#endif
 // band storage: entry (i, j), j <= i, i - j <= bw, of a symmetric matrix; W = bw + 1
 __device__ __host__ inline int band_index(int i, int j, int W) { return i * W + (W - 1) - (i - j); }
 __device__ inline double band_get(const double* B, int i, int j, int W) {
@@ -1257,6 +1313,27 @@ __device__ __forceinline__ void window_block_tail(const EvalBlock& eb, const dou
 
 constexpr int kLoc = kAccU + 1;   // per TSDF block: 78 (upper triangle of its 12 x 12 local system) + 12 + 1, padded
 
+#ifdef HG_BIG
+// Big build: the band matrices, the staged local systems and the index tables live in device memory
+// (LmState and its work area, L2-resident: 3 x 124 KB of bands alone); the head and the vectors stay in LDS.
+// A workgroup's own global stores are visible to its waves behind a barrier (one CU, one vector L1).
+struct LmShared {
+  LmHead h;
+  double* H;
+  double* Hc;
+  double* A;
+  double rhs[kMaxCols], y[kMaxCols];
+  double invd[kMaxCols];
+  double (*loc)[kLoc];
+  double (*small)[kSmallLoc];
+  LmTables* Tp;
+  double red[kMaxPoses + 8];
+  int solve_ok;
+};
+#define LM_T(S) (*(S).Tp)
+typedef double lds_f64;  // the block solvers take generic pointers here (A is in device memory)
+typedef int lds_i32;
+#else
 struct LmShared {
   LmHead h;
   double H[kHCap];
@@ -1267,9 +1344,12 @@ struct LmShared {
   double loc[kMaxBlocks][kLoc];         // local normal equations of the TSDF blocks (k_window_residuals tail)
   double small[kMaxSmall][kSmallLoc];   // the same of the odometry / IMU blocks (lower triangle, row-major)
   LmTables T;
-  double red[16];         // per-pose partial results
+  double red[kMaxPoses + 8];  // per-pose partial results (+ scalar slots)
   int solve_ok;           // wavefront 0's factorisation succeeded
 };
+#define LM_T(S) ((S).T)
+#endif
+constexpr int kRedScalar = kMaxPoses + 5;  // slot of S.red that carries a scalar between barriers
 
 __device__ inline double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -1486,7 +1566,9 @@ __device__ __attribute__((noinline)) bool cholesky_solve_wave(int n, int W, lds_
 // window: 30 us, 49 us with its substitutions); here a BLOCK costs ~2000 cycles. Groups smaller than 9
 // are padded with identity rows in registers. Entries outside the band are structural zeros: they are
 // read as 0 and never written (fill-in stays inside the band).
+#ifndef HG_BIG
 typedef __attribute__((address_space(3))) int lds_i32;
+#endif
 // Entry (i, j), j <= i, of the band matrix when `on`, else 0 -- as an unconditional load from an address
 // that is always valid plus a select, so that a run of reads stays straight-line code with all of its
 // LDS loads in flight (as conditional loads every entry became a branch with its own wait).
@@ -1811,7 +1893,7 @@ __device__ __attribute__((noinline)) bool cholesky_solve_btd_full(int W, lds_f64
 // then the levels are unwound: x_p = L_p^-T (y_p - X_l^T x_l - X_r^T x_r). Same factorisation up to the
 // elimination order (a symmetric permutation of the system), hence the same solution to rounding.
 // Workspace: dense blocks in LDS (`ws`, kCrStride doubles per group).
-constexpr int kCrStride = 5 * 81 + 3 * 9 + 5;  // D/L, E, Xl, Xr, fill scratch | b/y, x, inv
+// (kCrStride = 5 * 81 + 3 * 9 + 5: D/L, E, Xl, Xr, fill scratch | b/y, x, inv)
 template <int MB>
 __device__ __forceinline__ bool cholesky_solve_cr(int W, const double* A, const double* b, double* x, double* ws,
                                                   int groups, int* ok_flag) {
@@ -2171,8 +2253,14 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
     const bool use_cr = h.btd_groups >= 3 && (h.btd_uniform == 9 || h.btd_uniform == 6) && h.btd_cr != 0 &&
                         (h.btd_groups + 1) / 2 <= static_cast<int>(blockDim.x) / kWave;
     if (use_cr) {
+#ifdef HG_BIG
+      double* ws = S.small ? nullptr : nullptr;
+      ws = S.A + (kHCap + 1);  // LmState::cr_ws follows A
+      static_assert(offsetof(LmState, cr_ws) == offsetof(LmState, A) + sizeof(double) * (kHCap + 1), "cr_ws behind A");
+#else
       double* ws = &S.loc[0][0];  // (the local systems were consumed by the assembly)
       static_assert(sizeof(S.loc) + sizeof(S.small) >= sizeof(double) * kCrStride * kMaxPoses, "cyclic-reduction workspace");
+#endif
       if (h.btd_uniform == 9) cholesky_solve_cr<9>(W, S.A, S.rhs, h.step, ws, h.btd_groups, &S.solve_ok);
       else cholesky_solve_cr<6>(W, S.A, S.rhs, h.step, ws, h.btd_groups, &S.solve_ok);
     } else if (tid < kLmThreads) {
@@ -2234,10 +2322,10 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
         double part = 0.0;
         for (int a = tid; a < n; a += kLmThreads) part += S.y[a];
         const double m = -wave_sum(part);
-        if (tid == 0) S.red[15] = m;
+        if (tid == 0) S.red[kRedScalar] = m;
       }
       __syncthreads();
-      mcc = S.red[15];
+      mcc = S.red[kRedScalar];
       valid = mcc > 0.0;
     }
     __syncthreads();
@@ -2293,18 +2381,18 @@ __device__ __forceinline__ void assemble(LmShared& S) {
   const int nb = h.num_blocks, ns = h.num_small;
   int a = tid / W, c = tid - a * W;
   const int da = nthreads / W, dc = nthreads - da * W;
-  const bool by_pairs = S.T.pair_overflow == 0;
+  const bool by_pairs = LM_T(S).pair_overflow == 0;
   for (int idx = tid; idx < n * W; idx += nthreads) {
     const int b = a - (W - 1) + c;  // entry (a, b), b <= a
     double v = 0.0;
     if (b >= 0 && by_pairs) {
       // the blocks that cover both columns' control points, from the pair's list
-      const int cpa = S.T.colcp[a], cpb = S.T.colcp[b];
+      const int cpa = LM_T(S).colcp[a], cpb = LM_T(S).colcp[b];
       const int p = cpa >> 4, q = cpb >> 4, sa = cpa & 15, sb = cpb & 15;
       const bool sw = p < q;  // the list is kept for (larger, smaller) control point
       const int hi_p = sw ? q : p, lo_p = sw ? p : q;
-      const int* list = S.T.pair_list[hi_p][lo_p];
-      const int cnt = S.T.pair_count[hi_p][lo_p];
+      const int* list = LM_T(S).pair_list[hi_p][lo_p];
+      const int cnt = LM_T(S).pair_count[hi_p][lo_p];
       for (int k = 0; k < cnt; ++k) {
         const int e = list[k];
         const int blk = e & 255, small = (e >> 8) & 1;
@@ -2318,10 +2406,10 @@ __device__ __forceinline__ void assemble(LmShared& S) {
         v += on ? t : 0.0;
       }
     } else if (b >= 0) {
-      const int cpa = S.T.colcp[a], cpb = S.T.colcp[b];
+      const int cpa = LM_T(S).colcp[a], cpb = LM_T(S).colcp[b];
 #pragma unroll 4
       for (int k = 0; k < nb; ++k) {
-        const int d = S.T.desc[k];
+        const int d = LM_T(S).desc[k];
         const int pa = d & 255, pb = (d >> 8) & 255;
         const int l1 = local_col_tsdf(cpa, pa, pb), l2 = local_col_tsdf(cpb, pa, pb);
         const bool on = (d >> 16) && l1 >= 0 && l2 >= 0;
@@ -2331,7 +2419,7 @@ __device__ __forceinline__ void assemble(LmShared& S) {
       }
 #pragma unroll 4
       for (int k = 0; k < ns; ++k) {
-        const int d = S.T.desc[kMaxBlocks + k];
+        const int d = LM_T(S).desc[kMaxBlocks + k];
         const int pa = d & 255, pb = (d >> 8) & 255;
         const int l1 = local_col_small(cpa, pa, pb), l2 = local_col_small(cpb, pa, pb);
         const bool on = (d >> 16) && l1 >= 0 && l2 >= 0;
@@ -2346,11 +2434,11 @@ __device__ __forceinline__ void assemble(LmShared& S) {
     if (c >= W) { c -= W; ++a; }
   }
   for (int i = tid; i < n; i += nthreads) {
-    const int cp = S.T.colcp[i];
+    const int cp = LM_T(S).colcp[i];
     double v = 0.0;
 #pragma unroll 4
     for (int k = 0; k < nb; ++k) {
-      const int d = S.T.desc[k];
+      const int d = LM_T(S).desc[k];
       const int l = local_col_tsdf(cp, d & 255, (d >> 8) & 255);
       const bool on = (d >> 16) && l >= 0;
       const double t = S.loc[k][on ? 78 + l : 0];
@@ -2358,7 +2446,7 @@ __device__ __forceinline__ void assemble(LmShared& S) {
     }
 #pragma unroll 4
     for (int k = 0; k < ns; ++k) {
-      const int d = S.T.desc[kMaxBlocks + k];
+      const int d = LM_T(S).desc[kMaxBlocks + k];
       const int l = local_col_small(cp, d & 255, (d >> 8) & 255);
       const bool on = (d >> 16) && l >= 0;
       const double t = S.small[k][on ? kSmallTri + l : 0];
@@ -2394,7 +2482,7 @@ __device__ __forceinline__ void assemble_gathered(LmShared& S, const LmState* G,
     return on ? v : 0.0;
   };
   for (int idx = tid; idx < n * W; idx += nthreads) {
-    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    typedef unsigned short us8 __attribute__((ext_vector_type(kGatherMax)));
     const us8 at = *reinterpret_cast<const us8*>(&G->gather_h[idx][0]);
     double t[kGatherMax];
 #pragma unroll
@@ -2405,7 +2493,7 @@ __device__ __forceinline__ void assemble_gathered(LmShared& S, const LmState* G,
     S.Hc[idx] = v;
   }
   for (int i = tid; i < n; i += nthreads) {
-    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    typedef unsigned short us8 __attribute__((ext_vector_type(kGatherMax)));
     const us8 at = *reinterpret_cast<const us8*>(&G->gather_g[i][0]);
     double t[kGatherMax];
 #pragma unroll
@@ -2417,8 +2505,9 @@ __device__ __forceinline__ void assemble_gathered(LmShared& S, const LmState* G,
   }
   // cost: the blocks' r^T r, added in block order by thread 0 (loads by one thread each)
   const int nb = h.num_blocks, ns = h.num_small;
-  if (tid < nb) S.A[tid] = h.blocks[tid].active ? loc_sums[tid * kLoc + 90] : 0.0;  // (A is free until the next solve)
-  if (tid >= 64 && tid < 64 + ns) S.A[kMaxBlocks + tid - 64] = h.small[tid - 64].active ? small[(tid - 64) * kSmallLoc + kSmallTri + 18] : 0.0;
+  for (int k = tid; k < nb; k += nthreads) S.A[k] = h.blocks[k].active ? loc_sums[k * kLoc + 90] : 0.0;  // (A is free until the next solve)
+  for (int k = tid; k < ns; k += nthreads)
+    S.A[kMaxBlocks + k] = h.small[k].active ? small[k * kSmallLoc + kSmallTri + 18] : 0.0;
   __syncthreads();
   if (tid == 0) {
     double cost = 0.0;
@@ -2441,30 +2530,30 @@ __device__ __forceinline__ void prepare_all(const LmHead& h, BlockXform* xf) {
 }
 
 // Builds the index tables of the problem in LDS (head already there) and stores them for the LM steps.
-// Workgroup-wide, at least 192 + kMaxPoses^2 threads.
+// Workgroup-wide.
 __device__ __forceinline__ void build_tables(LmShared& S, LmState* G) {
   const LmHead& h = S.h;
   const int tid = threadIdx.x, nthreads = blockDim.x;
-  if (tid == 0) S.T.pair_overflow = 0;
+  if (tid == 0) LM_T(S).pair_overflow = 0;
   __syncthreads();
   if (tid < h.num_poses) {
     const int p = tid;
     if (!h.constant[p])
-      for (int k = 0; k < 6; ++k) S.T.colcp[h.col[p] + k] = p * 16 + k;
+      for (int k = 0; k < 6; ++k) LM_T(S).colcp[h.col[p] + k] = p * 16 + k;
     if (h.vfree[p])
-      for (int k = 0; k < 3; ++k) S.T.colcp[h.vcol[p] + k] = p * 16 + 6 + k;
+      for (int k = 0; k < 3; ++k) LM_T(S).colcp[h.vcol[p] + k] = p * 16 + 6 + k;
   }
-  if (tid >= 64 && tid < 64 + h.num_blocks) {
-    const BlockInfo& bi = h.blocks[tid - 64];
-    S.T.desc[tid - 64] = (bi.active ? 1 << 16 : 0) | ((bi.pose_b & 255) << 8) | (bi.pose_a & 255);
+  for (int b = tid; b < h.num_blocks; b += nthreads) {
+    const BlockInfo& bi = h.blocks[b];
+    LM_T(S).desc[b] = (bi.active ? 1 << 16 : 0) | ((bi.pose_b & 255) << 8) | (bi.pose_a & 255);
   }
-  if (tid >= 128 && tid < 128 + h.num_small) {
-    const SmallBlockDev& sb = h.small[tid - 128];
-    S.T.desc[kMaxBlocks + tid - 128] = (sb.active ? 1 << 16 : 0) | ((sb.b & 255) << 8) | (sb.a & 255);
+  for (int b = tid; b < h.num_small; b += nthreads) {
+    const SmallBlockDev& sb = h.small[b];
+    LM_T(S).desc[kMaxBlocks + b] = (sb.active ? 1 << 16 : 0) | ((sb.b & 255) << 8) | (sb.a & 255);
   }
-  if (tid >= 192 && tid < 192 + kMaxPoses * kMaxPoses) {
-    // thread (p, q), q <= p: the blocks covering both control points, in block order
-    const int p = (tid - 192) / kMaxPoses, q = (tid - 192) % kMaxPoses;
+  for (int pq = tid; pq < kMaxPoses * kMaxPoses; pq += nthreads) {
+    // (p, q), q <= p: the blocks covering both control points, in block order
+    const int p = pq / kMaxPoses, q = pq % kMaxPoses;
     if (q <= p && p < h.num_poses) {
       int cnt = 0;
       bool over = false;
@@ -2473,7 +2562,7 @@ __device__ __forceinline__ void build_tables(LmShared& S, LmState* G) {
         const bool hp = bi.pose_a == p || bi.pose_b == p, hq = bi.pose_a == q || bi.pose_b == q;
         if (!bi.active || !hp || !hq) continue;
         if (cnt < kPairMax)
-          S.T.pair_list[p][q][cnt] = k | ((bi.pose_a == p ? 0 : 6) << 12) | ((bi.pose_a == q ? 0 : 6) << 20);
+          LM_T(S).pair_list[p][q][cnt] = k | ((bi.pose_a == p ? 0 : 6) << 12) | ((bi.pose_a == q ? 0 : 6) << 20);
         else over = true;
         ++cnt;
       }
@@ -2482,34 +2571,36 @@ __device__ __forceinline__ void build_tables(LmShared& S, LmState* G) {
         const bool hp = sb.a == p || sb.b == p, hq = sb.a == q || sb.b == q;
         if (!sb.active || !hp || !hq) continue;
         if (cnt < kPairMax)
-          S.T.pair_list[p][q][cnt] = k | (1 << 8) | ((sb.a == p ? 0 : 9) << 12) | ((sb.a == q ? 0 : 9) << 20);
+          LM_T(S).pair_list[p][q][cnt] = k | (1 << 8) | ((sb.a == p ? 0 : 9) << 12) | ((sb.a == q ? 0 : 9) << 20);
         else over = true;
         ++cnt;
       }
-      S.T.pair_count[p][q] = cnt < kPairMax ? cnt : kPairMax;
-      if (over) S.T.pair_overflow = 1;
+      LM_T(S).pair_count[p][q] = cnt < kPairMax ? cnt : kPairMax;
+      if (over) LM_T(S).pair_overflow = 1;
     }
   }
   __syncthreads();
+#ifndef HG_BIG
   {
-    const int* src = reinterpret_cast<const int*>(&S.T);
+    const int* src = reinterpret_cast<const int*>(&LM_T(S));
     int* td = reinterpret_cast<int*>(&G->T);
     for (int i = tid; i < static_cast<int>(sizeof(LmTables) / sizeof(int)); i += nthreads) td[i] = src[i];
   }
-  if (S.T.pair_overflow) return;  // uniform: the step scans the blocks per entry instead
+#endif
+  if (LM_T(S).pair_overflow) return;  // uniform: the step scans the blocks per entry instead
   // gather lists from the pair lists (same contributions, same order as assemble's by-pairs loop)
   const int n = h.ncols, W = h.bw + 1;
   for (int idx = tid; idx < n * W; idx += nthreads) {
     const int a = idx / W, b = a - (W - 1) + (idx - a * W);
     int k_out = 0;
     if (b >= 0) {
-      const int cpa = S.T.colcp[a], cpb = S.T.colcp[b];
+      const int cpa = LM_T(S).colcp[a], cpb = LM_T(S).colcp[b];
       const int p = cpa >> 4, q = cpb >> 4, sa = cpa & 15, sb = cpb & 15;
       const bool sw = p < q;
       const int hi_p = sw ? q : p, lo_p = sw ? p : q;
-      const int cnt = S.T.pair_count[hi_p][lo_p];
+      const int cnt = LM_T(S).pair_count[hi_p][lo_p];
       for (int k = 0; k < cnt; ++k) {
-        const int e = S.T.pair_list[hi_p][lo_p][k];
+        const int e = LM_T(S).pair_list[hi_p][lo_p][k];
         const int blk = e & 255, small = (e >> 8) & 1;
         const int o_hi = (e >> 12) & 255, o_lo = (e >> 20) & 255;
         const int l1 = sa + (sw ? o_lo : o_hi), l2 = sb + (sw ? o_hi : o_lo);
@@ -2523,12 +2614,12 @@ __device__ __forceinline__ void build_tables(LmShared& S, LmState* G) {
     for (; k_out < kGatherMax; ++k_out) G->gather_h[idx][k_out] = 0xFFFFu;
   }
   for (int i = tid; i < n; i += nthreads) {
-    const int cp = S.T.colcp[i];
+    const int cp = LM_T(S).colcp[i];
     const int p = cp >> 4, sl = cp & 15;
-    const int cnt = S.T.pair_count[p][p];
+    const int cnt = LM_T(S).pair_count[p][p];
     int k_out = 0;
     for (int k = 0; k < cnt; ++k) {
-      const int e = S.T.pair_list[p][p][k];
+      const int e = LM_T(S).pair_list[p][p][k];
       const int blk = e & 255, small = (e >> 8) & 1, off = (e >> 12) & 255;
       if (!small && sl >= 6) continue;
       const unsigned at = small ? kGatherSmallBase + blk * kSmallLoc + kSmallTri + off + sl : blk * kLoc + 78 + off + sl;
@@ -2548,13 +2639,26 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
 #ifdef HG_LM_STAMPS
   const long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef HG_BIG
+  // the big build works on the matrices, local systems and tables where they are (device memory)
+  if (threadIdx.x == 0) {
+    S.H = G->H;
+    S.Hc = G->Hc;
+    S.A = G->A;
+    S.loc = reinterpret_cast<double (*)[kLoc]>(const_cast<double*>(loc_sums));
+    S.small = reinterpret_cast<double (*)[kSmallLoc]>(const_cast<SmallOut*>(small_out));
+    S.Tp = &G->T;
+  }
+  __syncthreads();
+#endif
   if (mode == MODE_PREPARE && host_up) {
     // zero-copy upload: scatter the non-zero words the host left in the mailbox
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&S.h);
-    unsigned long long val[5];
-    unsigned idx[5];
+    constexpr int kUp = static_cast<int>((sizeof(LmHead) / 8 + kLmBlock - 1) / kLmBlock);  // words per thread
+    unsigned long long val[kUp];
+    unsigned idx[kUp];
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {  // all host reads in flight together (5 * 256 >= words of the head)
+    for (int u = 0; u < kUp; ++u) {  // all host reads in flight together
       const unsigned w = threadIdx.x + u * blockDim.x;
       idx[u] = w < up_words ? host_up->up_idx[w] : 0xFFFFFFFFu;
       val[u] = w < up_words ? host_up->up_val[w] : 0ull;
@@ -2562,7 +2666,7 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
     for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = 0ull;
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 5; ++u)
+    for (int u = 0; u < kUp; ++u)
       if (idx[u] < sizeof(LmHead) / 8) dst[idx[u]] = val[u];
   } else {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
@@ -2593,12 +2697,15 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
   // H at x; the assembly gathers from device memory through the static lists, or -- more than kPairMax
   // blocks on a pair of control points -- stages the local systems and the tables and searches per entry
   const bool gathered = G->T.pair_overflow == 0;  // uniform
+#ifndef HG_BIG
   if (h.phase != PHASE_INIT)
     for (int i = tid; i < nW; i += nthreads) S.H[i] = G->H[i];
+#endif
   if (gathered) {
     HG_STAMP(S, 1);
     assemble_gathered(S, G, loc_sums, small_out);
   } else {
+#ifndef HG_BIG
     double* dst = &S.loc[0][0];
     for (int i = tid; i < h.num_blocks * kLoc; i += nthreads) dst[i] = loc_sums[i];
     {
@@ -2609,16 +2716,19 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
     }
     {
       const int* src = reinterpret_cast<const int*>(&G->T);
-      int* td = reinterpret_cast<int*>(&S.T);
+      int* td = reinterpret_cast<int*>(&LM_T(S));
       for (int i = tid; i < static_cast<int>(sizeof(LmTables) / sizeof(int)); i += nthreads) td[i] = src[i];
     }
     __syncthreads();
+#endif
     HG_STAMP(S, 1);
     assemble(S);
   }
   HG_STAMP(S, 2);
   if (mode == MODE_ASSEMBLE) {
+#ifndef HG_BIG
     for (int i = tid; i < nW; i += nthreads) G->Hc[i] = S.Hc[i];
+#endif
     for (int i = tid; i < n; i += nthreads) G->h.gc[i] = h.gc[i];
     if (tid == 0) G->h.cand_cost = h.cand_cost;
     return;
@@ -2726,8 +2836,12 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&G->h);
     for (unsigned i = tid; i < sizeof(LmHead) / 8; i += nthreads) dst[i] = src[i];
   }
+#ifndef HG_BIG
   if (h_changed)
     for (int i = tid; i < nW; i += nthreads) G->H[i] = S.H[i];
+#else
+  (void)h_changed;
+#endif
   if (h.done && h.box) {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&h.box->h);
@@ -2768,8 +2882,7 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   const int stripes0 = static_cast<int>(blockDim.x) / kAcc;
   LmHead& sh = *reinterpret_cast<LmHead*>(scratch + (stripes0 + 1) * kAcc);
   double* sH = reinterpret_cast<double*>(&sh + 1);
-  constexpr int kUp = 3;  // mailbox words per thread (512-thread workgroups)
-  static_assert(sizeof(LmHead) / 8 <= kUp * kEvalThreads, "head upload");
+  constexpr int kUp = static_cast<int>((sizeof(LmHead) / 8 + kEvalThreads - 1) / kEvalThreads);  // mailbox words per thread: 3
   unsigned long long up_val[FIRST ? kUp : 1];
   unsigned up_idx[FIRST ? kUp : 1];
   if (FIRST) {
@@ -3492,8 +3605,12 @@ __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k
   int b;
   {
     const int lane = threadIdx.x % kWave;
-    const bool le = lane < num_eval && blocks[lane].wg_begin <= blockIdx.x;
-    b = __builtin_amdgcn_readfirstlane(__popcll(__ballot(le)) - 1);  // wg_begin ascends; entry 0 starts at 0
+    int count = 0;
+    for (int base = 0; base < num_eval; base += kWave) {  // (one round in the plain build: kMaxBlocks <= 64)
+      const bool le = base + lane < num_eval && blocks[base + lane].wg_begin <= blockIdx.x;
+      count += __popcll(__ballot(le));
+    }
+    b = __builtin_amdgcn_readfirstlane(count - 1);  // wg_begin ascends; entry 0 starts at 0
   }
   const EvalBlock& eb = blocks[b];
   const unsigned wg = blockIdx.x - eb.wg_begin;
@@ -3513,12 +3630,11 @@ __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, con
                                                  const SmallOut* small_out, int mode,
                                                  const PinBox* host_up, unsigned up_words) {
   __shared__ LmShared S;
-  static_assert(5 * kLmBlock >= sizeof(LmHead) / 8, "upload words per thread");
   if (mode == MODE_STEP && G->h.done) return;
   lm_step(S, G, xf, partials, small_out, mode, host_up, up_words);
 }
 
-}  // namespace hg
+HG_CAP_NS_CLOSE
 
 using namespace hg;
 
@@ -3564,6 +3680,13 @@ struct hg_problem {
   unsigned up_words = 0;
   bool prof_grouped = false;  // the residual launches of this solve share one event pair
   int single_threads = 0;      // > 0: single-pose registration step with this workgroup size
+#ifndef HG_BIG
+  // A problem beyond the plain build's limits (kMaxPoses / kMaxBlocks / kMaxSmall, band capacity) is
+  // mirrored into a problem of the big build, which then evaluates and solves it (promote()). The vectors
+  // above stay the record of what the caller added; poses and velocities are copied back after a solve.
+  hg_problem_big* big = nullptr;
+  bool promoted = false;
+#endif
   LmState h_state;            // host copy
 };
 
@@ -3601,10 +3724,12 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   // register-resident LM tail: one free pose without velocity, one per-scan block, nothing else
   // (bw and the activity of the block are checked below, once they are known)
   p->single_threads = 0;
+#ifndef HG_BIG  // (a problem of that shape never reaches the big build)
   if (opts && S.num_poses == 1 && !p->constant[0] && !p->vfree[0] && S.num_blocks == 1 && p->small.empty() &&
       !p->blocks[0].d_factor && p->blocks[0].pose_b < 0 && p->blocks[0].n > 0 && std::getenv("HG_LM_GENERAL") == nullptr) {
     p->single_threads = kEvalThreads;  // 256-thread workgroups were measured 19 % slower per step
   }
+#endif
   // Window pass: a workgroup walks `tiles` tiles of 256 returns, chosen so that all workgroups of an
   // iteration are resident at once (one round on the chip, no tail round).
   p->tiles = 1;
@@ -3862,7 +3987,55 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
 
 }  // namespace
 
-void hg::orphan_problem(hg_problem* p) { p->ctx = nullptr; }
+#ifdef HG_BIG
+void hg::big_orphan(hg_problem* p) { p->ctx = nullptr; }
+const double* hg::big_device_poses(hg_problem* p, int* stride) {
+  *stride = kState;
+  return (p->h_state.h.ncols == 0) ? nullptr : &p->d_state->h.x[0][0];
+}
+#else
+void hg::orphan_problem(hg_problem* p) {
+  p->ctx = nullptr;
+  if (p->big) big_orphan(p->big);
+}
+
+namespace {
+// Mirrors the problem as recorded so far into its big twin (created on first use, kept across resets).
+// TSDF blocks are handed over as device pointers: the uploads of host-memory blocks stay owned here.
+int promote(hg_problem* p) {
+  if (p->promoted) return HG_OK;
+  if (!p->ctx) return HG_ERR_INVALID;
+  int rc;
+  if (!p->big && (rc = hg_problem_create_big(p->ctx, &p->big)) != HG_OK) return rc;
+  if ((rc = hg_problem_reset_big(p->big)) != HG_OK) return rc;
+  for (size_t i = 0; i < p->poses.size(); ++i) {
+    if ((rc = hg_problem_add_pose_big(p->big, p->poses[i].data(), p->constant[i])) < 0) return rc;
+    if ((rc = hg_problem_set_velocity_big(p->big, static_cast<int>(i), p->velocity[i].data(), p->vfree[i] ? 0 : 1)) != HG_OK) return rc;
+  }
+  for (const SmallBlockDev& sb : p->small) {
+    rc = sb.type == 1 ? hg_problem_add_odometry_block_big(p->big, sb.a, sb.b, sb.w[0], sb.w[1], sb.delta)
+                      : hg_problem_add_imu_block_big(p->big, sb.a, sb.b, sb.w[0], sb.w[1], sb.w[2], sb.dt, sb.delta + 3);
+    if (rc < 0) return rc;
+  }
+  for (const hg_problem::Block& b : p->blocks) {
+    rc = b.d_factor ? hg_problem_add_unwarped_block_big(p->big, b.d_xyz, b.d_factor, b.n, HG_DEVICE, b.pyramid.data(),
+                                                        static_cast<int>(b.pyramid.size()), b.multi_res, b.scaling, b.pose_a, b.pose_b)
+                    : hg_problem_add_block_big(p->big, b.d_xyz, b.n, HG_DEVICE, b.pyramid.data(),
+                                               static_cast<int>(b.pyramid.size()), b.multi_res, b.scaling, b.pose_a, b.pose_b, b.factor);
+    if (rc < 0) return rc;
+  }
+  p->promoted = true;
+  return HG_OK;
+}
+// The problem's poses and velocities as the big twin holds them (after its fetch).
+void pull_from_big(hg_problem* p) {
+  for (size_t i = 0; i < p->poses.size(); ++i) {
+    (void)hg_problem_get_pose_big(p->big, static_cast<int>(i), p->poses[i].data());
+    (void)hg_problem_get_velocity_big(p->big, static_cast<int>(i), p->velocity[i].data());
+  }
+}
+}  // namespace
+#endif
 
 extern "C" {
 
@@ -3888,10 +4061,12 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
   HG_HIP_CHECK(hipSetDevice(ctx->device));
   hg_problem* p = new hg_problem();
   p->ctx = ctx;
-  ctx->live_problems.push_back(p);
+#ifndef HG_BIG
+  ctx->live_problems.push_back(p);  // (a big twin belongs to its plain problem, which orphans it)
+#endif
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_state), sizeof(LmState));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_xf), sizeof(BlockXform) * kMaxBlocks);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), 256);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_ticket), sizeof(unsigned) * (64 + kMaxBlocks));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_small), sizeof(SmallOut) * kMaxSmall);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_loc), sizeof(double) * kLoc * kMaxBlocks);
   if (e == hipSuccess) e = hipMemset(p->d_loc, 0, sizeof(double) * kLoc * kMaxBlocks);
@@ -3906,7 +4081,7 @@ int hg_problem_create(hg_ctx* ctx, hg_problem** out) {
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_pv), sizeof(PyramidView) * kMaxBlocks);
   if (e == hipSuccess) std::memset(p->h_pv, 0, sizeof(PyramidView) * kMaxBlocks);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&p->h_eval), sizeof(EvalBlock) * kMaxBlocks);
-  if (e == hipSuccess) e = hipMemset(p->d_ticket, 0, 256);
+  if (e == hipSuccess) e = hipMemset(p->d_ticket, 0, sizeof(unsigned) * (64 + kMaxBlocks));
   if (e != hipSuccess) {
     set_last_error(std::string("hipMalloc problem: ") + hipGetErrorString(e));
     hg_problem_destroy(p);
@@ -3921,9 +4096,14 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->ctx) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+#ifndef HG_BIG
     auto& live = p->ctx->live_problems;
     live.erase(std::remove(live.begin(), live.end(), p), live.end());
+#endif
   }
+#ifndef HG_BIG
+  if (p->big) (void)hg_problem_destroy_big(p->big);
+#endif
   for (auto& b : p->blocks)
     if (b.owned) (void)hipFree(b.owned);
   if (p->d_state) (void)hipFree(p->d_state);
@@ -3955,13 +4135,22 @@ int hg_problem_reset(hg_problem* p) {
   p->velocity.clear();
   p->vfree.clear();
   p->small.clear();
+#ifndef HG_BIG
+  if (p->promoted) (void)hg_problem_reset_big(p->big);
+  p->promoted = false;
+#endif
   return HG_OK;
 }
 
 int hg_problem_add_pose(hg_problem* p, const double tq[7], int constant) {
   if (!p || !tq) return HG_ERR_INVALID;
-  if (p->poses.size() >= static_cast<size_t>(kMaxPoses)) {
-    set_last_error("too many pose blocks");
+#ifdef HG_BIG
+  constexpr size_t limit = kMaxPoses;
+#else
+  constexpr size_t limit = kBigMaxPoses;
+#endif
+  if (p->poses.size() >= limit) {
+    set_last_error("too many pose blocks (limit " + std::to_string(limit) + ")");
     return HG_ERR_CAPACITY;
   }
   std::array<double, 7> a;
@@ -3970,12 +4159,24 @@ int hg_problem_add_pose(hg_problem* p, const double tq[7], int constant) {
   p->constant.push_back(constant ? 1 : 0);
   p->velocity.push_back({{0.0, 0.0, 0.0}});
   p->vfree.push_back(0);
+#ifndef HG_BIG
+  if (p->promoted) {
+    const int rc = hg_problem_add_pose_big(p->big, tq, constant);
+    if (rc < 0) return rc;
+  } else if (p->poses.size() > static_cast<size_t>(kMaxPoses)) {
+    const int rc = promote(p);
+    if (rc != HG_OK) return rc;
+  }
+#endif
   return static_cast<int>(p->poses.size()) - 1;
 }
 
 int hg_problem_set_pose(hg_problem* p, int index, const double tq[7]) {
   if (!p || !tq || index < 0 || index >= static_cast<int>(p->poses.size())) return HG_ERR_INVALID;
   std::memcpy(p->poses[index].data(), tq, sizeof(double) * 7);
+#ifndef HG_BIG
+  if (p->promoted) return hg_problem_set_pose_big(p->big, index, tq);
+#endif
   return HG_OK;
 }
 
@@ -3989,6 +4190,9 @@ int hg_problem_set_velocity(hg_problem* p, int index, const double v[3], int con
   if (!p || !v || index < 0 || index >= static_cast<int>(p->poses.size())) return HG_ERR_INVALID;
   std::memcpy(p->velocity[index].data(), v, sizeof(double) * 3);
   p->vfree[index] = constant ? 0 : 1;
+#ifndef HG_BIG
+  if (p->promoted) return hg_problem_set_velocity_big(p->big, index, v, constant);
+#endif
   return HG_OK;
 }
 
@@ -4001,11 +4205,26 @@ int hg_problem_get_velocity(hg_problem* p, int index, double v[3]) {
 static int add_small(hg_problem* p, const SmallBlockDev& sb) {
   const int np = static_cast<int>(p->poses.size());
   if (sb.a < 0 || sb.a >= np || sb.b < 0 || sb.b >= np || sb.a == sb.b) return HG_ERR_INVALID;
-  if (p->small.size() >= static_cast<size_t>(kMaxSmall)) {
-    set_last_error("too many odometry / IMU blocks");
+#ifdef HG_BIG
+  constexpr size_t limit = kMaxSmall;
+#else
+  constexpr size_t limit = kBigMaxSmall;
+#endif
+  if (p->small.size() >= limit) {
+    set_last_error("too many odometry / IMU blocks (limit " + std::to_string(limit) + ")");
     return HG_ERR_CAPACITY;
   }
   p->small.push_back(sb);
+#ifndef HG_BIG
+  if (p->promoted) {
+    const int rc = sb.type == 1 ? hg_problem_add_odometry_block_big(p->big, sb.a, sb.b, sb.w[0], sb.w[1], sb.delta)
+                                : hg_problem_add_imu_block_big(p->big, sb.a, sb.b, sb.w[0], sb.w[1], sb.w[2], sb.dt, sb.delta + 3);
+    if (rc < 0) return rc;
+  } else if (p->small.size() > static_cast<size_t>(kMaxSmall)) {
+    const int rc = promote(p);
+    if (rc != HG_OK) return rc;
+  }
+#endif
   return static_cast<int>(p->small.size()) - 1;
 }
 
@@ -4039,8 +4258,13 @@ static int add_block_impl(hg_problem* p, const float* xyz, const double* factors
   if (!p || !pyramid || levels < 1 || levels > kMaxLevels || (n && !xyz)) return HG_ERR_INVALID;
   const int np = static_cast<int>(p->poses.size());
   if (pose_a < 0 || pose_a >= np || pose_b >= np) return HG_ERR_INVALID;
-  if (p->blocks.size() >= static_cast<size_t>(kMaxBlocks)) {
-    set_last_error("too many residual blocks");
+#ifdef HG_BIG
+  constexpr size_t block_limit = kMaxBlocks;
+#else
+  constexpr size_t block_limit = kBigMaxBlocks;
+#endif
+  if (p->blocks.size() >= block_limit) {
+    set_last_error("too many residual blocks (limit " + std::to_string(block_limit) + ")");
     return HG_ERR_CAPACITY;
   }
   if (n > 0xFFFFFFFFull) return HG_ERR_INVALID;
@@ -4083,6 +4307,19 @@ static int add_block_impl(hg_problem* p, const float* xyz, const double* factors
     b.d_factor = factors;
   }
   p->blocks.push_back(b);
+#ifndef HG_BIG
+  if (p->promoted) {
+    const hg_problem::Block& nb = p->blocks.back();
+    const int rc = nb.d_factor ? hg_problem_add_unwarped_block_big(p->big, nb.d_xyz, nb.d_factor, nb.n, HG_DEVICE, nb.pyramid.data(),
+                                                                   levels, nb.multi_res, nb.scaling, nb.pose_a, nb.pose_b)
+                               : hg_problem_add_block_big(p->big, nb.d_xyz, nb.n, HG_DEVICE, nb.pyramid.data(), levels,
+                                                          nb.multi_res, nb.scaling, nb.pose_a, nb.pose_b, nb.factor);
+    if (rc < 0) return rc;
+  } else if (p->blocks.size() > static_cast<size_t>(kMaxBlocks)) {
+    const int rc = promote(p);
+    if (rc != HG_OK) return rc;
+  }
+#endif
   return static_cast<int>(p->blocks.size()) - 1;
 }
 
@@ -4129,10 +4366,17 @@ int hg_problem_num_columns(hg_problem* p) {
 }
 
 int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* gradient, double* JtJ) {
-  if (!p) return HG_ERR_INVALID;
+  if (!p || !p->ctx) return HG_ERR_INVALID;
   hipStream_t s = p->ctx->stream;
   HG_HIP_CHECK(hipSetDevice(p->ctx->device));
+#ifndef HG_BIG
+  if (p->promoted) return hg_problem_evaluate_big(p->big, cost, residuals, gradient, JtJ);
+#endif
   int rc = upload_state(p, nullptr);
+#ifndef HG_BIG
+  if (rc == HG_ERR_CAPACITY && promote(p) == HG_OK)  // the band outgrew the LDS-resident solver
+    return hg_problem_evaluate_big(p->big, cost, residuals, gradient, JtJ);
+#endif
   if (rc != HG_OK) return rc;
   const int nres = hg_problem_num_residuals(p);
   double* d_res = nullptr;
@@ -4165,10 +4409,17 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
 }
 
 int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
-  if (!p) return HG_ERR_INVALID;
+  if (!p || !p->ctx) return HG_ERR_INVALID;
   hipStream_t s = p->ctx->stream;
   HG_HIP_CHECK(hipSetDevice(p->ctx->device));
+#ifndef HG_BIG
+  if (p->promoted) return hg_problem_solve_async_big(p->big, opts);
+#endif
   int rc = upload_state(p, opts);
+#ifndef HG_BIG
+  if (rc == HG_ERR_CAPACITY && promote(p) == HG_OK)  // the band outgrew the LDS-resident solver
+    return hg_problem_solve_async_big(p->big, opts);
+#endif
   if (rc != HG_OK) return rc;
   const LmHead& S0 = p->h_state.h;
   p->solve_pending = true;
@@ -4197,6 +4448,13 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
 }
 
 int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
+#ifndef HG_BIG
+  if (p && p->promoted) {
+    const int rc = hg_problem_fetch_big(p->big, summary);
+    if (rc == HG_OK) pull_from_big(p);
+    return rc;
+  }
+#endif
   if (!p || !p->solve_pending) return HG_ERR_INVALID;
   hipStream_t s = p->ctx->stream;
   p->solve_pending = false;
@@ -4303,6 +4561,16 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
 }  // extern "C"
 
 namespace {
+// Where a solve leaves the control poses in device memory (pose k at base + k * stride doubles), or nullptr
+// for a problem without free parameters (nothing is launched: its poses are the host's).
+const double* device_poses(hg_problem* p, int* stride) {
+#ifndef HG_BIG
+  if (p->promoted) return big_device_poses(p->big, stride);
+#endif
+  *stride = kState;
+  return (p->h_state.h.ncols == 0) ? nullptr : &p->d_state->h.x[0][0];
+}
+
 // The gather rate of the residual pass saturates well below this; larger lists go through in groups.
 constexpr int kBatchGroup = 64;
 
@@ -4321,7 +4589,20 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   int rc = HG_OK;
   for (int i = 0; i < count && rc == HG_OK; ++i) {
     hg_problem* p = problems[i];
+#ifndef HG_BIG
+    if (p->promoted) {  // a big problem is solved on its own
+      batchable = false;
+      continue;
+    }
+#endif
     rc = upload_state(p, opts);
+#ifndef HG_BIG
+    if (rc == HG_ERR_CAPACITY) {  // ditto (hg_problem_solve promotes it)
+      rc = HG_OK;
+      batchable = false;
+      continue;
+    }
+#endif
     if (rc != HG_OK) break;
     const LmHead& S = p->h_state.h;
     if (!(p->single_threads && S.ncols == 6 && S.bw == 5 && S.num_blocks == 1 && S.num_small == 0 &&
@@ -4639,9 +4920,10 @@ int hg_register_scan_unwarped(hg_problem* p, const hg_solver_opts* sopts, hg_gri
   // parameters launches nothing: its poses are the host's.
   std::vector<double> guess(static_cast<size_t>(n_control) * 7);
   for (int k = 0; k < n_control; ++k) std::memcpy(&guess[7 * k], p->poses[pose_index[k]].data(), sizeof(double) * 7);
-  const double* d_poses = (p->h_state.h.ncols == 0) ? nullptr : &p->d_state->h.x[0][0];
+  int stride = kState;
+  const double* d_poses = device_poses(p, &stride);
   rc = unwarp_insert(grids, iopts, levels, points, n, width, memspace, clouds, n_clouds, guess.data(), d_poses,
-                     d_poses ? pose_index : nullptr, kState, control_times, n_control, pose_tq, insert_mode, nullptr);
+                     d_poses ? pose_index : nullptr, stride, control_times, n_control, pose_tq, insert_mode, nullptr);
   const int rc2 = hg_problem_fetch(p, summary);
   if (rc == HG_OK) rc = rc2;
   if (rc == HG_OK && poses_out)
@@ -4681,7 +4963,9 @@ static int register_scan_step(hg_problem* p, const hg_solver_opts* sopts, int po
   // guess, which sizes the key window
   float approx[7];
   for (int k = 0; k < 7; ++k) approx[k] = static_cast<float>(p->poses[pose_index][k]);
-  const double* d_pose = (p->h_state.h.ncols == 0) ? nullptr : &p->d_state->h.x[pose_index][0];
+  int stride = kState;
+  const double* d_pose = device_poses(p, &stride);
+  if (d_pose) d_pose += static_cast<size_t>(pose_index) * stride;
   const uint64_t offsets[2] = {0, n};
   rc = pyramid_insert_impl(grids, iopts, levels, origin, xyz, offsets, 1, width, approx, d_pose,
                            insert_mode, memspace, nullptr);

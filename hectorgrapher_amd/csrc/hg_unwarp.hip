@@ -37,6 +37,9 @@ struct UnwarpCloudDev {
   float pad;
 };
 
+constexpr int kUnwarpInlineControl = 48;  // control points / clouds that travel as kernel arguments
+constexpr int kUnwarpInlineClouds = 4;
+
 struct UnwarpParams {
   const float* points;        // n x 4: x y z time[s relative to its cloud]
   unsigned long long n;
@@ -55,6 +58,18 @@ struct UnwarpParams {
   float* origin_out;          // 3 floats
   unsigned* first_valid;      // index of the first non-NaN return (initialised to 0xFFFFFFFF)
   uint32_t* flag_words[4];    // counters[1] of the grids the cloud goes to (sticky error flags) or nullptr
+};
+
+// The small tables of a call as kernel arguments (the usual case: a window's control points and one or two
+// clouds): no upload, no staging buffer whose reuse would have to be fenced. The kernels read them with
+// per-lane indices straight from the kernel-argument segment.
+struct UnwarpInline {
+  long long times[kUnwarpInlineControl];
+  int pose_index[kUnwarpInlineControl];
+  UnwarpCloudDev clouds[kUnwarpInlineClouds];
+};
+struct UnwarpInlinePoses {
+  double poses[kUnwarpInlineControl * 7];
 };
 
 struct RigidD {
@@ -163,7 +178,7 @@ __device__ inline int unwarp_find_cloud(const UnwarpParams& P, unsigned long lon
   return c;
 }
 
-__global__ __launch_bounds__(256) void k_unwarp_points(UnwarpParams P) {
+__device__ __forceinline__ void unwarp_points_body(const UnwarpParams& P) {
   const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool in = i < P.n;
   bool valid = false, outside = false;
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(256) void k_unwarp_points(UnwarpParams P) {
 
 // accumulated_range_data_in_tracking.origin = transform * front().origin at the first unwarped return
 // (:1370-1374); Vector3f::Zero() when every return is NaN (:1298-1299).
-__global__ void k_unwarp_origin(UnwarpParams P) {
+__device__ __forceinline__ void unwarp_origin_body(const UnwarpParams& P) {
   const unsigned i = *P.first_valid;
   float ox = 0.f, oy = 0.f, oz = 0.f;
   if (i != 0xFFFFFFFFu) {
@@ -211,6 +226,40 @@ __global__ void k_unwarp_origin(UnwarpParams P) {
   P.origin_out[0] = ox;
   P.origin_out[1] = oy;
   P.origin_out[2] = oz;
+}
+
+// Tables in device memory (more control points or clouds than the inline form holds).
+__global__ __launch_bounds__(256) void k_unwarp_points(UnwarpParams P) { unwarp_points_body(P); }
+__global__ void k_unwarp_origin(UnwarpParams P) { unwarp_origin_body(P); }
+
+// Tables as kernel arguments; the control poses in device memory (what a solve left there) ...
+__global__ __launch_bounds__(256) void k_unwarp_points_inline(UnwarpParams P, const UnwarpInline T) {
+  P.times = T.times;
+  P.pose_index = P.pose_index ? T.pose_index : nullptr;
+  P.clouds = T.clouds;
+  unwarp_points_body(P);
+}
+__global__ void k_unwarp_origin_inline(UnwarpParams P, const UnwarpInline T) {
+  P.times = T.times;
+  P.pose_index = P.pose_index ? T.pose_index : nullptr;
+  P.clouds = T.clouds;
+  unwarp_origin_body(P);
+}
+// ... or as kernel arguments as well (poses given by the host).
+__global__ __launch_bounds__(256) void k_unwarp_points_inline_poses(UnwarpParams P, const UnwarpInline T,
+                                                                    const UnwarpInlinePoses X) {
+  P.times = T.times;
+  P.pose_index = nullptr;
+  P.clouds = T.clouds;
+  P.poses = X.poses;
+  unwarp_points_body(P);
+}
+__global__ void k_unwarp_origin_inline_poses(UnwarpParams P, const UnwarpInline T, const UnwarpInlinePoses X) {
+  P.times = T.times;
+  P.pose_index = nullptr;
+  P.clouds = T.clouds;
+  P.poses = X.poses;
+  unwarp_origin_body(P);
 }
 
 }  // namespace hg
@@ -248,52 +297,69 @@ int hg::unwarp_enqueue(hg_ctx* c, hg_grid* const* grids, int levels, const float
   }
   hipStream_t s = c->stream;
   HG_HIP_CHECK(hipSetDevice(c->device));
-  // device layout of the small tables: [clouds | times | pose indices | poses | first_valid | origin]
-  const size_t cloud_bytes = sizeof(UnwarpCloudDev) * static_cast<size_t>(n_clouds);
-  const size_t time_bytes = sizeof(long long) * static_cast<size_t>(n_control);
-  const size_t index_bytes = (sizeof(int) * static_cast<size_t>(n_control) + 7u) & ~size_t(7);
-  const size_t pose_bytes = d_poses ? 0 : sizeof(double) * 7u * static_cast<size_t>(n_control);
-  const size_t table_bytes = cloud_bytes + time_bytes + index_bytes + pose_bytes;
   int rc;
-  if ((rc = c->ws_unwarp_tab.reserve(table_bytes + 64)) != HG_OK) return rc;
   if ((rc = c->ws_unwarp.reserve(n * 3 * sizeof(float))) != HG_OK) return rc;
-  // the staging vector must outlive the copy: pageable hipMemcpyAsync stages before it returns
-  std::vector<unsigned char> host(table_bytes + 64, 0);
-  UnwarpCloudDev* hc = reinterpret_cast<UnwarpCloudDev*>(host.data());
-  for (int k = 0; k < n_clouds; ++k) {
-    hc[k].time = clouds[k].time;
-    hc[k].begin = clouds[k].begin;
-    hc[k].count = clouds[k].count;
-    std::memcpy(hc[k].origin, clouds[k].origin, sizeof(hc[k].origin));
-    hc[k].pad = 0.f;
-  }
-  std::memcpy(host.data() + cloud_bytes, control_times, time_bytes);
-  if (pose_index) std::memcpy(host.data() + cloud_bytes + time_bytes, pose_index, sizeof(int) * n_control);
-  if (!d_poses) std::memcpy(host.data() + cloud_bytes + time_bytes + index_bytes, control_poses, pose_bytes);
-  const unsigned init_first = 0xFFFFFFFFu;
-  std::memcpy(host.data() + table_bytes, &init_first, sizeof(init_first));
-  char* base = c->ws_unwarp_tab.as<char>();
-  HG_HIP_CHECK(hipMemcpyAsync(base, host.data(), table_bytes + 64, hipMemcpyHostToDevice, s));
   const float* d_points = points;
   if (memspace == HG_HOST) {
     if ((rc = c->ws_unwarp_in.reserve(n * 4 * sizeof(float))) != HG_OK) return rc;
     HG_HIP_CHECK(hipMemcpyAsync(c->ws_unwarp_in.ptr, points, n * 4 * sizeof(float), hipMemcpyHostToDevice, s));
     d_points = c->ws_unwarp_in.as<float>();
   }
+  const bool inline_tables = n_control <= kUnwarpInlineControl && n_clouds <= kUnwarpInlineClouds;
+  // device layout of the small tables: [clouds | times | pose indices | poses] (only when they do not travel
+  // as kernel arguments), then the first-valid word and the origin slot
+  const size_t cloud_bytes = sizeof(UnwarpCloudDev) * static_cast<size_t>(n_clouds);
+  const size_t time_bytes = sizeof(long long) * static_cast<size_t>(n_control);
+  const size_t index_bytes = (sizeof(int) * static_cast<size_t>(n_control) + 7u) & ~size_t(7);
+  const size_t pose_bytes = d_poses ? 0 : sizeof(double) * 7u * static_cast<size_t>(n_control);
+  const size_t table_bytes = inline_tables ? 0 : cloud_bytes + time_bytes + index_bytes + pose_bytes;
+  if ((rc = c->ws_unwarp_tab.reserve(table_bytes + 64)) != HG_OK) return rc;
+  char* base = c->ws_unwarp_tab.as<char>();
   UnwarpParams P;
   std::memset(&P, 0, sizeof(P));
+  UnwarpInline T;
+  UnwarpInlinePoses X;
+  if (inline_tables) {
+    std::memset(&T, 0, sizeof(T));
+    for (int k = 0; k < n_clouds; ++k) {
+      T.clouds[k].time = clouds[k].time;
+      T.clouds[k].begin = clouds[k].begin;
+      T.clouds[k].count = clouds[k].count;
+      std::memcpy(T.clouds[k].origin, clouds[k].origin, sizeof(T.clouds[k].origin));
+    }
+    std::memcpy(T.times, control_times, time_bytes);
+    if (pose_index) std::memcpy(T.pose_index, pose_index, sizeof(int) * n_control);
+    if (!d_poses) std::memcpy(X.poses, control_poses, pose_bytes);
+    P.pose_index = pose_index ? reinterpret_cast<const int*>(1) : nullptr;  // (the kernel points it at its argument)
+  } else {
+    // the staging vector must outlive the copy: a copy from pageable memory is staged before it returns
+    std::vector<unsigned char> host(table_bytes, 0);
+    UnwarpCloudDev* hc = reinterpret_cast<UnwarpCloudDev*>(host.data());
+    for (int k = 0; k < n_clouds; ++k) {
+      hc[k].time = clouds[k].time;
+      hc[k].begin = clouds[k].begin;
+      hc[k].count = clouds[k].count;
+      std::memcpy(hc[k].origin, clouds[k].origin, sizeof(hc[k].origin));
+      hc[k].pad = 0.f;
+    }
+    std::memcpy(host.data() + cloud_bytes, control_times, time_bytes);
+    if (pose_index) std::memcpy(host.data() + cloud_bytes + time_bytes, pose_index, sizeof(int) * n_control);
+    if (!d_poses) std::memcpy(host.data() + cloud_bytes + time_bytes + index_bytes, control_poses, pose_bytes);
+    HG_HIP_CHECK(hipMemcpyAsync(base, host.data(), table_bytes, hipMemcpyHostToDevice, s));
+    P.clouds = reinterpret_cast<const UnwarpCloudDev*>(base);
+    P.times = reinterpret_cast<const long long*>(base + cloud_bytes);
+    P.pose_index = pose_index ? reinterpret_cast<const int*>(base + cloud_bytes + time_bytes) : nullptr;
+    if (!d_poses) P.poses = reinterpret_cast<const double*>(base + cloud_bytes + time_bytes + index_bytes);
+  }
+  HG_HIP_CHECK(hipMemsetAsync(base + table_bytes, 0xFF, sizeof(unsigned), s));  // first_valid = none yet
   P.points = d_points;
   P.n = n;
-  P.clouds = reinterpret_cast<const UnwarpCloudDev*>(base);
   P.n_clouds = n_clouds;
-  P.times = reinterpret_cast<const long long*>(base + cloud_bytes);
   P.n_control = n_control;
-  P.pose_index = pose_index ? reinterpret_cast<const int*>(base + cloud_bytes + time_bytes) : nullptr;
   if (d_poses) {
     P.poses = d_poses;
     P.pose_stride = pose_stride;
   } else {
-    P.poses = reinterpret_cast<const double*>(base + cloud_bytes + time_bytes + index_bytes);
     P.pose_stride = 7;
   }
   P.optimized = optimized;
@@ -306,8 +372,17 @@ int hg::unwarp_enqueue(hg_ctx* c, hg_grid* const* grids, int levels, const float
   for (int l = 0; l < levels && l < 4; ++l) P.flag_words[l] = grids && grids[l] ? grids[l]->view.counters + 1 : nullptr;
   {
     ProfScope ps(c, HG_K_UNWARP, n);
-    hipLaunchKernelGGL(k_unwarp_points, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, P);
-    hipLaunchKernelGGL(k_unwarp_origin, dim3(1), dim3(1), 0, s, P);
+    const dim3 grid(static_cast<unsigned>((n + 255) / 256));
+    if (inline_tables && d_poses) {
+      hipLaunchKernelGGL(k_unwarp_points_inline, grid, dim3(256), 0, s, P, T);
+      hipLaunchKernelGGL(k_unwarp_origin_inline, dim3(1), dim3(1), 0, s, P, T);
+    } else if (inline_tables) {
+      hipLaunchKernelGGL(k_unwarp_points_inline_poses, grid, dim3(256), 0, s, P, T, X);
+      hipLaunchKernelGGL(k_unwarp_origin_inline_poses, dim3(1), dim3(1), 0, s, P, T, X);
+    } else {
+      hipLaunchKernelGGL(k_unwarp_points, grid, dim3(256), 0, s, P);
+      hipLaunchKernelGGL(k_unwarp_origin, dim3(1), dim3(1), 0, s, P);
+    }
   }
   HG_HIP_CHECK(hipGetLastError());
   c->unwarp_xyz = P.xyz_out;
