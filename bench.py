@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--no-window-unwarp", action="store_true",
                     help="--workload window: insert the leaving scan at control point 1's pose instead of unwarping it "
                          "per point between control points 0 and 1 (hg_register_scan_unwarped)")
-    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "register_filtered", "match_batch", "register_batch"],
+    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "window_batch", "register_filtered", "match_batch", "register_batch"],
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
@@ -679,6 +679,141 @@ def run_window(args):
     }
 
 
+def run_window_batch(args):
+    """BASELINE configs[3] with the reference's real builder: S independent submaps, each advanced by the
+    OptimizingLocalTrajectoryBuilder step -- a sliding window of --window control points over (window - 1)
+    100k-point scans, IMU + odometry blocks -- with shared launches: hg_register_scan_batch on S window problems
+    (k_window_residuals / k_lm over a table of problems, grid row = problem), then the scans leaving the
+    windows inserted at control point 1's solved pose through the insert kernels' job table. Submap 0's first
+    timed step is replayed by the oracle inside the run."""
+    import torch
+    from hectorgrapher_amd import api, synth
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0)
+    n_pts = args.rings * args.cols
+    n_cp, S = args.window, args.batch_submaps
+    total = args.warmup + args.steps
+    inserters = [api.TSDFRangeDataInserter3D() for _ in RESOLUTIONS]
+    subs = []
+    for j in range(S):
+        sb = 100000 * (j + 1) if j else 0  # PRNG streams of submap j (submap 0 = the single-window workload's)
+        map_scans = make_scans(args.rings, args.cols, 0, args.map_scans, sb)
+        scans = [synth.generate_scan(synth.pose_k(args.map_scans + k), args.rings, args.cols, stream=sb + args.map_scans + k)
+                 for k in range(total + n_cp)]
+        grids = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+        for pose, pts in map_scans:
+            api.insert_pyramid(inserters, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                               pose_tq=pose.astype(np.float32))
+        d_scans = [torch.from_numpy(p_).to(dev) for p_ in scans]
+        problem = api.Problem(ctx)
+        specs = [window_spec(synth, args.map_scans - 1 + s_, n_cp) for s_ in range(total)]
+        builds = [window_prepare(problem, specs[s_], d_scans[s_:s_ + n_cp - 1], grids, n_pts) for s_ in range(total)]
+        subs.append({"map": map_scans, "scans": scans, "d": d_scans, "grids": grids, "problem": problem, "builds": builds})
+    torch.cuda.synchronize()
+    its, evals, solved0, inserted0 = [], [], [], []
+    problems = [sub["problem"] for sub in subs]
+    pyramids = [sub["grids"] for sub in subs]
+
+    def step(s_, sample=False):
+        for sub in subs:
+            sub["builds"][s_]()
+        poses, summ = api.register_scan_batch(problems, [1] * S, inserters,
+                                              [api.RangeData([0, 0, 0], sub["d"][s_]) for sub in subs], pyramids)
+        its.extend(x.num_iterations for x in summ)
+        if sample:
+            evals.append(sum(x.num_cost_evaluations for x in summ) / S)
+        solved0.append((np.array([problems[0].get_pose(i) for i in range(n_cp)]), summ[0].num_iterations,
+                        summ[0].termination_type, summ[0].termination_reason))
+        inserted0.append(poses[0].astype(np.float32))
+
+    for s_ in range(args.warmup):
+        step(s_)
+    its.clear()
+    ctx.prof_reset()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(args.warmup, total):
+        on = args.prof_every > 0 and (s_ - args.warmup) % args.prof_every == 0
+        ctx.prof_enable(on)
+        step(s_, on)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    for sub in subs:
+        for g in sub["grids"]:
+            g.status()
+    base = parity = None
+    lbar = 4.0 / 3.0
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        sub = subs[0]
+        og = [po.Grid(r) for r in RESOLUTIONS]
+        for pose, pts in sub["map"]:
+            loc = synth.transform_points(pose, pts)
+            for g in og:
+                g.insert(pose[:3], loc)
+        for w in range(args.warmup):
+            loc = synth.transform_points(inserted0[w], sub["scans"][w])
+            for g in og:
+                g.insert(inserted0[w][:3], loc)
+        s0 = args.warmup
+        t1 = time.perf_counter()
+        pr = po.Problem()
+        window_problem(pr, synth, args.map_scans - 1 + s0, n_cp, sub["scans"][s0:s0 + n_cp - 1], og, n_pts)
+        so = pr.solve()
+        est = pr.get_pose(1)
+        loc = synth.transform_points(est, sub["scans"][s0])
+        for g in og:
+            g.insert(est[:3].astype(np.float32), loc)
+        cpu_s = time.perf_counter() - t1
+        lk, pb = pr.lookup_stats()
+        lbar = pb / max(1, lk)
+        g_poses, g_it, g_tt, g_tr = solved0[s0]
+        max_dt = max_dr = 0.0
+        for i in range(n_cp):
+            o = pr.get_pose(i)
+            max_dt = max(max_dt, float(np.linalg.norm(o[:3] - g_poses[i][:3])))
+            max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(np.dot(o[3:], g_poses[i][3:])))))))
+        parity = {"max_dt_m": max_dt, "max_dr_rad": max_dr, "windows": 1, "control_points": n_cp, "tolerance": 1e-4,
+                  "same_iterations_and_termination": bool((so.num_iterations, so.termination_type, so.termination_reason)
+                                                          == (g_it, g_tt, g_tr)),
+                  "step": "submap 0 of the batch, its first timed window (%d x %d-pt blocks)" % (n_cp - 1, n_pts)}
+        if not (max_dt <= 1e-4 and max_dr <= 1e-4):
+            raise SystemExit("bench.py: parity gate failed, GPU and oracle window poses differ: %r" % (parity,))
+        base = {"value": 1.0 / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
+                "sample": "1 window of the same workload (solve %d iterations + insert), oracle -O3 1 thread" % so.num_iterations}
+    n_launch = max(1, prof["residuals"][0])
+    avg_ms = prof["residuals"][1] / n_launch
+    share = min(1.0, sum(evals) / n_launch) if evals else 1.0
+    bytes_per_launch = S * (n_cp - 1) * n_pts * (12.0 + 32.0 * lbar) * share
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    value = args.steps * S / elapsed
+    return {
+        "metric": "scans/s (%d submaps x sliding window of %d control points over %d x 100k-pt scans, 3-res TSDF)" % (S, n_cp, n_cp - 1),
+        "value": value, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "window_batch: %d independent submaps, each a window of %d control points (%d multi-res scan blocks + IMU/odometry "
+                               "blocks) solved with shared launches (hg_register_scan_batch), exact insert of every leaving scan"
+                               % (S, n_cp, n_cp - 1),
+                   "submaps": S, "mean_lm_iterations": float(np.mean(its)),
+                   "problem_build": "pre-marshalled C-ABI calls per window (window_prepare); initial guesses from the synthetic ground truth + a fixed perturbation",
+                   "resident_voxel_gib": S * len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_window_residuals_jobs<false>",
+                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "launches_evaluating": share, "mean_levels_probed": lbar,
+                     "lm_avg_launch_ms": prof["lm"][1] / max(1, prof["lm"][0]),
+                     "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
+                     "per_kernel_launches": {k: v[0] for k, v in prof.items()},
+                     "hip_event_sampling": "every %d-th of the %d timed steps" % (max(1, args.prof_every), args.steps)},
+        "parity": parity, "cpu_baseline": base,
+        "gpu_over_cpu": value / base["value"] if base else None,
+    }
+
+
 def run_register_filtered(args):
     """Context run: the registration step with the reference's Lua-default matching
     set -- the adaptive voxel filter (max_length 2 m, >= 150 points, max_range 15 m,
@@ -1276,6 +1411,8 @@ def run(args, out_fd=None):
         return run_register_filtered(args)
     if args.workload == "window":
         return run_window(args)
+    if args.workload == "window_batch":
+        return run_window_batch(args)
     import torch
     dist, rank, local_rank, world = init_dist(args)
     from hectorgrapher_amd import api, synth

@@ -3588,14 +3588,15 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm_single_batch(const SingleJo
 #define HG_WINDOW_WAVES 3
 #endif
 template <bool UNWARP>
-__global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals(
+__device__ __forceinline__ void window_eval(
     const EvalBlock* __restrict__ blocks, int num_eval, unsigned tiles, double* __restrict__ residuals,
     LmState* G, const BlockXform* __restrict__ xf_all, double* __restrict__ partials_all, SmallOut* small_out,
-    unsigned tsdf_wg, unsigned* tickets, double* __restrict__ loc_all) {
+    unsigned tsdf_wg, unsigned num_small, unsigned* tickets, double* __restrict__ loc_all, unsigned bx) {
   if (G->h.done) return;
-  if (blockIdx.x >= tsdf_wg) {
+  if (bx >= tsdf_wg) {
 #ifndef HG_NO_SMALL_FOLD
-    if (threadIdx.x < kWave) small_block_eval(G, static_cast<int>(blockIdx.x - tsdf_wg), small_out, residuals);
+    if (bx - tsdf_wg < num_small && threadIdx.x < kWave)
+      small_block_eval(G, static_cast<int>(bx - tsdf_wg), small_out, residuals);
 #endif
     return;
   }
@@ -3607,13 +3608,13 @@ __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k
     const int lane = threadIdx.x % kWave;
     int count = 0;
     for (int base = 0; base < num_eval; base += kWave) {  // (one round in the plain build: kMaxBlocks <= 64)
-      const bool le = base + lane < num_eval && blocks[base + lane].wg_begin <= blockIdx.x;
+      const bool le = base + lane < num_eval && blocks[base + lane].wg_begin <= bx;
       count += __popcll(__ballot(le));
     }
     b = __builtin_amdgcn_readfirstlane(count - 1);  // wg_begin ascends; entry 0 starts at 0
   }
   const EvalBlock& eb = blocks[b];
-  const unsigned wg = blockIdx.x - eb.wg_begin;
+  const unsigned wg = bx - eb.wg_begin;
   if (wg >= eb.num_wg) return;  // padding up to the next block's multiple of 8
   double* res = residuals ? residuals + eb.row_offset : nullptr;
   if (UNWARP)
@@ -3624,6 +3625,49 @@ __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k
   // (the barrier at the head of the tail also ends this workgroup's use of the tiles in smem)
   window_block_tail<UNWARP>(eb, partials_all + eb.partial_offset, tickets + 8 + eb.index, xf_all + eb.index,
                             loc_all + static_cast<size_t>(eb.index) * kLoc, reinterpret_cast<double*>(smem));
+}
+
+template <bool UNWARP>
+__global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals(
+    const EvalBlock* __restrict__ blocks, int num_eval, unsigned tiles, double* __restrict__ residuals,
+    LmState* G, const BlockXform* __restrict__ xf_all, double* __restrict__ partials_all, SmallOut* small_out,
+    unsigned tsdf_wg, unsigned* tickets, double* __restrict__ loc_all) {
+  window_eval<UNWARP>(blocks, num_eval, tiles, residuals, G, xf_all, partials_all, small_out, tsdf_wg, gridDim.x - tsdf_wg,
+                      tickets, loc_all, blockIdx.x);
+}
+
+// Several INDEPENDENT general problems (sliding windows of different submaps) per launch: grid row = problem,
+// every problem with its own block table, state, partials, tickets and local systems -- the arithmetic of
+// k_window_residuals + k_lm per problem, the launches shared (one registration chain of a window leaves most
+// of the chip idle, and k_lm is a single workgroup).
+struct WindowJob {
+  const EvalBlock* blocks;   // per-scan blocks first, then the blocks with a ratio per return
+  int num_plain, num_unwarp;
+  unsigned wg_plain, wg_unwarp, num_small, tiles;
+  LmState* G;
+  BlockXform* xf;
+  double* partials;
+  SmallOut* small_out;
+  unsigned* tickets;
+  double* loc;
+  const PinBox* box;
+  unsigned up_words, pad;
+};
+template <bool UNWARP>
+__global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals_jobs(
+    const WindowJob* __restrict__ jobs) {
+  const WindowJob& J = jobs[blockIdx.y];
+  // the odometry / IMU blocks ride on the per-scan launch
+  const unsigned tsdf_wg = UNWARP ? J.wg_unwarp : J.wg_plain, small = UNWARP ? 0u : J.num_small;
+  if (blockIdx.x >= tsdf_wg + small) return;
+  window_eval<UNWARP>(J.blocks + (UNWARP ? J.num_plain : 0), UNWARP ? J.num_unwarp : J.num_plain, J.tiles, nullptr, J.G,
+                      J.xf, J.partials, J.small_out, tsdf_wg, small, J.tickets, J.loc, blockIdx.x);
+}
+__global__ __launch_bounds__(kLmBlock) void k_lm_jobs(const WindowJob* __restrict__ jobs, int mode) {
+  __shared__ LmShared S;
+  const WindowJob& J = jobs[blockIdx.x];
+  if (mode == MODE_STEP && J.G->h.done) return;
+  lm_step(S, J.G, J.xf, J.loc, J.small_out, mode, mode == MODE_PREPARE ? J.box : nullptr, J.up_words);
 }
 
 __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
@@ -3674,6 +3718,8 @@ struct hg_problem {
   unsigned wg_plain = 0, wg_unwarp = 0;  // workgroups of the two launches (blocks start at multiples of 8)
   unsigned tiles = 1;           // 256-return tiles per workgroup of the window pass
   unsigned cap_plain = 0, cap_unwarp = 0;  // workgroups of k_window_residuals the device holds at once
+  int batch_share = 1;          // problems that share the launches of this solve (hg_problem_solve_batch): each
+                                // sizes its window pass for its share of the chip
   PinBox* h_box = nullptr;   // mapped pinned mailbox: upload source and result sink
   PinBox* d_box = nullptr;   // its device address
   unsigned long long seq = 0;
@@ -3748,10 +3794,12 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       if (block_active(p, hb)) (hb.d_factor ? tiles_unwarp : tiles_plain) += (hb.n + kBatchThreads - 1) / kBatchThreads;
     // every block rounds its workgroups up (and to a multiple of 8 in the grid): leave room for that
     const unsigned slack = 8u * static_cast<unsigned>(p->blocks.size());
-    const unsigned long long tp = (tiles_plain + std::max(1u, p->cap_plain - std::min(p->cap_plain - 1u, slack)) - 1) /
-                                  std::max(1u, p->cap_plain - std::min(p->cap_plain - 1u, slack));
-    const unsigned long long tu = (tiles_unwarp + std::max(1u, p->cap_unwarp - std::min(p->cap_unwarp - 1u, slack)) - 1) /
-                                  std::max(1u, p->cap_unwarp - std::min(p->cap_unwarp - 1u, slack));
+    const unsigned share = static_cast<unsigned>(std::max(1, p->batch_share));
+    const unsigned cap_p = std::max(1u, p->cap_plain / share), cap_u = std::max(1u, p->cap_unwarp / share);
+    const unsigned long long tp = (tiles_plain + std::max(1u, cap_p - std::min(cap_p - 1u, slack)) - 1) /
+                                  std::max(1u, cap_p - std::min(cap_p - 1u, slack));
+    const unsigned long long tu = (tiles_unwarp + std::max(1u, cap_u - std::min(cap_u - 1u, slack)) - 1) /
+                                  std::max(1u, cap_u - std::min(cap_u - 1u, slack));
     p->tiles = static_cast<unsigned>(std::min<unsigned long long>(kMaxTiles, std::max<unsigned long long>(1, std::max(tp, tu))));
     if (const char* e = std::getenv("HG_WINDOW_TILES")) p->tiles = std::max(1, std::min(kMaxTiles, std::atoi(e)));
   }
@@ -4586,20 +4634,23 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   HG_HIP_CHECK(hipSetDevice(c->device));
   // the batched launch covers problems that take the register-resident single-pose step
   bool batchable = count >= 2;
+  bool windows = count >= 2 && std::getenv("HG_NO_WINDOW_BATCH") == nullptr;  // general problems sharing their launches
   int rc = HG_OK;
   for (int i = 0; i < count && rc == HG_OK; ++i) {
     hg_problem* p = problems[i];
 #ifndef HG_BIG
     if (p->promoted) {  // a big problem is solved on its own
-      batchable = false;
+      batchable = windows = false;
       continue;
     }
 #endif
+    p->batch_share = count;
     rc = upload_state(p, opts);
+    p->batch_share = 1;
 #ifndef HG_BIG
     if (rc == HG_ERR_CAPACITY) {  // ditto (hg_problem_solve promotes it)
       rc = HG_OK;
-      batchable = false;
+      batchable = windows = false;
       continue;
     }
 #endif
@@ -4608,8 +4659,74 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     if (!(p->single_threads && S.ncols == 6 && S.bw == 5 && S.num_blocks == 1 && S.num_small == 0 &&
           S.blocks[0].active && S.opt.max_num_iterations == problems[0]->h_state.h.opt.max_num_iterations))
       batchable = false;
+    if (p->single_threads || S.ncols == 0 || S.opt.max_num_iterations != problems[0]->h_state.h.opt.max_num_iterations)
+      windows = false;
   }
   if (rc != HG_OK) return rc;
+  if (!batchable && windows) {
+    // window batch: k_lm / k_window_residuals over a table of problems (grid row = problem)
+    const size_t bytes = static_cast<size_t>(count) * sizeof(WindowJob);
+    if (c->jobs_capacity < bytes) {
+      if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
+      c->pinned_jobs = nullptr;
+      c->jobs_capacity = 0;
+      const size_t cap = std::max<size_t>(kBatchGroup * std::max(sizeof(SingleJob), sizeof(WindowJob)), bytes);
+      HG_HIP_CHECK(hipHostMalloc(&c->pinned_jobs, cap));
+      c->jobs_capacity = cap;
+    }
+    WindowJob* jobs = static_cast<WindowJob*>(c->pinned_jobs);
+    unsigned max_plain = 0, max_unwarp = 0;
+    unsigned long long units_plain = 0, units_unwarp = 0;
+    for (int i = 0; i < count; ++i) {
+      hg_problem* p = problems[i];
+      const LmHead& S = p->h_state.h;
+      WindowJob& J = jobs[i];
+      std::memset(&J, 0, sizeof(J));
+      J.blocks = p->d_eval;
+      J.num_plain = p->num_plain;
+      J.num_unwarp = p->num_unwarp;
+      J.wg_plain = p->wg_plain;
+      J.wg_unwarp = p->wg_unwarp;
+      J.num_small = static_cast<unsigned>(S.num_small);
+      J.tiles = p->tiles;
+      J.G = p->d_state;
+      J.xf = p->d_xf;
+      J.partials = p->partials.as<double>();
+      J.small_out = p->d_small;
+      J.tickets = p->d_ticket;
+      J.loc = p->d_loc;
+      J.box = p->d_box;
+      J.up_words = p->up_words;
+      max_plain = std::max(max_plain, J.wg_plain + J.num_small);
+      max_unwarp = std::max(max_unwarp, J.wg_unwarp);
+      for (int b = 0; b < S.num_blocks; ++b)
+        if (S.blocks[b].active) (p->blocks[b].d_factor ? units_unwarp : units_plain) += S.blocks[b].n;
+    }
+    if ((rc = c->ws_misc.reserve(bytes)) != HG_OK) return rc;
+    const WindowJob* d_jobs = static_cast<const WindowJob*>(c->ws_misc.ptr);
+    HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs, bytes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_lm_jobs, dim3(count), dim3(kLmBlock), 0, s, d_jobs, static_cast<int>(MODE_PREPARE));
+    HG_HIP_CHECK(hipGetLastError());
+    const int max_it = problems[0]->h_state.h.opt.max_num_iterations;
+    for (int it = 0; it <= max_it; ++it) {
+      if (max_plain > 0) {
+        ProfScope ps(c, HG_K_RESIDUALS, units_plain);
+        hipLaunchKernelGGL(k_window_residuals_jobs<false>, dim3(max_plain, count), dim3(kBatchThreads), 0, s, d_jobs);
+      }
+      if (max_unwarp > 0) {
+        ProfScope ps(c, HG_K_RESIDUALS, units_unwarp);
+        hipLaunchKernelGGL(k_window_residuals_jobs<true>, dim3(max_unwarp, count), dim3(kBatchThreads), 0, s, d_jobs);
+      }
+      {
+        ProfScope ps(c, HG_K_LM, count);
+        hipLaunchKernelGGL(k_lm_jobs, dim3(count), dim3(kLmBlock), 0, s, d_jobs, static_cast<int>(MODE_STEP));
+      }
+    }
+    HG_HIP_CHECK(hipGetLastError());
+    for (int i = 0; i < count; ++i) problems[i]->solve_pending = true;
+    *batched = true;
+    return HG_OK;
+  }
   if (!batchable) return HG_OK;
   // job table: pinned staging owned by the context (the previous batch has been fetched, so its copy
   // has completed), one asynchronous copy, no stream synchronisation

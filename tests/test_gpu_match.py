@@ -720,3 +720,58 @@ def test_register_scan_sequence_with_host_scans_equals_device_scans(hg, ctx):
         a.status()
         for x, y in zip(a.export(), b.export()):
             assert np.array_equal(x, y)
+
+
+def test_solve_batch_of_windows_equals_individual_solves(po, hg, ctx, maps):
+    """hg_problem_solve_batch on GENERAL problems: sliding windows of different submaps share the launches of
+    k_window_residuals / k_lm (grid row = problem). Every window keeps its own state: iterations and
+    termination are those of solving it alone, poses agree to the rounding of the normal-equation sums (a
+    window sizes its residual pass for its share of the chip: other workgroup partials, same terms). Windows of
+    different sizes in one batch, one of them with a per-point-unwarped block; window 0 against the oracle."""
+    og, gg = maps
+
+    def build(api_problem, grids, first, n_cp, unwarped):
+        pr = api_problem
+        poses = [synth.pose_k(first + i) if i == 0 else synth.pose_mul(synth.pose_k(first + i), synth.perturbation())
+                 for i in range(n_cp)]
+        for i in range(n_cp):
+            pr.add_pose(poses[i], i == 0)
+            pr.set_velocity(i, np.array([0.5, 0.2, 0.0]), i == 0)
+        for i in range(1, n_cp):
+            k = first + i
+            delta = synth.pose_mul(synth.pose_inverse(synth.pose_k(k)), synth.pose_k(k - 1))
+            dq = synth.pose_mul(synth.pose_inverse(synth.pose_k(k - 1)), synth.pose_k(k))[3:]
+            pr.add_odometry_block(i - 1, i, 12.0, 30.0, delta)
+            pr.add_imu_block(i - 1, i, 3.0, 2.0, 70.0, 0.1, dq)
+            pts = synth.generate_scan(synth.pose_k(k), 16, 120 + 7 * i, stream=1000 + 10 * first + i)
+            s = 1.0 / np.sqrt(len(pts))
+            if unwarped and i == 1 and hasattr(pr, "add_unwarped_block"):
+                f = np.linspace(0.1, 0.9, len(pts))
+                pr.add_unwarped_block(pts, f, [grids[0], grids[1], grids[2]], s, 0, 1, multi_res=True)
+            elif unwarped and i == 1:
+                continue
+            else:
+                pr.add_block(pts, [grids[0], grids[1], grids[2]], s, i, -1, 0.0, True)
+        return pr
+
+    shapes = [(2, 6, False), (3, 4, False), (1, 7, True), (4, 3, False), (2, 5, False)]
+    single = [build(hg.Problem(ctx), gg, f, n, u) for f, n, u in shapes]
+    s_single = [p.solve() for p in single]
+    batch = [build(hg.Problem(ctx), gg, f, n, u) for f, n, u in shapes]
+    s_batch = hg.solve_batch(batch)
+    for (f, n, u), a, b, sa, sb in zip(shapes, single, batch, s_single, s_batch):
+        assert (sa.num_iterations, sa.termination_type, sa.termination_reason, sa.num_successful_steps) == \
+               (sb.num_iterations, sb.termination_type, sb.termination_reason, sb.num_successful_steps)
+        assert sa.num_iterations > 1
+        for i in range(n):
+            np.testing.assert_allclose(b.get_pose(i), a.get_pose(i), rtol=0, atol=1e-9)
+            np.testing.assert_allclose(b.get_velocity(i), a.get_velocity(i), rtol=0, atol=1e-8)
+        assert abs(sa.final_cost - sb.final_cost) <= 1e-10 * max(1.0, abs(sa.final_cost))
+    op = build(po.Problem(), og, *shapes[0])
+    so = op.solve()
+    assert so.num_iterations == s_batch[0].num_iterations and so.termination_reason == s_batch[0].termination_reason
+    for i in range(shapes[0][1]):
+        a, b = op.get_pose(i), batch[0].get_pose(i)
+        assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M and rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
+    for p in single + batch:
+        p.close()
