@@ -465,7 +465,7 @@ def window_build(pr, spec, clouds, pyramid, n_pts):
         pr.add_block(clouds[i - 1], pyramid, scale, i, multi_res=True)
 
 
-def window_prepare(pr, spec, clouds, pyramid, n_pts):
+def window_prepare(pr, spec, clouds, pyramid, n_pts, width=0):
     """window_build with the arguments marshalled up front: returns run() that makes the same C-ABI calls
     (hg_problem_reset, add_pose, set_velocity, add_odometry_block, add_imu_block, add_block) with nothing but
     the foreign calls inside -- what a C++ host spends on building a window's problem. The timed loop of
@@ -497,6 +497,8 @@ def window_prepare(pr, spec, clouds, pyramid, n_pts):
         keep.append(cloud)
         calls.append((L.hg_problem_add_block, (h, cloud.data_ptr(), int(cloud.shape[0]), _lib.HG_DEVICE, garr, len(pyramid), 1,
                                                scale, i, -1, 0.0)))
+        if width:
+            calls.append((L.hg_problem_set_block_width, (h, i - 1, int(width))))
 
     def run():
         for f, a in calls:
@@ -539,9 +541,9 @@ def run_window(args):
 
     # control point 0 of window s sits on the last inserted scan
     specs = [window_spec(synth, args.map_scans - 1 + s, n_cp) for s in range(total)]
-    builds = [window_prepare(problem, specs[s], d_scans[s:s + n_cp - 1], grids, n_pts) for s in range(total)]
+    builds = [window_prepare(problem, specs[s], d_scans[s:s + n_cp - 1], grids, n_pts, args.rings) for s in range(total)]
 
-    leaving = [api.RangeData([0, 0, 0], d_scans[s]) for s in range(total)]
+    leaving = [api.RangeData([0, 0, 0], d_scans[s], width=args.rings) for s in range(total)]
     # Per-point unwarping of the scan that leaves the window (use_per_point_unwarping, oltb.cc:1331-1379):
     # control point i of window s sits at time (first + i) * 0.1 s; the leaving scan belongs to control
     # point 1 and its returns carry per-point times (all 0 here: the synthetic scans are taken from a
@@ -707,7 +709,7 @@ def run_window_batch(args):
         d_scans = [torch.from_numpy(p_).to(dev) for p_ in scans]
         problem = api.Problem(ctx)
         specs = [window_spec(synth, args.map_scans - 1 + s_, n_cp) for s_ in range(total)]
-        builds = [window_prepare(problem, specs[s_], d_scans[s_:s_ + n_cp - 1], grids, n_pts) for s_ in range(total)]
+        builds = [window_prepare(problem, specs[s_], d_scans[s_:s_ + n_cp - 1], grids, n_pts, args.rings) for s_ in range(total)]
         subs.append({"map": map_scans, "scans": scans, "d": d_scans, "grids": grids, "problem": problem, "builds": builds})
     torch.cuda.synchronize()
     its, evals, solved0, inserted0 = [], [], [], []
@@ -718,7 +720,7 @@ def run_window_batch(args):
         for sub in subs:
             sub["builds"][s_]()
         poses, summ = api.register_scan_batch(problems, [1] * S, inserters,
-                                              [api.RangeData([0, 0, 0], sub["d"][s_]) for sub in subs], pyramids)
+                                              [api.RangeData([0, 0, 0], sub["d"][s_], width=args.rings) for sub in subs], pyramids)
         its.extend(x.num_iterations for x in summ)
         if sample:
             evals.append(sum(x.num_cost_evaluations for x in summ) / S)
@@ -844,7 +846,7 @@ def run_register_filtered(args):
         problem.reset()
         pi = problem.add_pose(guesses[i])
         problem.add_block(sel, grids, 1.0 / np.sqrt(float(len(idx))), pi, multi_res=True)
-        est, _ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i]), grids)
+        est, _ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i], width=args.rings), grids)
         errs.append(float(np.linalg.norm(est[:3] - query[i][0][:3])))
         kept.append(len(idx))
 
@@ -932,7 +934,7 @@ def run_match_batch(args):
         for p, (_, _, d, guess) in zip(problems, queries):
             p.reset()
             i = p.add_pose(guess)
-            p.add_block(d, grids, scale, i, multi_res=True)
+            p.add_block(d, grids, scale, i, multi_res=True, width=args.rings)
         summ = api.solve_batch(problems)
         stats["its"].append(np.mean([s_.num_iterations for s_ in summ]))
         stats["last"] = summ
@@ -1143,7 +1145,7 @@ def run_offline_batch(args, out_fd=None):
                 p.add_pose(self.guesses[j][k])
                 p.add_block(self.queries[j][k][1], self.pyramids[j], scale, 0, multi_res=True)
             poses, summ = api.register_scan_batch(self.problems, [0] * n, self.ins,
-                                                  [api.RangeData([0, 0, 0], self.queries[j][k][1]) for j in range(n)],
+                                                  [api.RangeData([0, 0, 0], self.queries[j][k][1], width=args.rings) for j in range(n)],
                                                   self.pyramids)
             self.steps0[i] = (poses[0].copy(), summ[0].num_iterations, summ[0].termination_type, summ[0].termination_reason)
             if i >= args.warmup:
@@ -1258,7 +1260,7 @@ def run_register_batch(args):
                 p.add_pose(self.guesses[j][i])
                 p.add_block(self.queries[j][i][1], self.pyramids[j], scale, 0, multi_res=True)
             poses, summ = api.register_scan_batch(self.problems, [0] * n, self.ins,
-                                                  [api.RangeData([0, 0, 0], self.queries[j][i][1]) for j in range(n)],
+                                                  [api.RangeData([0, 0, 0], self.queries[j][i][1], width=args.rings) for j in range(n)],
                                                   self.pyramids)
             self.steps0[i] = (poses[0].copy(), summ[0].num_iterations, summ[0].termination_type, summ[0].termination_reason)
             for j in range(n):
@@ -1453,7 +1455,7 @@ def run(args, out_fd=None):
         problem.reset()
         pi = problem.add_pose(guesses[i])
         problem.add_block(d_scans[i], grids, scale, pi, multi_res=True)
-        est, summ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i]), grids)
+        est, summ = api.register_scan(problem, pi, inserters, api.RangeData([0, 0, 0], d_scans[i], width=args.rings), grids)
         errs.append(float(np.linalg.norm(est[:3] - query[i][0][:3])))
         gpu_steps.append((est, summ.num_iterations, summ.termination_type, summ.termination_reason))
         if sampling[0]:
@@ -1472,7 +1474,7 @@ def run(args, out_fd=None):
         the interpreter's per-step work and its GIL hand-overs stay out of the timed region). Kernel
         durations are sampled with HIP events on every prof_every-th step: the residual family each time,
         the insert kernels on every fifth of those (an event pair costs ~8 us of stream serialisation)."""
-        scans = [api.RangeData([0, 0, 0], d_scans[i]) for i in range(lo, hi)]
+        scans = [api.RangeData([0, 0, 0], d_scans[i], width=args.rings) for i in range(lo, hi)]
         call = api.register_scan_sequence(problem, inserters, scans, guesses[lo:hi], grids, scale,
                                           multi_res=True, prof_every=prof_every, prepare_only=True)
 
@@ -1523,10 +1525,10 @@ def run(args, out_fd=None):
     host_inclusive = None
     if host_steps > 0:
         lo = args.warmup + args.steps
-        w_scans = [api.RangeData([0, 0, 0], np.ascontiguousarray(query[i][1], np.float32)) for i in range(lo, lo + host_warm)]
+        w_scans = [api.RangeData([0, 0, 0], np.ascontiguousarray(query[i][1], np.float32), width=args.rings) for i in range(lo, lo + host_warm)]
         api.register_scan_sequence(problem, inserters, w_scans, guesses[lo:lo + host_warm], grids, scale, multi_res=True)
         lo += host_warm
-        h_scans = [api.RangeData([0, 0, 0], np.ascontiguousarray(query[i][1], np.float32)) for i in range(lo, lo + host_steps)]
+        h_scans = [api.RangeData([0, 0, 0], np.ascontiguousarray(query[i][1], np.float32), width=args.rings) for i in range(lo, lo + host_steps)]
         h_call = api.register_scan_sequence(problem, inserters, h_scans, guesses[lo:lo + host_steps], grids, scale,
                                             multi_res=True, prof_every=0, prepare_only=True)
         barrier()
@@ -1540,7 +1542,7 @@ def run(args, out_fd=None):
                           "handover": "scans in pageable host memory (HG_HOST), 1.2 MB each; copy of scan k + 1 overlapped with step k"}
     # accounting pass (untimed): N_in and U of one more scan of the same workload
     last = args.warmup + args.steps - 1
-    acc = api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d_scans[last]), grids,
+    acc = api.insert_pyramid(inserters, api.RangeData([0, 0, 0], d_scans[last], width=args.rings), grids,
                              pose_tq=query[last][0].astype(np.float32))
     stats["U"] = sum(a.num_updates for a in acc)
     stats["N_in"] = sum(a.num_hits for a in acc)

@@ -31,7 +31,7 @@ SYMBOLS = [
     "hg_problem_create", "hg_problem_destroy", "hg_problem_reset", "hg_problem_add_pose",
     "hg_problem_set_pose", "hg_problem_get_pose", "hg_problem_set_velocity", "hg_problem_get_velocity",
     "hg_problem_add_odometry_block", "hg_problem_add_imu_block", "hg_problem_add_block",
-    "hg_problem_add_unwarped_block",
+    "hg_problem_add_unwarped_block", "hg_problem_set_block_width",
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
     "hg_solver_default_opts", "hg_problem_solve", "hg_problem_solve_batch", "hg_problem_solve_async", "hg_problem_fetch",
     "hg_register_scan", "hg_register_scan_mode", "hg_register_scan_batch", "hg_register_scan_sequence", "hg_match_evaluate", "hg_match_solve",
@@ -178,6 +178,7 @@ def load():
     L.hg_problem_add_imu_block.argtypes = [vp, i32, i32, f64, f64, f64, f64, vp]
     L.hg_problem_add_block.argtypes = [vp, vp, sz, i32, vp, i32, i32, f64, i32, i32, f64]
     L.hg_problem_add_unwarped_block.argtypes = [vp, vp, vp, sz, i32, vp, i32, i32, f64, i32, i32]
+    L.hg_problem_set_block_width.argtypes = [vp, i32, sz]
     L.hg_problem_num_residuals.argtypes = [vp]
     L.hg_problem_num_columns.argtypes = [vp]
     L.hg_problem_evaluate.argtypes = [vp, vp, vp, vp, vp]

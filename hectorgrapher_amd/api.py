@@ -536,7 +536,9 @@ class Problem:
                                                       float(dt), _p(d)), "add_imu_block")
 
     def add_block(self, xyz, grids, scaling_factor, pose_a, pose_b=-1, interpolation_ratio=0.0,
-                  multi_res=False):
+                  multi_res=False, width=0):
+        """width > 0: the cloud is a structured scan with `width` returns per column (hg_problem_set_block_width:
+        a performance hint, see include/hg_mi355x.h)."""
         arr = (C.c_void_p * len(grids))(*[g._h for g in grids])
         if _is_device(xyz):
             n, ptr, space = xyz.shape[0], xyz.data_ptr(), _lib.HG_DEVICE
@@ -545,9 +547,15 @@ class Problem:
             xyz = _host(xyz, np.float32, 3)
             n, ptr, space = len(xyz), _p(xyz), _lib.HG_HOST
         self._keep.append(grids)
-        return check(self._L.hg_problem_add_block(self._h, ptr, n, space, arr, len(grids),
-                                                  int(multi_res), float(scaling_factor), pose_a,
-                                                  pose_b, float(interpolation_ratio)), "add_block")
+        b = check(self._L.hg_problem_add_block(self._h, ptr, n, space, arr, len(grids),
+                                               int(multi_res), float(scaling_factor), pose_a,
+                                               pose_b, float(interpolation_ratio)), "add_block")
+        if width:
+            check(self._L.hg_problem_set_block_width(self._h, b, int(width)), "set_block_width")
+        return b
+
+    def set_block_width(self, block, width):
+        check(self._L.hg_problem_set_block_width(self._h, int(block), int(width)), "set_block_width")
 
     def add_unwarped_block(self, xyz, interpolation_ratios, grids, scaling_factor, pose_a, pose_b,
                            multi_res=False):

@@ -395,6 +395,7 @@ struct DirectFetch {
   uint32_t s0[3];    // lower corner cell index + kIndexOffset per axis
   uint32_t byte[8];  // byte offsets of the 8 corners inside the direct area
   uint32_t code[8];  // corner order c = dx*4 + dy*2 + dz
+  uint32_t face[4];  // the dx = 1 corners of a lane whose x pair crosses a block face (direct_merge)
 };
 
 // Lower-corner cell and the addresses of the 8 corners of one level. The offsets are masked into
@@ -440,20 +441,46 @@ __device__ inline void direct_setup(const GridView& g, double x, double y, doubl
 // The voxel loads of one level (independent of each other and of the other levels'). The two x
 // neighbours of a corner pair are adjacent words unless the pair crosses a block face (x & 7 == 7):
 // one 8-byte load fetches both, and only the lanes on a face load their second voxel separately --
-// half the requests the cache has to serve.
+// half the requests the cache has to serve. The face loads land in registers of their own and are merged
+// by direct_merge AFTER the loads of every level have been issued: written over the pair's second word
+// right away (round 3), they made the compiler wait for the pair loads before issuing them -- some lane
+// of nearly every wavefront sits on a face -- so the levels' round trips ran one after the other.
+// Loads through the global address space with a 32-bit offset from the (uniform) pool base: one address
+// register per load and no flat-aperture check; flat loads also count against lgkmcnt and complete out of
+// order, which forces full waits.
+typedef const __attribute__((address_space(1))) char* gmem_bytes;
+__device__ inline gmem_bytes as_global(const void* p) {
+  return reinterpret_cast<gmem_bytes>(reinterpret_cast<uintptr_t>(p));
+}
 __device__ inline void direct_load(const GridView& g, DirectFetch& f) {
-  const char* base = reinterpret_cast<const char*>(g.voxels);
+  gmem_bytes base = as_global(g.voxels);
   const bool face = (f.s0[0] & 7u) == 7u;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {  // corner k = (dy, dz) at dx = 0, corner 4 + k at dx = 1
     typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(4)));
-    const u2 v = *reinterpret_cast<const u2*>(base + f.byte[k]);
+    const u2 v = *reinterpret_cast<const __attribute__((address_space(1))) u2*>(base + f.byte[k]);
     f.code[k] = v.x;
     f.code[4 + k] = v.y;
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f.face[k] = 0u;
   if (face) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) f.code[4 + k] = *reinterpret_cast<const uint32_t*>(base + f.byte[4 + k]);
+    for (int k = 0; k < 4; ++k)
+      f.face[k] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(base + f.byte[4 + k]);
+  }
+}
+__device__ inline void direct_merge(DirectFetch& f) {
+  const bool face = (f.s0[0] & 7u) == 7u;
+  if (face) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // an opaque move: written as a plain select, the compiler loads the face word straight into the
+      // pair's register under the face lanes' mask, which is the wait this function exists to avoid
+      uint32_t t;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(f.face[k]));
+      f.code[4 + k] = t;
+    }
   }
 }
 // Inside the window anchored at the bounding-box minimum (which implies inside the index range)?
@@ -462,10 +489,20 @@ __device__ inline bool direct_inside(const GridView& g, const uint32_t* wmin, bo
   bool in = usable;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const uint32_t mask = (1u << g.dir_bits[a]) - 1u;
-    in = in && ((f.s0[a] >> 3) - wmin[a]) <= mask && (((f.s0[a] + 1u) >> 3) - wmin[a]) <= mask;
+    // blocks of cells s0 and s0 + 1 both within [wmin, wmin + 2^bits): one unsigned compare of the cell
+    // against the window's first cell and its length minus two (the operands are wave-uniform)
+    const uint32_t first = wmin[a] << 3, span = (8u << g.dir_bits[a]) - 2u;
+    in = in && (f.s0[a] - first) <= span;
   }
   return in;
+}
+// All 8 weights non-zero: weight code (bits 16..30, the marker bit masked as GetWeight does) above 1.
+__device__ inline bool all_weights_valid(const uint32_t* code) {
+  constexpr uint32_t kAbove1 = 0x7FFE0000u;
+  const uint32_t m0 = min(min(code[0] & kAbove1, code[1] & kAbove1), code[2] & kAbove1);
+  const uint32_t m1 = min(min(code[3] & kAbove1, code[4] & kAbove1), code[5] & kAbove1);
+  const uint32_t m2 = min(min(code[6] & kAbove1, code[7] & kAbove1), m0);
+  return min(m1, m2) != 0u;
 }
 __device__ inline void direct_accept(const GridView& g, const uint32_t* wmin, bool usable, DirectFetch& f) {
   const bool in = direct_inside(g, wmin, usable, f);
@@ -477,6 +514,12 @@ __device__ inline void direct_accept(const GridView& g, const uint32_t* wmin, bo
 // InterpolateLinear takes its interpolating branch, so the validity tests and the weights drop out.
 // Same operations in the same order as interp_selected; terms that are exactly zero there (the
 // derivative slots no stage has touched yet) are left out, which can only change the sign of a zero.
+__device__ inline double rcp_span(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
 __device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offset, float min_tsd,
                                       const float* c3, const uint32_t* code, double x, double y, double z) {
   (void)min_tsd;
@@ -491,8 +534,11 @@ __device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offs
   }
   const double x1 = c3[0], y1 = c3[1], z1 = c3[2];
   const double x2 = c3[0] + res, y2 = c3[1] + res, z2 = c3[2] + res;  // float adds, as the reference
-  // Jet / double: Ceres multiplies by the inverse (jet.h operator/(Jet, T))
-  const double ix = 1.0 / (x2 - x1), iy = 1.0 / (y2 - y1), iz = 1.0 / (z2 - z1);
+  // Jet / double: Ceres multiplies by the inverse (jet.h operator/(Jet, T)). The inverse of the voxel span
+  // (a float sum minus a float: within a few ulps of the resolution, never tiny or huge) by two Newton steps
+  // on v_rcp_f64 -- within an ulp of the IEEE quotient in 5 instructions instead of the division's 11;
+  // continuous outputs only, as the lerps below.
+  const double ix = rcp_span(x2 - x1), iy = rcp_span(y2 - y1), iz = rcp_span(z2 - z1);
   const double nx = (x - x1) * ix, ny = (y - y1) * iy, nz = (z - z1) * iz;
   // the lerps as fused multiply-adds (continuous outputs only: agreement with the reference to rounding)
   // along z: value and d/dz
@@ -575,6 +621,8 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   BODY_STAMP(2);
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) direct_load(pv.level[l], f[l]);
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) direct_merge(f[l]);
   const DirectPyramid dp = direct_resolve(pv, raw);  // the counters have long arrived
   *ok = dp.ok;
   if (!dp.ok) return {0.0, 0.0, 0.0, 0.0};  // wave-uniform: the caller takes the general path
@@ -613,9 +661,7 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   for (int l = 0; l < LEVELS; ++l) {
     // valid: inside the window (outside it no block exists: the voxels read as unknown, whatever the
     // toroidal slot holds) and all 8 weights non-zero
-    bool valid = direct_inside(pv.level[l], dp.min_b[l], usable, f[l]);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) valid = valid && ((f[l].code[c] >> 16) & 0x7FFFu) > 1u;
+    const bool valid = direct_inside(pv.level[l], dp.min_b[l], usable, f[l]) && all_weights_valid(f[l].code);
     if (l > 0) {
       const bool take = !found && valid;
 #pragma unroll
@@ -815,20 +861,64 @@ __device__ inline double load_partial(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Which return a lane takes. The vector L1 prices a gather by the distinct 128-byte lines the four lanes of
+// every aligned quad touch (scripts/tcp_bench.hip: one cycle per line and quad, no merging beyond adjacent
+// lanes), and the voxel lookups of the batched and window passes are bound by exactly that (round 4: L1 busy 91 %,
+// 0.71 tag lookups per cycle and CU, VALU 40 %). A structured scan is stored azimuth-major (`width` = returns per
+// column, sensor/range_data.h): adjacent returns are VERTICAL neighbours, whose voxels differ in z -- the slowest
+// dimension of a block -- so the lanes of a quad hit four different lines per load (3.6 / 2.8 / 2.2 lines per quad
+// at 0.05 / 0.10 / 0.20 m on the bench scene). When the caller has told the width (hg_problem_set_block_width,
+// the width argument of hg_register_scan*), lane order is remapped: four adjacent lanes take the same ring of four
+// adjacent columns -- horizontal neighbours 0.18 degrees apart, the same or neighbouring x / y cells: 1.55 / 1.30 /
+// 1.33 lines per quad. A permutation of the summation order only: residuals keep their positions.
+struct ScanOrder {
+  unsigned width, group, full;  // group = 4 * width returns (four columns); returns >= full keep their order
+  float inv_group;
+};
+__device__ inline ScanOrder make_scan_order(unsigned n, unsigned width) {
+  ScanOrder so;
+  so.width = width;
+  so.group = (width != 0u && n < (1u << 24)) ? 4u * width : 0u;
+  so.inv_group = so.group ? 1.0f / static_cast<float>(so.group) : 0.f;
+  unsigned q = static_cast<unsigned>(static_cast<float>(n) * so.inv_group);
+  if (so.group && q * so.group > n) --q;
+  so.full = q * so.group;
+  return so;
+}
+__device__ inline unsigned scan_index(const ScanOrder& so, unsigned i) {
+  if (so.group == 0u || i >= so.full) return i;
+  // i / group by a float reciprocal (i < 2^24: exact conversion) and one correction step either way
+  unsigned q = static_cast<unsigned>(static_cast<float>(i) * so.inv_group);
+  int r = static_cast<int>(i - q * so.group);
+  if (r < 0) { r += static_cast<int>(so.group); --q; }
+  else if (r >= static_cast<int>(so.group)) { r -= static_cast<int>(so.group); ++q; }
+  return q * so.group + (static_cast<unsigned>(r) & 3u) * so.width + (static_cast<unsigned>(r) >> 2);
+}
+// The return's coordinates as ONE 12-byte load (three 4-byte loads cost three passes through the L1).
+__device__ inline void load_point(const float* __restrict__ xyz, unsigned i, double* v) {
+  typedef float f3 __attribute__((ext_vector_type(3), aligned(4)));
+  const f3 p = *reinterpret_cast<const __attribute__((address_space(1))) f3*>(as_global(xyz) + 12ull * i);
+  v[0] = static_cast<double>(p.x);
+  v[1] = static_cast<double>(p.y);
+  v[2] = static_cast<double>(p.z);
+}
+
 // residuals of one block at its current transform + 36 partial sums per workgroup
 template <int THREADS = kEvalThreads>
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
     double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64], unsigned wg,
-    const double* pose_tq = nullptr /* the transform when it does not come from xf (first launch) */) {
-  const unsigned i = wg * THREADS + threadIdx.x;
+    const double* pose_tq = nullptr /* the transform when it does not come from xf (first launch) */,
+    unsigned width = 0) {
+  const unsigned i0 = wg * THREADS + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   BODY_STAMP(0);
   const DirectRaw dp = direct_issue(pv);
-  if (i < n) {
-    const double v[3] = {static_cast<double>(xyz[3 * i]), static_cast<double>(xyz[3 * i + 1]),
-                         static_cast<double>(xyz[3 * i + 2])};
+  if (i0 < n) {
+    const unsigned i = scan_index(make_scan_order(n, width), i0);
+    double v[3];
+    load_point(xyz, i, v);
     // (THREADS == 256: the batched kernel)
     if (pose_tq) return_row<THREADS == 256>(pv, dp, pose_tq, pose_tq + 3, v, scaling, row8);
     else return_row<THREADS == 256>(pv, dp, xf->t, xf->q, v, scaling, row8);
@@ -851,14 +941,27 @@ __device__ __forceinline__ void tsdf_residuals_body(
   typedef double d4 __attribute__((ext_vector_type(4)));
   d4 cacc = {0.0, 0.0, 0.0, 0.0};
   const int mj = lane & 15, mk = lane >> 4;
+  // Round 4: the 16-wide operand carries TWO row groups -- columns 0..7 the returns 0..31 of the wavefront,
+  // columns 8..15 the returns 32..63 -- so 8 instead of 16 MFMAs (64 cycles each, dependent) form X^T X: its
+  // upper-left 8 x 8 block is the sum over the first 32 returns, the lower-right one over the other 32, the
+  // off-diagonal blocks (cross terms) are dropped.
+  {
+    const int half = (mj >> 3) * 32, col = mj & 7;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const double a = (mj < 8) ? xs[wave][4 * s + mk][mj] : 0.0;
-    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+    for (int s = 0; s < 8; ++s) {
+      const double a = xs[wave][half + 4 * s + mk][col];
+      cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+    }
   }
-  if (mj < 8) {  // rows 0..7 of D sit in accumulator registers 0 and 1 (row = l/16 + 4v)
-    cs[wave][mk * 8 + mj] = cacc[0];
-    cs[wave][(mk + 4) * 8 + mj] = cacc[1];
+  wave_sync();  // the operand reads are done: the wavefront's X tile takes the second block
+  {
+    // D[l/16 + 4v][l%16] sits in accumulator register v: lanes with mj < 8 hold rows mk, mk + 4 of the first
+    // block (registers 0, 1), lanes with mj >= 8 rows mk, mk + 4 of the second (registers 2, 3)
+    double* second = &xs[wave][0][0];
+    double* dst = (mj < 8) ? &cs[wave][0] : second;
+    const int col = mj & 7;
+    dst[mk * 8 + col] = (mj < 8) ? cacc[0] : cacc[2];
+    dst[(mk + 4) * 8 + col] = (mj < 8) ? cacc[1] : cacc[3];
   }
   __syncthreads();
   if (threadIdx.x < kAcc) {
@@ -878,7 +981,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
     }
     double s = 0.0;
 #pragma unroll
-    for (int wv = 0; wv < THREADS / kWave; ++wv) s += cs[wv][a * 8 + b];
+    for (int wv = 0; wv < THREADS / kWave; ++wv) s += cs[wv][a * 8 + b] + xs[wv][0][a * 8 + b];
     store_partial(&partials[static_cast<size_t>(wg) * kAcc + threadIdx.x], s);
   }
   BODY_STAMP(5);
@@ -1046,6 +1149,8 @@ struct EvalBlock {
   double scaling;
   unsigned n, wg_begin, num_wg, partial_offset, row_offset;
   int pose_a, pose_b, index;
+  unsigned width;  // returns per column of a structured scan (0 = unknown: lanes take returns in order)
+  unsigned pad;
 };
 
 // Per-scan blocks (one transform per block; the map to the local parameters is applied after the
@@ -1065,15 +1170,17 @@ __device__ __forceinline__ void window_body_plain(const EvalBlock& eb, const Blo
   d4 cacc = {0.0, 0.0, 0.0, 0.0};
   const unsigned n = eb.n;
   const double scaling = eb.scaling;
+  const ScanOrder order = make_scan_order(n, eb.width);
   const unsigned first = xcd_chunk(wg, eb.num_wg) * tiles;
   for (unsigned tile = 0; tile < tiles; ++tile) {
     const unsigned base = (first + tile) * kBatchThreads;
     if (base >= n) break;  // uniform
-    const unsigned i = base + threadIdx.x;
+    const unsigned i0 = base + threadIdx.x;
     double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (i < n) {
-      const double v[3] = {static_cast<double>(eb.xyz[3 * i]), static_cast<double>(eb.xyz[3 * i + 1]),
-                           static_cast<double>(eb.xyz[3 * i + 2])};
+    if (i0 < n) {
+      const unsigned i = scan_index(order, i0);
+      double v[3];
+      load_point(eb.xyz, i, v);
       return_row(pv, dp, xf->t, xf->q, v, scaling, row8);
       if (residuals) residuals[i] = row8[7];
     }
@@ -1081,16 +1188,23 @@ __device__ __forceinline__ void window_body_plain(const EvalBlock& eb, const Blo
 #pragma unroll
     for (int c = 0; c < 4; ++c) dst[c] = d2{row8[2 * c], row8[2 * c + 1]};
     wave_sync();  // xs[wave] is written and read by this wavefront only
+    {
+      // two row groups in the 16-wide operand: 8 MFMAs per tile (tsdf_residuals_body)
+      const int half = (mj >> 3) * 32, col = mj & 7;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const double a = (mj < 8) ? xs[wave][4 * s + mk][mj] : 0.0;
-      cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+      for (int s = 0; s < 8; ++s) {
+        const double a = xs[wave][half + 4 * s + mk][col];
+        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+      }
     }
     wave_sync();  // the operand reads are done before the next tile overwrites the tile
   }
-  if (mj < 8) {  // rows 0..7 of D sit in accumulator registers 0 and 1 (row = l/16 + 4v)
-    cs[wave][mk * 8 + mj] = cacc[0];
-    cs[wave][(mk + 4) * 8 + mj] = cacc[1];
+  {
+    double* second = &xs[wave][0][0];
+    double* dst = (mj < 8) ? &cs[wave][0] : second;
+    const int col = mj & 7;
+    dst[mk * 8 + col] = (mj < 8) ? cacc[0] : cacc[2];
+    dst[(mk + 4) * 8 + col] = (mj < 8) ? cacc[1] : cacc[3];
   }
   __syncthreads();
   if (threadIdx.x < kAcc) {
@@ -1110,7 +1224,7 @@ __device__ __forceinline__ void window_body_plain(const EvalBlock& eb, const Blo
     }
     double sum = 0.0;
 #pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv) sum += cs[wv][a * 8 + b];
+    for (int wv = 0; wv < kWaves; ++wv) sum += cs[wv][a * 8 + b] + xs[wv][0][a * 8 + b];
     store_partial(&partials[static_cast<size_t>(wg) * kAcc + threadIdx.x], sum);
   }
 }
@@ -1135,15 +1249,17 @@ __device__ __forceinline__ void window_body_unwarp(const EvalBlock& eb, const do
   d4 cacc = {0.0, 0.0, 0.0, 0.0};
   const unsigned n = eb.n;
   const double scaling = eb.scaling;
+  const ScanOrder order = make_scan_order(eb.n, eb.width);
   const unsigned first = xcd_chunk(wg, eb.num_wg) * tiles;
   for (unsigned tile = 0; tile < tiles; ++tile) {
     const unsigned base = (first + tile) * kBatchThreads;
     if (base >= n) break;  // uniform
-    const unsigned i = base + threadIdx.x;
+    const unsigned i0 = base + threadIdx.x;
     double row[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) row[k] = 0.0;
-    if (i < n) {
+    if (i0 < n) {
+      const unsigned i = scan_index(order, i0);
       const double f = eb.factor[i];
       double pja[12], pjb[12];
       quaternion_plus_jacobian(pa + 3, pja);
@@ -1153,8 +1269,8 @@ __device__ __forceinline__ void window_body_unwarp(const EvalBlock& eb, const do
       DJ<8> qj[4];
       slerp_jets(pa + 3, pb + 3, f, qj);
       for (int r = 0; r < 4; ++r) q[r] = qj[r].a;
-      const double v[3] = {static_cast<double>(eb.xyz[3 * i]), static_cast<double>(eb.xyz[3 * i + 1]),
-                           static_cast<double>(eb.xyz[3 * i + 2])};
+      double v[3];
+      load_point(eb.xyz, i, v);
       double row8[8];
       return_row(pv, dp, t, q, v, scaling, row8);
       if (residuals) residuals[i] = row8[7];
@@ -3471,7 +3587,7 @@ struct FirstUpload {
 
 template <int THREADS, bool FIRST = false>
 __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* __restrict__ xyz, unsigned n,
-                                            double scaling, const BlockXform* __restrict__ xf,
+                                            unsigned width, double scaling, const BlockXform* __restrict__ xf,
                                             double* __restrict__ partials, LmState* G, unsigned* ticket,
                                             unsigned wg_index, unsigned num_wg, const FirstUpload* up = nullptr) {
   if (!FIRST && G->h.done) return;
@@ -3486,7 +3602,7 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
   tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, partials, nullptr,
                                reinterpret_cast<double (*)[kWave][8]>(smem),
                                reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
-                               xcd_chunk(wg_index, num_wg), FIRST ? up->pose : nullptr);
+                               xcd_chunk(wg_index, num_wg), FIRST ? up->pose : nullptr, width);
   EVAL_STAMP(1);
   __shared__ int s_last;
   // hand-over of the partials without fences: sc1 stores drained here, one counted arrival per
@@ -3508,16 +3624,16 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
-    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
+    PyramidView pv, const float* __restrict__ xyz, unsigned n, unsigned width, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket) {
-  single_eval<THREADS>(pv, xyz, n, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x);
+  single_eval<THREADS>(pv, xyz, n, width, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x);
 }
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_first(
-    PyramidView pv, const float* __restrict__ xyz, unsigned n, double scaling,
+    PyramidView pv, const float* __restrict__ xyz, unsigned n, unsigned width, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket,
     FirstUpload up) {
-  single_eval<THREADS, true>(pv, xyz, n, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x, &up);
+  single_eval<THREADS, true>(pv, xyz, n, width, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x, &up);
 }
 
 // Several INDEPENDENT single-pose problems per launch (blockIdx.y = problem): each keeps its own
@@ -3537,7 +3653,7 @@ struct SingleJob {
   unsigned num_wg;
   const PinBox* box;  // the problem's mailbox (compact upload of its solver head)
   unsigned up_words;
-  unsigned pad;
+  unsigned width;     // returns per column of the structured scan, or 0 (scan_index)
 };
 
 // Throughput form: the residual pass of all problems in one launch WITHOUT the LM step in its tail
@@ -3557,7 +3673,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_tsdf_residuals_single_batch(cons
   tsdf_residuals_body<THREADS>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
                                      reinterpret_cast<double (*)[kWave][8]>(smem),
                                      reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
-                                     xcd_chunk(blockIdx.x, J.num_wg));
+                                     xcd_chunk(blockIdx.x, J.num_wg), nullptr, J.width);
 }
 // Uploads every problem's solver head from its mailbox and prepares its first transform (k_lm
 // MODE_PREPARE for all problems of a batch in one launch).
@@ -3694,6 +3810,7 @@ struct hg_problem {
     int pose_a = 0, pose_b = -1;
     double factor = 0.0;
     const double* d_factor = nullptr;  // per-return interpolation factors (unwarped block)
+    unsigned width = 0;  // returns per column when the cloud is a structured scan (hg_problem_set_block_width)
   };
   std::vector<Block> blocks;
   std::vector<std::array<double, 7>> poses;
@@ -3935,6 +4052,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       eb.pose_a = bi.pose_a;
       eb.pose_b = bi.pose_b;
       eb.index = b;
+      eb.width = hb.width;
       ++p->num_eval;
       ++(kind ? p->num_unwarp : p->num_plain);
     }
@@ -3982,10 +4100,10 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
       up.up_words = p->up_words;
       up.pad = 0;
       hipLaunchKernelGGL(k_tsdf_residuals_single_first<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
-                         hb.d_xyz, bi.n, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket, up);
+                         hb.d_xyz, bi.n, hb.width, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket, up);
     } else {
       hipLaunchKernelGGL(k_tsdf_residuals_single<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
-                         hb.d_xyz, bi.n, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket);
+                         hb.d_xyz, bi.n, hb.width, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket);
     }
     HG_HIP_CHECK(hipGetLastError());
     return HG_OK;
@@ -4071,6 +4189,7 @@ int promote(hg_problem* p) {
                     : hg_problem_add_block_big(p->big, b.d_xyz, b.n, HG_DEVICE, b.pyramid.data(),
                                                static_cast<int>(b.pyramid.size()), b.multi_res, b.scaling, b.pose_a, b.pose_b, b.factor);
     if (rc < 0) return rc;
+    if (b.width && (rc = hg_problem_set_block_width_big(p->big, rc, b.width)) != HG_OK) return rc;
   }
   p->promoted = true;
   return HG_OK;
@@ -4390,6 +4509,17 @@ int hg_problem_add_unwarped_block(hg_problem* p, const float* xyz, const double*
                         scaling_factor, pose_a, pose_b, 0.0);
 }
 
+int hg_problem_set_block_width(hg_problem* p, int block, size_t width) {
+  if (!p || block < 0 || block >= static_cast<int>(p->blocks.size())) return HG_ERR_INVALID;
+  hg_problem::Block& b = p->blocks[block];
+  // a structured cloud has n = columns x width returns; anything else keeps the plain order
+  b.width = (width > 1 && width < (1u << 20) && b.n % width == 0) ? static_cast<unsigned>(width) : 0u;
+#ifndef HG_BIG
+  if (p->promoted) return hg_problem_set_block_width_big(p->big, block, width);
+#endif
+  return HG_OK;
+}
+
 int hg_problem_num_residuals(hg_problem* p) {
   if (!p) return HG_ERR_INVALID;
   size_t n = 0;
@@ -4619,6 +4749,15 @@ const double* device_poses(hg_problem* p, int* stride) {
   return (p->h_state.h.ncols == 0) ? nullptr : &p->d_state->h.x[0][0];
 }
 
+// hg_register_scan*: the scan that is inserted (xyz, n, width) is normally the cloud of one of the problem's
+// TSDF blocks; that block learns the scan's structure (hg_problem_set_block_width).
+void apply_scan_width(hg_problem* p, const float* xyz, size_t n, size_t width) {
+  if (width < 2) return;
+  for (size_t b = 0; b < p->blocks.size(); ++b)
+    if (p->blocks[b].n == n && p->blocks[b].width == 0 && (p->blocks[b].d_xyz == xyz || p->blocks.size() == 1))
+      (void)hg_problem_set_block_width(p, static_cast<int>(b), width);
+}
+
 // The gather rate of the residual pass saturates well below this; larger lists go through in groups.
 constexpr int kBatchGroup = 64;
 
@@ -4759,6 +4898,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     J.n = bi.n;
     J.box = p->d_box;
     J.up_words = p->up_words;
+    J.width = p->blocks[0].width;
     max_wg = std::max(max_wg, J.num_wg);
     units += bi.n;
   }
@@ -4846,6 +4986,7 @@ int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solv
     if (problems[j]->ctx != c) return HG_ERR_INVALID;  // one job table, one stream
   int rc = async_status_grids(grids, count * levels);  // an insertion of an earlier step that failed reports here
   if (rc != HG_OK) return rc;
+  for (int j = 0; j < count; ++j) apply_scan_width(problems[j], xyz[j], n[j], width);
   bool batched = false;
   if (memspace == HG_DEVICE) {
     rc = solve_batch_enqueue(problems, count, sopts, &batched);
@@ -5071,6 +5212,7 @@ static int register_scan_step(hg_problem* p, const hg_solver_opts* sopts, int po
   if (levels < 1) return HG_ERR_INVALID;
   int rc = async_status_grids(grids, levels);
   if (rc != HG_OK) return rc;
+  apply_scan_width(p, xyz, n, width);
   rc = hg_problem_solve_async(p, sopts);
   if (rc != HG_OK) return rc;
 #ifdef HG_HOST_STAMPS

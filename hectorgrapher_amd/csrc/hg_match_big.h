@@ -25,6 +25,7 @@ int hg_problem_add_block_big(hg_problem_big* p, const float* xyz, size_t n, int 
 int hg_problem_add_unwarped_block_big(hg_problem_big* p, const float* xyz, const double* interpolation_ratios,
                                       size_t n, int memspace, hg_grid* const* pyramid, int levels, int multi_res,
                                       double scaling_factor, int pose_a, int pose_b);
+int hg_problem_set_block_width_big(hg_problem_big* p, int block, size_t width);
 int hg_problem_evaluate_big(hg_problem_big* p, double* cost, double* residuals, double* gradient, double* JtJ);
 int hg_problem_solve_async_big(hg_problem_big* p, const hg_solver_opts* opts);
 int hg_problem_fetch_big(hg_problem_big* p, hg_solver_summary* summary);

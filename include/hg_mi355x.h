@@ -337,6 +337,14 @@ int hg_problem_add_odometry_block(hg_problem* p, int pose_a, int pose_b, double 
 int hg_problem_add_imu_block(hg_problem* p, int pose_a, int pose_b, double translation_weight,
                              double velocity_weight, double rotation_weight, double delta_time_seconds,
                              const double delta_rotation_wxyz[4]);
+/* Tells that the cloud of TSDF block `block` is a structured scan stored azimuth-major with `width` returns
+ * per column (sensor::RangeData::width / TimedPointCloudData::width: vertical neighbours adjacent, as the
+ * inserter's CLOUD_STRUCTURE code assumes, tsdf_range_data_inserter_3d.cc:505-508). A performance hint only:
+ * the residual kernels then let adjacent lanes take horizontally adjacent returns, whose voxels share cache
+ * lines (the residual sums are formed in another order: results agree to rounding, residual positions are
+ * unchanged). width = 0, or a return count that is not a multiple of width, keeps the plain order.
+ * hg_register_scan* apply their `width` argument to the block that holds the same cloud. */
+int hg_problem_set_block_width(hg_problem* p, int block, size_t width);
 int hg_problem_num_residuals(hg_problem* p);
 int hg_problem_num_columns(hg_problem* p);
 /* ceres::Problem::Evaluate shape: cost = 0.5 |r|^2; residuals[num_residuals]; gradient and JtJ in

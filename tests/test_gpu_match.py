@@ -775,3 +775,51 @@ def test_solve_batch_of_windows_equals_individual_solves(po, hg, ctx, maps):
         assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M and rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
     for p in single + batch:
         p.close()
+
+
+@pytest.mark.parametrize("shape", ["single", "two_pose", "unwarped"])
+def test_structured_lane_order_is_a_permutation_of_the_sums(po, hg, ctx, maps, shape):
+    """hg_problem_set_block_width lets adjacent lanes take horizontally adjacent returns of a structured scan
+    (four columns at a time): the residuals keep their positions and values, the normal equations are the same
+    sums in another order -- evaluation within rounding, solve with the same iterations and poses within 1e-9;
+    a return count that is not a multiple of the width keeps the plain order."""
+    og, gg = maps
+    rings, cols = 16, 203  # 203 columns: 50 groups of four + 3 columns that keep their order
+    pts = synth.generate_scan(synth.pose_k(5), rings, cols, stream=77)
+    guess = synth.pose_mul(synth.pose_k(5), synth.perturbation())
+
+    def build(width):
+        pr = hg.Problem(ctx)
+        if shape == "single":
+            i = pr.add_pose(guess)
+            pr.add_block(pts, gg, 1.0 / np.sqrt(len(pts)), i, multi_res=True, width=width)
+        else:
+            a = pr.add_pose(synth.pose_k(4), True)
+            b = pr.add_pose(guess)
+            if shape == "two_pose":
+                pr.add_block(pts, gg, 1.0 / np.sqrt(len(pts)), a, b, 0.7, multi_res=True, width=width)
+            else:
+                k = pr.add_unwarped_block(pts, np.linspace(0.2, 1.0, len(pts)), gg, 1.0 / np.sqrt(len(pts)), a, b, multi_res=True)
+                pr.set_block_width(k, width)
+        return pr
+
+    plain, structured = build(0), build(rings)
+    c0, r0, g0, H0 = plain.evaluate()
+    c1, r1, g1, H1 = structured.evaluate()
+    np.testing.assert_array_equal(r1, r0)  # per-return values do not depend on which lane computes them
+    assert abs(c0 - c1) <= 1e-13 * max(1.0, abs(c0))
+    np.testing.assert_allclose(g1, g0, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(H1, H0, rtol=1e-11, atol=1e-14)
+    s0, s1 = plain.solve(), structured.solve()
+    assert (s0.num_iterations, s0.termination_reason) == (s1.num_iterations, s1.termination_reason)
+    last = 0 if shape == "single" else 1
+    np.testing.assert_allclose(structured.get_pose(last), plain.get_pose(last), rtol=0, atol=1e-9)
+    odd = hg.Problem(ctx)
+    i = odd.add_pose(guess)
+    odd.add_block(pts[:-5], gg, 1.0, i, multi_res=True, width=rings)  # not a multiple: plain order, still correct
+    ref = hg.Problem(ctx)
+    ref.add_pose(guess)
+    ref.add_block(pts[:-5], gg, 1.0, 0, multi_res=True)
+    np.testing.assert_array_equal(odd.evaluate()[2], ref.evaluate()[2])
+    for pr in (plain, structured, odd, ref):
+        pr.close()
