@@ -683,8 +683,9 @@ class OptimizingLocalTrajectoryBuilder {
                                               delta.data()), "hg_problem_add_odometry_block");
         }
       }
-      hg_solver_summary summary;
+      hg_solver_summary& summary = last_summary_;
       Check(hg_problem_solve(problem_, &solver_, &summary), "hg_problem_solve");
+      ++num_solves_;
       for (size_t i = 0; i < window_.size(); ++i) {
         Check(hg_problem_get_pose(problem_, static_cast<int>(i), window_[i].pose.data()), "hg_problem_get_pose");
         if (imu_blocks)
@@ -707,6 +708,7 @@ class OptimizingLocalTrajectoryBuilder {
                                 out.cloud[0].data(), out.cloud.size(), 0, pf.data(), options_.insert_mode, HG_HOST, nullptr),
               "hg_pyramid_insert");
         out.inserted = true;
+        last_inserted_pose_ = out.pose;
         std::unique_ptr<InsertionResult> ins(new InsertionResult);
         for (auto& g : grids_) ins->insertion_grids.push_back(g.get());
         result->insertion_result = std::move(ins);
@@ -721,6 +723,10 @@ class OptimizingLocalTrajectoryBuilder {
   }
   const std::vector<std::unique_ptr<HybridGridTSDF>>& grids() const { return grids_; }
   size_t window_size() const { return window_.size(); }
+  const Pose& pose(size_t control_point) const { return window_[control_point].pose; }
+  const hg_solver_summary& last_summary() const { return last_summary_; }  // of the last MaybeOptimize solve
+  int num_solves() const { return num_solves_; }
+  const Pose& last_inserted_pose() const { return last_inserted_pose_; }  // where the last leaving scan went into the map
 
  private:
   struct ControlPoint {
@@ -739,6 +745,9 @@ class OptimizingLocalTrajectoryBuilder {
   std::vector<ControlPoint> window_;
   std::deque<sensor::ImuData> imu_data_;
   int last_imu_blocks_ = 0;
+  hg_solver_summary last_summary_{};
+  int num_solves_ = 0;
+  Pose last_inserted_pose_{{0, 0, 0, 1, 0, 0, 0}};
   sensor::OdometryData last_odom_{};
   bool have_odom_ = false, map_has_data_ = false;
 };

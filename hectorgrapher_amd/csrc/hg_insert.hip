@@ -995,18 +995,26 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
       if (range_err) atomicOr(&L.g.counters[1], kFlagRange);
     }
   }
-  // block slots: all probes of the wave in flight together, inserts only where the block is new
+  // block slots: the block's DIRECT slot first (round 4) -- block_keys[direct_slot(key)] == key + 1 says the
+  // block exists and sits there: one load, no probe chain, and true for every block of a map inside its
+  // window (what pyramid_tsd_direct does for the matcher). Round 3 probed the hash table first, where a
+  // quarter of the keys need a second probe, so nearly every wavefront went through the probe / insert loop
+  // (k_bin_count_jobs on maps in HBM: 85 % of its wave cycles waiting). All loads of the wave in flight
+  // together; the hash path only for blocks that are new or live in the overflow area. (A block's key word is
+  // set before its hash entry is published: seeing it is enough, the pool slot is pre-zeroed.)
   unsigned long long entry[kMaxRuns];
-  uint32_t slot[kMaxRuns];
+  uint32_t slot[kMaxRuns], dslot[kMaxRuns];
 #pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k)
-    entry[k] = (k < nr) ? L.g.table[hash_key(run_key[k]) & L.g.table_mask] : 0ull;
+  for (int k = 0; k < kMaxRuns; ++k) {
+    dslot[k] = (k < nr) ? direct_slot(L.g, run_key[k]) : 0u;
+    entry[k] = (k < nr) ? __hip_atomic_load(&L.g.block_keys[dslot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  }
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
     slot[k] = 0xFFFFFFFFu;
     if (k < nr) {
-      if ((entry[k] >> 24) == run_key[k] + 1ull && (entry[k] & 0xFFFFFFu) != kSlotPending)
-        slot[k] = static_cast<uint32_t>(entry[k] & 0xFFFFFFu);
+      if (entry[k] == run_key[k] + 1ull)
+        slot[k] = dslot[k];
       else
         slot[k] = insert_block_shared(L.g, run_key[k]);
     }

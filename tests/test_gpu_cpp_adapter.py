@@ -116,3 +116,173 @@ def test_cpp_gather_rccl_transport_two_ranks():
         outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert re.search(r"^gather ok: ranks 2 levels 3 blocks (\d+) voxels (\d+)", outs[0][0], re.M), outs[0][0]
+
+
+def _pose_mul(a, b):
+    """Rigid3d operator* with the normalisation of rigid_transform.h:184-190 (as hg_adapter.h transform::Multiply)."""
+    from hectorgrapher_amd import synth
+    import numpy as np
+    t = synth.quat_rotate(np.asarray(a[3:], np.float64), np.asarray(b[:3], np.float64)) + a[:3]
+    q = synth.quat_mul(a[3:], b[3:])
+    return np.concatenate([t, q / np.sqrt(q @ q)])
+
+
+def _pose_inv(a):
+    import numpy as np
+    from hectorgrapher_amd import synth
+    qc = np.array([a[3], -a[4], -a[5], -a[6]])
+    return np.concatenate([synth.quat_rotate(qc, -np.asarray(a[:3], np.float64)), qc])
+
+
+def _imu_delta_rotation(imu, start, end):
+    """Rotation recurrence of IntegrateImuWithTranslationEuler (imu_integration.h:99-131): piecewise-constant
+    angular velocity, delta *= AngleAxisVectorToRotationQuaternion(w dt) (transform/transform.h:121-135)."""
+    import numpy as np
+    q = np.array([1.0, 0.0, 0.0, 0.0])
+    if not imu or not (start < end):
+        return q
+    it = 0
+    while it + 1 < len(imu) and imu[it + 1][0] <= start:
+        it += 1
+    cur = start
+    while cur < end:
+        nxt_imu = imu[it + 1][0] if it + 1 < len(imu) else float("inf")
+        nxt = min(nxt_imu, end)
+        a = np.asarray(imu[it][1]) * (nxt - cur)
+        sq = float(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
+        scale, w = 0.5, 1.0
+        if sq > 1e-8:
+            norm = np.sqrt(sq)
+            scale, w = np.sin(norm / 2.0) / norm, np.cos(norm / 2.0)
+        x, y, z = scale * a
+        q = np.array([q[0] * w - q[1] * x - q[2] * y - q[3] * z, q[0] * x + q[1] * w + q[2] * z - q[3] * y,
+                      q[0] * y + q[2] * w + q[3] * x - q[1] * z, q[0] * z + q[3] * w + q[1] * y - q[2] * x])
+        cur = nxt
+        if cur == nxt_imu:
+            it += 1
+    return q
+
+
+def test_cpp_window_builder_against_oracle(tmp_path):
+    """The C++ OptimizingLocalTrajectoryBuilder-shaped adapter (cpp/hg_adapter.h) against the CPU oracle: the
+    example dumps every input it feeds the adapter; this test states the window wiring a second time --
+    range crop (oltb.cc:214-227), prediction from the odometry delta, first control point constant with its
+    velocity (:1268-1275), IMU pre-integration blocks between neighbours (:928-1000), one multi-resolution scan
+    block per free control point (:343-364), odometry blocks with delta = inverse(next) * previous (:1025-1029),
+    insertion of the scans that leave the window -- over pyoracle, replays the same inputs and compares every
+    control point of every step: 1e-4 m / 1e-4 rad, same iterations and termination."""
+    import struct
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    exe = os.path.join(CPP, "example_parity")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", os.path.join(CPP, "example_parity.cc"),
+                               "-L" + os.path.join(ROOT, "hectorgrapher_amd"), "-lhg_mi355x",
+                               "-Wl,-rpath," + os.path.join(ROOT, "hectorgrapher_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    dump = str(tmp_path / "inputs.bin")
+    out = subprocess.run([exe, dump, "9"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    # what the adapter reported
+    gpu = {}
+    step = None
+    for line in out.stdout.splitlines():
+        m = re.match(r"step (\d+) solved (\d+) iterations (\d+) termination (\d+) (\d+) window (\d+)", line)
+        if m:
+            step = int(m.group(1))
+            gpu[step] = {"solved": int(m.group(2)), "it": int(m.group(3)), "term": (int(m.group(4)), int(m.group(5))), "cps": []}
+            continue
+        m = re.match(r"\s+inserted at (.*)", line)
+        if m:
+            gpu[step]["inserted_at"] = np.array([float(v) for v in m.group(1).split()])
+            continue
+        m = re.match(r"\s+cp \d+ pose (.*) vel (.*)", line)
+        if m:
+            gpu[step]["cps"].append((np.array([float(v) for v in m.group(1).split()]), np.array([float(v) for v in m.group(2).split()])))
+    assert len(gpu) == 9
+    # the inputs
+    raw = open(dump, "rb").read()
+    off = 0
+    (n_scans,) = struct.unpack_from("i", raw, off)
+    off += 4
+    steps = []
+    for _ in range(n_scans):
+        (t,) = struct.unpack_from("d", raw, off); off += 8
+        (n,) = struct.unpack_from("i", raw, off); off += 4
+        pts = np.frombuffer(raw, np.float32, n * 4, off).reshape(n, 4).copy(); off += 16 * n
+        odom = np.frombuffer(raw, np.float64, 7, off).copy(); off += 56
+        (n_imu,) = struct.unpack_from("i", raw, off); off += 4
+        imu = []
+        for _ in range(n_imu):
+            vals = np.frombuffer(raw, np.float64, 4, off).copy(); off += 32
+            imu.append((float(vals[0]), vals[1:4]))
+        steps.append((t, pts, odom, imu))
+    # the window builder over the oracle (options of example_parity.cc)
+    res = [0.10, 0.20]
+    window_max, w_imu, w_odom = 4, (1.0, 0.05, 2.0), (3.0, 5.0)
+    grids = [po.Grid(r) for r in res]
+    window, imu_all, map_has_data = [], [], False
+    max_dt = max_dr = 0.0
+    for k, (t, pts, odom, imu) in enumerate(steps):
+        imu_all.extend(imu)
+        r = np.sqrt((pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1] + pts[:, 2] * pts[:, 2]).astype(np.float32))
+        cloud = np.ascontiguousarray(pts[(r >= np.float32(1.0)) & (r <= np.float32(60.0)), :3])
+        cp = {"time": t, "cloud": cloud, "odom": odom, "vel": np.zeros(3), "inserted": False}
+        if not window:
+            cp["pose"] = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+        else:
+            cp["pose"] = _pose_mul(window[-1]["pose"], _pose_mul(_pose_inv(window[-1]["odom"]), odom))
+            if t > window[-1]["time"]:
+                cp["vel"] = (cp["pose"][:3] - window[-1]["pose"][:3]) / (t - window[-1]["time"])
+        window.append(cp)
+        solved = 0
+        if map_has_data:
+            pr = po.Problem()
+            for i, c in enumerate(window):
+                first = i == 0 and len(window) > 1
+                pr.add_pose(c["pose"], first)
+                pr.set_velocity(i, c["vel"], first)
+            for i in range(1, len(window)):
+                dq = _imu_delta_rotation(imu_all, window[i - 1]["time"], window[i]["time"])
+                pr.add_imu_block(i - 1, i, w_imu[0], w_imu[1], w_imu[2], window[i]["time"] - window[i - 1]["time"], dq)
+            for i in range(1 if len(window) > 1 else 0, len(window)):
+                c = window[i]["cloud"]
+                pr.add_block(c, grids, 1.0 / np.sqrt(float(len(c))), i, multi_res=True)
+                if i > 0:
+                    delta = _pose_mul(_pose_inv(window[i]["odom"]), window[i - 1]["odom"])
+                    pr.add_odometry_block(i - 1, i, w_odom[0], w_odom[1], delta)
+            so = pr.solve()
+            solved = 1
+            for i, c in enumerate(window):
+                c["pose"], c["vel"] = pr.get_pose(i), pr.get_velocity(i)
+            while len(imu_all) > 1 and imu_all[1][0] <= window[0]["time"]:
+                imu_all.pop(0)
+            g = gpu[k]
+            assert g["solved"] == 1
+            assert (so.num_iterations, so.termination_type, so.termination_reason) == (g["it"], g["term"][0], g["term"][1]), k
+        # the scans that leave the window are inserted at the poses the ADAPTER used (float casts of its doubles),
+        # so that a last-bit difference of a pose cannot move a voxel and fork the two runs
+        while window and (not map_has_data or len(window) > window_max):
+            outcp = window[0]
+            if not outcp["inserted"]:
+                at = gpu[k]["inserted_at"]  # within 1e-4 of the oracle's own pose (asserted below), bit-identical cast
+                assert np.linalg.norm(at[:3] - outcp["pose"][:3]) < 1e-4
+                loc = po.transform_points(np.asarray(at, np.float64).astype(np.float32), outcp["cloud"])
+                origin = po.transform_points(np.asarray(at, np.float64).astype(np.float32), np.zeros((1, 3), np.float32))[0]
+                for gr in grids:
+                    gr.insert(origin, loc)
+                outcp["inserted"] = True
+            if not map_has_data:
+                map_has_data = True
+                break
+            window.pop(0)
+        # compare the window as it stands after the step
+        g = gpu[k]
+        assert len(g["cps"]) == len(window), (k, len(g["cps"]), len(window))
+        for (gp, gv), c in zip(g["cps"], window):
+            max_dt = max(max_dt, float(np.linalg.norm(gp[:3] - c["pose"][:3])))
+            max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(gp[3:] @ c["pose"][3:]))))))
+            np.testing.assert_allclose(gv, c["vel"], atol=1e-5)
+    assert max_dt < 1e-4 and max_dr < 1e-4, (max_dt, max_dr)
+    assert sum(g["solved"] for g in gpu.values()) == 8
