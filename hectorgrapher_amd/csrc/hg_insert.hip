@@ -1706,6 +1706,11 @@ __device__ inline void apply_small_bin(const GridView& g, float maximum_weight, 
                                        const uint32_t* __restrict__ bk, const uint32_t* __restrict__ bv,
                                        uint32_t* lds) {
   const unsigned lane = threadIdx.x & (kWave - 1);
+  // (Round 4, measured and dropped: requesting the block's 16 lines here, and the work items' voxels at item
+  // start, so that the chains' reads at the very end hit the L2 -- a scan stream over 64 rooms, 320 MB of voxel
+  // blocks, ran at 8.9k scans/s either way and k_bin_apply took 7 spills at its 64-register cap: whatever makes
+  // the apply pass take 88 us per scan on maps in HBM against 37 us on cached ones, it is not these reads.)
+  uint32_t* vox = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock;
   uint32_t* cb = lds;                 // per voxel: count (after the scan: count | base << 16)
   uint32_t* gk = lds + kVoxelsPerBlock;  // records grouped by voxel; later the list of non-empty voxels
   uint32_t* gv = gk + CAP;
@@ -1800,7 +1805,6 @@ __device__ inline void apply_small_bin(const GridView& g, float maximum_weight, 
       if (cb[kVox * lane + j] & 0xFFFFu) gk[pos++] = kVox * lane + j;
   }
   wave_sync_lds();
-  uint32_t* vox = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock;
   for (unsigned base = 0; base < m; base += kWave) {
     const unsigned idx = base + lane;
     if (idx < m) {
