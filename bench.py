@@ -1609,17 +1609,28 @@ def run(args, out_fd=None):
     # rocprofv3 --pmc passes, MI355X guide), so the figure comes from the committed passes of this same
     # command (scripts/r03_profile.sh -> profiles/r03_bench_pmc_traffic.json) and is labelled as such
     traffic = None
+    traffic_source = None
+    build_digest = api._lib.source_digest()
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_bench_pmc_traffic.json")) as f:
-            pmc = json.load(f)["kernels"]
-        if dom == "k_tsdf_residuals":
-            # the single-pose registration step runs the k_tsdf_residuals_single<512> instantiation
-            key = [k for k in pmc if "k_tsdf_residuals" in k]
-            traffic = max(pmc[k]["traffic_bytes"] for k in key)
+        with open(os.path.join(ROOT, "profiles", "r04_bench_pmc_traffic.json")) as f:
+            doc = json.load(f)
+        pmc = doc["kernels"]
+        if doc.get("csrc_sha16") != build_digest:
+            # the committed passes were taken on other sources: their bytes are not this build's
+            traffic_source = ("none: profiles/r04_bench_pmc_traffic.json was collected on sources %s, this build is %s "
+                              "(re-run scripts/r04_profile.sh)" % (doc.get("csrc_sha16"), build_digest))
         else:
-            traffic = sum(pmc[k]["traffic_bytes"] for k in pmc if k.startswith("hg::k_bin_"))
-    except Exception:
+            if dom == "k_tsdf_residuals":
+                # the single-pose registration step runs the k_tsdf_residuals_single<512> instantiation
+                key = [k for k in pmc if "k_tsdf_residuals" in k]
+                traffic = max(pmc[k]["traffic_bytes"] for k in key)
+            else:
+                traffic = sum(pmc[k]["traffic_bytes"] for k in pmc if k.startswith("hg::k_bin_"))
+            traffic_source = ("from_profile: profiles/r04_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                              "this command on the same sources, scripts/r04_profile.sh), not collected by this run")
+    except Exception as e:
         traffic = None
+        traffic_source = "none: %r" % (e,)
     achieved = bytes_per / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     families = {}
     for name, (ms, nbytes, _) in fam.items():
@@ -1627,13 +1638,16 @@ def run(args, out_fd=None):
         families[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": nbytes, "achieved": gbs,
                           "frac": gbs / HBM_PEAK_GBS}
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "from_profile: profiles/r03_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scripts/r03_profile.sh), not collected by this run", "kernel": dom,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel": dom,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per,
                 "per_kernel_ms_total": {k: round(v[1], 4) for k, v in prof.items()},
                 "per_kernel_launches": {k: v[0] for k, v in prof.items()},
                 "families": families,
-                "hip_event_sampling": "residual family on every %d-th of the %d timed steps, insert kernels on every %d-th"
+                "hip_event_sampling": "residual family on every %d-th of the %d timed steps, insert kernels on every %d-th; "
+                                      "an event pair serialises the stream (~8 us), so sampled steps run longer than the others "
+                                      "and per_kernel_ms_total does not add up to ms_per_step (rocprofv3 trace: profiles/r04_trace_gaps.txt)"
                                       % (max(1, args.prof_every), args.steps, 5 * max(1, args.prof_every)),
+                "build": {"version": api._lib.load().hg_version().decode(), "csrc_sha16": build_digest},
                 "residual_launches_evaluating": active_share}
 
     out = {

@@ -108,6 +108,22 @@ class HgError(RuntimeError):
     pass
 
 
+def source_digest():
+    """sha256[:16] over the library's sources (csrc/*.hip, csrc/*.h, csrc/Makefile, include/*.h): what a committed
+    rocprof / PMC profile was taken on. bench.py quotes a profile's HBM traffic only when this still matches."""
+    import glob
+    import hashlib
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   [os.path.join(_HERE, "csrc", "Makefile")] + glob.glob(os.path.join(root, "include", "*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

@@ -348,25 +348,13 @@ int hg_prof_read(hg_ctx* c, int kernel, uint64_t* launches, double* total_ms, ui
 int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_distance,
                    float max_weight, uint32_t max_blocks, hg_grid** out) {
   if (!ctx || !out || !(resolution > 0.f) || !(max_weight > 0.f) ||
-      !(relative_truncation_distance > 0.f) || max_blocks == 0 || max_blocks >= kSlotPending / 2)
+      !(relative_truncation_distance > 0.f) || max_blocks == 0 || max_blocks >= (1u << 22))
     return HG_ERR_INVALID;
   *out = nullptr;
   HG_HIP_CHECK(hipSetDevice(ctx->device));
   hg_grid* g = new hg_grid();
   g->ctx = ctx;
   g->relative_truncation_distance = relative_truncation_distance;
-  ctx->live_grids.push_back(g);
-  if (!ctx->flag_free.empty()) {
-    g->flag_slot = ctx->flag_free.back();
-    ctx->flag_free.pop_back();
-  } else if (ctx->flag_next < hg_ctx::kFlagSlots) {
-    g->flag_slot = ctx->flag_next++;
-  } else {
-    set_last_error("too many grids on one context (4096 sticky-error words)");
-    ctx->live_grids.pop_back();
-    delete g;
-    return HG_ERR_CAPACITY;
-  }
   GridView& v = g->view;
   v.max_blocks = max_blocks;
   // direct window: as many slots as the grid may hold blocks (rounded up to a power of two, at most
@@ -381,10 +369,22 @@ int hg_grid_create(hg_ctx* ctx, float resolution, float relative_truncation_dist
     v.dir_blocks = 1u << bits;
     v.pool_blocks = v.dir_blocks + max_blocks;
   }
-  if (v.pool_blocks >= kSlotPending) {
+  if (v.pool_blocks >= kSlotPending) {  // (unreachable: max_blocks < 2^22 gives at most 2^21 + 2^22 slots)
     delete g;
     return HG_ERR_INVALID;
   }
+  // every check has passed: only now does the context learn about the grid and hand out its flag word
+  if (!ctx->flag_free.empty()) {
+    g->flag_slot = ctx->flag_free.back();
+    ctx->flag_free.pop_back();
+  } else if (ctx->flag_next < hg_ctx::kFlagSlots) {
+    g->flag_slot = ctx->flag_next++;
+  } else {
+    set_last_error("too many grids on one context (4096 sticky-error words)");
+    delete g;
+    return HG_ERR_CAPACITY;
+  }
+  ctx->live_grids.push_back(g);
   g->table_capacity = next_pow2(std::max<uint32_t>(1024u, max_blocks * 2u));
   v.table_mask = g->table_capacity - 1;
   v.resolution = resolution;
@@ -454,9 +454,18 @@ int hg_grid_destroy(hg_grid* g) {
 }
 
 int hg_grid_clear(hg_grid* g) {
-  if (!g) return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(g);
   hipStream_t s = g->ctx->stream;
   const GridView& v = g->view;
+  // a cleared grid starts without sticky errors: its own word only. An insertion still in flight could
+  // publish into it after the host has cleared it, so a busy stream is drained first; an idle one (the usual
+  // case: grids are created and cleared between maps, not between scans) costs one query. The memsets
+  // below then run asynchronously.
+  if (hipStreamQuery(s) != hipSuccess) {
+    (void)hipGetLastError();
+    HG_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  g->ctx->flag_words[g->flag_slot] = 0u;
   HG_HIP_CHECK(hipMemsetAsync(v.table, 0, sizeof(unsigned long long) * g->table_capacity, s));
   HG_HIP_CHECK(hipMemsetAsync(v.voxels, 0, sizeof(uint32_t) * kVoxelsPerBlock * static_cast<size_t>(v.pool_blocks), s));
   HG_HIP_CHECK(hipMemsetAsync(v.block_keys, 0, sizeof(unsigned long long) * v.pool_blocks, s));
@@ -466,14 +475,6 @@ int hg_grid_clear(hg_grid* g) {
   HG_HIP_CHECK(hipMemsetAsync(v.bin_count, 0, sizeof(uint32_t) * 2 * static_cast<size_t>(v.pool_blocks), s));
   if (v.accum)
     HG_HIP_CHECK(hipMemsetAsync(v.accum, 0, sizeof(unsigned long long) * kVoxelsPerBlock * static_cast<size_t>(v.pool_blocks), s));
-  // a cleared grid starts without sticky errors: its own word only. An insertion still in flight could
-  // publish into it after the host has cleared it, so the stream is drained first -- unless it is idle
-  // already (the usual case: grids are cleared between maps, not between scans)
-  if (hipStreamQuery(s) != hipSuccess) {
-    (void)hipGetLastError();
-    HG_HIP_CHECK(hipStreamSynchronize(s));
-  }
-  g->ctx->flag_words[g->flag_slot] = 0u;
   return HG_OK;
 }
 
@@ -497,6 +498,7 @@ static int read_counters(hg_grid* g, uint32_t* out8) {
 }
 
 int hg_grid_num_blocks(hg_grid* g, uint32_t* num_blocks) {
+  HG_REQUIRE_CTX(g);
   if (!g || !num_blocks) return HG_ERR_INVALID;
   uint32_t c[8];
   int rc = read_counters(g, c);
@@ -506,6 +508,7 @@ int hg_grid_num_blocks(hg_grid* g, uint32_t* num_blocks) {
 }
 
 int hg_grid_window_status(hg_grid* g, uint32_t out[9]) {
+  HG_REQUIRE_CTX(g);
   if (!g || !out) return HG_ERR_INVALID;
   uint32_t c[16];
   HG_HIP_CHECK(hipMemcpyAsync(c, g->view.counters, sizeof(c), hipMemcpyDeviceToHost, g->ctx->stream));
@@ -524,6 +527,7 @@ int hg_grid_window_status(hg_grid* g, uint32_t out[9]) {
 
 int hg_grid_set_cells(hg_grid* g, const int32_t* ijk, size_t m, const float* tsd,
                       const float* weight) {
+  HG_REQUIRE_CTX(g);
   if (!g || (m && (!ijk || !tsd || !weight))) return HG_ERR_INVALID;
   if (m == 0) return HG_OK;
   hipStream_t s = g->ctx->stream;
@@ -549,6 +553,7 @@ int hg_grid_set_cells(hg_grid* g, const int32_t* ijk, size_t m, const float* tsd
 }
 
 int hg_grid_read_cells(hg_grid* g, const int32_t* ijk, size_t m, uint16_t* tsd, uint16_t* weight) {
+  HG_REQUIRE_CTX(g);
   if (!g || (m && (!ijk || !tsd || !weight))) return HG_ERR_INVALID;
   if (m == 0) return HG_OK;
   hipStream_t s = g->ctx->stream;
@@ -624,17 +629,20 @@ static int export_impl(hg_grid* g, int32_t* ijk, uint16_t* tsd, uint16_t* weight
 }
 
 int hg_grid_count(hg_grid* g, size_t* count) {
+  HG_REQUIRE_CTX(g);
   if (!g || !count) return HG_ERR_INVALID;
   return export_impl(g, nullptr, nullptr, nullptr, 0, count);
 }
 
 int hg_grid_export(hg_grid* g, int32_t* ijk, uint16_t* tsd, uint16_t* weight, size_t cap,
                    size_t* count) {
+  HG_REQUIRE_CTX(g);
   if (!g || !count || (cap && (!ijk || !tsd || !weight))) return HG_ERR_INVALID;
   return export_impl(g, ijk, tsd, weight, cap, count);
 }
 
 int hg_grid_block_arrays(hg_grid* g, void** keys_dev, void** voxels_dev, uint32_t* num_blocks) {
+  HG_REQUIRE_CTX(g);
   if (!g || !keys_dev || !voxels_dev || !num_blocks) return HG_ERR_INVALID;
   *keys_dev = *voxels_dev = nullptr;
   uint32_t nb = 0;
@@ -658,6 +666,7 @@ int hg_grid_block_arrays(hg_grid* g, void** keys_dev, void** voxels_dev, uint32_
 
 int hg_grid_import_blocks(hg_grid* g, const void* keys, const void* voxels, uint32_t nb,
                           int memspace) {
+  HG_REQUIRE_CTX(g);
   if (!g || (nb && (!keys || !voxels))) return HG_ERR_INVALID;
   if (nb == 0) return HG_OK;
   hipStream_t s = g->ctx->stream;
@@ -725,6 +734,7 @@ bool get_varint(const uint8_t*& p, const uint8_t* end, uint64_t* v) {
 extern "C" {
 
 int hg_grid_to_proto(hg_grid* g, uint8_t* buf, size_t cap, size_t* len) {
+  HG_REQUIRE_CTX(g);
   if (!g || !len) return HG_ERR_INVALID;
   size_t n = 0;
   int rc = hg_grid_count(g, &n);

@@ -930,8 +930,10 @@ __device__ inline int ray_block_runs(const Ray& r, unsigned long long* run_key, 
     // (the truncated product with v_rcp is that floor: exact for powers of two, far from an integer otherwise)
     const unsigned y = 2u * static_cast<unsigned>(ad);
     const unsigned x = static_cast<unsigned>(r.n * (2 * t - 1)) + y - 1u;
-    const unsigned m = static_cast<unsigned>(32768.0f * __builtin_amdgcn_rcpf(static_cast<float>(ad))) + 1u;
-    const int pos = static_cast<int>((x * m) >> 16);
+    // (an axis the ray does not move along never crosses: its reciprocal is taken of 1, not of 0 -- an infinity
+    // converted to unsigned and then used as a shift count is undefined, even though the result is discarded)
+    const unsigned m = static_cast<unsigned>(32768.0f * __builtin_amdgcn_rcpf(static_cast<float>(ad ? ad : 1))) + 1u;
+    const int pos = static_cast<int>((x * m) >> 16) & 15;
     cross[k] = (ad >= t) ? pos : 8;
     chg |= (ad >= t) ? (1u << pos) : 0u;
   }
@@ -3083,7 +3085,10 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     return HG_ERR_INVALID;
   if (mode != HG_INSERT_EXACT && mode != HG_INSERT_FAST) return HG_ERR_INVALID;
   hg_ctx* c = grids[0] ? grids[0]->ctx : nullptr;
-  if (!c) return HG_ERR_INVALID;
+  if (!c) {
+    if (grids[0]) set_last_error("the handle's context has been destroyed");
+    return HG_ERR_INVALID;
+  }
   for (int l = 0; l < levels; ++l) {
     if (!grids[l] || grids[l]->ctx != c) return HG_ERR_INVALID;
     if (opts[l].project_sdf_distance_to_scan_normal && opts[l].normal_computation_method != 1) {
@@ -3344,7 +3349,7 @@ int hg_pyramid_insert(hg_grid* const* grids, const hg_insert_opts* opts, int lev
 }
 
 int hg_grid_status(hg_grid* grid, hg_insert_stats* stats) {
-  if (!grid) return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(grid);
   return read_stats(grid, stats);
 }
 

@@ -176,6 +176,16 @@ struct ProfScope {
 };
 }  // namespace hg
 
+// A grid or problem whose context has been destroyed keeps its memory until it is destroyed itself (hg_ctx_destroy
+// orphans its children), but nothing can run on it any more: every entry point refuses it.
+#define HG_REQUIRE_CTX(handle)                                                              \
+  do {                                                                                      \
+    if (!(handle) || !(handle)->ctx) {                                                      \
+      if (handle) ::hg::set_last_error("the handle's context has been destroyed");         \
+      return HG_ERR_INVALID;                                                                \
+    }                                                                                       \
+  } while (0)
+
 namespace hg {
 int flags_to_status(uint32_t flags);
 // Status of the asynchronous insert calls issued so far on this context (HG_OK or the error of a

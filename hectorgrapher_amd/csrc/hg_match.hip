@@ -4290,7 +4290,7 @@ int hg_problem_destroy(hg_problem* p) {
 }
 
 int hg_problem_reset(hg_problem* p) {
-  if (!p) return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(p);
   bool owned = false;
   for (auto& b : p->blocks) owned = owned || b.owned;
   if (owned) (void)hipStreamSynchronize(p->ctx->stream);
@@ -4423,6 +4423,7 @@ static int add_block_impl(hg_problem* p, const float* xyz, const double* factors
                           int memspace, hg_grid* const* pyramid, int levels, int multi_res,
                           double scaling_factor, int pose_a, int pose_b, double interpolation_ratio) {
   if (!p || !pyramid || levels < 1 || levels > kMaxLevels || (n && !xyz)) return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(p);
   const int np = static_cast<int>(p->poses.size());
   if (pose_a < 0 || pose_a >= np || pose_b >= np) return HG_ERR_INVALID;
 #ifdef HG_BIG
@@ -4544,7 +4545,7 @@ int hg_problem_num_columns(hg_problem* p) {
 }
 
 int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* gradient, double* JtJ) {
-  if (!p || !p->ctx) return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(p);
   hipStream_t s = p->ctx->stream;
   HG_HIP_CHECK(hipSetDevice(p->ctx->device));
 #ifndef HG_BIG
@@ -4587,7 +4588,7 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
 }
 
 int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
-  if (!p || !p->ctx) return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(p);
   hipStream_t s = p->ctx->stream;
   HG_HIP_CHECK(hipSetDevice(p->ctx->device));
 #ifndef HG_BIG
@@ -4768,6 +4769,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   *batched = false;
   for (int i = 0; i < count; ++i)
     if (!problems[i] || problems[i]->ctx != problems[0]->ctx) return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(problems[0]);
   hg_ctx* c = problems[0]->ctx;
   hipStream_t s = c->stream;
   HG_HIP_CHECK(hipSetDevice(c->device));
@@ -4981,6 +4983,7 @@ int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solv
     }
     return HG_OK;
   }
+  HG_REQUIRE_CTX(problems[0]);
   hg_ctx* c = problems[0]->ctx;
   for (int j = 0; j < count; ++j)
     if (problems[j]->ctx != c) return HG_ERR_INVALID;  // one job table, one stream
@@ -5029,6 +5032,7 @@ int hg_register_scan_sequence(hg_problem* p, const hg_solver_opts* sopts, hg_gri
                               int memspace, int insert_mode, const double* guesses, int count,
                               int prof_every, double* poses_out, hg_solver_summary* summaries) {
   if (!p || !grids || !iopts || !origins || !xyz || !n || !scaling || !guesses || count < 0) return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(p);
   // prof_every > 0 samples kernel durations on some steps; the caller's own hg_prof_enable state comes
   // back on every exit path
   struct ProfRestore {
@@ -5201,6 +5205,7 @@ static int register_scan_step(hg_problem* p, const hg_solver_opts* sopts, int po
   if (!p || !grids || !iopts || !origin || pose_index < 0 ||
       pose_index >= static_cast<int>(p->poses.size()))
     return HG_ERR_INVALID;
+  HG_REQUIRE_CTX(p);
 #ifdef HG_HOST_STAMPS
   static double acc[4] = {0, 0, 0, 0};
   static int calls = 0;

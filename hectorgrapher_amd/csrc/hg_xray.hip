@@ -211,6 +211,7 @@ using namespace hg;
 
 extern "C" int hg_grid_xray(hg_grid* g, const double* global_submap_pose, uint8_t* cells, size_t cap,
                             int32_t* width, int32_t* height, int32_t* max_index_xy, size_t* bytes) {
+  HG_REQUIRE_CTX(g);
   if (!g || !global_submap_pose || !width || !height || !max_index_xy || !bytes) return HG_ERR_INVALID;
   static XrayThresholds thresholds;
   static bool thresholds_ok = false;

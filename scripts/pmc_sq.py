@@ -4,6 +4,9 @@ import collections
 import csv
 import json
 import sys
+import os as _os
+sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+from hectorgrapher_amd._lib import source_digest
 
 COMMAND = ("rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
            "SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
@@ -26,6 +29,7 @@ def main():
     json.dump({"command": COMMAND if len(sys.argv) < 4 else COMMAND.split(" -- ")[0] + " -- python3 " + sys.argv[3] + " --no-cpu-baseline",
                "unit": "counter totals per launch, averaged over the launches of the run (early-exit launches of "
                        "the residual kernel included); per_wave = total / SQ_WAVES",
+               "csrc_sha16": source_digest(),
                "kernels": out}, open(sys.argv[2], "w"), indent=1)
 
 

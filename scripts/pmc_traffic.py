@@ -11,6 +11,9 @@ import csv
 import json
 import os
 import sys
+import os as _os
+sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+from hectorgrapher_amd._lib import source_digest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -49,6 +52,7 @@ def main():
                 "calibrated only for wide 16-B/lane streams, these kernels issue 4/8-byte gathers "
                 "(MI355X_MICROARCH.md HBM section: other widths uncalibrated); early-exit launches of the residual "
                 "kernel (solver already terminated) are excluded",
+        "csrc_sha16": source_digest(),
         "kernels": kernels,
     }
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")

@@ -70,3 +70,31 @@ def test_null_arguments_are_refused_before_any_device_work():
     assert L.hg_grid_to_proto(None, None, 0, C.byref(n)) == -1
     assert L.hg_voxel_filter(None, 0.1, None, 0, 3, 0, None, C.byref(n)) == -1
     assert L.hg_adaptive_voxel_filter(None, 2.0, 150.0, 15.0, None, 0, 3, 0, None, C.byref(n)) == -1
+
+
+@pytest.mark.gpu
+def test_handles_of_a_destroyed_context_are_refused():
+    """hg_ctx_destroy orphans the grids and problems that outlive it (a garbage-collected host destroys in any
+    order): every entry point then returns HG_ERR_INVALID instead of dereferencing the dead context, and
+    destroying the orphans still frees them."""
+    import ctypes as C
+    from hectorgrapher_amd import _lib
+    L = _lib.load()
+    ctx, grid, prob = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.hg_ctx_create(0, None, C.byref(ctx)) == 0
+    assert L.hg_grid_create(ctx, 0.1, 2.5, 1000.0, 1 << 10, C.byref(grid)) == 0
+    assert L.hg_problem_create(ctx, C.byref(prob)) == 0
+    assert L.hg_ctx_destroy(ctx) == 0
+    n = C.c_uint32()
+    st = _lib.InsertStats()
+    assert L.hg_grid_clear(grid) == -1
+    assert L.hg_grid_num_blocks(grid, C.byref(n)) == -1
+    assert L.hg_grid_status(grid, C.byref(st)) == -1
+    cnt = C.c_size_t()
+    assert L.hg_grid_count(grid, C.byref(cnt)) == -1
+    assert L.hg_problem_reset(prob) == -1
+    assert L.hg_problem_solve_async(prob, None) == -1
+    assert L.hg_problem_evaluate(prob, None, None, None, None) == -1
+    assert b"context" in L.hg_last_error()
+    assert L.hg_problem_destroy(prob) == 0
+    assert L.hg_grid_destroy(grid) == 0
