@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "hg_internal.h"
@@ -133,6 +135,39 @@ static uint32_t next_pow2(uint32_t v) {
 
 using namespace hg;
 
+namespace {
+// CU-mask streams of destroyed contexts, kept for the next context of the same device (see hg_ctx_destroy).
+std::mutex g_stream_pool_mutex;
+std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+}  // namespace
+
+hipStream_t hg::acquire_masked_stream(int device) {
+  {
+    std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+    for (size_t i = 0; i < g_stream_pool.size(); ++i)
+      if (g_stream_pool[i].first == device) {
+        hipStream_t s = g_stream_pool[i].second;
+        g_stream_pool.erase(g_stream_pool.begin() + static_cast<long>(i));
+        return s;
+      }
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) return nullptr;
+  std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
+  for (int cu = 0; cu < prop.multiProcessorCount; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, static_cast<uint32_t>(mask.size()), mask.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return s;
+}
+void hg::release_masked_stream(int device, hipStream_t stream) {
+  (void)hipStreamSynchronize(stream);
+  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+  g_stream_pool.push_back({device, stream});
+}
+
 extern "C" {
 
 const char* hg_last_error(void) { return g_last_error.c_str(); }
@@ -221,12 +256,10 @@ int hg_ctx_create(int device, void* stream, hg_ctx** out) {
       const char* pin = std::getenv("HG_STREAM_PRIORITY");
       if (pin) prio = std::atoi(pin);
       if (!pin) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
-          std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
-          for (int cu = 0; cu < prop.multiProcessorCount; ++cu) mask[cu / 32] |= 1u << (cu % 32);
-          e = hipExtStreamCreateWithCUMask(&c->stream, static_cast<uint32_t>(mask.size()), mask.data());
-          if (e != hipSuccess) (void)hipGetLastError();
+        c->stream = acquire_masked_stream(device);
+        if (c->stream) {
+          e = hipSuccess;
+          c->pooled_stream = true;
         }
       }
       if (e != hipSuccess) e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio);
@@ -290,7 +323,8 @@ int hg_ctx_destroy(hg_ctx* c) {
   }
   if (c->apply_stream) {
     (void)hipStreamSynchronize(c->apply_stream);
-    (void)hipStreamDestroy(c->apply_stream);
+    if (c->apply_stream_pooled) release_masked_stream(c->device, c->apply_stream);
+    else (void)hipStreamDestroy(c->apply_stream);
     for (int i = 0; i < 2; ++i) {
       if (c->ev_front[i]) (void)hipEventDestroy(c->ev_front[i]);
       if (c->ev_apply[i]) (void)hipEventDestroy(c->ev_apply[i]);
@@ -304,7 +338,17 @@ int hg_ctx_destroy(hg_ctx* c) {
   if (c->pinned_ijobs) (void)hipHostFree(c->pinned_ijobs);
   if (c->pinned_sjobs) (void)hipHostFree(c->pinned_sjobs);
   if (c->ev_sjobs) (void)hipEventDestroy(c->ev_sjobs);
-  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) {
+    if (c->pooled_stream) {
+      // A stream with a CU mask goes back to the process-wide pool instead of being destroyed: destroying one
+      // shortly before the process exits deadlocks inside the runtime (ROCm 7.2: the completion thread that
+      // tears the hardware queue down against the module destructor's lock; one run in six of
+      // cpp/example_parity hung in exit(), none of 40 with an ordinary stream or with the stream kept).
+      release_masked_stream(c->device, c->stream);
+    } else {
+      (void)hipStreamDestroy(c->stream);
+    }
+  }
   delete c;
   return HG_OK;
 }

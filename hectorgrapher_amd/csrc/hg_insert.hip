@@ -2473,12 +2473,10 @@ int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans,
 int ensure_apply_stream(hg_ctx* c) {
   if (c->apply_stream) return HG_OK;
   hipError_t e = hipErrorUnknown;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) {
-    std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
-    for (int cu = 0; cu < prop.multiProcessorCount; ++cu) mask[cu / 32] |= 1u << (cu % 32);
-    e = hipExtStreamCreateWithCUMask(&c->apply_stream, static_cast<uint32_t>(mask.size()), mask.data());
-    if (e != hipSuccess) (void)hipGetLastError();
+  c->apply_stream = acquire_masked_stream(c->device);
+  if (c->apply_stream) {
+    e = hipSuccess;
+    c->apply_stream_pooled = true;
   }
   if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->apply_stream, hipStreamNonBlocking);
   HG_HIP_CHECK(e);

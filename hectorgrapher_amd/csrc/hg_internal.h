@@ -80,6 +80,7 @@ struct hg_ctx {
   double prof_ms[16] = {0};
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  bool pooled_stream = false;  // a CU-mask stream: returned to the process-wide pool, never destroyed
   // insertion workspace
   hg::DeviceBuffer ws_points, ws_scan_table, ws_gate, ws_counts, ws_offsets, ws_keys_a, ws_keys_b,
       ws_vals_a, ws_vals_b, ws_temp, ws_misc, ws_filter, ws_jobs;
@@ -111,6 +112,7 @@ struct hg_ctx {
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
   hipStream_t apply_stream = nullptr;
+  bool apply_stream_pooled = false;
   hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr};
   const uint32_t* filter_idx = nullptr;  // results of the last voxel-filter call (device)
   const float* filter_xyz = nullptr;
@@ -220,6 +222,11 @@ int unwarp_insert(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
 }
 
 namespace hg {
+// Streams with a CU mask of all CUs (a hardware queue of their own, hg_ctx_create) from a process-wide pool:
+// such a stream is never destroyed -- hipStreamDestroy on one shortly before exit() deadlocks inside the
+// runtime (hg_ctx_destroy) -- but handed to the next context of the device. nullptr if none can be made.
+hipStream_t acquire_masked_stream(int device);
+void release_masked_stream(int device, hipStream_t stream);
 int grid_block_order(hg_grid* g, std::vector<uint32_t>* order);
 void orphan_problem(hg_problem* p);  // hg_match.hip: the problem's context is going away
 }
