@@ -336,9 +336,9 @@ __device__ inline D3 interp_selected(const LevelSel& s, double both_invalid, dou
 // the window is read from the grid's counters by every wavefront (uniform loads): inserts of the
 // same stream may have changed it since the host enqueued the launch, so only the device knows.
 // ------------------------------------------------------------------------------------------
-struct DirectRaw {  // counters [8..15] of every level as loaded (same address in every lane)
-  uint4 lo[kMaxLevels];  // overflow blocks, bounding-box minimum x, y, z
-  uint4 hi[kMaxLevels];  // bounding-box maximum x, y, z, unused
+typedef unsigned su8 __attribute__((ext_vector_type(8)));
+struct DirectRaw {  // counters [8..15] of every level: overflow blocks, bounding-box minimum x y z, maximum x y z, unused
+  su8 w[kMaxLevels];  // in SCALAR registers (direct_issue)
 };
 struct DirectPyramid {
   uint32_t min_b[kMaxLevels][3];  // bounding-box minimum (block coordinates) = window anchor
@@ -348,35 +348,52 @@ struct DirectPyramid {
 // Issues the loads; nothing waits for them until direct_resolve, which callers place behind the
 // voxel loads (those are addressed without the window anchor), so the counters' round trip is not
 // on the critical path of a lookup.
+// Round 4: SCALAR loads (s_load_dwordx8, one per level). As vector loads of one address in every lane they
+// went through the vector L1 like any gather -- 16 quads x 6 instructions, a sixth of the tag lookups of a
+// wavefront in the batched pass, which that unit bounds -- and came back through 24 v_readfirstlane. The
+// scalar cache is invalidated at every kernel start, so the inserts of earlier launches are seen; the
+// compiler cannot pick the scalar form itself (it cannot prove that no store of the kernel aliases the counters).
 __device__ inline DirectRaw direct_issue(const PyramidView& pv) {
   DirectRaw r;
-  const int levels = pv.multi_res ? pv.levels : 1;
+  const int levels = __builtin_amdgcn_readfirstlane(pv.multi_res ? pv.levels : 1);
+  // the addresses are the same in every lane; spelled out for the places where the compiler cannot see that.
+  // A level that is not looked up reads level 0's words and is overridden below.
+  unsigned long long c[kMaxLevels];
 #pragma unroll
   for (int l = 0; l < kMaxLevels; ++l) {
-    r.lo[l] = make_uint4(1u, 0u, 0u, 0u);
-    r.hi[l] = make_uint4(0u, 0u, 0u, 0u);
-    if (l < levels) {
-      const uint4* c = reinterpret_cast<const uint4*>(pv.level[l].counters);
-      r.lo[l] = c[2];
-      r.hi[l] = c[3];
-    }
+    const unsigned long long a = reinterpret_cast<unsigned long long>(pv.level[l < levels ? l : 0].counters);
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(a)));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(a >> 32)));
+    c[l] = (static_cast<unsigned long long>(hi) << 32) | lo;
   }
+  // One statement issues the loads AND waits for them: the compiler does not know that the registers are
+  // still in flight behind a bare s_load and may copy them before the data lands (it did, in the window pass).
+  // The wait overlaps the wavefront's first vector loads, which are issued before it.
+  static_assert(kMaxLevels == 4, "four scalar loads");
+  asm volatile(
+      "s_load_dwordx8 %0, %4, 0x20\n\ts_load_dwordx8 %1, %5, 0x20\n\ts_load_dwordx8 %2, %6, 0x20\n\t"
+      "s_load_dwordx8 %3, %7, 0x20\n\ts_waitcnt lgkmcnt(0)"
+      : "=&s"(r.w[0]), "=&s"(r.w[1]), "=&s"(r.w[2]), "=&s"(r.w[3])
+      : "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]));
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l)
+    if (l >= levels) r.w[l][0] = 1u;  // never reported direct
   return r;
 }
 __device__ inline DirectPyramid direct_resolve(const PyramidView& pv, const DirectRaw& r) {
   DirectPyramid d;
   d.ok = true;
-  const int levels = pv.multi_res ? pv.levels : 1;
+  const int levels = __builtin_amdgcn_readfirstlane(pv.multi_res ? pv.levels : 1);
 #pragma unroll
   for (int l = 0; l < kMaxLevels; ++l) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) d.min_b[l][a] = 0;
     if (l < levels) {
       const GridView& g = pv.level[l];
-      auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
-      const uint32_t mn[3] = {uni(r.lo[l].y), uni(r.lo[l].z), uni(r.lo[l].w)};
-      const uint32_t mx[3] = {uni(r.hi[l].x), uni(r.hi[l].y), uni(r.hi[l].z)};
-      bool ok = uni(r.lo[l].x) == 0u;  // no block in the overflow area
+      const su8 w = r.w[l];
+      const uint32_t mn[3] = {w[1], w[2], w[3]};
+      const uint32_t mx[3] = {w[4], w[5], w[6]};
+      bool ok = w[0] == 0u;  // no block in the overflow area
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         // a grid without blocks has min = 0xFFFFFFFF, max = 0: the test passes and every lookup reads
@@ -914,11 +931,12 @@ __device__ __forceinline__ void tsdf_residuals_body(
   const unsigned i0 = wg * THREADS + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   BODY_STAMP(0);
+  // (the point load is issued in front of the scalar loads of direct_issue, whose wait it then overlaps)
+  const unsigned i = scan_index(make_scan_order(n, width), i0 < n ? i0 : 0u);
+  double v[3];
+  load_point(xyz, i, v);
   const DirectRaw dp = direct_issue(pv);
   if (i0 < n) {
-    const unsigned i = scan_index(make_scan_order(n, width), i0);
-    double v[3];
-    load_point(xyz, i, v);
     // (THREADS == 256: the batched kernel)
     if (pose_tq) return_row<THREADS == 256>(pv, dp, pose_tq, pose_tq + 3, v, scaling, row8);
     else return_row<THREADS == 256>(pv, dp, xf->t, xf->q, v, scaling, row8);
@@ -3663,8 +3681,11 @@ struct SingleJob {
 // kernel boundary here, so no hand-over protocol is needed.
 // (compiled for four workgroups per CU: 128 VGPRs instead of 134, 212 against 230 us per launch of 64 matches;
 // five -- 102 VGPRs, 75 of them spilled -- 326 us)
+#ifndef HG_BATCH_WAVES
+#define HG_BATCH_WAVES 4
+#endif
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
+__global__ __launch_bounds__(THREADS, HG_BATCH_WAVES) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
   const SingleJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.num_wg) return;
   if (J.G->h.done) return;
