@@ -1358,6 +1358,9 @@ def secondary_workloads(args):
         # blocks touched per call, beyond the 256 MB Infinity Cache); insert_stream_32 above stays in cache
         ("insert_stream_64_hbm", run_insert_stream, {"workload": "insert_stream", "stream_scans": 64, "stream_tiles": 64,
                                                      "steps": 3, "warmup": 1, "prof_every": 1, "cpu_scans": 2}),
+        # configs[3] with the reference's real builder: 8 submaps, each a 10-control-point window per step, shared launches
+        ("window_batch_8", run_window_batch, {"workload": "window_batch", "window": 10, "batch_submaps": 8, "steps": 4, "warmup": 2,
+                                              "prof_every": 2}),
         # BASELINE configs[3] bounded: 8 submaps x 10 scans on this GPU, then the gather of all finished blocks
         # through a one-rank process group and its import / export-digest check (the full 8 x 500 run is
         # `bench.py --total-submaps 8 --scans-per-submap 500`, profiles/r04_bench_offline8x500.json)

@@ -487,6 +487,12 @@ __device__ inline void direct_load(const GridView& g, DirectFetch& f) {
       f.face[k] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(base + f.byte[4 + k]);
   }
 }
+// (Round 4, measured and dropped: the face words in compacted form -- an exec-masked gather costs the L1 its
+// 16-cycle minimum however few lanes take part (scripts/tcp_bench.hip), so the face lanes of a level queued their
+// four addresses in LDS and the first 4 x (face lanes) lanes fetched one word each: 3 dense loads instead of 12
+// sparse ones, results routed back through LDS. Bit-identical, and slower everywhere -- 64-match batch 24.2k ->
+// 23.6k matches/s, headline 3534 -> 3417 scans/s, window 1357 -> 1261: the two LDS round trips and the ballots
+// sit on every wavefront's critical path, and the L1 is no longer the only bound.)
 __device__ inline void direct_merge(DirectFetch& f) {
   const bool face = (f.s0[0] & 7u) == 7u;
   if (face) {

@@ -23,6 +23,40 @@ __global__ __launch_bounds__(256) void k_gather(const unsigned long long* __rest
   out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// exec-masked variant: only one lane in MASKN takes part (the face words of the matcher: one lane in eight)
+template <int MASKN>
+__global__ __launch_bounds__(256) void k_gather_masked(const unsigned long long* __restrict__ buf, unsigned long long* out, int iters, unsigned lines_mask) {
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned long long acc = 0;
+  unsigned line = (lane * 37u + blockIdx.x * 11u + (threadIdx.x >> 6) * 5u) & lines_mask;
+  const unsigned long long* base = buf + (blockIdx.x % 8) * 4096;
+  if (lane % MASKN == MASKN - 1) {
+#pragma unroll 8
+    for (int i = 0; i < iters; ++i) {
+      acc += base[line * 16u + (lane & 15u)];
+      line = (line + 13u) & lines_mask;
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+template <int MASKN>
+void run_masked(const unsigned long long* d, unsigned long long* o, unsigned mask) {
+  const int iters = 4096, blocks = 256 * 8;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL((k_gather_masked<MASKN>), dim3(blocks), dim3(256), 0, 0, d, o, 64, mask);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  hipLaunchKernelGGL((k_gather_masked<MASKN>), dim3(blocks), dim3(256), 0, 0, d, o, iters, mask);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  const double wave_instr = double(blocks) * 4 * iters;
+  printf("one lane in %2d active (%2d lines per instruction): %.3f ms, %.1f cycles per wave-instruction per CU\n", MASKN, 64 / MASKN, ms,
+         ms * 1e-3 * 2.4e9 / (wave_instr / 256.0));
+}
+
 template <int G, int ADJ>
 void run(const unsigned long long* d, unsigned long long* o, unsigned mask) {
   const int iters = 4096, blocks = 256 * 8;
@@ -50,5 +84,6 @@ int main() {
   const unsigned mask = 127;  // 128 lines = 16 KB per window: L1-resident
   run<1, 1>(d, o, mask); run<2, 1>(d, o, mask); run<4, 1>(d, o, mask); run<8, 1>(d, o, mask); run<16, 1>(d, o, mask); run<64, 1>(d, o, mask);
   run<2, 0>(d, o, mask); run<4, 0>(d, o, mask); run<16, 0>(d, o, mask);
+  run_masked<1>(d, o, mask); run_masked<2>(d, o, mask); run_masked<4>(d, o, mask); run_masked<8>(d, o, mask); run_masked<16>(d, o, mask); run_masked<64>(d, o, mask);
   return 0;
 }
