@@ -540,6 +540,43 @@ class LocalTrajectoryBuilder3D {
   int num_scans_ = 0;
 };
 
+// use_per_point_unwarping, second half (optimizing_local_trajectory_builder.cc:1331-1379, then :1437-1440 and
+// submap_3d.cc:436-437): the clouds that leave the window are unwarped return by return with the window's solved
+// control poses and inserted, all on the device (hg_pyramid_insert_unwarped). Times in seconds as elsewhere in this
+// header; they become 100 ns ticks as common::FromSeconds makes them. control_poses.front() is optimized_pose.
+inline void InsertUnwarped(const std::vector<HybridGridTSDF*>& grids, const hg_insert_opts& inserter,
+                           const std::vector<sensor::TimedPointCloudData>& clouds, size_t width,
+                           const std::vector<Pose>& control_poses, const std::vector<double>& control_times,
+                           const std::array<float, 7>* submap_from_local = nullptr, int insert_mode = HG_INSERT_EXACT) {
+  if (grids.empty() || clouds.empty() || control_poses.size() < 2 || control_poses.size() != control_times.size())
+    throw Error("InsertUnwarped: needs grids, clouds and at least two control points", HG_ERR_INVALID);
+  std::vector<hg_grid*> pyr;
+  for (HybridGridTSDF* g : grids) pyr.push_back(g->get());
+  std::vector<hg_insert_opts> opts(grids.size(), inserter);
+  std::vector<hg_timed_cloud> table;
+  std::vector<float> points;
+  for (const auto& c : clouds) {
+    hg_timed_cloud t{};
+    t.time = static_cast<int64_t>(c.time * 1e7);
+    t.begin = points.size() / 4;
+    t.count = c.ranges.size();
+    for (int k = 0; k < 3; ++k) t.origin[k] = c.origin[k];
+    table.push_back(t);
+    for (const auto& p : c.ranges) points.insert(points.end(), p.begin(), p.end());
+  }
+  std::vector<double> poses;
+  std::vector<int64_t> times;
+  for (size_t k = 0; k < control_poses.size(); ++k) {
+    poses.insert(poses.end(), control_poses[k].begin(), control_poses[k].end());
+    times.push_back(static_cast<int64_t>(control_times[k] * 1e7));
+  }
+  Check(hg_pyramid_insert_unwarped(pyr.data(), opts.data(), static_cast<int>(pyr.size()), points.data(), points.size() / 4,
+                                   width, HG_HOST, table.data(), static_cast<int>(table.size()), poses.data(), times.data(),
+                                   static_cast<int>(times.size()), submap_from_local ? submap_from_local->data() : nullptr,
+                                   insert_mode, nullptr),
+        "hg_pyramid_insert_unwarped");
+}
+
 // Pre-integrated rotation between two control points, the only part of the pre-integration result
 // PredictionImuPreintegrationCostFunctor reads (prediction_imu_preintegration_cost_functor.h:81-84):
 // the rotation recurrence of IntegrateImuWithTranslationEuler (imu_integration.h:99-131) --
