@@ -428,11 +428,17 @@ __device__ inline float cell_quotient_fast(float p, float res, float r) {
 }
 // `q` = the quotients p / resolution of the three coordinates (cell_quotient_fast), handed in so that the
 // levels of a pyramid whose resolutions double can share them (pyramid_tsd_direct).
+// a | b | c in one instruction (left to itself the compiler shares two-way ors between the corners: 12 instead of 8)
+__device__ inline uint32_t or3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_or3_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ inline void direct_setup(const GridView& g, double x, double y, double z, const float* q, DirectFetch& f) {
   const float res = g.resolution;
   const double w[3] = {x, y, z};
-  uint32_t off[3][2];
-  uint32_t shift = 9;
+  uint32_t off[3][2];  // BYTE offsets: block part | voxel part of one axis
+  uint32_t shift = 9 + 2;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     // CenterOfLowerVoxel (interpolated_tsdf.h:176-192): float centre, compared against the double
@@ -443,17 +449,20 @@ __device__ inline void direct_setup(const GridView& g, double x, double y, doubl
     if (static_cast<double>(c) > w[a]) { c -= res; i0 -= 1; }
     f.c[a] = c;
     f.s0[a] = static_cast<uint32_t>(i0 + kIndexOffset);
-    const uint32_t mask = (1u << g.dir_bits[a]) - 1u;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
+      // four instructions per offset (bit-field extract, shift, and, shift-or) and one three-way or per corner:
+      // the address arithmetic was a quarter of the batched pass's vector instructions
       const uint32_t s = f.s0[a] + d;
-      off[a][d] = (((s >> 3) & mask) << shift) | ((s & 7u) << (3 * a));
+      const uint32_t blk = __builtin_amdgcn_ubfe(s, 3u, g.dir_bits[a]);  // (s >> 3) & mask
+      // (the dx = 1 corners are only read by lanes whose x pair crosses a block face: their voxel bits are 0)
+      off[a][d] = (a == 0 && d == 1) ? (blk << shift) : ((blk << shift) | ((s & 7u) << (3 * a + 2)));
     }
     shift += g.dir_bits[a];
   }
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
-    f.byte[c] = (off[0][c >> 2] | off[1][(c >> 1) & 1] | off[2][c & 1]) << 2;  // direct area < 2^30 voxels
+  for (int c = 0; c < 8; ++c)  // direct area < 2^30 voxels
+    f.byte[c] = or3(off[0][c >> 2], off[1][(c >> 1) & 1], off[2][c & 1]);
 }
 // The voxel loads of one level (independent of each other and of the other levels'). The two x
 // neighbours of a corner pair are adjacent words unless the pair crosses a block face (x & 7 == 7):
@@ -926,6 +935,31 @@ __device__ inline void load_point(const float* __restrict__ xyz, unsigned i, dou
   v[2] = static_cast<double>(p.z);
 }
 
+// The transform (t, q) of a block from device memory by SCALAR loads: the address is the same in every lane, but
+// the compiler cannot prove that no store of the kernel aliases it and emits four 16-byte vector loads of one
+// address -- four passes through the vector L1 per wavefront (round 4: that unit and the VALU share the bound of
+// the batched pass). Written by an earlier launch (k_lm* / the LM tail); the scalar cache starts every kernel
+// invalidated. Issue and wait in one statement (see direct_issue).
+__device__ inline void load_transform_uniform(const double* tq, double* out7) {
+  typedef unsigned su4 __attribute__((ext_vector_type(4)));
+  typedef unsigned su2 __attribute__((ext_vector_type(2)));
+  const unsigned long long a = reinterpret_cast<unsigned long long>(tq);
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(a)));
+  const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(a >> 32)));
+  const unsigned long long ua = (static_cast<unsigned long long>(hi) << 32) | lo;
+  su8 w0; su4 w1; su2 w2;
+  asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(w0), "=&s"(w1), "=&s"(w2) : "s"(ua));
+  out7[0] = __hiloint2double(static_cast<int>(w0[1]), static_cast<int>(w0[0]));
+  out7[1] = __hiloint2double(static_cast<int>(w0[3]), static_cast<int>(w0[2]));
+  out7[2] = __hiloint2double(static_cast<int>(w0[5]), static_cast<int>(w0[4]));
+  out7[3] = __hiloint2double(static_cast<int>(w0[7]), static_cast<int>(w0[6]));
+  out7[4] = __hiloint2double(static_cast<int>(w1[1]), static_cast<int>(w1[0]));
+  out7[5] = __hiloint2double(static_cast<int>(w1[3]), static_cast<int>(w1[2]));
+  out7[6] = __hiloint2double(static_cast<int>(w2[1]), static_cast<int>(w2[0]));
+}
+
 // residuals of one block at its current transform + 36 partial sums per workgroup
 template <int THREADS = kEvalThreads>
 __device__ __forceinline__ void tsdf_residuals_body(
@@ -942,10 +976,17 @@ __device__ __forceinline__ void tsdf_residuals_body(
   double v[3];
   load_point(xyz, i, v);
   const DirectRaw dp = direct_issue(pv);
+  double tq[7];
+  if (pose_tq) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tq[k] = pose_tq[k];
+  } else {
+    static_assert(offsetof(BlockXform, q) == 3 * sizeof(double), "t and q are contiguous");
+    load_transform_uniform(xf->t, tq);
+  }
   if (i0 < n) {
     // (THREADS == 256: the batched kernel)
-    if (pose_tq) return_row<THREADS == 256>(pv, dp, pose_tq, pose_tq + 3, v, scaling, row8);
-    else return_row<THREADS == 256>(pv, dp, xf->t, xf->q, v, scaling, row8);
+    return_row<THREADS == 256>(pv, dp, tq, tq + 3, v, scaling, row8);
     if (residuals) residuals[i] = row8[7];
   }
   BODY_STAMP(4);
@@ -1196,6 +1237,8 @@ __device__ __forceinline__ void window_body_plain(const EvalBlock& eb, const Blo
   const double scaling = eb.scaling;
   const ScanOrder order = make_scan_order(n, eb.width);
   const unsigned first = xcd_chunk(wg, eb.num_wg) * tiles;
+  double tq[7];
+  load_transform_uniform(xf->t, tq);
   for (unsigned tile = 0; tile < tiles; ++tile) {
     const unsigned base = (first + tile) * kBatchThreads;
     if (base >= n) break;  // uniform
@@ -1205,7 +1248,7 @@ __device__ __forceinline__ void window_body_plain(const EvalBlock& eb, const Blo
       const unsigned i = scan_index(order, i0);
       double v[3];
       load_point(eb.xyz, i, v);
-      return_row(pv, dp, xf->t, xf->q, v, scaling, row8);
+      return_row(pv, dp, tq, tq + 3, v, scaling, row8);
       if (residuals) residuals[i] = row8[7];
     }
     d2* dst = reinterpret_cast<d2*>(&xs[wave][lane][0]);
