@@ -257,6 +257,14 @@ __device__ unsigned long long g_body_stamps[1024][8];
 #else
 #define BODY_STAMP(i) do {} while (0)
 #endif
+// Analysis build only (scripts/isa_budget.py: -DHG_ISA_REGIONS -S): comment markers between the phases of a
+// return's evaluation, and only the 3-level doubling variant of the lookup instantiated, so that the hot path
+// is one straight run of instructions that can be counted per phase.
+#ifdef HG_ISA_REGIONS
+#define ISA_MARK(name) asm volatile("; HG_REGION " name ::: "memory")
+#else
+#define ISA_MARK(name) do {} while (0)
+#endif
 
 // InterpolateLinear (interpolated_tsdf.h:30-46 / interpolated_multi_resolution_tsdf.h:30-46)
 __device__ inline void interpolate_linear(double both_invalid, const D3& q1, const D3& q2, double w1,
@@ -345,9 +353,7 @@ struct DirectPyramid {
   bool ok;                        // every level of the lookup is directly addressable
 };
 
-// Issues the loads; nothing waits for them until direct_resolve, which callers place behind the
-// voxel loads (those are addressed without the window anchor), so the counters' round trip is not
-// on the critical path of a lookup.
+// Loads the counters (the point's load is issued in front of them and overlaps the wait).
 // Round 4: SCALAR loads (s_load_dwordx8, one per level). As vector loads of one address in every lane they
 // went through the vector L1 like any gather -- 16 quads x 6 instructions, a sixth of the tag lookups of a
 // wavefront in the batched pass, which that unit bounds -- and came back through 24 v_readfirstlane. The
@@ -380,39 +386,13 @@ __device__ inline DirectRaw direct_issue(const PyramidView& pv) {
     if (l >= levels) r.w[l][0] = 1u;  // never reported direct
   return r;
 }
-__device__ inline DirectPyramid direct_resolve(const PyramidView& pv, const DirectRaw& r) {
-  DirectPyramid d;
-  d.ok = true;
-  const int levels = __builtin_amdgcn_readfirstlane(pv.multi_res ? pv.levels : 1);
-#pragma unroll
-  for (int l = 0; l < kMaxLevels; ++l) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) d.min_b[l][a] = 0;
-    if (l < levels) {
-      const GridView& g = pv.level[l];
-      const su8 w = r.w[l];
-      const uint32_t mn[3] = {w[1], w[2], w[3]};
-      const uint32_t mx[3] = {w[4], w[5], w[6]};
-      bool ok = w[0] == 0u;  // no block in the overflow area
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        // a grid without blocks has min = 0xFFFFFFFF, max = 0: the test passes and every lookup reads
-        // the all-zero pool, which is the right answer
-        ok = ok && (mx[a] - mn[a]) < (1u << g.dir_bits[a]);
-        d.min_b[l][a] = mn[a];
-      }
-      d.ok = d.ok && ok;
-    }
-  }
-  return d;
-}
-
 struct DirectFetch {
   float c[3];        // centre of the lower corner voxel per axis (CenterOfLowerVoxel)
   uint32_t s0[3];    // lower corner cell index + kIndexOffset per axis
   uint32_t byte[8];  // byte offsets of the 8 corners inside the direct area
   uint32_t code[8];  // corner order c = dx*4 + dy*2 + dz
   uint32_t face[4];  // the dx = 1 corners of a lane whose x pair crosses a block face (direct_merge)
+  bool in;           // both cells of every axis lie in blocks of the window (direct_setup)
 };
 
 // Lower-corner cell and the addresses of the 8 corners of one level. The offsets are masked into
@@ -428,17 +408,43 @@ __device__ inline float cell_quotient_fast(float p, float res, float r) {
 }
 // `q` = the quotients p / resolution of the three coordinates (cell_quotient_fast), handed in so that the
 // levels of a pyramid whose resolutions double can share them (pyramid_tsd_direct).
+// What a direct lookup needs of one level, in scalar registers: fetched from the pyramid description in ONE
+// group of scalar loads with one wait, before anything else of the lookup (pin_level). Left to the compiler the
+// fields were fetched where they are used -- a dozen scalar loads strewn over the address arithmetic and the
+// level selection, each followed by a full wait (and the window bits fetched twice).
+struct LevelPin {
+  uint32_t vox_lo, vox_hi;  // voxel pool
+  uint32_t bits[3];         // window bits per axis
+  float res, tsd_scale, tsd_offset;
+};
+__device__ inline LevelPin pin_level(const GridView& g) {
+  LevelPin p;
+  const unsigned long long v = reinterpret_cast<unsigned long long>(g.voxels);
+  p.vox_lo = __builtin_amdgcn_readfirstlane(static_cast<int>(v));
+  p.vox_hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
+#pragma unroll
+  for (int a = 0; a < 3; ++a) p.bits[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(g.dir_bits[a]));
+  p.res = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(g.resolution)));
+  p.tsd_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(g.tsd_scale)));
+  p.tsd_offset = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(g.tsd_offset)));
+  asm volatile("" : "+s"(p.vox_lo), "+s"(p.vox_hi), "+s"(p.bits[0]), "+s"(p.bits[1]), "+s"(p.bits[2]),
+                    "+s"(p.res), "+s"(p.tsd_scale), "+s"(p.tsd_offset));
+  return p;
+}
 // a | b | c in one instruction (left to itself the compiler shares two-way ors between the corners: 12 instead of 8)
 __device__ inline uint32_t or3(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t r;
   asm("v_or3_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-__device__ inline void direct_setup(const GridView& g, double x, double y, double z, const float* q, DirectFetch& f) {
-  const float res = g.resolution;
+// `wmin`: the window anchor of the level (pyramid_tsd_direct); `usable`: the point has a cell at all.
+__device__ inline void direct_setup(const LevelPin& g, double x, double y, double z, const float* q,
+                                    const uint32_t* wmin, bool usable, DirectFetch& f) {
+  const float res = g.res;
   const double w[3] = {x, y, z};
   uint32_t off[3][2];  // BYTE offsets: block part | voxel part of one axis
   uint32_t shift = 9 + 2;
+  bool inside = usable;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     // CenterOfLowerVoxel (interpolated_tsdf.h:176-192): float centre, compared against the double
@@ -449,20 +455,29 @@ __device__ inline void direct_setup(const GridView& g, double x, double y, doubl
     if (static_cast<double>(c) > w[a]) { c -= res; i0 -= 1; }
     f.c[a] = c;
     f.s0[a] = static_cast<uint32_t>(i0 + kIndexOffset);
+    // Inside the window anchored at the bounding-box minimum (which implies inside the index range)? Outside it
+    // no block exists and the voxels read as unknown. Blocks of cells s0 and s0 + 1 both within
+    // [wmin, wmin + 2^bits): one unsigned compare of the cell against the window's first cell and its length
+    // minus two (the operands are wave-uniform). Decided HERE, next to the address arithmetic that reads the same
+    // window bits (round 4): left to the level selection behind the loads, the compiler fetched the bits again
+    // from the pyramid description inside nested branches -- nine scalar loads, each awaited, per wavefront.
+    const uint32_t first = wmin[a] << 3, span = (8u << g.bits[a]) - 2u;
+    inside = inside & ((f.s0[a] - first) <= span);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       // four instructions per offset (bit-field extract, shift, and, shift-or) and one three-way or per corner:
       // the address arithmetic was a quarter of the batched pass's vector instructions
       const uint32_t s = f.s0[a] + d;
-      const uint32_t blk = __builtin_amdgcn_ubfe(s, 3u, g.dir_bits[a]);  // (s >> 3) & mask
+      const uint32_t blk = __builtin_amdgcn_ubfe(s, 3u, g.bits[a]);  // (s >> 3) & mask
       // (the dx = 1 corners are only read by lanes whose x pair crosses a block face: their voxel bits are 0)
       off[a][d] = (a == 0 && d == 1) ? (blk << shift) : ((blk << shift) | ((s & 7u) << (3 * a + 2)));
     }
-    shift += g.dir_bits[a];
+    shift += g.bits[a];
   }
 #pragma unroll
   for (int c = 0; c < 8; ++c)  // direct area < 2^30 voxels
     f.byte[c] = or3(off[0][c >> 2], off[1][(c >> 1) & 1], off[2][c & 1]);
+  f.in = inside;
 }
 // The voxel loads of one level (independent of each other and of the other levels'). The two x
 // neighbours of a corner pair are adjacent words unless the pair crosses a block face (x & 7 == 7):
@@ -478,8 +493,8 @@ typedef const __attribute__((address_space(1))) char* gmem_bytes;
 __device__ inline gmem_bytes as_global(const void* p) {
   return reinterpret_cast<gmem_bytes>(reinterpret_cast<uintptr_t>(p));
 }
-__device__ inline void direct_load(const GridView& g, DirectFetch& f) {
-  gmem_bytes base = as_global(g.voxels);
+__device__ inline void direct_load(const LevelPin& g, DirectFetch& f) {
+  gmem_bytes base = reinterpret_cast<gmem_bytes>((static_cast<uintptr_t>(g.vox_hi) << 32) | g.vox_lo);
   const bool face = (f.s0[0] & 7u) == 7u;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {  // corner k = (dy, dz) at dx = 0, corner 4 + k at dx = 1
@@ -488,8 +503,7 @@ __device__ inline void direct_load(const GridView& g, DirectFetch& f) {
     f.code[k] = v.x;
     f.code[4 + k] = v.y;
   }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) f.face[k] = 0u;
+  // (the face words stay undefined in the other lanes: direct_merge reads them under the same predicate)
   if (face) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -515,19 +529,6 @@ __device__ inline void direct_merge(DirectFetch& f) {
     }
   }
 }
-// Inside the window anchored at the bounding-box minimum (which implies inside the index range)?
-// Outside it no block exists: the voxels read as unknown.
-__device__ inline bool direct_inside(const GridView& g, const uint32_t* wmin, bool usable, const DirectFetch& f) {
-  bool in = usable;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    // blocks of cells s0 and s0 + 1 both within [wmin, wmin + 2^bits): one unsigned compare of the cell
-    // against the window's first cell and its length minus two (the operands are wave-uniform)
-    const uint32_t first = wmin[a] << 3, span = (8u << g.dir_bits[a]) - 2u;
-    in = in && (f.s0[a] - first) <= span;
-  }
-  return in;
-}
 // All 8 weights non-zero: weight code (bits 16..30, the marker bit masked as GetWeight does) above 1.
 __device__ inline bool all_weights_valid(const uint32_t* code) {
   constexpr uint32_t kAbove1 = 0x7FFE0000u;
@@ -536,10 +537,9 @@ __device__ inline bool all_weights_valid(const uint32_t* code) {
   const uint32_t m2 = min(min(code[6] & kAbove1, code[7] & kAbove1), m0);
   return min(m1, m2) != 0u;
 }
-__device__ inline void direct_accept(const GridView& g, const uint32_t* wmin, bool usable, DirectFetch& f) {
-  const bool in = direct_inside(g, wmin, usable, f);
+__device__ inline void direct_accept(DirectFetch& f) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) f.code[c] = in ? f.code[c] : 0u;
+  for (int c = 0; c < 8; ++c) f.code[c] = f.in ? f.code[c] : 0u;
 }
 
 // InterpolatedTSDF::GetTSD (interpolated_tsdf.h:72-116) when all 8 weights are non-zero: every
@@ -552,17 +552,20 @@ __device__ inline double rcp_span(double d) {
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
 }
-__device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offset, float min_tsd,
+__device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offset,
                                       const float* c3, const uint32_t* code, double x, double y, double z) {
-  (void)min_tsd;
   double q[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
+  for (int c = 0; c < 8; c += 2) {
     // decode as the LUT does (float multiply, then float add: never fused). A voxel with a non-zero weight
     // code has a non-zero tsd code (SetCell writes both), so the unknown-code case cannot occur on a level
-    // that is all valid; callers discard the result otherwise.
-    const uint32_t v = code[c] & 0x7FFFu;
-    q[c] = static_cast<double>(static_cast<float>(v) * tsd_scale + tsd_offset);
+    // that is all valid; callers discard the result otherwise. Two codes per packed multiply / add.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 t = {static_cast<float>(code[c] & 0x7FFFu), static_cast<float>(code[c + 1] & 0x7FFFu)};
+    t = t * f2{tsd_scale, tsd_scale};
+    t = t + f2{tsd_offset, tsd_offset};
+    q[c] = static_cast<double>(t.x);
+    q[c + 1] = static_cast<double>(t.y);
   }
   const double x1 = c3[0], y1 = c3[1], z1 = c3[2];
   const double x2 = c3[0] + res, y2 = c3[1] + res, z2 = c3[2] + res;  // float adds, as the reference
@@ -605,6 +608,31 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
                                         double z, bool* ok) {
   // a coordinate this large has no cell; NaN passes and indexes cell 0 like the general path
   const bool usable = !(fabs(x) >= 1e30 || fabs(y) >= 1e30 || fabs(z) >= 1e30);
+  LevelPin lp[LEVELS];
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) lp[l] = pin_level(pv.level[l]);
+  int multi = __builtin_amdgcn_readfirstlane(pv.multi_res);
+  float min_tsd0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pv.level[0].min_tsd)));
+  asm volatile("" : "+s"(multi), "+s"(min_tsd0));
+  // every level directly addressable? (direct_issue has waited for the counters; LEVELS is the number of levels
+  // the caller looks up)
+  DirectPyramid dp;
+  dp.ok = true;
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) {
+    const su8 w = raw.w[l];
+    bool lok = w[0] == 0u;  // no block in the overflow area
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      // a grid without blocks has min = 0xFFFFFFFF, max = 0: the test passes and every lookup reads
+      // the all-zero pool, which is the right answer
+      lok = lok & ((w[4 + a] - w[1 + a]) < (1u << lp[l].bits[a]));
+      dp.min_b[l][a] = w[1 + a];
+    }
+    dp.ok = dp.ok & lok;
+  }
+  *ok = dp.ok;
+  if (!dp.ok) return {0.0, 0.0, 0.0, 0.0};  // wave-uniform: the caller takes the general path
   DirectFetch f[LEVELS];
   {
     // p / res per level and axis. SHARE (the batched kernel, bound by instruction issue): when every level's
@@ -614,10 +642,13 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
     // axis and level (64 matches: 210 -> 197 us per launch). Two copies of the set-up code, chosen per
     // wavefront; the latency-bound kernels keep the single copy (the window pass lost 2.6 % with both).
     if constexpr (SHARE) {
-      const float r0 = pv.level[0].resolution;
+      const float r0 = lp[0].res;
       bool doubling = true;
 #pragma unroll
-      for (int l = 1; l < LEVELS; ++l) doubling = doubling && pv.level[l].resolution == r0 * static_cast<float>(1 << l);
+      for (int l = 1; l < LEVELS; ++l) doubling = doubling & (lp[l].res == r0 * static_cast<float>(1 << l));
+#ifdef HG_ISA_REGIONS
+      doubling = true;
+#endif
       if (doubling) {
         const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
         const float rr = refined_rcp(r0);
@@ -628,39 +659,38 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
         for (int l = 0; l < LEVELS; ++l) {
           const float scale = 1.0f / static_cast<float>(1 << l);
           const float ql[3] = {q[0] * scale, q[1] * scale, q[2] * scale};
-          direct_setup(pv.level[l], x, y, z, ql, f[l]);
+          direct_setup(lp[l], x, y, z, ql, dp.min_b[l], usable, f[l]);
         }
       } else {
         const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
 #pragma unroll
         for (int l = 0; l < LEVELS; ++l) {
-          const float res = pv.level[l].resolution, rr = refined_rcp(res);
+          const float res = lp[l].res, rr = refined_rcp(res);
           const float ql[3] = {cell_quotient_fast(p[0], res, rr), cell_quotient_fast(p[1], res, rr), cell_quotient_fast(p[2], res, rr)};
-          direct_setup(pv.level[l], x, y, z, ql, f[l]);
+          direct_setup(lp[l], x, y, z, ql, dp.min_b[l], usable, f[l]);
         }
       }
     } else {
       const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
 #pragma unroll
       for (int l = 0; l < LEVELS; ++l) {
-        const float res = pv.level[l].resolution, rr = refined_rcp(res);
+        const float res = lp[l].res, rr = refined_rcp(res);
         const float ql[3] = {cell_quotient_fast(p[0], res, rr), cell_quotient_fast(p[1], res, rr), cell_quotient_fast(p[2], res, rr)};
-        direct_setup(pv.level[l], x, y, z, ql, f[l]);
+        direct_setup(lp[l], x, y, z, ql, dp.min_b[l], usable, f[l]);
       }
     }
   }
   BODY_STAMP(1);
   BODY_STAMP(2);
+  ISA_MARK("cells+addresses|loads");
 #pragma unroll
-  for (int l = 0; l < LEVELS; ++l) direct_load(pv.level[l], f[l]);
+  for (int l = 0; l < LEVELS; ++l) direct_load(lp[l], f[l]);
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) direct_merge(f[l]);
-  const DirectPyramid dp = direct_resolve(pv, raw);  // the counters have long arrived
-  *ok = dp.ok;
-  if (!dp.ok) return {0.0, 0.0, 0.0, 0.0};  // wave-uniform: the caller takes the general path
   BODY_STAMP(3);
-  if (!pv.multi_res) {
-    direct_accept(pv.level[0], dp.min_b[0], usable, f[0]);
+  ISA_MARK("loads|select");
+  if (!multi) {
+    direct_accept(f[0]);
     const GridView& g = pv.level[0];
     LevelSel s;
     s.x1 = f[0].c[0]; s.y1 = f[0].c[1]; s.z1 = f[0].c[2];
@@ -681,34 +711,33 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   // The per-level codec constants are pinned to scalar registers (readfirstlane): left as plain
   // kernel-argument loads the compiler built a lookup table of them in PRIVATE memory and indexed it
   // per lane (eight scratch stores per lane at kernel start: 3 MB of writes per launch).
-  auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
   float c3[3] = {f[0].c[0], f[0].c[1], f[0].c[2]};
   uint32_t code[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) code[c] = f[0].code[c];
-  float res = uni(pv.level[0].resolution), tsd_scale = uni(pv.level[0].tsd_scale),
-        tsd_offset = uni(pv.level[0].tsd_offset), min_tsd = uni(pv.level[0].min_tsd);
+  float res = lp[0].res, tsd_scale = lp[0].tsd_scale, tsd_offset = lp[0].tsd_offset;
   bool found = false;
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) {
     // valid: inside the window (outside it no block exists: the voxels read as unknown, whatever the
     // toroidal slot holds) and all 8 weights non-zero
-    const bool valid = direct_inside(pv.level[l], dp.min_b[l], usable, f[l]) && all_weights_valid(f[l].code);
+    const bool valid = f[l].in & all_weights_valid(f[l].code);
     if (l > 0) {
       const bool take = !found && valid;
 #pragma unroll
       for (int c = 0; c < 8; ++c) code[c] = take ? f[l].code[c] : code[c];
 #pragma unroll
       for (int a = 0; a < 3; ++a) c3[a] = take ? f[l].c[a] : c3[a];
-      res = take ? uni(pv.level[l].resolution) : res;
-      tsd_scale = take ? uni(pv.level[l].tsd_scale) : tsd_scale;
-      tsd_offset = take ? uni(pv.level[l].tsd_offset) : tsd_offset;
-      min_tsd = take ? uni(pv.level[l].min_tsd) : min_tsd;
+      res = take ? lp[l].res : res;
+      tsd_scale = take ? lp[l].tsd_scale : tsd_scale;
+      tsd_offset = take ? lp[l].tsd_offset : tsd_offset;
     }
     found = found || valid;
   }
-  const D3 r = interp_all_valid(res, tsd_scale, tsd_offset, min_tsd, c3, code, x, y, z);
-  if (!found) return {static_cast<double>(pv.level[0].min_tsd), 0.0, 0.0, 0.0};  // :136
+  ISA_MARK("select|interpolation");
+  const D3 r = interp_all_valid(res, tsd_scale, tsd_offset, c3, code, x, y, z);
+  ISA_MARK("interpolation|row");
+  if (!found) return {static_cast<double>(min_tsd0), 0.0, 0.0, 0.0};  // :136
   return r;
 }
 
@@ -803,6 +832,12 @@ __device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, do
   const int levels = pv.multi_res ? pv.levels : 1;
   bool ok;
   D3 r;
+#ifdef HG_ISA_REGIONS
+  (void)levels;
+  r = pyramid_tsd_direct<3, SHARE>(pv, raw, x, y, z, &ok);
+  if (ok) return r;
+  return pyramid_tsd_general(pv.self_mem, x, y, z);
+#endif
   switch (levels) {  // wave-uniform
     case 1: r = pyramid_tsd_direct<1, SHARE>(pv, raw, x, y, z, &ok); break;
     case 2: r = pyramid_tsd_direct<2, SHARE>(pv, raw, x, y, z, &ok); break;
@@ -833,6 +868,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRa
   const double wx = (v[0] + qw * uv[0] + c2[0]) + t[0];
   const double wy = (v[1] + qw * uv[1] + c2[1]) + t[1];
   const double wz = (v[2] + qw * uv[2] + c2[2]) + t[2];
+  ISA_MARK("transform|cells+addresses");
   const D3 tsd = pyramid_tsd<SHARE>(pv, dp, wx, wy, wz);
   const double r = scaling * tsd.a;
   const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
@@ -869,6 +905,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRa
     row8[6] = fma(g[2], c2k, fma(g[1], c1, g[0] * c0));
   }
   row8[7] = r;
+  ISA_MARK("row|tile");
 }
 
 // A wavefront executes its LDS instructions in order, so lanes that exchange data through LDS with
@@ -971,6 +1008,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
   const unsigned i0 = wg * THREADS + threadIdx.x;
   double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   BODY_STAMP(0);
+  ISA_MARK("entry|transform");
   // (the point load is issued in front of the scalar loads of direct_issue, whose wait it then overlaps)
   const unsigned i = scan_index(make_scan_order(n, width), i0 < n ? i0 : 0u);
   double v[3];
@@ -1050,6 +1088,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
     store_partial(&partials[static_cast<size_t>(wg) * kAcc + threadIdx.x], s);
   }
   BODY_STAMP(5);
+  ISA_MARK("tile|exit");
 }
 
 // ------------------------------------------------------------------------------------------
