@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--batch-submaps", type=int, default=8,
                     help="--workload register_batch: independent submaps registered together in ONE process "
                          "(hg_register_scan_batch: shared launches), BASELINE configs[3] at G = 1")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="offline batch (--total-submaps): host threads per rank, each mapping its share of the rank's "
+                         "submaps on a context of its own (0 = 2 from eight owned submaps on, else 1)")
     ap.add_argument("--batch-threads", type=int, default=1,
                     help="--workload register_batch: host threads, each with its own context (stream) and an equal share of the submaps")
     ap.add_argument("--no-secondary", action="store_true",
@@ -1117,7 +1120,9 @@ def run_offline_batch(args, out_fd=None):
     total = args.warmup + steps
     distinct = min(total, 120)  # the bench trajectory folds back after 120 poses: longer runs revisit them
 
-    class Engine:
+    class Group:
+        """The submaps one host thread maps: a context (stream) of its own, one hg_register_scan_batch per step."""
+
         def open(self, owned):
             self.ctx = api.Context(local_rank)
             self.ins = [api.TSDFRangeDataInserter3D() for _ in RESOLUTIONS]
@@ -1153,12 +1158,71 @@ def run_offline_batch(args, out_fd=None):
                     self.errs.append(float(np.linalg.norm(poses[j][:3] - self.queries[j][k][0][:3])))
                     self.its.append(summ[j].num_iterations)
 
-        def sync(self):
-            self.ctx.synchronize()
-            torch.cuda.synchronize()
-
         def grids(self):
             return [g for pyr in self.pyramids for g in pyr]
+
+    class Engine:
+        """A rank's submaps in T groups, one host thread and one context each (--host-threads; default 2 from eight
+        owned submaps on): the groups run free of each other, so one group's insertion kernels -- a few long
+        per-voxel chains on an otherwise idle chip -- overlap another group's match launches."""
+
+        def open(self, owned):
+            T = args.host_threads if args.host_threads > 0 else (2 if len(owned) >= 8 else 1)
+            T = max(1, min(T, len(owned)))
+            self.groups = []
+            for t in range(T):
+                g = Group()
+                g.open(owned[t::T])
+                self.groups.append(g)
+            self.ctx = self.groups[0].ctx
+            self.host_threads = T
+
+        def run_steps(self, first, last):
+            if len(self.groups) == 1:
+                for i in range(first, last):
+                    self.groups[0].step(i)
+                return
+            import threading
+            errors = []
+
+            def work(g):
+                try:
+                    for i in range(first, last):
+                        g.step(i)
+                except BaseException as e:  # surfaced in the caller's thread
+                    errors.append(e)
+
+            threads = [threading.Thread(target=work, args=(g,)) for g in self.groups]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            if errors:
+                raise errors[0]
+
+        def sync(self):
+            for g in self.groups:
+                g.ctx.synchronize()
+            torch.cuda.synchronize()
+
+        def grids(self):  # in submap order
+            by = {}
+            for g in self.groups:
+                for j, pyr in zip(g.owned, g.pyramids):
+                    by[j] = pyr
+            return [gr for j in sorted(by) for gr in by[j]]
+
+        @property
+        def errs(self):
+            return [e for g in self.groups for e in g.errs]
+
+        @property
+        def its(self):
+            return [e for g in self.groups for e in g.its]
+
+        @property
+        def steps0(self):  # of the rank's first submap
+            return self.groups[0].steps0
 
     def barrier():
         if dist is not None:
@@ -1201,9 +1265,11 @@ def run_offline_batch(args, out_fd=None):
         "ms_per_step": res["elapsed"] / steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "offline_batch: %d submaps x %d scans of %d points farmed to %d rank(s); a step registers one scan "
-                               "(multi-res LM match + exact insert x3) of each of a rank's %d submaps together (hg_register_scan_batch)"
-                               % (S, steps, n_pts, world, per_rank),
+                               "(multi-res LM match + exact insert x3) of each of a rank's %d submaps together (hg_register_scan_batch, "
+                               "%d host thread(s) / context(s) per rank)"
+                               % (S, steps, n_pts, world, per_rank, eng.host_threads),
                    "total_submaps": S, "submaps_per_gpu": per_rank, "scans_per_submap": steps,
+                   "host_threads_per_rank": eng.host_threads,
                    "parallelism": "submap s on rank s mod %d, no data-path collective; one gather at the end" % world,
                    "mean_lm_iterations": mean_its, "mean_pose_error_m": mean_err,
                    "resident_voxel_gib_per_gpu": per_rank * len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30,

@@ -131,6 +131,29 @@ static uint32_t next_pow2(uint32_t v) {
   return p;
 }
 
+// The second stream of a context -- the apply stream of a pipelined scan stream, the second lane of a split
+// batched solve (hg_match.hip) -- created on first use: a stream with a CU mask of all
+// CUs, which gets a hardware queue of its own (see hg_ctx_create); ordinary streams may share one
+// with the context's stream and then run strictly after it.
+int ensure_apply_stream(hg_ctx* c) {
+  if (c->apply_stream) return HG_OK;
+  hipError_t e = hipErrorUnknown;
+  c->apply_stream = acquire_masked_stream(c->device);
+  if (c->apply_stream) {
+    e = hipSuccess;
+    c->apply_stream_pooled = true;
+  }
+  if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->apply_stream, hipStreamNonBlocking);
+  HG_HIP_CHECK(e);
+  for (int i = 0; i < 2; ++i) {
+    HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_front[i], hipEventDisableTiming));
+    HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_apply[i], hipEventDisableTiming));
+    HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_batch[i], hipEventDisableTiming));
+  }
+  return HG_OK;
+}
+
+
 }  // namespace hg
 
 using namespace hg;
@@ -328,6 +351,7 @@ int hg_ctx_destroy(hg_ctx* c) {
     for (int i = 0; i < 2; ++i) {
       if (c->ev_front[i]) (void)hipEventDestroy(c->ev_front[i]);
       if (c->ev_apply[i]) (void)hipEventDestroy(c->ev_apply[i]);
+      if (c->ev_batch[i]) (void)hipEventDestroy(c->ev_batch[i]);
     }
   }
   prof_resolve(c);

@@ -2467,26 +2467,6 @@ int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans,
 }
 
 // ---- binned path (single scan, unit weight) ------------------------------------------------
-// The apply stream of a pipelined scan stream, created on first use: a stream with a CU mask of all
-// CUs, which gets a hardware queue of its own (see hg_ctx_create); ordinary streams may share one
-// with the context's stream and then run strictly after it.
-int ensure_apply_stream(hg_ctx* c) {
-  if (c->apply_stream) return HG_OK;
-  hipError_t e = hipErrorUnknown;
-  c->apply_stream = acquire_masked_stream(c->device);
-  if (c->apply_stream) {
-    e = hipSuccess;
-    c->apply_stream_pooled = true;
-  }
-  if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->apply_stream, hipStreamNonBlocking);
-  HG_HIP_CHECK(e);
-  for (int i = 0; i < 2; ++i) {
-    HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_front[i], hipEventDisableTiming));
-    HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_apply[i], hipEventDisableTiming));
-  }
-  return HG_OK;
-}
-
 // `pipe` >= 0: chunk number of a pipelined scan stream (several binned chunks in one call). The front
 // end (count, offsets, scatter) of chunk k runs on the context's stream, its apply pass on the apply
 // stream: with known poses the front end of scan k + 1 does not depend on the apply pass of scan k,

@@ -114,6 +114,7 @@ struct hg_ctx {
   hipStream_t apply_stream = nullptr;
   bool apply_stream_pooled = false;
   hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_apply[2] = {nullptr, nullptr};
+  hipEvent_t ev_batch[2] = {nullptr, nullptr};  // fork / join of a split batched solve (hg_match.hip)
   const uint32_t* filter_idx = nullptr;  // results of the last voxel-filter call (device)
   const float* filter_xyz = nullptr;
   size_t filter_count = 0;
@@ -226,6 +227,7 @@ namespace hg {
 // such a stream is never destroyed -- hipStreamDestroy on one shortly before exit() deadlocks inside the
 // runtime (hg_ctx_destroy) -- but handed to the next context of the device. nullptr if none can be made.
 hipStream_t acquire_masked_stream(int device);
+int ensure_apply_stream(hg_ctx* c);  // the context's second stream (apply_stream) and its events, on first use
 void release_masked_stream(int device, hipStream_t stream);
 int grid_block_order(hg_grid* g, std::vector<uint32_t>* order);
 void orphan_problem(hg_problem* p);  // hg_match.hip: the problem's context is going away

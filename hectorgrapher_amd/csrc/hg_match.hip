@@ -5018,6 +5018,12 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   hipLaunchKernelGGL(k_lm_prepare_batch, dim3(count), dim3(kLmBlock), 0, s, static_cast<const SingleJob*>(c->ws_misc.ptr));
   HG_HIP_CHECK(hipGetLastError());
   const int max_it = problems[0]->h_state.h.opt.max_num_iterations;
+  // (Round 4, measured and dropped: the batch cut in two halves on two streams, the second one residual pass behind
+  // the first, so that one half's step kernel -- `count` workgroups on an otherwise idle chip, 10 us per iteration
+  // against 22 us of residual pass for eight 100k-point scans -- would run under the other half's residual pass.
+  // The two chains fall into step within two iterations (a residual pass of four scans alone takes 17 us, of eight
+  // 22 us: sharing the chip costs it little), both step kernels then run side by side as before: 10.26k against
+  // 10.20k scans/s for eight submaps, no gain at 16 or 64.)
   {
     ProfScope group(c, HG_K_RESIDUALS, units * (max_it + 1), static_cast<unsigned>(max_it + 1), true);
     for (int it = 0; it <= max_it; ++it) {

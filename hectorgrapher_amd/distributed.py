@@ -126,7 +126,8 @@ def map_sharded(total_submaps, rank, world, engine, steps, warmup, barrier, dist
     """BASELINE configs[3]: `total_submaps` independent submaps farmed to `world` ranks, rank r owning
     shard(total_submaps, r, world) -- no data-path collective while mapping. `engine` maps the owned
     submaps: engine.open(owned) builds them, engine.step(i) registers scan i of EVERY owned submap (the
-    batched registration step), engine.sync() drains the device. Times `steps` steps behind `warmup`
+    batched registration step; or engine.run_steps(first, last) for a range of steps), engine.sync() drains the
+    device. Times `steps` steps behind `warmup`
     untimed ones, bracketed by `barrier()`; returns {"owned", "elapsed": max over ranks, "scans": all
     ranks' scans in the timed region}."""
     import time
@@ -134,13 +135,18 @@ def map_sharded(total_submaps, rank, world, engine, steps, warmup, barrier, dist
         raise ValueError("map_sharded: %d submaps do not divide over %d ranks" % (total_submaps, world))
     owned = shard(total_submaps, rank, world)
     engine.open(owned)
-    for i in range(warmup):
-        engine.step(i)
+    # an engine that maps its submaps in several host threads (one context each, so that one group's insertions
+    # overlap another group's matches) runs a range of steps itself: engine.run_steps(first, last)
+    run = getattr(engine, "run_steps", None)
+    if run is None:
+        def run(first, last):
+            for i in range(first, last):
+                engine.step(i)
+    run(0, warmup)
     engine.sync()
     barrier()
     t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        engine.step(i)
+    run(warmup, warmup + steps)
     engine.sync()
     barrier()
     elapsed = time.perf_counter() - t0
