@@ -368,6 +368,15 @@ struct UnitChain {
 //     reached its fixed point (the clamp at maximum_weight: the heavy voxels next to the sensor sit
 //     there from their second scan on) the weight arithmetic is skipped for as long as every lane of
 //     the wavefront that still has updates is there too.
+// (Round 4, measured and dropped: a double-precision shortcut for the tail of a pass, where one or a few voxels
+// next to the sensor still have thousands of updates. With the weight at its fixed point the new code is
+// floor(A c + Ku u + B) in real arithmetic -- one f64 fma and one floor on the dependent chain -- and equals the
+// reference's code unless that value lies within E = 2^-24 res (4 T + 3 R) of an integer (the six fp32 roundings of
+// the exact chain; about one update in forty), near the clamps, or u is out of range, in which case the block of
+// four is redone exactly. Bit-exact in every test, but the guards make the block as many instructions as the 64
+// dependent fp32 operations it replaces, the fall-backs come on top, and the constants cost the apply kernels
+// scratch at their 64 registers: exact stream B = 32 18.4k -> 15.0k scans/s, B = 64 9.9k -> 7.8k. The chain stays
+// as it is: 16 dependent operations per update.)
 struct ChainState {
   float d, w;    // decoded TSD value and weight
   float rt, rw;  // their codes (lround(..) + 1) as floats, valid after the first update
