@@ -1416,7 +1416,7 @@ def secondary_workloads(args):
     import copy
     out = {}
     plan = [
-        ("match_batch_64", run_match_batch, {"workload": "match_batch", "batch": 64, "steps": 3, "warmup": 1, "prof_every": 1, "cpu_scans": 2}),
+        ("match_batch_64", run_match_batch, {"workload": "match_batch", "batch": 64, "steps": 8, "warmup": 2, "prof_every": 2, "cpu_scans": 2}),
         ("register_batch_8", run_register_batch, {"workload": "register_batch", "batch_submaps": 8, "batch_threads": 1, "steps": 6, "warmup": 2, "prof_every": 2, "cpu_scans": 2}),
         ("insert_stream_32", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "steps": 4, "warmup": 1, "prof_every": 2, "cpu_scans": 2}),
         ("window_10", run_window, {"workload": "window", "window": 10, "steps": 6, "warmup": 2, "prof_every": 2}),

@@ -1278,15 +1278,27 @@ __device__ __forceinline__ void window_body_plain(const EvalBlock& eb, const Blo
   const unsigned first = xcd_chunk(wg, eb.num_wg) * tiles;
   double tq[7];
   load_transform_uniform(xf->t, tq);
+  // The return of tile t + 1 is fetched while tile t is evaluated (round 4): a wavefront works through its tiles
+  // one after the other, and each began with the round trip of its point load in front of the voxel round trip.
+  typedef float f3 __attribute__((ext_vector_type(3), aligned(4)));
+  auto fetch = [&](unsigned tile, unsigned* index) {
+    const unsigned i0 = (first + tile) * kBatchThreads + threadIdx.x;
+    const unsigned i = scan_index(order, (tile < tiles && i0 < n) ? i0 : 0u);
+    *index = i;
+    return *reinterpret_cast<const __attribute__((address_space(1))) f3*>(as_global(eb.xyz) + 12ull * i);
+  };
+  unsigned i_next;
+  f3 p_next = fetch(0, &i_next);
   for (unsigned tile = 0; tile < tiles; ++tile) {
     const unsigned base = (first + tile) * kBatchThreads;
     if (base >= n) break;  // uniform
     const unsigned i0 = base + threadIdx.x;
+    const unsigned i = i_next;
+    const f3 p = p_next;
+    p_next = fetch(tile + 1, &i_next);
     double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (i0 < n) {
-      const unsigned i = scan_index(order, i0);
-      double v[3];
-      load_point(eb.xyz, i, v);
+      const double v[3] = {static_cast<double>(p.x), static_cast<double>(p.y), static_cast<double>(p.z)};
       return_row(pv, dp, tq, tq + 3, v, scaling, row8);
       if (residuals) residuals[i] = row8[7];
     }
