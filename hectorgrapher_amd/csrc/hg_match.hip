@@ -1004,13 +1004,13 @@ __device__ __forceinline__ void tsdf_residuals_body(
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
     double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64], unsigned wg,
     const double* pose_tq = nullptr /* the transform when it does not come from xf (first launch) */,
-    unsigned width = 0) {
-  const unsigned i0 = wg * THREADS + threadIdx.x;
-  double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    unsigned width = 0, unsigned tiles = 1 /* tiles of THREADS returns per workgroup (the batched kernel) */) {
+  const ScanOrder order = make_scan_order(n, width);
+  const unsigned first_i0 = wg * tiles * THREADS + threadIdx.x;
   BODY_STAMP(0);
   ISA_MARK("entry|transform");
   // (the point load is issued in front of the scalar loads of direct_issue, whose wait it then overlaps)
-  const unsigned i = scan_index(make_scan_order(n, width), i0 < n ? i0 : 0u);
+  unsigned i = scan_index(order, first_i0 < n ? first_i0 : 0u);
   double v[3];
   load_point(xyz, i, v);
   const DirectRaw dp = direct_issue(pv);
@@ -1022,10 +1022,46 @@ __device__ __forceinline__ void tsdf_residuals_body(
     static_assert(offsetof(BlockXform, q) == 3 * sizeof(double), "t and q are contiguous");
     load_transform_uniform(xf->t, tq);
   }
-  if (i0 < n) {
-    // (THREADS == 256: the batched kernel)
-    return_row<THREADS == 256>(pv, dp, tq, tq + 3, v, scaling, row8);
-    if (residuals) residuals[i] = row8[7];
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 cacc = {0.0, 0.0, 0.0, 0.0};
+  const int mj = lane & 15, mk = lane >> 4;
+  // The batched kernel (THREADS == 256) gives a workgroup `tiles` tiles of 256 returns: the accumulators of the
+  // matrix cores run through them, so the prologue, the reduction over the wavefronts and the 36 partial sums per
+  // workgroup (which the step kernel has to read back) are paid once per `tiles` tiles; the next tile's return is
+  // fetched while the current one is evaluated.
+  for (unsigned tile = 0; tile < tiles; ++tile) {
+    const unsigned i0 = first_i0 + tile * THREADS;
+    if (tile > 0 && i0 - threadIdx.x >= n) break;  // uniform
+    double row8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const unsigned i_cur = i;
+    const double vc[3] = {v[0], v[1], v[2]};
+    if (tile + 1 < tiles) {
+      const unsigned i1 = i0 + THREADS;
+      i = scan_index(order, i1 < n ? i1 : 0u);
+      load_point(xyz, i, v);
+    }
+    if (i0 < n) {
+      // (THREADS == 256: the batched kernel)
+      return_row<THREADS == 256>(pv, dp, tq, tq + 3, vc, scaling, row8);
+      if (residuals) residuals[i_cur] = row8[7];
+    }
+    if (tile > 0) wave_sync();  // the operand reads of the tile before are done
+    {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      d2* dst = reinterpret_cast<d2*>(&xs[wave][lane][0]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dst[c] = d2{row8[2 * c], row8[2 * c + 1]};
+    }
+    wave_sync();  // xs[wave] is written and read by this wavefront only
+    {
+      const int half = (mj >> 3) * 32, col = mj & 7;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const double a = xs[wave][half + 4 * s + mk][col];
+        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
+      }
+    }
   }
   BODY_STAMP(4);
   // J^T J accumulation on the matrix cores: per wavefront X = [row | r] is 64 x 8 (padded to 16
@@ -1033,29 +1069,10 @@ __device__ __forceinline__ void tsdf_residuals_body(
   // J^T J (7x7), J^T r (column 7) and r^T r. Operand layout: lane l feeds A[i = l%16][k = l/16] and
   // B[k = l/16][j = l%16] — here the same element X[4s + l/16][l%16]; D[l/16 + 4v][l%16] comes back
   // in accumulator register v (verified against the CPU oracle by the parity tests).
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    d2* dst = reinterpret_cast<d2*>(&xs[wave][lane][0]);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c] = d2{row8[2 * c], row8[2 * c + 1]};
-  }
-  wave_sync();  // xs[wave] is written and read by this wavefront only
-  typedef double d4 __attribute__((ext_vector_type(4)));
-  d4 cacc = {0.0, 0.0, 0.0, 0.0};
-  const int mj = lane & 15, mk = lane >> 4;
-  // Round 4: the 16-wide operand carries TWO row groups -- columns 0..7 the returns 0..31 of the wavefront,
+  // (Round 4: the 16-wide operand carries TWO row groups -- columns 0..7 the returns 0..31 of the wavefront,
   // columns 8..15 the returns 32..63 -- so 8 instead of 16 MFMAs (64 cycles each, dependent) form X^T X: its
   // upper-left 8 x 8 block is the sum over the first 32 returns, the lower-right one over the other 32, the
-  // off-diagonal blocks (cross terms) are dropped.
-  {
-    const int half = (mj >> 3) * 32, col = mj & 7;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const double a = xs[wave][half + 4 * s + mk][col];
-      cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, cacc, 0, 0, 0);
-    }
-  }
+  // off-diagonal blocks (cross terms) are dropped.)
   wave_sync();  // the operand reads are done: the wavefront's X tile takes the second block
   {
     // D[l/16 + 4v][l%16] sits in accumulator register v: lanes with mj < 8 hold rows mk, mk + 4 of the first
@@ -3772,6 +3789,8 @@ struct SingleJob {
   const PinBox* box;  // the problem's mailbox (compact upload of its solver head)
   unsigned up_words;
   unsigned width;     // returns per column of the structured scan, or 0 (scan_index)
+  unsigned tiles;     // tiles of kBatchThreads returns per workgroup
+  unsigned pad;
 };
 
 // Throughput form: the residual pass of all problems in one launch WITHOUT the LM step in its tail
@@ -3794,7 +3813,7 @@ __global__ __launch_bounds__(THREADS, HG_BATCH_WAVES) void k_tsdf_residuals_sing
   tsdf_residuals_body<THREADS>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
                                      reinterpret_cast<double (*)[kWave][8]>(smem),
                                      reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
-                                     xcd_chunk(blockIdx.x, J.num_wg), nullptr, J.width);
+                                     xcd_chunk(blockIdx.x, J.num_wg), nullptr, J.width, J.tiles);
 }
 // Uploads every problem's solver head from its mailbox and prepares its first transform (k_lm
 // MODE_PREPARE for all problems of a batch in one launch).
@@ -5012,7 +5031,12 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     J.pv = p->h_pv[0];  // built by upload_state; also resident at p->d_pv (self_mem)
     J.xyz = p->blocks[0].d_xyz;
     J.xf = p->d_xf;
-    J.num_wg = (bi.n + kBatchThreads - 1) / kBatchThreads;  // the batched pass has its own workgroup size
+    // the batched pass has its own workgroup size; several tiles per workgroup once the batch fills the chip more
+    // than once (64 matches of 100k returns: 25.5k / 27.5k / 28.3k / 27.9k matches/s at 1 / 2 / 4 / 8 tiles; 32: 22.7k /
+    // 24.6k / 24.5k at 1 / 2 / 4; 8 and 16: + 3 - 5 % at 2, back to where it was at 4). HG_BATCH_TILES overrides.
+    static const int env_tiles = std::getenv("HG_BATCH_TILES") ? std::atoi(std::getenv("HG_BATCH_TILES")) : 0;
+    J.tiles = env_tiles > 0 ? static_cast<unsigned>(env_tiles) : (count >= 48 ? 4u : count >= 8 ? 2u : 1u);
+    J.num_wg = (bi.n + kBatchThreads * J.tiles - 1) / (kBatchThreads * J.tiles);
     if ((rc = p->partials.reserve(static_cast<size_t>(J.num_wg) * kAcc * sizeof(double))) != HG_OK) return rc;
     J.partials = p->partials.as<double>();
     J.G = p->d_state;
