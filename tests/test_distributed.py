@@ -236,6 +236,27 @@ def test_sharded_offline_batch_driver_gloo_world2():
     assert got[0][6] == [[7, 7]] * 8
 
 
+def test_map_sharded_hands_step_ranges_to_an_engine_that_runs_them_itself():
+    """An engine that maps its submaps in host-thread groups (bench.py's offline-batch Engine) exposes
+    run_steps(first, last): map_sharded hands it the warm-up range and the timed range instead of stepping."""
+    from hectorgrapher_amd import distributed as hgd
+
+    class Ranged(_FakeEngine):
+        def open(self, owned):
+            super().open(owned)
+            self.ranges = []
+
+        def run_steps(self, first, last):
+            self.ranges.append((first, last))
+            for i in range(first, last):
+                self.step(i)
+
+    eng = Ranged()
+    res = hgd.map_sharded(4, 0, 1, eng, steps=3, warmup=2, barrier=lambda: None)
+    assert eng.ranges == [(0, 2), (2, 5)] and eng.steps == [0, 1, 2, 3, 4]
+    assert res["owned"] == [0, 1, 2, 3] and res["scans"] == 12
+
+
 def test_map_sharded_refuses_uneven_split():
     from hectorgrapher_amd import distributed as hgd
     with pytest.raises(ValueError):

@@ -580,6 +580,59 @@ def test_solve_batch_equals_individual_solves(po, hg, ctx):
     assert s_mixed[2].num_iterations >= 1
 
 
+@pytest.mark.parametrize("count", [9, 50])
+def test_solve_batch_with_several_tiles_per_workgroup(po, hg, ctx, count):
+    """From 8 problems on the batched residual pass gives a workgroup two tiles of 256 returns, from 48 on four
+    (accumulators run through, next return prefetched): ragged sizes -- fewer returns than one tile, one return more
+    than a workgroup's share, sizes that leave the last workgroup's later tiles empty -- against solving one by one,
+    and the first two problems against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    res = (0.05, 0.10, 0.20)
+    grids = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in res]
+    ogrids = [po.Grid(r) for r in res]
+    for k in range(4):
+        pose = synth.pose_k(k)
+        loc = synth.transform_points(pose, synth.generate_scan(pose, 32, 900, stream=k))
+        for g in grids:
+            hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(pose[:3], loc), g)
+        for g in ogrids:
+            g.insert(pose[:3], loc)
+    shapes = [(8, 25), (16, 64), (16, 65), (8, 257), (4, 513), (32, 33), (2, 1025), (1, 255), (8, 129), (3, 683)]
+    cases = []
+    for j in range(count):
+        rings, cols = shapes[j % len(shapes)]
+        pose = synth.pose_k(4 + j % 3)
+        pts = synth.generate_scan(pose, rings, cols, stream=400 + j)
+        cases.append((pts, synth.pose_mul(pose, synth.perturbation())))
+
+    def build():
+        ps = []
+        for pts, guess in cases:
+            p = hg.Problem(ctx)
+            i = p.add_pose(guess)
+            p.add_block(torch.from_numpy(pts).to(dev), grids, 1.0 / np.sqrt(len(pts)), i, multi_res=True)
+            ps.append(p)
+        return ps
+
+    single = build()
+    s_single = [p.solve() for p in single]
+    batch = build()
+    s_batch = hg.solve_batch(batch)
+    for a, b, sa, sb in zip(single, batch, s_single, s_batch):
+        np.testing.assert_allclose(b.get_pose(0), a.get_pose(0), rtol=0, atol=1e-9)
+        assert (sa.num_iterations, sa.termination_type, sa.termination_reason) == \
+               (sb.num_iterations, sb.termination_type, sb.termination_reason)
+        assert abs(sa.final_cost - sb.final_cost) <= 1e-12 * max(1.0, abs(sa.final_cost))
+    for j in range(2):
+        pr = po.Problem()
+        i = pr.add_pose(cases[j][1])
+        pr.add_block(cases[j][0], ogrids, 1.0 / np.sqrt(len(cases[j][0])), i, multi_res=True)
+        so = pr.solve()
+        assert so.num_iterations == s_batch[j].num_iterations
+        assert np.abs(pr.get_pose(i) - batch[j].get_pose(0)).max() < 1e-9
+
+
 def test_register_scan_batch_equals_individual_registrations(po, hg, ctx):
     """hg_register_scan_batch: the registration step of several independent submaps with shared
     launches (batched matcher + insert kernels over a table of pyramids) gives every submap what
