@@ -1419,7 +1419,7 @@ def secondary_workloads(args):
         ("match_batch_64", run_match_batch, {"workload": "match_batch", "batch": 64, "steps": 8, "warmup": 2, "prof_every": 2, "cpu_scans": 2}),
         ("register_batch_8", run_register_batch, {"workload": "register_batch", "batch_submaps": 8, "batch_threads": 1, "steps": 6, "warmup": 2, "prof_every": 2, "cpu_scans": 2}),
         ("insert_stream_32", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "steps": 4, "warmup": 1, "prof_every": 2, "cpu_scans": 2}),
-        ("window_10", run_window, {"workload": "window", "window": 10, "steps": 6, "warmup": 2, "prof_every": 2}),
+        ("window_10", run_window, {"workload": "window", "window": 10, "steps": 12, "warmup": 3, "prof_every": 3}),
         # BASELINE configs[2] with the voxels in HBM: 64 scans over 64 copies of the room (~0.4 GB of voxel
         # blocks touched per call, beyond the 256 MB Infinity Cache); insert_stream_32 above stays in cache
         ("insert_stream_64_hbm", run_insert_stream, {"workload": "insert_stream", "stream_scans": 64, "stream_tiles": 64,
@@ -1427,10 +1427,10 @@ def secondary_workloads(args):
         # configs[3] with the reference's real builder: 8 submaps, each a 10-control-point window per step, shared launches
         ("window_batch_8", run_window_batch, {"workload": "window_batch", "window": 10, "batch_submaps": 8, "steps": 4, "warmup": 2,
                                               "prof_every": 2}),
-        # BASELINE configs[3] bounded: 8 submaps x 10 scans on this GPU, then the gather of all finished blocks
+        # BASELINE configs[3] bounded: 8 submaps x 30 scans on this GPU, then the gather of all finished blocks
         # through a one-rank process group and its import / export-digest check (the full 8 x 500 run is
         # `bench.py --total-submaps 8 --scans-per-submap 500`, profiles/r04_bench_offline8x500.json)
-        ("offline8", run_offline_batch, {"total_submaps": 8, "scans_per_submap": 10, "steps": 10, "warmup": 2, "cpu_scans": 2,
+        ("offline8", run_offline_batch, {"total_submaps": 8, "scans_per_submap": 30, "steps": 30, "warmup": 2, "cpu_scans": 2,
                                          "_force_dist": True}),
     ]
     for name, fn, kw in plan:
