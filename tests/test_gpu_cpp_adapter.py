@@ -286,3 +286,60 @@ def test_cpp_window_builder_against_oracle(tmp_path):
             np.testing.assert_allclose(gv, c["vel"], atol=1e-5)
     assert max_dt < 1e-4 and max_dr < 1e-4, (max_dt, max_dr)
     assert sum(g["solved"] for g in gpu.values()) == 8
+
+
+def test_cpp_insert_unwarped_against_oracle(tmp_path):
+    """mapping::InsertUnwarped of cpp/hg_adapter.h (the clouds that leave the window, unwarped return by return
+    with the window's control poses and inserted: oltb.cc:1331-1379, :1437-1440, submap_3d.cc:436-437): the
+    example dumps its inputs and the voxels of both grids; the oracle replays the inputs -- times as
+    common::FromSeconds makes them, NaN returns kept, origin from the first return -- and every cell, code and
+    the export order must be the same."""
+    import struct
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    exe = os.path.join(CPP, "example_unwarp")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", os.path.join(CPP, "example_unwarp.cc"),
+                               "-L" + os.path.join(ROOT, "hectorgrapher_amd"), "-lhg_mi355x",
+                               "-Wl,-rpath," + os.path.join(ROOT, "hectorgrapher_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    dump = str(tmp_path / "unwarp.bin")
+    out = subprocess.run([exe, dump], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    raw = open(dump, "rb").read()
+    off = 0
+    (n_cp,) = struct.unpack_from("i", raw, off); off += 4
+    times, poses = [], []
+    for _ in range(n_cp):
+        (t,) = struct.unpack_from("d", raw, off); off += 8
+        poses.append(np.frombuffer(raw, np.float64, 7, off).copy()); off += 56
+        times.append(int(t * 1e7))  # static_cast<int64_t>(seconds * 1e7), as the adapter
+    submap = np.frombuffer(raw, np.float32, 7, off).copy(); off += 28
+    (n_clouds,) = struct.unpack_from("i", raw, off); off += 4
+    clouds = []
+    for _ in range(n_clouds):
+        (t,) = struct.unpack_from("d", raw, off); off += 8
+        origin = np.frombuffer(raw, np.float32, 3, off).copy(); off += 12
+        (n,) = struct.unpack_from("i", raw, off); off += 4
+        pts = np.frombuffer(raw, np.float32, n * 4, off).reshape(n, 4).copy(); off += 16 * n
+        clouds.append((int(t * 1e7), origin, pts))
+    assert any(np.isnan(c[2][:, 1]).any() for c in clouds)
+    poses = np.asarray(poses)
+    xyz, origin, ok = po.unwarp_range_data(np.asarray(times, np.int64), poses, clouds)
+    assert ok
+    opt = poses[0].astype(np.float32)
+    xyz, origin = po.transform_points(opt, xyz), po.transform_points(opt, origin[None])[0]
+    xyz, origin = po.transform_points(submap, xyz), po.transform_points(submap, origin[None])[0]
+    for res in (0.10, 0.20):
+        (n,) = struct.unpack_from("i", raw, off); off += 4
+        cells = np.frombuffer(raw, np.int32, n * 3, off).reshape(n, 3); off += 12 * n
+        tsd = np.frombuffer(raw, np.uint16, n, off); off += 2 * n
+        weight = np.frombuffer(raw, np.uint16, n, off); off += 2 * n
+        og = po.Grid(res)
+        og.insert(origin, xyz, width=16)
+        o_cells, o_tsd, o_weight = og.export()
+        assert n == len(o_tsd) and n > 1000
+        assert np.array_equal(cells, o_cells) and np.array_equal(tsd, o_tsd) and np.array_equal(weight, o_weight)
+    assert off == len(raw)
+
