@@ -970,13 +970,31 @@ __device__ inline int ray_block_runs(const Ray& r, unsigned long long* run_key, 
   return nr;
 }
 
-// Per-thread result of k_bin_count, consumed by k_bin_scatter: for each of <= 4 runs the block
-// slot and the run's first record position inside the block's bin. 32 bytes (two 16-byte stores):
-// the run's begin / len (4 bits each) ride in the top byte of its slot word (slots have 24 bits).
+// Per-thread result of k_bin_count, consumed by k_bin_scatter: for each of <= 4 runs which block it falls into and
+// where its records start inside the block's bin. Round 4: 16 bytes instead of 32. The workgroup writes ONE table
+// entry per distinct block it touches -- {slot, first record of the workgroup's share in the bin} -- and a run names
+// the entry (10 bits) and its offset inside the share (13 bits: a workgroup has at most 1024 runs of <= 8 records)
+// next to its begin (3 bits) and length (4 bits, 0 = no run). The run info was 21 of the insert family's 55 MB of
+// memory traffic per scan; the scatter pass now resolves ~40 table entries per workgroup (one bin-offset load each)
+// instead of four bin-offset gathers per return.
 struct RunInfo {
-  uint32_t slot[kMaxRuns];  // run k: slot | begin << 24 | len << 28; len 0 = no run
-  uint32_t off[kMaxRuns];
+  uint32_t run[kMaxRuns];  // entry | offset << 10 | begin << 23 | len << 26
 };
+constexpr unsigned kWgTableEntries = 1024u;  // = the entries of the count pass's LDS table
+struct WgTable {  // one per (workgroup, level), behind the run info of the call (wg_table)
+  uint32_t count, pad[3];
+  uint2 entry[kWgTableEntries];  // {slot, base of the workgroup's share inside the bin}
+};
+static_assert(sizeof(WgTable) % sizeof(RunInfo) == 0, "tables live in the run-info buffer");
+// Run-info buffer of a scan of n returns (nwg workgroups of 256) and `levels` levels, in RunInfo units:
+// [levels x n run infos][levels x nwg tables]
+__host__ __device__ inline size_t run_info_units(size_t n, size_t nwg, size_t levels) {
+  return levels * (n + nwg * (sizeof(WgTable) / sizeof(RunInfo)));
+}
+__device__ inline WgTable* wg_table(const RunInfo* runs, unsigned n, unsigned nwg, int levels, int level, unsigned wg) {
+  WgTable* t = reinterpret_cast<WgTable*>(const_cast<RunInfo*>(runs) + static_cast<size_t>(levels) * n);
+  return t + static_cast<size_t>(level) * nwg + wg;
+}
 
 // Bodies of the four kernels of the binned path, shared by the single-pyramid launches (pyramid in
 // the kernel arguments) and the batched launches (a table of jobs in device memory, one job = one
@@ -986,8 +1004,9 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
                                                unsigned n, RunInfo* runs, unsigned* wg_hits) {
   const unsigned i = xcd_chunk(bx, nbx) * 256u + threadIdx.x;  // see hg_device.h
   const int lane = threadIdx.x & (kWave - 1);
-  __shared__ unsigned s_hits, s_first, s_first_base;
-  if (threadIdx.x == 0) { s_hits = 0; s_first = 0; }
+  WgTable* const tab = wg_table(runs, n, nbx, P.levels, level, bx);
+  __shared__ unsigned s_hits, s_first, s_first_base, s_ntab;
+  if (threadIdx.x == 0) { s_hits = 0; s_first = 0; s_ntab = 0; }
   __syncthreads();
   bool hit = false;
   unsigned long long run_key[kMaxRuns];
@@ -1054,17 +1073,13 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
     prefix[k] = 0;
     if (want[k]) {
       unsigned h = (slot[k] * 2654435761u) >> 22;  // 10 bits
-      for (int tries = 0; tries < 32; ++tries) {
+      // (at most 1024 runs, hence at most 1024 distinct blocks, in 1024 entries: the probe always ends)
+      for (unsigned tries = 0; tries < kTable; ++tries) {
         const uint32_t old = atomicCAS(&t_key[h], 0u, slot[k] + 1u);
         if (old == 0u || old == slot[k] + 1u) { ent[k] = h; break; }
         h = (h + 1u) & (kTable - 1u);
       }
-      if (ent[k] != kNone) {
-        prefix[k] = atomicAdd(&t_cnt[ent[k]], static_cast<unsigned>(run_len[k]));
-      } else {  // table region crowded (cannot happen with <= 1024 runs and 32 probes in practice): reserve directly
-        prefix[k] = atomicAdd(&L.g.bin_count[slot[k]], static_cast<unsigned>(run_len[k]));
-        if (prefix[k] == 0u) { first_pos[k] = atomicAdd(&s_first, 1u); first_slot[k] = slot[k]; }
-      }
+      prefix[k] = atomicAdd(&t_cnt[ent[k]], static_cast<unsigned>(run_len[k]));
     }
   }
   __syncthreads();
@@ -1080,7 +1095,10 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
   for (unsigned j = 0; j < kTable / 256u; ++j) {
     const unsigned e = threadIdx.x + 256u * j;
     if (e_key[j]) {
-      t_cnt[e] = e_base[j];
+      // the workgroup's table entry of the block: {slot, base of its share}; the runs name it by its position
+      const unsigned cid = atomicAdd(&s_ntab, 1u);
+      tab->entry[cid] = make_uint2(e_key[j] - 1u, e_base[j]);
+      t_cnt[e] = cid;
       // blocks that receive their first records of this call are enlisted in `touched`. The list's
       // cursor is ONE device-wide word: the workgroup reserves its entries with a single atomic
       if (e_base[j] == 0u) { first_pos[kMaxRuns + j] = atomicAdd(&s_first, 1u); first_slot[kMaxRuns + j] = e_key[j] - 1u; }
@@ -1092,15 +1110,14 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
   if (threadIdx.x == 0) {
     wg_hits[level * nbx + bx] = s_hits;
     s_first_base = s_first ? atomicAdd(&L.g.call[0], s_first) : 0u;
+    tab->count = s_ntab;
   }
   RunInfo info;
 #pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k) {
-    info.slot[k] = want[k] ? (slot[k] | (static_cast<uint32_t>(run_begin[k]) << 24) |
-                              (static_cast<uint32_t>(run_len[k]) << 28))
-                           : 0u;
-    info.off[k] = (ent[k] != kNone ? t_cnt[ent[k]] : 0u) + prefix[k];
-  }
+  for (int k = 0; k < kMaxRuns; ++k)
+    info.run[k] = want[k] ? (t_cnt[ent[k]] | (prefix[k] << 10) | (static_cast<uint32_t>(run_begin[k]) << 23) |
+                             (static_cast<uint32_t>(run_len[k]) << 26))
+                          : 0u;
   if (i < n) runs[static_cast<size_t>(level) * n + i] = info;
   __syncthreads();
 #pragma unroll
@@ -1614,9 +1631,22 @@ __device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, const Leve
                                                  unsigned n, const RunInfo* runs, uint32_t* rec_keys,
                                                  uint32_t* rec_vals) {
   const unsigned i = xcd_chunk(bx, nbx) * 256u + threadIdx.x;
-  if (i >= n) return;
-  const RunInfo info = runs[static_cast<size_t>(level) * n + i];
-  if ((info.slot[0] | info.slot[1] | info.slot[2] | info.slot[3]) == 0u) return;
+  // the workgroup's block table: entry -> first record of the workgroup's share (bin offset + base inside the bin)
+  __shared__ uint32_t s_base[kWgTableEntries];
+  RunInfo info;
+#pragma unroll
+  for (int k = 0; k < kMaxRuns; ++k) info.run[k] = 0u;
+  if (i < n) info = runs[static_cast<size_t>(level) * n + i];  // in flight while the table is resolved
+  {
+    const WgTable* tab = wg_table(runs, n, nbx, P.levels, level, bx);
+    const unsigned nt = tab->count;
+    for (unsigned e = threadIdx.x; e < nt; e += 256u) {
+      const uint2 v = tab->entry[e];
+      s_base[e] = L.g.bin_offset[v.x] + v.y;
+    }
+  }
+  __syncthreads();
+  if ((info.run[0] | info.run[1] | info.run[2] | info.run[3]) == 0u) return;
   const ScanTable sc = scans ? scans[find_scan(scans, n_scans, i)] : scan_of(P);
   const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
   // One pass over the sample positions for all lanes (the per-run loops made a wavefront walk
@@ -1629,10 +1659,10 @@ __device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, const Leve
   unsigned base[kMaxRuns], len[kMaxRuns];
   int beg[kMaxRuns];
 #pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k) {  // the four bin offsets in flight together
-    len[k] = info.slot[k] >> 28;
-    beg[k] = static_cast<int>((info.slot[k] >> 24) & 15u);
-    base[k] = len[k] ? L.g.bin_offset[info.slot[k] & 0xFFFFFFu] + info.off[k] - static_cast<unsigned>(beg[k]) : 0u;
+  for (int k = 0; k < kMaxRuns; ++k) {
+    len[k] = info.run[k] >> 26;
+    beg[k] = static_cast<int>((info.run[k] >> 23) & 7u);
+    base[k] = len[k] ? s_base[info.run[k] & 1023u] + ((info.run[k] >> 10) & 8191u) - static_cast<unsigned>(beg[k]) : 0u;
   }
   RayWalk walk;  // (every ray that left run info has n <= 7: the integer walk is exact)
   walk.begin(r);
@@ -2522,7 +2552,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
   if ((rc = buf_vals.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
   const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
   if ((rc = c->ws_counts.reserve(sizeof(unsigned) * static_cast<size_t>(nwg_e) * kMaxInsLevels)) != HG_OK) return rc;
-  if ((rc = c->ws_keys_b.reserve(sizeof(RunInfo) * n * P.levels)) != HG_OK) return rc;
+  if ((rc = c->ws_keys_b.reserve(sizeof(RunInfo) * run_info_units(n, nwg_e, P.levels))) != HG_OK) return rc;
   unsigned* wg_hits = c->ws_counts.as<unsigned>();
   uint32_t* rk = buf_keys.as<uint32_t>();
   uint32_t* rv = buf_vals.as<uint32_t>();
@@ -2775,7 +2805,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
     const unsigned nwg = (nj + 255u) / 256u;
     max_nwg = std::max(max_nwg, nwg);
     rec_words += static_cast<size_t>(nj) * kSlots * levels;
-    run_items += static_cast<size_t>(nj) * levels;
+    run_items += run_info_units(nj, nwg, levels);
     hit_words += static_cast<size_t>(nwg) * kMaxInsLevels;
     size_t max_pool = 0;
     for (int l = 0; l < levels; ++l) {
@@ -2806,7 +2836,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
     J.runs = c->ws_keys_b.as<RunInfo>() + run_off;
     J.wg_hits = c->ws_counts.as<unsigned>() + hit_off;
     rec_off += static_cast<size_t>(nj) * kSlots * levels;
-    run_off += static_cast<size_t>(nj) * levels;
+    run_off += run_info_units(nj, J.nwg, levels);
     hit_off += static_cast<size_t>(J.nwg) * kMaxInsLevels;
     PyramidIns& P = J.P;
     P.levels = levels;
@@ -2914,7 +2944,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
       const unsigned long long nj = scan_offsets[scans[j] + 1] - scan_offsets[scans[j]];
       n_max = std::max(n_max, static_cast<unsigned>(nj));
       rw += nj * kSlots * levels;
-      ri += nj * levels;
+      ri += run_info_units(nj, (nj + 255u) / 256u, levels);
       hw += ((nj + 255u) / 256u) * kMaxInsLevels;
       wi += (std::min<size_t>(nj * kMaxRuns, max_blocks) + nj * kSlots / 256u + 64u) * levels;
     }
@@ -2967,7 +2997,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
     for (int k = g * group; k < j; ++k) {
       const unsigned long long nk = scan_offsets[scans[k] + 1] - scan_offsets[scans[k]];
       rec_off += nk * kSlots * levels;
-      run_off += nk * levels;
+      run_off += run_info_units(nk, (nk + 255u) / 256u, levels);
       hit_off += ((nk + 255u) / 256u) * kMaxInsLevels;
       work_off += (std::min<size_t>(nk * kMaxRuns, max_blocks) + nk * kSlots / 256u + 64u) * levels;
     }
