@@ -120,6 +120,14 @@ struct hg_ctx {
   size_t filter_count = 0;
   void* pinned = nullptr;  // small pinned host staging (4 KiB)
   void* pinned_jobs = nullptr;  // pinned staging of a batched solve's job table
+  // a batched solve of general problems holds its last launches back until some problem is seen to need them
+  // (hg_match.hip, batch_settle): how many iterations are left, what to launch, whose mailboxes to watch
+  int lazy_batch_left = 0;
+  unsigned lazy_batch_dims[3] = {0, 0, 0};            // workgroups of the plain / unwarp pass, problems
+  unsigned long long lazy_batch_units[2] = {0, 0};    // profiling units of the two passes
+  std::vector<const volatile unsigned long long*> lazy_batch_flags;
+  std::vector<unsigned long long> lazy_batch_seqs;
+  hipEvent_t ev_lazy_batch = nullptr;
   size_t jobs_capacity = 0;
   void* pinned_ijobs = nullptr;  // pinned staging of a batched insertion's job table
   size_t ijobs_capacity = 0;

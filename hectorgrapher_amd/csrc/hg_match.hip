@@ -3982,6 +3982,9 @@ struct hg_problem {
   unsigned long long seq = 0;
   unsigned up_words = 0;
   bool prof_grouped = false;  // the residual launches of this solve share one event pair
+  // the last launches of a general solve, held back until the solve is seen to need them (solve_settle)
+  int lazy_left = 0;
+  hipEvent_t ev_lazy = nullptr;
   int single_threads = 0;      // > 0: single-pose registration step with this workgroup size
 #ifndef HG_BIG
   // A problem beyond the plain build's limits (kMaxPoses / kMaxBlocks / kMaxSmall, band capacity) is
@@ -4419,6 +4422,7 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->d_small) (void)hipFree(p->d_small);
   if (p->d_loc) (void)hipFree(p->d_loc);
   if (p->h_box) (void)hipHostFree(p->h_box);
+  if (p->ev_lazy) (void)hipEventDestroy(p->ev_lazy);
   if (p->d_eval) (void)hipFree(p->d_eval);
   if (p->d_pv) (void)hipFree(p->d_pv);
   if (p->h_pv) (void)hipHostFree(p->h_pv);
@@ -4727,8 +4731,13 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
   return HG_OK;
 }
 
-int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
+// `lazy`: the caller settles the solve (solve_settle) before it enqueues anything that depends on it; the entry of
+// the C ABI enqueues every launch, because its callers may follow it with work of their own.
+static int solve_async_impl(hg_problem* p, const hg_solver_opts* opts, bool lazy);
+int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) { return solve_async_impl(p, opts, false); }
+static int solve_async_impl(hg_problem* p, const hg_solver_opts* opts, bool lazy) {
   HG_REQUIRE_CTX(p);
+  p->lazy_left = 0;
   hipStream_t s = p->ctx->stream;
   HG_HIP_CHECK(hipSetDevice(p->ctx->device));
 #ifndef HG_BIG
@@ -4757,12 +4766,55 @@ int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts) {
   p->prof_grouped = first_uploads || (p->single_threads && S0.ncols == 6 && S0.bw == 5 && S0.blocks[0].active);
   ProfScope group(p->ctx, HG_K_RESIDUALS, static_cast<unsigned long long>(S0.blocks[0].n) * (max_it + 1),
                   static_cast<unsigned>(max_it + 1), p->prof_grouped);
-  for (int it = 0; it <= max_it; ++it) {
+  // General problems (two launches per iteration, 5 us each even when the solve has terminated; a window of ten
+  // control points converges in nine or ten of its twelve iterations): the last three iterations are enqueued only
+  // if the solve turns out to need them (solve_settle, called before anything that depends on the solve is
+  // enqueued). The single-pose chain keeps its launches together: its insertion follows without the host.
+#ifndef HG_BIG
+  static const bool lazy_ok = std::getenv("HG_EAGER_SOLVE") == nullptr;
+  static const int kLazyTail = std::getenv("HG_LAZY_TAIL") ? std::max(1, std::atoi(std::getenv("HG_LAZY_TAIL"))) : 3;
+  if (lazy && lazy_ok && !p->prof_grouped && max_it + 1 >= 2 * kLazyTail + 2) p->lazy_left = kLazyTail;
+#endif
+  for (int it = 0; it <= max_it - p->lazy_left; ++it) {
     // residuals of every block at the candidate + one LM step
     rc = launch_eval(p, nullptr, true, first_uploads && it == 0);
     if (rc != HG_OK) return rc;
   }
+  if (p->lazy_left > 0) {
+    if (!p->ev_lazy) HG_HIP_CHECK(hipEventCreateWithFlags(&p->ev_lazy, hipEventDisableTiming));
+    HG_HIP_CHECK(hipEventRecord(p->ev_lazy, s));
+  }
   p->prof_grouped = false;
+  return HG_OK;
+}
+
+// Behind hg_problem_solve_async of a general problem: returns once the solve has terminated on the device or all
+// of its launches are enqueued, so that work which depends on the solve can follow on the stream.
+static int solve_settle(hg_problem* p) {
+  if (!p || p->lazy_left <= 0) return HG_OK;
+  volatile unsigned long long* flag = &p->h_box->flag;
+  for (unsigned long long spin = 0;; ++spin) {
+    if (*flag == p->seq) break;  // terminated: the held-back launches are not needed
+    __builtin_ia32_pause();
+    if ((spin & 0xFFull) == 0xFFull) {
+      const hipError_t q = hipEventQuery(p->ev_lazy);
+      if (q == hipSuccess) {
+        if (*flag == p->seq) break;
+        const int left = p->lazy_left;
+        p->lazy_left = 0;
+        for (int it = 0; it < left; ++it) {
+          const int rc = launch_eval(p, nullptr, true, false);
+          if (rc != HG_OK) return rc;
+        }
+        return HG_OK;
+      }
+      if (q != hipErrorNotReady) {
+        set_last_error(std::string("solve: ") + hipGetErrorString(q));
+        return HG_ERR_HIP;
+      }
+    }
+  }
+  p->lazy_left = 0;
   return HG_OK;
 }
 
@@ -4776,6 +4828,10 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
 #endif
   if (!p || !p->solve_pending) return HG_ERR_INVALID;
   hipStream_t s = p->ctx->stream;
+  {
+    const int rc = solve_settle(p);
+    if (rc != HG_OK) return rc;
+  }
   p->solve_pending = false;
   if (p->h_state.h.ncols == 0) {
     if (summary) std::memset(summary, 0, sizeof(*summary));
@@ -4872,7 +4928,7 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
 }
 
 int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summary* summary) {
-  int rc = hg_problem_solve_async(p, opts);
+  int rc = solve_async_impl(p, opts, true);
   if (rc != HG_OK) return rc;
   return hg_problem_fetch(p, summary);
 }
@@ -4901,6 +4957,52 @@ void apply_scan_width(hg_problem* p, const float* xyz, size_t n, size_t width) {
 
 // The gather rate of the residual pass saturates well below this; larger lists go through in groups.
 constexpr int kBatchGroup = 64;
+
+// One iteration of a batch of general problems: residual passes + the step kernel over the job table.
+static void window_jobs_iteration(hg_ctx* c, const WindowJob* d_jobs) {
+  hipStream_t s = c->stream;
+  const unsigned max_plain = c->lazy_batch_dims[0], max_unwarp = c->lazy_batch_dims[1], count = c->lazy_batch_dims[2];
+  if (max_plain > 0) {
+    ProfScope ps(c, HG_K_RESIDUALS, c->lazy_batch_units[0]);
+    hipLaunchKernelGGL(k_window_residuals_jobs<false>, dim3(max_plain, count), dim3(kBatchThreads), 0, s, d_jobs);
+  }
+  if (max_unwarp > 0) {
+    ProfScope ps(c, HG_K_RESIDUALS, c->lazy_batch_units[1]);
+    hipLaunchKernelGGL(k_window_residuals_jobs<true>, dim3(max_unwarp, count), dim3(kBatchThreads), 0, s, d_jobs);
+  }
+  {
+    ProfScope ps(c, HG_K_LM, count);
+    hipLaunchKernelGGL(k_lm_jobs, dim3(count), dim3(kLmBlock), 0, s, d_jobs, static_cast<int>(MODE_STEP));
+  }
+}
+// Behind a batched solve of general problems: returns once every problem has terminated on the device or all
+// launches are enqueued (see solve_settle).
+static int batch_settle(hg_ctx* c) {
+  if (!c || c->lazy_batch_left <= 0) return HG_OK;
+  const WindowJob* d_jobs = static_cast<const WindowJob*>(c->ws_misc.ptr);
+  for (unsigned long long spin = 0;; ++spin) {
+    bool all = true;
+    for (size_t i = 0; i < c->lazy_batch_flags.size() && all; ++i) all = *c->lazy_batch_flags[i] == c->lazy_batch_seqs[i];
+    if (all) break;
+    __builtin_ia32_pause();
+    if ((spin & 0xFFull) == 0xFFull) {
+      const hipError_t q = hipEventQuery(c->ev_lazy_batch);
+      if (q == hipSuccess) {
+        const int left = c->lazy_batch_left;
+        c->lazy_batch_left = 0;
+        for (int it = 0; it < left; ++it) window_jobs_iteration(c, d_jobs);
+        HG_HIP_CHECK(hipGetLastError());
+        return HG_OK;
+      }
+      if (q != hipErrorNotReady) {
+        set_last_error(std::string("solve: ") + hipGetErrorString(q));
+        return HG_ERR_HIP;
+      }
+    }
+  }
+  c->lazy_batch_left = 0;
+  return HG_OK;
+}
 
 // Uploads every problem and, if all of them have the single-pose shape, enqueues their solves with
 // shared launches (*batched = true; results are collected by hg_problem_fetch on each problem).
@@ -4989,21 +5091,27 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     hipLaunchKernelGGL(k_lm_jobs, dim3(count), dim3(kLmBlock), 0, s, d_jobs, static_cast<int>(MODE_PREPARE));
     HG_HIP_CHECK(hipGetLastError());
     const int max_it = problems[0]->h_state.h.opt.max_num_iterations;
-    for (int it = 0; it <= max_it; ++it) {
-      if (max_plain > 0) {
-        ProfScope ps(c, HG_K_RESIDUALS, units_plain);
-        hipLaunchKernelGGL(k_window_residuals_jobs<false>, dim3(max_plain, count), dim3(kBatchThreads), 0, s, d_jobs);
-      }
-      if (max_unwarp > 0) {
-        ProfScope ps(c, HG_K_RESIDUALS, units_unwarp);
-        hipLaunchKernelGGL(k_window_residuals_jobs<true>, dim3(max_unwarp, count), dim3(kBatchThreads), 0, s, d_jobs);
-      }
-      {
-        ProfScope ps(c, HG_K_LM, count);
-        hipLaunchKernelGGL(k_lm_jobs, dim3(count), dim3(kLmBlock), 0, s, d_jobs, static_cast<int>(MODE_STEP));
+    // the last three iterations are held back until some window is seen to need them (batch_settle), as in the
+    // solve of one general problem (solve_async_impl)
+    c->lazy_batch_left = 0;
+    c->lazy_batch_dims[0] = max_plain; c->lazy_batch_dims[1] = max_unwarp; c->lazy_batch_dims[2] = static_cast<unsigned>(count);
+    c->lazy_batch_units[0] = units_plain; c->lazy_batch_units[1] = units_unwarp;
+    static const bool lazy_ok = std::getenv("HG_EAGER_SOLVE") == nullptr;
+    if (lazy_ok && max_it + 1 >= 8) {
+      c->lazy_batch_left = 3;
+      c->lazy_batch_flags.clear();
+      c->lazy_batch_seqs.clear();
+      for (int i = 0; i < count; ++i) {
+        c->lazy_batch_flags.push_back(&problems[i]->h_box->flag);
+        c->lazy_batch_seqs.push_back(problems[i]->seq);
       }
     }
+    for (int it = 0; it <= max_it - c->lazy_batch_left; ++it) window_jobs_iteration(c, d_jobs);
     HG_HIP_CHECK(hipGetLastError());
+    if (c->lazy_batch_left > 0) {
+      if (!c->ev_lazy_batch) HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_lazy_batch, hipEventDisableTiming));
+      HG_HIP_CHECK(hipEventRecord(c->ev_lazy_batch, s));
+    }
     for (int i = 0; i < count; ++i) problems[i]->solve_pending = true;
     *batched = true;
     return HG_OK;
@@ -5108,6 +5216,7 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     }
     return HG_OK;
   }
+  if ((rc = batch_settle(problems[0]->ctx)) != HG_OK) return rc;
   for (int i = 0; i < count; ++i) {
     const int r2 = hg_problem_fetch(problems[i], summaries ? summaries + i : nullptr);
     if (r2 != HG_OK) rc = r2;
@@ -5158,6 +5267,7 @@ int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solv
   // insertion of every scan at the pose its solve leaves in device memory, with shared launches
   std::vector<const double*> d_poses(count);
   for (int j = 0; j < count; ++j) d_poses[j] = &problems[j]->d_state->h.x[pose_index[j]][0];
+  if ((rc = batch_settle(c)) != HG_OK) return rc;  // (windows hold their last launches back)
   rc = pyramid_insert_jobs(c, count, grids, iopts, levels, origins, xyz, n, width, d_poses.data());
   if (rc == HG_ERR_UNSUPPORTED) {  // insertion options outside the binned path: pyramid by pyramid
     rc = HG_OK;
@@ -5326,7 +5436,7 @@ int hg_register_scan_unwarped(hg_problem* p, const hg_solver_opts* sopts, hg_gri
     if (pose_index[k] < 0 || pose_index[k] >= static_cast<int>(p->poses.size())) return HG_ERR_INVALID;
   int rc = async_status_grids(grids, levels);
   if (rc != HG_OK) return rc;
-  rc = hg_problem_solve_async(p, sopts);
+  rc = solve_async_impl(p, sopts, true);
   if (rc != HG_OK) return rc;
   // the unwarping reads the solved control poses where the solve leaves them (LmHead::x, kState doubles per
   // control point); the host's copy (the initial guesses) only sizes the key window. A problem without free
@@ -5335,6 +5445,7 @@ int hg_register_scan_unwarped(hg_problem* p, const hg_solver_opts* sopts, hg_gri
   for (int k = 0; k < n_control; ++k) std::memcpy(&guess[7 * k], p->poses[pose_index[k]].data(), sizeof(double) * 7);
   int stride = kState;
   const double* d_poses = device_poses(p, &stride);
+  if ((rc = solve_settle(p)) != HG_OK) return rc;  // (a general problem holds its last launches back)
   rc = unwarp_insert(grids, iopts, levels, points, n, width, memspace, clouds, n_clouds, guess.data(), d_poses,
                      d_poses ? pose_index : nullptr, stride, control_times, n_control, pose_tq, insert_mode, nullptr);
   const int rc2 = hg_problem_fetch(p, summary);
@@ -5369,8 +5480,9 @@ static int register_scan_step(hg_problem* p, const hg_solver_opts* sopts, int po
   int rc = async_status_grids(grids, levels);
   if (rc != HG_OK) return rc;
   apply_scan_width(p, xyz, n, width);
-  rc = hg_problem_solve_async(p, sopts);
+  rc = solve_async_impl(p, sopts, true);
   if (rc != HG_OK) return rc;
+  if ((rc = solve_settle(p)) != HG_OK) return rc;  // (a general problem holds its last launches back)
 #ifdef HG_HOST_STAMPS
   const auto h1 = std::chrono::steady_clock::now();
 #endif
