@@ -33,6 +33,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations below are its whole export list. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct hg_ctx hg_ctx;
 typedef struct hg_grid hg_grid;
@@ -445,6 +449,9 @@ int hg_match_solve(hg_ctx* ctx, hg_grid* const* pyramid, int levels, int multi_r
                    double interpolation_ratio, const hg_solver_opts* opts,
                    hg_solver_summary* summary);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,51 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == names
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden + csrc/hg_exports.map: the dynamic symbol table holds the header's entry points and no
+    hg:: internal, kernel handle or hg_*_big twin of the second solver build."""
+    import subprocess
+    from hectorgrapher_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == header_functions()
+    listed = re.findall(r"^\s+(hg_[a-z0-9_]+);", open(os.path.join(ROOT, "hectorgrapher_amd", "csrc",
+                                                                    "hg_exports.map")).read(), flags=re.M)
+    assert sorted(listed) == header_functions()
+
+
+def test_two_solver_builds_define_no_common_symbol():
+    """hg_match.hip is compiled twice (hg_match.o and -DHG_BIG hg_match_big.o) behind the rename list
+    csrc/hg_match_big_names.h: a global the list misses would be defined by both objects (a silent ODR clash,
+    weak symbols of templates and inline functions aside)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "hectorgrapher_amd", "csrc")
+    defined = []
+    for obj in ("hg_match.o", "hg_match_big.o"):
+        path = os.path.join(csrc, obj)
+        assert os.path.exists(path), "run __graft_entry__.build() first"
+        out = subprocess.check_output(["nm", "--defined-only", "-g", path], text=True)
+        # strong definitions only: T/D/B/R (W/V/u = weak or unique template / inline instantiations the linker folds)
+        defined.append({l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TDBR"})
+    common = sorted(defined[0] & defined[1])
+    assert not common, common[:10]
+    assert len(defined[0]) > 20 and len(defined[1]) > 20
+    # weak definitions the linker folds into one must be the same code in both builds: the standard library and the
+    # inline helpers of hg_internal.h (which does not depend on HG_BIG), nothing that hg_match.hip itself defines
+    weak = []
+    for obj in ("hg_match.o", "hg_match_big.o"):
+        out = subprocess.check_output(["nm", "--defined-only", "-g", os.path.join(csrc, obj)], text=True)
+        weak.append({l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "WVu"})
+    shared_header = open(os.path.join(csrc, "hg_internal.h")).read()
+    for sym in sorted(weak[0] & weak[1]):
+        if sym.startswith(("_ZNSt", "_ZSt", "_ZNKSt", "DW.ref.", "__clang_")):
+            continue
+        m = re.match(r"_ZN2hg(\d+)", sym)
+        assert m, sym
+        name = sym[len(m.group(0)):][:int(m.group(1))]
+        assert re.search(r"\b(struct|class)\s+%s\b" % name, shared_header), sym
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU the product path fails loudly (HG_ERR_NO_DEVICE), it never computes on the CPU."""
     import torch
