@@ -35,7 +35,7 @@ SYMBOLS = [
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
     "hg_solver_default_opts", "hg_problem_solve", "hg_problem_solve_batch", "hg_problem_solve_async", "hg_problem_fetch",
     "hg_register_scan", "hg_register_scan_mode", "hg_register_scan_batch", "hg_register_scan_sequence", "hg_match_evaluate", "hg_match_solve",
-    "hg_pyramid_insert_unwarped", "hg_unwarp_range_data", "hg_unwarp_last_device", "hg_register_scan_unwarped",
+    "hg_pyramid_insert_unwarped", "hg_unwarp_range_data", "hg_unwarp_last_device", "hg_unwarp_status", "hg_register_scan_unwarped",
 ]
 
 
@@ -215,6 +215,7 @@ def load():
     L.hg_pyramid_insert_unwarped.argtypes = [vp, vp, i32, vp, sz, sz, i32, vp, i32, vp, vp, i32, vp, i32, vp]
     L.hg_unwarp_range_data.argtypes = [vp, vp, sz, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp]
     L.hg_unwarp_last_device.argtypes = [vp, P(vp), P(vp), P(sz)]
+    L.hg_unwarp_status.argtypes = [vp]
     L.hg_register_scan_unwarped.argtypes = [vp, P(SolverOpts), vp, vp, i32, vp, sz, sz, i32, vp, i32, vp, vp, i32,
                                             vp, i32, vp, P(SolverSummary)]
     for name in SYMBOLS:

@@ -408,6 +408,12 @@ def _timed_clouds(clouds):
         begin += int(pts.shape[0])
     if len(clouds) == 1 and _is_device(clouds[0][2]):
         p = clouds[0][2]
+        # the kernels read float4 rows straight from this pointer: anything else must be converted first
+        if p.dim() != 2 or p.shape[1] != 4:
+            raise ValueError("timed cloud on the device must be [n, 4] (x y z time), got %s" % (tuple(p.shape),))
+        import torch
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            p = p.to(torch.float32).contiguous()
         return arr, p, p.data_ptr(), begin, _lib.HG_DEVICE
     allp = np.ascontiguousarray(np.concatenate([_host(c[2], np.float32, 4) for c in clouds], 0))
     return arr, allp, allp.ctypes.data, begin, _lib.HG_HOST
@@ -448,6 +454,33 @@ def unwarp_range_data(ctx, clouds, control_times, control_poses, frame=0, pose_t
                                  _p(pose), _p(xyz), _p(origin)), "hg_unwarp_range_data")
     del keep
     return xyz, origin
+
+
+def unwarp_range_data_async(ctx, clouds, control_times, control_poses, frame=0, pose_tq=None):
+    """hg_unwarp_range_data without host outputs: the result stays on the device (hg_unwarp_last_device);
+    `unwarp_status(ctx)` waits for it and raises HG_ERR_TIME like the synchronous form."""
+    L = _lib.load()
+    arr, keep, ptr, n, space = _timed_clouds(clouds)
+    ct = np.ascontiguousarray(control_times, np.int64)
+    cp = np.ascontiguousarray(control_poses, np.float64).reshape(-1, 7)
+    pose = None if pose_tq is None else np.ascontiguousarray(pose_tq, np.float32)
+    check(L.hg_unwarp_range_data(ctx._h, ptr, n, space, arr, len(clouds), _p(cp), _p(ct), len(ct), int(frame),
+                                 _p(pose), None, None), "hg_unwarp_range_data")
+    ctx._keep_unwarp = keep  # a device input must outlive the enqueued kernels
+    return n
+
+
+def unwarp_status(ctx):
+    """hg_unwarp_status: waits for the context's stream; raises HgError(HG_ERR_TIME) when the last unwarp call
+    met a return outside the control points."""
+    check(_lib.load().hg_unwarp_status(ctx._h), "hg_unwarp_status")
+
+
+def unwarp_last_device(ctx):
+    """(device pointer of xyz [n, 3], device pointer of the origin, n) of the context's last unwarp call."""
+    xyz, org, cnt = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    check(_lib.load().hg_unwarp_last_device(ctx._h, C.byref(xyz), C.byref(org), C.byref(cnt)), "hg_unwarp_last_device")
+    return xyz.value, org.value, cnt.value
 
 
 def register_scan_unwarped(problem, inserters, clouds, width, pose_index, control_times, grids, pose_tq=None,

@@ -22,6 +22,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "hg_internal.h"
+#include "hg_chain.h"
 
 namespace hg {
 
@@ -283,201 +284,7 @@ __device__ inline uint32_t update_cell(const GridView& g, float maximum_weight, 
   return (tsd_to_value(g, updated_sdf) + kUpdateMarker) | (weight_to_value(g, updated_weight) << 16);
 }
 
-// lround(t) for 0 <= t < 2^23 without the generic half-away-from-zero sequence: trunc is exact,
-// the fraction t - trunc(t) is exact, ties (>= 0.5) go up. Returns the rounded value as float.
-__device__ inline float round_nonneg(float t) {
-  const float r = truncf(t);
-  return (t - r >= 0.5f) ? r + 1.0f : r;
-}
-
-// lround(t) + 1 for t = v * resolution >= 0, given y = v * (2 * resolution) = 2t (scaling by two
-// commutes with the rounding of the product): floor(y) = 2n + [frac(t) >= 0.5] for t = n + frac, so
-// floor((floor(y) + 1) / 2) = lround(t); every step is exact in fp32 for t < 2^22. Four
-// instructions instead of the six of trunc / subtract / compare / select / add.
-__device__ inline float round_nonneg_plus1(float y) {
-  return floorf(__builtin_fmaf(floorf(y), 0.5f, 1.5f));
-}
-
-// num / den, correctly rounded, for the operands of the unit-weight update chain: den = w + 1 in
-// [1, maximum_weight + 1], |num| <= (|tsd| * w + |update|) — far inside the range where
-// v_div_scale_f32 leaves both operands unscaled and v_div_fixup_f32 has nothing to fix. This is the
-// Newton-Raphson sequence the compiler emits for an IEEE fdiv without those two wrappers (same
-// instructions, same operands, hence the same bits); only the sign of a zero quotient can differ,
-// which the quantisation that follows does not see. The reciprocal depends on the weight chain
-// only, so the dependent chain through the TSD value is 5 FMAs instead of 10 instructions.
-__device__ inline bool div_in_range_ok(const GridView& g) {
-  return g.max_weight <= 1.0e6f && g.max_tsd <= 1.0e3f && g.min_tsd >= -1.0e3f;
-}
-__device__ inline float div_in_range(float num, float den) {
-  const float r0 = __builtin_amdgcn_rcpf(den);
-  const float e0 = __builtin_fmaf(-den, r0, 1.0f);
-  const float r = __builtin_fmaf(e0, r0, r0);
-  const float q0 = num * r;
-  const float rem0 = __builtin_fmaf(-den, q0, num);
-  const float q1 = __builtin_fmaf(rem0, r, q0);
-  const float rem1 = __builtin_fmaf(-den, q1, num);
-  return __builtin_fmaf(rem1, r, q1);
-}
-
-// Incremental form of the same chain: begin(code) ... step(u) ... end() == update_cell in a loop
-// with update weight 1.
-struct UnitChain {
-  float d, w, rt, rw;
-  uint32_t code0;
-  bool any, fast;
-  __device__ inline void begin(const GridView& g, uint32_t code) {
-    fast = div_in_range_ok(g);
-    const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
-    d = tc == 0 ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
-    w = wc == 0 ? 0.f : static_cast<float>(wc) * g.weight_scale + g.weight_offset;
-    rt = rw = 0.f;
-    code0 = code;
-    any = false;
-  }
-  template <bool FAST>
-  __device__ inline void step_t(const GridView& g, float maximum_weight, float u) {
-    float uw = w + 1.0f;
-    const float ud = FAST ? div_in_range(d * w + u, uw) : (d * w + u) / uw;
-    uw = (maximum_weight < uw) ? maximum_weight : uw;
-    rt = round_nonneg_plus1((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * (2.0f * g.tsd_resolution));
-    rw = round_nonneg_plus1((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * (2.0f * g.weight_resolution));
-    d = rt * g.tsd_scale + g.tsd_offset;  // rt, rw hold code = lround(..) + 1
-    w = rw * g.weight_scale + g.weight_offset;
-    any = true;
-  }
-  __device__ inline void step(const GridView& g, float maximum_weight, float u) {
-    if (fast) step_t<true>(g, maximum_weight, u); else step_t<false>(g, maximum_weight, u);
-  }
-  // `count` consecutive steps on LDS values (blocked prefetch, see chain_run below)
-  __device__ inline void run(const GridView& g, float maximum_weight, const uint32_t* vals, unsigned count);
-  __device__ inline uint32_t end() const {
-    if (!any) return code0;
-    const uint32_t nt = static_cast<uint32_t>(static_cast<int>(rt));
-    const uint32_t nw = static_cast<uint32_t>(static_cast<int>(rw));
-    return (nt + kUpdateMarker) | (nw << 16);
-  }
-};
-
-// `count` consecutive UpdateCell calls with update weight 1 on one voxel (values vals[0..count)),
-// bit-identical to calling update_cell in a loop: codes stay in float form (code - 1 as a float)
-// between updates. One update is a chain of 15 dependent fp32 operations through the TSD value
-// (about 7 cycles each for a wavefront on its own); everything else has to stay off that chain:
-//   * the values come from LDS four at a time, one block AHEAD of their use (a read issued and
-//     awaited inside an update exposes an LDS round trip, which used to double the time per update);
-//   * the weight follows its own recurrence, which does not depend on the TSD value; once it has
-//     reached its fixed point (the clamp at maximum_weight: the heavy voxels next to the sensor sit
-//     there from their second scan on) the weight arithmetic is skipped for as long as every lane of
-//     the wavefront that still has updates is there too.
-// (Round 4, measured and dropped: a double-precision shortcut for the tail of a pass, where one or a few voxels
-// next to the sensor still have thousands of updates. With the weight at its fixed point the new code is
-// floor(A c + Ku u + B) in real arithmetic -- one f64 fma and one floor on the dependent chain -- and equals the
-// reference's code unless that value lies within E = 2^-24 res (4 T + 3 R) of an integer (the six fp32 roundings of
-// the exact chain; about one update in forty), near the clamps, or u is out of range, in which case the block of
-// four is redone exactly. Bit-exact in every test, but the guards make the block as many instructions as the 64
-// dependent fp32 operations it replaces, the fall-backs come on top, and the constants cost the apply kernels
-// scratch at their 64 registers: exact stream B = 32 18.4k -> 15.0k scans/s, B = 64 9.9k -> 7.8k. The chain stays
-// as it is: 16 dependent operations per update.)
-struct ChainState {
-  float d, w;    // decoded TSD value and weight
-  float rt, rw;  // their codes (lround(..) + 1) as floats, valid after the first update
-  bool fixed;    // the weight no longer changes under updates
-};
-template <bool FAST>
-__device__ inline void chain_run(const GridView& g, float maximum_weight, ChainState& st, const uint32_t* vals,
-                                 unsigned count) {
-  float d = st.d, w = st.w, rt = st.rt, rw = st.rw;
-  bool fixed = st.fixed;
-  const float res2_t = 2.0f * g.tsd_resolution, res2_w = 2.0f * g.weight_resolution;
-  auto step = [&](float u) {
-    float uw = w + 1.0f;
-    const float ud = FAST ? div_in_range(d * w + u, uw) : (d * w + u) / uw;  // u * 1.0f == u
-    uw = (maximum_weight < uw) ? maximum_weight : uw;
-    // TSDToValue / WeightToValue (values are finite: med3 == the reference's two-sided clamp);
-    // rt, rw hold the codes lround(..) + 1 as floats
-    rt = round_nonneg_plus1((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * res2_t);
-    rw = round_nonneg_plus1((__builtin_amdgcn_fmed3f(uw, 0.f, g.max_weight) - 0.f) * res2_w);
-    // ValueToTSD / ValueToWeight of the codes (never 0)
-    d = rt * g.tsd_scale + g.tsd_offset;
-    const float wn = rw * g.weight_scale + g.weight_offset;
-    fixed = wn == w;
-    w = wn;
-  };
-  constexpr unsigned K = 4;  // a block of 4 updates (~450 cycles) covers the LDS latency; 8 costs a workgroup per CU in registers
-  unsigned base = 0;
-  if (count >= K) {
-    uint32_t cur[K], nx[K];
-#pragma unroll
-    for (unsigned k = 0; k < K; ++k) cur[k] = vals[k];
-    while (base + K <= count) {
-      const unsigned nb = base + K;
-#pragma unroll
-      for (unsigned k = 0; k < K; ++k) nx[k] = vals[min(nb + k, count - 1u)];  // in flight during this block
-      if (__all(fixed)) {
-        // fixed weight: the update is d <- quantise((d * w + u) / (w + 1)) with constants w, 1 / (w + 1)
-        const float uw = w + 1.0f;
-        const float r0 = __builtin_amdgcn_rcpf(uw);
-        const float r = __builtin_fmaf(__builtin_fmaf(-uw, r0, 1.0f), r0, r0);
-#pragma unroll
-        for (unsigned k = 0; k < K; ++k) {
-          const float num = d * w + __uint_as_float(cur[k]);
-          float ud;
-          if (FAST) {  // div_in_range with the reciprocal hoisted
-            const float q0 = num * r;
-            const float q1 = __builtin_fmaf(__builtin_fmaf(-uw, q0, num), r, q0);
-            ud = __builtin_fmaf(__builtin_fmaf(-uw, q1, num), r, q1);
-          } else {
-            ud = num / uw;
-          }
-          rt = round_nonneg_plus1((__builtin_amdgcn_fmed3f(ud, g.min_tsd, g.max_tsd) - g.min_tsd) * res2_t);
-          d = rt * g.tsd_scale + g.tsd_offset;
-        }
-      } else {
-#pragma unroll
-        for (unsigned k = 0; k < K; ++k) step(__uint_as_float(cur[k]));
-      }
-#pragma unroll
-      for (unsigned k = 0; k < K; ++k) cur[k] = nx[k];
-      base = nb;
-    }
-  }
-  if (base < count) {
-    uint32_t next = vals[base];
-    for (unsigned j = base; j < count; ++j) {
-      const float u = __uint_as_float(next);
-      if (j + 1 < count) next = vals[j + 1];
-      step(u);
-    }
-  }
-  st.d = d; st.w = w; st.rt = rt; st.rw = rw; st.fixed = fixed;
-}
-template <bool FAST>
-__device__ inline uint32_t update_chain_unit_t(const GridView& g, float maximum_weight, uint32_t code,
-                                               const uint32_t* vals, unsigned count) {
-  const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
-  ChainState st;
-  st.d = tc == 0 ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
-  st.w = wc == 0 ? 0.f : static_cast<float>(wc) * g.weight_scale + g.weight_offset;
-  st.rt = st.rw = 0.f;
-  st.fixed = false;
-  chain_run<FAST>(g, maximum_weight, st, vals, count);
-  const uint32_t nt = static_cast<uint32_t>(static_cast<int>(st.rt));
-  const uint32_t nw = static_cast<uint32_t>(static_cast<int>(st.rw));
-  return (nt + kUpdateMarker) | (nw << 16);
-}
-__device__ inline void UnitChain::run(const GridView& g, float maximum_weight, const uint32_t* vals, unsigned count) {
-  if (count == 0) return;
-  ChainState st{d, w, rt, rw, false};
-  if (fast) chain_run<true>(g, maximum_weight, st, vals, count);
-  else chain_run<false>(g, maximum_weight, st, vals, count);
-  d = st.d; w = st.w; rt = st.rt; rw = st.rw;
-  any = true;
-}
-__device__ inline uint32_t update_chain_unit(const GridView& g, float maximum_weight, uint32_t code,
-                                             const uint32_t* vals, unsigned count) {
-  if (count == 0) return code;
-  return div_in_range_ok(g) ? update_chain_unit_t<true>(g, maximum_weight, code, vals, count)
-                            : update_chain_unit_t<false>(g, maximum_weight, code, vals, count);
-}
+// (the exact per-voxel update chain -- UnitChain, chain_run, seg_chains -- lives in hg_chain.h)
 
 __global__ void k_apply_runs(GridView g, InsertParams p, const unsigned long long* keys,
                              const unsigned long long* vals, unsigned long long n) {

@@ -90,6 +90,7 @@ struct hg_ctx {
   const float* unwarp_xyz = nullptr;     // results of the last unwarp call (device)
   const float* unwarp_origin = nullptr;
   size_t unwarp_count = 0;
+  const unsigned* unwarp_time_ok = nullptr;  // status word of the last unwarp call (0 = a time outside the control points)
   // second set of record / work-list buffers and the apply stream of the pipelined scan stream
   // (insert_chunk_binned with `pipe`): the front end of scan k + 1 runs next to the apply pass of scan k
   hg::DeviceBuffer ws_keys_c, ws_vals_c, ws_offsets_b;

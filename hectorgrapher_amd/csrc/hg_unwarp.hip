@@ -57,6 +57,8 @@ struct UnwarpParams {
   float* xyz_out;             // n x 3
   float* origin_out;          // 3 floats
   unsigned* first_valid;      // index of the first non-NaN return (initialised to 0xFFFFFFFF)
+  unsigned* time_ok;          // the call's own status word: 0xFFFFFFFF, or 0 once a return's time lies outside the
+                              // control points (the reference CHECK-fails: nothing of the call may reach a map)
   uint32_t* flag_words[4];    // counters[1] of the grids the cloud goes to (sticky error flags) or nullptr
 };
 
@@ -204,6 +206,7 @@ __device__ __forceinline__ void unwarp_points_body(const UnwarpParams& P) {
     if (idx < *reinterpret_cast<volatile unsigned*>(P.first_valid)) atomicMin(P.first_valid, idx);
   }
   if (__ballot(outside) != 0ull && (threadIdx.x % kWave) == 0) {
+    atomicAnd(P.time_ok, 0u);
 #pragma unroll
     for (int l = 0; l < 4; ++l)
       if (P.flag_words[l]) atomicOr(P.flag_words[l], kFlagTime);
@@ -211,8 +214,20 @@ __device__ __forceinline__ void unwarp_points_body(const UnwarpParams& P) {
 }
 
 // accumulated_range_data_in_tracking.origin = transform * front().origin at the first unwarped return
-// (:1370-1374); Vector3f::Zero() when every return is NaN (:1298-1299).
+// (:1370-1374); Vector3f::Zero() when every return is NaN (:1298-1299). Launched over all returns: when the
+// points pass found a time outside the control points the reference would have CHECK-failed before anything
+// was inserted (:1358-1359), so every return of the failed call is replaced by NaN -- the gates of the
+// insertion (and of everything else that reads the device copy) drop NaN returns, the maps stay as they were
+// and the caller gets HG_ERR_TIME. The usual case costs one uniform load per workgroup.
 __device__ __forceinline__ void unwarp_origin_body(const UnwarpParams& P) {
+  const unsigned long long g = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (*P.time_ok == 0u && g < P.n) {
+    const float nan = __int_as_float(0x7FC00000);
+    P.xyz_out[3 * g] = nan;
+    P.xyz_out[3 * g + 1] = nan;
+    P.xyz_out[3 * g + 2] = nan;
+  }
+  if (g != 0) return;
   const unsigned i = *P.first_valid;
   float ox = 0.f, oy = 0.f, oz = 0.f;
   if (i != 0xFFFFFFFFu) {
@@ -230,7 +245,7 @@ __device__ __forceinline__ void unwarp_origin_body(const UnwarpParams& P) {
 
 // Tables in device memory (more control points or clouds than the inline form holds).
 __global__ __launch_bounds__(256) void k_unwarp_points(UnwarpParams P) { unwarp_points_body(P); }
-__global__ void k_unwarp_origin(UnwarpParams P) { unwarp_origin_body(P); }
+__global__ __launch_bounds__(256) void k_unwarp_origin(UnwarpParams P) { unwarp_origin_body(P); }
 
 // Tables as kernel arguments; the control poses in device memory (what a solve left there) ...
 __global__ __launch_bounds__(256) void k_unwarp_points_inline(UnwarpParams P, const UnwarpInline T) {
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(256) void k_unwarp_points_inline(UnwarpParams P, co
   P.clouds = T.clouds;
   unwarp_points_body(P);
 }
-__global__ void k_unwarp_origin_inline(UnwarpParams P, const UnwarpInline T) {
+__global__ __launch_bounds__(256) void k_unwarp_origin_inline(UnwarpParams P, const UnwarpInline T) {
   P.times = T.times;
   P.pose_index = P.pose_index ? T.pose_index : nullptr;
   P.clouds = T.clouds;
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(256) void k_unwarp_points_inline_poses(UnwarpParams
   P.poses = X.poses;
   unwarp_points_body(P);
 }
-__global__ void k_unwarp_origin_inline_poses(UnwarpParams P, const UnwarpInline T, const UnwarpInlinePoses X) {
+__global__ __launch_bounds__(256) void k_unwarp_origin_inline_poses(UnwarpParams P, const UnwarpInline T, const UnwarpInlinePoses X) {
   P.times = T.times;
   P.pose_index = nullptr;
   P.clouds = T.clouds;
@@ -351,7 +366,7 @@ int hg::unwarp_enqueue(hg_ctx* c, hg_grid* const* grids, int levels, const float
     P.pose_index = pose_index ? reinterpret_cast<const int*>(base + cloud_bytes + time_bytes) : nullptr;
     if (!d_poses) P.poses = reinterpret_cast<const double*>(base + cloud_bytes + time_bytes + index_bytes);
   }
-  HG_HIP_CHECK(hipMemsetAsync(base + table_bytes, 0xFF, sizeof(unsigned), s));  // first_valid = none yet
+  HG_HIP_CHECK(hipMemsetAsync(base + table_bytes, 0xFF, 2 * sizeof(unsigned), s));  // first_valid = none yet, time_ok
   P.points = d_points;
   P.n = n;
   P.n_clouds = n_clouds;
@@ -368,6 +383,7 @@ int hg::unwarp_enqueue(hg_ctx* c, hg_grid* const* grids, int levels, const float
   if (post_tq) std::memcpy(P.post_tq, post_tq, sizeof(P.post_tq));
   P.xyz_out = c->ws_unwarp.as<float>();
   P.first_valid = reinterpret_cast<unsigned*>(base + table_bytes);
+  P.time_ok = reinterpret_cast<unsigned*>(base + table_bytes + 4);
   P.origin_out = reinterpret_cast<float*>(base + table_bytes + 16);
   for (int l = 0; l < levels && l < 4; ++l) P.flag_words[l] = grids && grids[l] ? grids[l]->view.counters + 1 : nullptr;
   {
@@ -375,19 +391,20 @@ int hg::unwarp_enqueue(hg_ctx* c, hg_grid* const* grids, int levels, const float
     const dim3 grid(static_cast<unsigned>((n + 255) / 256));
     if (inline_tables && d_poses) {
       hipLaunchKernelGGL(k_unwarp_points_inline, grid, dim3(256), 0, s, P, T);
-      hipLaunchKernelGGL(k_unwarp_origin_inline, dim3(1), dim3(1), 0, s, P, T);
+      hipLaunchKernelGGL(k_unwarp_origin_inline, grid, dim3(256), 0, s, P, T);
     } else if (inline_tables) {
       hipLaunchKernelGGL(k_unwarp_points_inline_poses, grid, dim3(256), 0, s, P, T, X);
-      hipLaunchKernelGGL(k_unwarp_origin_inline_poses, dim3(1), dim3(1), 0, s, P, T, X);
+      hipLaunchKernelGGL(k_unwarp_origin_inline_poses, grid, dim3(256), 0, s, P, T, X);
     } else {
       hipLaunchKernelGGL(k_unwarp_points, grid, dim3(256), 0, s, P);
-      hipLaunchKernelGGL(k_unwarp_origin, dim3(1), dim3(1), 0, s, P);
+      hipLaunchKernelGGL(k_unwarp_origin, grid, dim3(256), 0, s, P);
     }
   }
   HG_HIP_CHECK(hipGetLastError());
   c->unwarp_xyz = P.xyz_out;
   c->unwarp_origin = P.origin_out;
   c->unwarp_count = n;
+  c->unwarp_time_ok = P.time_ok;
   return HG_OK;
 }
 
@@ -455,8 +472,18 @@ int hg_unwarp_range_data(hg_ctx* ctx, const float* points, size_t n, int memspac
     HG_HIP_CHECK(hipMemcpyAsync(xyz_out, ctx->unwarp_xyz, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (origin_out)
     HG_HIP_CHECK(hipMemcpyAsync(origin_out, ctx->unwarp_origin, 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  if (xyz_out || origin_out) HG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (xyz_out || origin_out) return hg_unwarp_status(ctx);  // waits for the copies; HG_ERR_TIME as the reference CHECKs
   return HG_OK;
+}
+
+int hg_unwarp_status(hg_ctx* ctx) {
+  if (!ctx) return HG_ERR_INVALID;
+  if (!ctx->unwarp_time_ok) return HG_OK;
+  unsigned ok = 0;
+  HG_HIP_CHECK(hipSetDevice(ctx->device));
+  HG_HIP_CHECK(hipMemcpyAsync(&ok, ctx->unwarp_time_ok, sizeof(ok), hipMemcpyDeviceToHost, ctx->stream));
+  HG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ok ? HG_OK : flags_to_status(kFlagTime);
 }
 
 int hg_unwarp_last_device(hg_ctx* ctx, const float** xyz_dev, const float** origin_dev, size_t* count) {

@@ -257,7 +257,10 @@ typedef struct hg_timed_cloud {
  *   pose_tq != NULL, pose_tq (float[7] = local_pose().inverse().cast<float>()).
  * control_poses: n_control x 7 doubles (host), control_times: ascending ticks (host). A return whose time
  * lies outside [control_times[0], control_times[n_control - 1]] raises HG_ERR_TIME (the reference
- * CHECK-fails), reported like the other sticky insert errors. width / mode / stats as hg_pyramid_insert. */
+ * CHECK-fails before anything is inserted, :1358-1359), reported like the other sticky insert errors; the
+ * failed call inserts NOTHING (on the device every return of such a call is replaced by NaN before the
+ * insertion reads the cloud, and NaN returns are dropped by its gates), so the grids hold what they held
+ * before. The flag stays set until hg_grid_clear. width / mode / stats as hg_pyramid_insert. */
 int hg_pyramid_insert_unwarped(hg_grid* const* grids, const hg_insert_opts* opts, int levels,
                                const float* points, size_t n, size_t width, int memspace,
                                const hg_timed_cloud* clouds, int n_clouds, const double* control_poses,
@@ -266,11 +269,16 @@ int hg_pyramid_insert_unwarped(hg_grid* const* grids, const hg_insert_opts* opts
 /* The unwarping alone. frame 0: accumulated_range_data_in_tracking (:1331-1379); frame 1: additionally
  * moved by control_poses[0].cast<float>() (range_data_in_local) and, if given, pose_tq. xyz_out (n x 3)
  * and origin_out are host arrays or NULL; the device copies stay valid until the context's next unwarp
- * call (hg_unwarp_last_device), e.g. as input of hg_voxel_filter / hg_pyramid_insert with HG_DEVICE. */
+ * call (hg_unwarp_last_device), e.g. as input of hg_voxel_filter / hg_pyramid_insert with HG_DEVICE.
+ * Returns HG_ERR_TIME when a return's time lies outside the control points (every return of the result is
+ * then NaN, on the host and in the device copy, so nothing of it can reach a map). With both outputs NULL
+ * the call only enqueues: hg_unwarp_status waits for the context's stream and returns the status of its
+ * last unwarp call (HG_OK / HG_ERR_TIME). */
 int hg_unwarp_range_data(hg_ctx* ctx, const float* points, size_t n, int memspace, const hg_timed_cloud* clouds,
                          int n_clouds, const double* control_poses, const int64_t* control_times, int n_control,
                          int frame, const float* pose_tq, float* xyz_out, float origin_out[3]);
 int hg_unwarp_last_device(hg_ctx* ctx, const float** xyz_dev, const float** origin_dev, size_t* count);
+int hg_unwarp_status(hg_ctx* ctx);
 /* Synchronises and returns the counters of the last insert call + sticky error flags. */
 int hg_grid_status(hg_grid* grid, hg_insert_stats* stats);
 

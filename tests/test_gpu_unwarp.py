@@ -139,6 +139,52 @@ def test_unwarp_time_outside_control_points(hg, ctx):
     g.close()
 
 
+def test_failed_unwarped_insert_leaves_the_map_untouched(po, hg, ctx):
+    """The reference aborts at :1358-1359 BEFORE anything of the scan is inserted: a call that raises HG_ERR_TIME
+    must not have modified the grid (the device replaces every return of the failed call by NaN, which the
+    insertion's gates drop), although half of its returns lie inside the control points."""
+    times, poses = control_points(3)
+    good = timed_scan(8, 64, synth.pose_k(1), 5, 0.08)
+    bad = timed_scan(8, 64, synth.pose_k(2), 6, 0.2)
+    g = hg.HybridGridTSDF(ctx, 0.10, max_blocks=1 << 12)
+    ins = [hg.TSDFRangeDataInserter3D()]
+    hg.insert_pyramid_unwarped(ins, [(int(times[0]), [0, 0, 0], good)], 8, times, poses, [g])
+    before = g.export()
+    assert len(before[0]) > 100
+    with pytest.raises(hg.HgError, match="HG_ERR_TIME"):
+        hg.insert_pyramid_unwarped(ins, [(int(times[0]), [0, 0, 0], bad)], 8, times, poses, [g])
+    after = g.export()
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
+    g.close()
+
+
+def test_unwarp_range_data_time_outside_control_points(po, hg, ctx):
+    """hg_unwarp_range_data alone (no grid to carry a sticky flag): HG_ERR_TIME from the call itself, and from
+    hg_unwarp_status for the enqueue-only form; the device copy a caller might feed on holds NaN only. The
+    oracle's restatement refuses the same input (ok = false)."""
+    times, poses = control_points(3)
+    pts = timed_scan(8, 64, synth.pose_k(1), 5, 0.2)
+    clouds = [(int(times[0]), [0, 0, 0], pts)]
+    assert not po.unwarp_range_data(times, poses, clouds)[2]
+    with pytest.raises(hg.HgError, match="HG_ERR_TIME"):
+        hg.unwarp_range_data(ctx, clouds, times, poses)
+    n = hg.unwarp_range_data_async(ctx, clouds, times, poses, frame=1)
+    with pytest.raises(hg.HgError, match="HG_ERR_TIME"):
+        hg.unwarp_status(ctx)
+    ptr, _, cnt = hg.unwarp_last_device(ctx)
+    assert cnt == n == len(pts)
+    # read the library's device copy back (plain hipMemcpy, device to host)
+    import ctypes as C
+    host = np.zeros((n, 3), np.float32)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(host.nbytes), 2) == 0
+    assert np.isnan(host).all()
+    # an in-range call on the same context clears the status again
+    ok = timed_scan(8, 64, synth.pose_k(1), 5, 0.08)
+    hg.unwarp_range_data_async(ctx, [(int(times[0]), [0, 0, 0], ok)], times, poses)
+    hg.unwarp_status(ctx)
+
+
 def test_register_scan_unwarped_uses_solved_poses(po, hg, ctx):
     """hg_register_scan_unwarped = hg_problem_solve, then hg_pyramid_insert_unwarped with the solved poses:
     same poses, same voxels (the device reads the control poses where the solve left them), and the
