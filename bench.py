@@ -1101,7 +1101,23 @@ def init_dist(args):
     return dist, rank, local_rank, world
 
 
-def run_offline_batch(args, out_fd=None):
+def process_group_info(dist):
+    """What the process group really is -- so that the line itself shows how many ranks the collectives saw and
+    which library carried them (backend "nccl" IS RCCL on ROCm)."""
+    if dist is None:
+        return None
+    info = {"backend": dist.get_backend(), "nranks": dist.get_world_size()}
+    if info["backend"] == "nccl":
+        try:
+            import torch
+            v = torch.cuda.nccl.version()
+            info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as e:  # a version query must never cost the measurement
+            info["rccl_version"] = "unknown (%r)" % (e,)
+    return info
+
+
+def run_offline_batch(args, out_fd=None, group=None):
     """BASELINE configs[3], one command: --total-submaps S independent submaps x K scans each farmed to
     the --gpus ranks (hectorgrapher_amd.distributed.map_sharded), every rank registering its S / G
     submaps together per step (hg_register_scan_batch; a single owned submap takes the single chain), then
@@ -1110,7 +1126,10 @@ def run_offline_batch(args, out_fd=None):
     import torch
     from hectorgrapher_amd import api, synth
     from hectorgrapher_amd import distributed as hgd
-    dist, rank, local_rank, world = init_dist(args)
+    # group: the (dist, rank, local_rank, world) of a process group the caller already runs in (the configs[3] leg of
+    # `bench.py --gpus N`); it is used as it is and left open
+    own_group = group is None
+    dist, rank, local_rank, world = init_dist(args) if own_group else group
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     S = args.total_submaps
@@ -1250,8 +1269,13 @@ def run_offline_batch(args, out_fd=None):
             acc = acc.to(dev)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     mean_err, mean_its = float(acc[0] / acc[2]), float(acc[1] / acc[2])
+    pg_info = process_group_info(dist)
+    for g in eng.groups:  # the maps of this leg are done with (a caller's group goes on)
+        for gr in g.grids():
+            gr.close()
+        g.ctx.close()
     if rank != 0:
-        if dist is not None:
+        if dist is not None and own_group:
             dist.destroy_process_group()
         return None
     value = res["scans"] / res["elapsed"]
@@ -1273,11 +1297,11 @@ def run_offline_batch(args, out_fd=None):
                    "parallelism": "submap s on rank s mod %d, no data-path collective; one gather at the end" % world,
                    "mean_lm_iterations": mean_its, "mean_pose_error_m": mean_err,
                    "resident_voxel_gib_per_gpu": per_rank * len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30,
-                   "gather_ms": gather_ms, "gather_check": gather_check},
+                   "gather_ms": gather_ms, "gather_check": gather_check, "process_group": pg_info},
         "roofline": None, "parity": parity, "cpu_baseline": base,
         "gpu_over_cpu": value / base["value"] if base else None,
     }
-    if dist is not None:
+    if dist is not None and own_group:
         dist.destroy_process_group()
     return out
 
@@ -1409,6 +1433,11 @@ def run_register_batch(args):
     }
 
 
+# BASELINE configs[3] bounded for the default line and for the --gpus N line: 8 submaps x 30 scans
+OFFLINE_SUBMAPS = 8
+OFFLINE_LEG = {"total_submaps": OFFLINE_SUBMAPS, "scans_per_submap": 30, "steps": 30, "warmup": 2, "cpu_scans": 2}
+
+
 def secondary_workloads(args):
     """Bounded runs of the other workloads inside the default command, so that the driver's record holds
     them too: each {value, unit, ms_per_step, frac (algorithmic bytes / HBM peak of its dominant kernel),
@@ -1430,8 +1459,7 @@ def secondary_workloads(args):
         # BASELINE configs[3] bounded: 8 submaps x 30 scans on this GPU, then the gather of all finished blocks
         # through a one-rank process group and its import / export-digest check (the full 8 x 500 run is
         # `bench.py --total-submaps 8 --scans-per-submap 500`, profiles/r04_bench_offline8x500.json)
-        ("offline8", run_offline_batch, {"total_submaps": 8, "scans_per_submap": 30, "steps": 30, "warmup": 2, "cpu_scans": 2,
-                                         "_force_dist": True}),
+        ("offline8", run_offline_batch, dict(OFFLINE_LEG, _force_dist=True)),
     ]
     for name, fn, kw in plan:
         a = copy.copy(args)
@@ -1456,7 +1484,7 @@ def secondary_workloads(args):
                          "parity_ok": None if ok is None else bool(ok), "parity": par or None,
                          "wall_s": round(time.perf_counter() - t0, 2)}
             cfg = r.get("config") or {}
-            for k in ("gather_ms", "gather_check", "voxel_working_set_mib", "room_copies"):
+            for k in ("gather_ms", "gather_check", "process_group", "voxel_working_set_mib", "room_copies"):
                 if cfg.get(k) is not None:
                     out[name][k] = cfg[k]
         except SystemExit as e:  # a failed parity gate of a secondary run is reported, the headline stands
@@ -1638,6 +1666,27 @@ def run(args, out_fd=None):
             sys.stderr.write("gather of TSDF blocks failed: %r\n" % (e,))
             gather_ms = None
 
+    # BASELINE configs[3] in the same process group: `bench.py --gpus N` (N > 1) is the command the driver's scaling
+    # step runs, so the line carries the strong-scaling job too -- 8 independent submaps farmed to the N ranks, the
+    # gather of their finished blocks over RCCL and its import / export check (N = 1: `secondary.offline8` of the
+    # default line is the same job in a one-rank group)
+    offline = None
+    if dist is not None and world > 1 and not args.no_secondary and args.insert_mode == "exact" and OFFLINE_SUBMAPS % world == 0:
+        import copy
+        a = copy.copy(args)
+        for k, v in OFFLINE_LEG.items():
+            setattr(a, k, v)
+        a.no_cpu_baseline = True
+        del problem
+        for g in grids:
+            g.close()
+        ctx.close()
+        try:
+            offline = run_offline_batch(a, group=(dist, rank, local_rank, world))
+        except Exception as e:  # never lose the timed headline over the extra leg
+            sys.stderr.write("offline batch leg failed on rank %d: %r\n" % (rank, e))
+            offline = {"error": repr(e)} if rank == 0 else None
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -1738,6 +1787,14 @@ def run(args, out_fd=None):
     }
     if host_inclusive:
         out["host_inclusive"] = host_inclusive
+    out["config"]["process_group"] = process_group_info(dist)
+    if offline is not None:
+        cfg = offline.get("config") or {}
+        out["secondary"] = {"offline8": {k: offline.get(k) for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "error")
+                                         if offline.get(k) is not None}}
+        for k in ("gather_ms", "gather_check", "process_group", "submaps_per_gpu", "total_submaps", "mean_pose_error_m"):
+            if cfg.get(k) is not None:
+                out["secondary"]["offline8"][k] = cfg[k]
     if lead and not args.no_secondary and args.insert_mode == "exact":
         # free this run's maps first: the secondary runs build their own
         del problem

@@ -30,7 +30,18 @@ __device__ inline float round_nonneg_plus1(float y) {
 // instructions, same operands, hence the same bits); only the sign of a zero quotient can differ,
 // which the quantisation that follows does not see. The reciprocal depends on the weight chain
 // only, so the dependent chain through the TSD value is 5 FMAs instead of 10 instructions.
-__device__ inline bool div_in_range_ok(const GridView& g) {
+// The codec constants of a grid, by value: what the chain needs of a GridView (the segmented evaluation is a
+// function of its own -- not inlined -- and must not drag the whole view along).
+struct ChainCodec {
+  float min_tsd, max_tsd, max_weight, tsd_resolution, weight_resolution, tsd_scale, tsd_offset, weight_scale, weight_offset;
+};
+template <typename G>
+__device__ inline ChainCodec chain_codec(const G& g) {
+  return ChainCodec{g.min_tsd, g.max_tsd, g.max_weight, g.tsd_resolution, g.weight_resolution,
+                    g.tsd_scale, g.tsd_offset, g.weight_scale, g.weight_offset};
+}
+template <typename G>
+__device__ inline bool div_in_range_ok(const G& g) {
   return g.max_weight <= 1.0e6f && g.max_tsd <= 1.0e3f && g.min_tsd >= -1.0e3f;
 }
 __device__ inline float div_in_range(float num, float den) {
@@ -107,8 +118,8 @@ struct ChainState {
   float rt, rw;  // their codes (lround(..) + 1) as floats, valid after the first update
   bool fixed;    // the weight no longer changes under updates
 };
-template <bool FAST>
-__device__ inline void chain_run(const GridView& g, float maximum_weight, ChainState& st, const uint32_t* vals,
+template <bool FAST, typename G>
+__device__ inline void chain_run(const G& g, float maximum_weight, ChainState& st, const uint32_t* vals,
                                  unsigned count) {
   float d = st.d, w = st.w, rt = st.rt, rw = st.rw;
   bool fixed = st.fixed;
@@ -175,8 +186,8 @@ __device__ inline void chain_run(const GridView& g, float maximum_weight, ChainS
   }
   st.d = d; st.w = w; st.rt = rt; st.rw = rw; st.fixed = fixed;
 }
-template <bool FAST>
-__device__ inline uint32_t update_chain_unit_t(const GridView& g, float maximum_weight, uint32_t code,
+template <bool FAST, typename G>
+__device__ inline uint32_t update_chain_unit_t(const G& g, float maximum_weight, uint32_t code,
                                                const uint32_t* vals, unsigned count) {
   const uint32_t tc = code & 0x7FFFu, wc = (code >> 16) & 0x7FFFu;
   ChainState st;
@@ -231,27 +242,45 @@ __device__ inline uint32_t update_chain_unit(const GridView& g, float maximum_we
 // Up to kSegUnits (voxel, segment) units share a round: the heavy voxels of a pass get segments in proportion to
 // their lengths (seg_assign), so several heavy voxels cost sum(n) / 8, not max(n).
 // ==========================================================================================================
+#ifdef HG_SEG_STATS
+__device__ long long g_seg_stamps[8];
+__device__ unsigned long long g_seg_longest;  // (diagnostics: the phases of the longest call so far are kept)
+#define SEG_STAMP(i) do { if (tid == 0) seg_ts[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned g_seg_stats[8];  // [0] table lookups, [1] misses, [2] failed weight checks, [3] max |c - p|, [4] sum |c - p|
+#else
+#define SEG_STAMP(i)
+#endif
 constexpr unsigned kSegUnits = 8;    // = wavefronts of the apply workgroup: one (voxel, segment) unit each
 constexpr int kSegHalf = 32;         // candidates p - 32 ... p + 31
-// LDS scratch of seg_chains, in 32-bit words (8-byte aligned base):
+// LDS scratch of seg_chains, in 32-bit words:
 constexpr unsigned kSegTab = 0;                                  // kSegUnits x 64 end codes
-constexpr unsigned kSegAB = kSegTab + kSegUnits * kWave;         // kSegUnits x (A, B) doubles
-constexpr unsigned kSegLo = kSegAB + kSegUnits * 4;              // kSegUnits window bases p - 32 (int)
+constexpr unsigned kSegAB = kSegTab + kSegUnits * kWave;         // kSegUnits x (A, B) floats
+constexpr unsigned kSegLo = kSegAB + kSegUnits * 2;              // kSegUnits window bases p - 32 (int)
 constexpr unsigned kSegBad = kSegLo + kSegUnits;                 // per voxel: the weight check failed
-constexpr unsigned kSegB0 = kSegBad + kSegUnits;                 // the heavy voxels of the round: first value,
-constexpr unsigned kSegCnt = kSegB0 + kSegUnits;                 //   number of updates,
-constexpr unsigned kSegVox = kSegCnt + kSegUnits;                //   voxel inside the block
-constexpr unsigned kSegWords = kSegVox + kSegUnits;
+constexpr unsigned kSegFrom = kSegBad + kSegUnits;               // per voxel: first segment the running round evaluates,
+constexpr unsigned kSegCur = kSegFrom + kSegUnits;               //   the voxel's exact TSD code at the start of that segment,
+constexpr unsigned kSegDone = kSegCur + kSegUnits;               //   the voxel has its result
+constexpr unsigned kSegAgain = kSegDone + kSegUnits;             // some voxel needs the second round
+constexpr unsigned kSegWords = kSegAgain + 1u;
+// the list of the round's heavy voxels (filled by the threads that own them), in words of `list`:
+constexpr unsigned kSegB0 = 0;                                   // first value of the voxel in `vals`,
+constexpr unsigned kSegCnt = kSegB0 + kSegUnits;                 // number of updates,
+constexpr unsigned kSegVox = kSegCnt + kSegUnits;                // voxel inside the block,
+constexpr unsigned kSegCode = kSegVox + kSegUnits;               // its code before the updates (afterwards: the new code)
+constexpr unsigned kSegListWords = kSegCode + kSegUnits;
+constexpr unsigned kSegMin = 64;                                 // shorter chains are never worth a unit
 
 // The weight code k unit updates after code `c0`: c0 + step k, pinned at cmax (see fast_survival in hg_insert.hip
 // for the same orbit in closed form; here every use is verified against the exact recurrence).
 struct WeightOrbit {
   int c0, step, cmax;
-  __device__ inline void init(const GridView& g, float maximum_weight, uint32_t wcode) {
+  __device__ inline void init(const ChainCodec& g, float maximum_weight, uint32_t wcode) {
     c0 = static_cast<int>(wcode & 0x7FFFu);
     if (c0 == 0) c0 = 1;  // unknown and code 1 both decode to weight 0
     step = static_cast<int>(roundf(g.weight_resolution));
-    cmax = static_cast<int>(weight_to_value(g, maximum_weight < g.max_weight ? maximum_weight : g.max_weight));
+    // weight_to_value (hg_device.h) of the smaller of the inserter's and the codec's maximum
+    const float wmax = maximum_weight < g.max_weight ? maximum_weight : g.max_weight;
+    cmax = static_cast<int>(roundf((clampf(wmax, 0.f, g.max_weight) - 0.f) * g.weight_resolution)) + 1;
   }
   __device__ inline int code(unsigned k) const {
     const long long c = static_cast<long long>(c0) + static_cast<long long>(step) * static_cast<long long>(k);
@@ -259,177 +288,288 @@ struct WeightOrbit {
   }
 };
 
-struct SegUnit {
-  unsigned h, s, nseg, ubase, sb, se;  // voxel, segment, segments of the voxel, first unit of the voxel, [sb, se)
-  bool active;
-};
-// Segments for the H <= kSegUnits heavy voxels of a round: the smallest common segment length m with
-// sum ceil(n_h / m) <= kSegUnits; unit index = wavefront. Every thread evaluates this from the list in LDS.
-__device__ inline SegUnit seg_assign(const uint32_t* cnt, unsigned H, unsigned wave) {
-  unsigned total = 0;
-  for (unsigned h = 0; h < H; ++h) total += cnt[h];
-  unsigned m = (total + kSegUnits - 1u) / kSegUnits;
-  if (m < 8u) m = 8u;
-  while (true) {
-    unsigned S = 0;
-    for (unsigned h = 0; h < H; ++h) S += (cnt[h] + m - 1u) / m;
-    if (S <= kSegUnits) break;
-    m += (m >> 3) + 1u;
-  }
-  SegUnit r;
-  r.h = r.s = r.nseg = r.ubase = r.sb = r.se = 0u;
-  r.active = false;
-  unsigned u = 0;
-  for (unsigned h = 0; h < H; ++h) {
-    const unsigned nseg = (cnt[h] + m - 1u) / m;
-    if (wave >= u && wave < u + nseg) {
-      r.h = h; r.s = wave - u; r.nseg = nseg; r.ubase = u;
-      r.sb = r.s * m;
-      r.se = min(r.sb + m, cnt[h]);
-      r.active = true;
-    }
-    u += nseg;
-  }
-  return r;
+// ceil(n / s) for n < 2^22, 1 <= s <= 8, without the integer-division sequence: the float quotient of two small
+// integers is either an exact integer or at least 1/8 away from one, so truncating the correctly rounded
+// quotient gives floor((n + s - 1) / s).
+__device__ inline unsigned seg_ceil_div(unsigned n, unsigned s) {
+  return static_cast<unsigned>(static_cast<float>(n + s - 1u) / static_cast<float>(s));
 }
 
-// Applies the H <= kSegUnits chains listed in scratch[kSegB0 / kSegCnt / kSegVox] (values vals[b0 .. b0 + cnt) in
-// LDS, in update order) to the voxels block[vox]. Called by all threads of a workgroup of kSegUnits wavefronts with
-// uniform arguments; the list must be visible (barrier) on entry; ends with a barrier (scratch and vals reusable).
-template <bool FAST>
-__device__ inline void seg_chains_t(const GridView& g, float maximum_weight, const uint32_t* vals, uint32_t* scratch,
-                                    unsigned H, uint32_t* block, unsigned tid) {
+// Segment counts for the H heavy voxels of a round over `units` wavefronts, evaluated in lanes 0..7 of every
+// wavefront (lane h holds voxel h): every voxel starts with one segment, the remaining wavefronts go one at a
+// time to the voxel with the longest segments. Returns this lane's count S_h (0 for lanes >= H).
+__device__ inline unsigned seg_counts(unsigned n_h, unsigned H, unsigned units, unsigned lane) {
+  unsigned S = lane < H ? 1u : 0u;
+  if (H == 1u) return lane == 0u ? units : 0u;
+  for (unsigned used = H; used < units; ++used) {
+    const unsigned m = lane < H ? seg_ceil_div(n_h, S) : 0u;
+    unsigned key = (m << 3) | (7u - (lane & 7u));  // longest segments first, lowest voxel on ties
+    key = max(key, static_cast<unsigned>(__shfl_xor(static_cast<int>(key), 1)));
+    key = max(key, static_cast<unsigned>(__shfl_xor(static_cast<int>(key), 2)));
+    key = max(key, static_cast<unsigned>(__shfl_xor(static_cast<int>(key), 4)));
+    if ((key >> 3) <= 16u) break;  // nothing left worth cutting
+    if (lane == 7u - (key & 7u)) ++S;
+  }
+  return S;
+}
+
+// Applies the H <= kSegUnits chains listed in list[kSegB0 / kSegCnt / kSegVox / kSegCode] (values
+// vals[b0 .. b0 + cnt) in LDS, in update order) to the voxels block[vox]. Called by all kSegUnits x 64 threads of a
+// workgroup with uniform arguments (tid: the thread's index); list and vals must be visible (barrier) on entry; the
+// caller places a barrier behind it before it reuses scratch, list or vals. When the plan does not pay (many short
+// chains), thread h < H applies chain h on its own, as k_bin_apply's passes do. Requires div_in_range_ok(g).
+// (first_wave > 0 keeps the wavefronts below it free of units; unused since the chains are applied in the tail of
+// k_bin_apply, where nothing runs next to them.)
+__device__ __forceinline__ void seg_chains(const ChainCodec& g, float maximum_weight, const uint32_t* vals,
+                                           uint32_t* list, uint32_t* scratch, uint32_t* block, unsigned H,
+                                           unsigned first_wave, unsigned tid) {
+  constexpr bool FAST = true;
+  auto light = [&](bool seg) {
+    if (!seg && tid < H && list[kSegCnt + tid] != 0u) {
+      const uint32_t c = update_chain_unit_t<true>(g, maximum_weight, list[kSegCode + tid], vals + list[kSegB0 + tid],
+                                                   list[kSegCnt + tid]);
+      block[list[kSegVox + tid]] = c;
+      list[kSegCode + tid] = c;
+    }
+  };
   const unsigned wave = tid / kWave, lane = tid % kWave;
-  const SegUnit U = seg_assign(scratch + kSegCnt, H, wave);
-  if (tid < kSegUnits) scratch[kSegBad + tid] = 0u;
+#ifdef HG_SEG_STATS
+  long long seg_ts[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  SEG_STAMP(0);
+  // ---- units: lane h < H of every wavefront holds voxel h ----
+  const unsigned n_l = lane < H ? list[kSegCnt + lane] : 0u;
+  const unsigned S_l = seg_counts(n_l, H, kSegUnits - first_wave, lane);
+  {
+    // does it pay? longest segment (at the pace of eight wavefronts sharing four SIMDs) + set-up against the
+    // longest chain as it stands, in update steps
+    unsigned key = (lane < H ? seg_ceil_div(n_l, S_l) : 0u) | (n_l << 16);  // n < 2^16 (one LDS pass), m <= n
+    unsigned mm = key & 0xFFFFu, nn = key >> 16;
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      mm = max(mm, static_cast<unsigned>(__shfl_xor(static_cast<int>(mm), off)));
+      nn = max(nn, static_cast<unsigned>(__shfl_xor(static_cast<int>(nn), off)));
+    }
+    mm = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(mm)));
+    nn = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(nn)));
+    if (!(mm + (mm >> 2) + 36u < nn)) {
+      light(false);
+      return;
+    }
+  }
+  unsigned incl = S_l;  // inclusive prefix over lanes 0..7
+  {
+    unsigned t = static_cast<unsigned>(__shfl_up(static_cast<int>(incl), 1));
+    if ((lane & 7u) >= 1u) incl += t;
+    t = static_cast<unsigned>(__shfl_up(static_cast<int>(incl), 2));
+    if ((lane & 7u) >= 2u) incl += t;
+    t = static_cast<unsigned>(__shfl_up(static_cast<int>(incl), 4));
+    if ((lane & 7u) >= 4u) incl += t;
+  }
+  const unsigned unit = wave - first_wave;  // (wraps for the light wavefronts: never below any prefix)
+  const unsigned long long later = __ballot(lane < H && incl > unit);
+  const bool active = wave >= first_wave && later != 0ull;
+  const int hsel = active ? __ffsll(static_cast<long long>(later)) - 1 : 0;
+  const unsigned u_h = static_cast<unsigned>(hsel);
+  const unsigned u_n = static_cast<unsigned>(__shfl(static_cast<int>(n_l), hsel));
+  const unsigned u_S = static_cast<unsigned>(__shfl(static_cast<int>(S_l), hsel));
+  const unsigned u_base = static_cast<unsigned>(__shfl(static_cast<int>(incl - S_l), hsel));  // first unit of the voxel
+  const unsigned u_s = unit - u_base;                                                         // this unit's segment
+  const unsigned u_m = active ? seg_ceil_div(u_n, u_S) : 0u;
+  const unsigned sb = min(u_s * u_m, u_n), se = min(sb + u_m, u_n);
+  if (tid < kSegUnits) {
+    scratch[kSegBad + tid] = 0u;
+    scratch[kSegFrom + tid] = 0u;
+    scratch[kSegDone + tid] = 0u;
+    scratch[kSegCur + tid] = tid < H ? (list[kSegCode + tid] & 0x7FFFu) : 0u;
+    if (tid == 0) scratch[kSegAgain] = 0u;
+  }
   uint32_t code0 = 0;
   WeightOrbit orbit;
   orbit.c0 = 1; orbit.step = 0; orbit.cmax = 1;
   const uint32_t* uv = vals;
-  if (U.active) {
-    code0 = block[scratch[kSegVox + U.h]];
+  if (active) {
+    code0 = list[kSegCode + u_h];
     orbit.init(g, maximum_weight, code0 >> 16);
-    uv = vals + scratch[kSegB0 + U.h];
+    uv = vals + list[kSegB0 + u_h];
   }
-  // ---- the segment's affine map d -> A d + B of the chain without re-quantisation (fp64) ----
-  if (U.active && U.nseg > 1u) {
-    const unsigned len = U.se - U.sb;
+  SEG_STAMP(1);
+  // ---- the segment's affine map d -> A d + B of the chain without re-quantisation ----
+  // (fp32: the map is only a prediction, and its rounding, ~1e-6 relative, is a fiftieth of a code)
+  if (active && u_S > 1u && u_s + 1u < u_S) {  // (nobody starts behind the last segment)
+    const unsigned len = se - sb;
     const unsigned q = (len + kWave - 1u) / kWave;
-    const unsigned j0 = min(U.sb + lane * q, U.se), j1 = min(j0 + q, U.se);
-    double A = 1.0, B = 0.0;
+    const unsigned j0 = min(sb + lane * q, se), j1 = min(j0 + q, se);
+    float A = 1.0f, B = 0.0f;
     for (unsigned j = j0; j < j1; ++j) {
-      const float wf = static_cast<float>(orbit.code(j)) * g.weight_scale + g.weight_offset;
-      const double w = static_cast<double>(wf);
-      double r = static_cast<double>(__builtin_amdgcn_rcpf(wf + 1.0f));
-      r = r * (2.0 - (w + 1.0) * r);  // one Newton step: ~1e-14
-      const double a = w * r, b = static_cast<double>(__uint_as_float(uv[j])) * r;
+      const float w = static_cast<float>(orbit.code(j)) * g.weight_scale + g.weight_offset;
+      const float r = refined_rcp(w + 1.0f);
+      const float a = w * r, b = __uint_as_float(uv[j]) * r;
       A = a * A;
       B = a * B + b;
     }
     // ordered tree reduction over the lanes: (earlier, later) -> later o earlier
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
-      const double A2 = __shfl_down(A, off), B2 = __shfl_down(B, off);
-      if ((lane & (2 * off - 1)) == 0) {
-        B = A2 * B + B2;
-        A = A2 * A;
-      }
+      const float A2 = __shfl_down(A, off), B2 = __shfl_down(B, off);
+      B = A2 * B + B2;  // (only lanes at multiples of 2 off hold meaningful values afterwards)
+      A = A2 * A;
     }
     if (lane == 0) {
-      double* ab = reinterpret_cast<double*>(scratch + kSegAB) + 2u * wave;
-      ab[0] = A;
-      ab[1] = B;
+      scratch[kSegAB + 2u * unit] = __float_as_uint(A);
+      scratch[kSegAB + 2u * unit + 1u] = __float_as_uint(B);
     }
   }
   __syncthreads();
-  // ---- prediction of the segment's start code, candidates, exact chain ----
-  if (U.active) {
-    int lo = 0;
-    uint32_t cand = code0 & 0x7FFFu;  // segment 0 starts from the voxel's code itself, in every lane
-    if (U.s > 0u) {
-      const uint32_t tc = code0 & 0x7FFFu;
-      double d = tc == 0u ? static_cast<double>(g.min_tsd)
-                          : static_cast<double>(static_cast<float>(tc) * g.tsd_scale + g.tsd_offset);
-      const double* ab = reinterpret_cast<const double*>(scratch + kSegAB) + 2u * U.ubase;
-      for (unsigned t = 0; t < U.s; ++t) d = ab[2 * t] * d + ab[2 * t + 1];
-      double x = (d - static_cast<double>(g.min_tsd)) * static_cast<double>(g.tsd_resolution);
-      x = x < 0.0 ? 0.0 : (x > 32766.0 ? 32766.0 : x);
-      lo = static_cast<int>(x + 0.5) + 1 - kSegHalf;
-      int c = lo + static_cast<int>(lane);
-      c = c < 1 ? 1 : (c > 32767 ? 32767 : c);
-      cand = static_cast<uint32_t>(c);
-      if (lane == 0) scratch[kSegLo + wave] = static_cast<uint32_t>(lo);
-    }
-    const int wc_begin = U.s == 0u ? static_cast<int>((code0 >> 16) & 0x7FFFu) : orbit.code(U.sb);
-    ChainState st;
-    st.d = cand == 0u ? g.min_tsd : static_cast<float>(cand) * g.tsd_scale + g.tsd_offset;
-    st.w = wc_begin == 0 ? 0.f : static_cast<float>(wc_begin) * g.weight_scale + g.weight_offset;
-    st.rt = static_cast<float>(cand);
-    st.rw = static_cast<float>(wc_begin);
-    st.fixed = false;
-    if (U.se > U.sb) chain_run<FAST>(g, maximum_weight, st, uv + U.sb, U.se - U.sb);
-    scratch[kSegTab + wave * kWave + lane] = static_cast<uint32_t>(static_cast<int>(st.rt));
-    // the weight orbit, verified: exact end of this segment == assumed start of the next (== final weight code)
-    if (lane == 0 && static_cast<int>(st.rw) != orbit.code(U.se)) scratch[kSegBad + U.h] = 1u;
+  SEG_STAMP(2);
+  // ---- rounds: candidates + exact chains per unit, then the walk per voxel ----
+  // Round 0 centres every segment's window on the affine prediction. That prediction is good while the chain
+  // contracts (young voxels) or its inputs scatter; it fails where the re-quantisation is NOT noise: at a saturated
+  // weight W an update moves the code only when it differs from it by more than (W + 1) / 2 codes, so a voxel
+  // whose updates agree (thousands of rays through one wall voxel) stays put while the affine chain drifts
+  // towards them -- hundreds of codes over a segment. There the candidates' own trajectories are the better
+  // prediction (they run parallel to the true one): a walk that leaves a window continues APPROXIMATELY through
+  // the remaining tables (edge value + distance x the table's own slope) and re-centres the later windows on what
+  // it finds; round 1 re-evaluates from the first miss on (its start code is exact by then). A miss in round 1
+  // runs that segment sequentially, as does every miss of a call that was not worth a second round.
+  int lo0 = 0;  // this unit's round-0 window base
+  if (active && u_s > 0u) {
+    const uint32_t tc = code0 & 0x7FFFu;
+    float d = tc == 0u ? g.min_tsd : static_cast<float>(tc) * g.tsd_scale + g.tsd_offset;
+    for (unsigned t = 0; t < u_s; ++t)
+      d = __uint_as_float(scratch[kSegAB + 2u * (u_base + t)]) * d + __uint_as_float(scratch[kSegAB + 2u * (u_base + t) + 1u]);
+    float x = (d - g.min_tsd) * g.tsd_resolution;
+    x = x < 0.f ? 0.f : (x > 32766.f ? 32766.f : x);
+    lo0 = static_cast<int>(x + 0.5f) + 1 - kSegHalf;
+    if (lane == 0) scratch[kSegLo + unit] = static_cast<uint32_t>(lo0);
   }
-  __syncthreads();
-  // ---- walk: wavefront h < H takes voxel h (its first lane) ----
-  if (wave < H && lane == 0) {
-    const unsigned h = wave, n = scratch[kSegCnt + h];
-    const uint32_t* hv = vals + scratch[kSegB0 + h];
-    uint32_t* cell = block + scratch[kSegVox + h];
-    const uint32_t c0 = *cell;
-    // (the voxel's units: recomputed for voxel h -- seg_assign of wave' = first unit of h)
-    unsigned ubase = 0, nseg = 0, m = 0;
-    {
-      unsigned total = 0;
-      for (unsigned k = 0; k < H; ++k) total += scratch[kSegCnt + k];
-      m = (total + kSegUnits - 1u) / kSegUnits;
-      if (m < 8u) m = 8u;
-      while (true) {
-        unsigned S = 0;
-        for (unsigned k = 0; k < H; ++k) S += (scratch[kSegCnt + k] + m - 1u) / m;
-        if (S <= kSegUnits) break;
-        m += (m >> 3) + 1u;
+  for (int round = 0; round < 2; ++round) {
+    if (active) {
+      const unsigned from = scratch[kSegFrom + u_h];
+      if (scratch[kSegDone + u_h] == 0u && u_s >= from && (round == 0 || se > sb)) {
+        uint32_t cand;
+        if (u_s == from) {
+          cand = scratch[kSegCur + u_h];  // exact: the voxel's code (round 0) or the code the walk arrived with
+        } else {
+          const int lo = round == 0 ? lo0 : static_cast<int>(scratch[kSegLo + unit]);
+          int c = lo + static_cast<int>(lane);
+          c = c < 1 ? 1 : (c > 32767 ? 32767 : c);
+          cand = static_cast<uint32_t>(c);
+        }
+        const int wc_begin = u_s == 0u ? static_cast<int>((code0 >> 16) & 0x7FFFu) : orbit.code(sb);
+        ChainState st;
+        st.d = cand == 0u ? g.min_tsd : static_cast<float>(cand) * g.tsd_scale + g.tsd_offset;
+        st.w = wc_begin == 0 ? 0.f : static_cast<float>(wc_begin) * g.weight_scale + g.weight_offset;
+        st.rt = static_cast<float>(cand);
+        st.rw = static_cast<float>(wc_begin);
+        st.fixed = false;
+        if (se > sb) chain_run<FAST>(g, maximum_weight, st, uv + sb, se - sb);
+        scratch[kSegTab + unit * kWave + lane] = static_cast<uint32_t>(static_cast<int>(st.rt));
+        // the weight orbit, verified: exact end of this segment == assumed start of the next (== final weight code)
+        if (lane == 0 && se > sb && static_cast<int>(st.rw) != orbit.code(se)) scratch[kSegBad + u_h] = 1u;
       }
-      for (unsigned k = 0; k < h; ++k) ubase += (scratch[kSegCnt + k] + m - 1u) / m;
-      nseg = (n + m - 1u) / m;
     }
-    uint32_t out;
-    if (scratch[kSegBad + h]) {
-      out = update_chain_unit_t<FAST>(g, maximum_weight, c0, hv, n);  // (never seen: the orbit is exact for the defaults)
-    } else {
-      WeightOrbit ob;
-      ob.init(g, maximum_weight, c0 >> 16);
-      uint32_t c = scratch[kSegTab + ubase * kWave];
-      for (unsigned s = 1; s < nseg; ++s) {
-        const int idx = static_cast<int>(c) - static_cast<int>(scratch[kSegLo + ubase + s]);
-        if (idx >= 0 && idx < kWave) {
-          c = scratch[kSegTab + (ubase + s) * kWave + static_cast<unsigned>(idx)];
-        } else {  // outside the window: this segment sequentially from the true code
-          const unsigned sb = s * m, se = min(sb + m, n);
-          const int wc = ob.code(sb);
-          ChainState st;
-          st.d = static_cast<float>(c) * g.tsd_scale + g.tsd_offset;
-          st.w = static_cast<float>(wc) * g.weight_scale + g.weight_offset;
-          st.rt = static_cast<float>(c);
-          st.rw = static_cast<float>(wc);
-          st.fixed = false;
-          chain_run<FAST>(g, maximum_weight, st, hv + sb, se - sb);
-          c = static_cast<uint32_t>(static_cast<int>(st.rt));
+    if (round == 0 && (first_wave == 0u || wave < first_wave)) light(true);
+    if (round == 0) { SEG_STAMP(3); }
+    __syncthreads();
+    // ---- walk: wavefront first_wave + h takes voxel h (its first lane) ----
+    {
+      const unsigned h = wave - first_wave;
+      const bool walker = wave >= first_wave && h < H;
+      const int hs = walker ? static_cast<int>(h) : 0;
+      const unsigned n = static_cast<unsigned>(__shfl(static_cast<int>(n_l), hs));
+      const unsigned nseg = static_cast<unsigned>(__shfl(static_cast<int>(S_l), hs));
+      const unsigned ubase = static_cast<unsigned>(__shfl(static_cast<int>(incl - S_l), hs));
+      if (walker && lane == 0 && n != 0u && scratch[kSegDone + h] == 0u) {
+        const unsigned m = seg_ceil_div(n, nseg);
+        const uint32_t* hv = vals + list[kSegB0 + h];
+        const uint32_t c0 = list[kSegCode + h];
+        uint32_t out = 0;
+        bool exact = true;
+#ifdef HG_SEG_STATS
+        if (scratch[kSegBad + h]) atomicAdd(&g_seg_stats[2], 1u);
+#endif
+        if (scratch[kSegBad + h]) {
+          out = update_chain_unit_t<FAST>(g, maximum_weight, c0, hv, n);  // (never seen: the orbit is exact for the defaults)
+        } else {
+          WeightOrbit ob;
+          ob.init(g, maximum_weight, c0 >> 16);
+          const unsigned from = scratch[kSegFrom + h];
+          uint32_t c = scratch[kSegTab + (ubase + from) * kWave];
+          int ca = 0;  // the approximate code once the walk has left a window (round 0)
+          for (unsigned s = from + 1u; s < nseg; ++s) {
+            const unsigned sb_s = s * m;
+            if (sb_s >= n) break;  // (empty trailing segments)
+            const uint32_t* tab = scratch + kSegTab + (ubase + s) * kWave;
+            const int lo_s = static_cast<int>(scratch[kSegLo + ubase + s]);
+            if (exact) {
+              const int idx = static_cast<int>(c) - lo_s;
+#if defined(HG_SEG_STATS) && HG_SEG_STATS > 1
+              {
+                const int dev = idx - kSegHalf < 0 ? kSegHalf - idx : idx - kSegHalf;
+                atomicAdd(&g_seg_stats[0], 1u);
+                atomicMax(&g_seg_stats[3], static_cast<unsigned>(dev));
+                atomicAdd(&g_seg_stats[4], static_cast<unsigned>(dev));
+                if (!(idx >= 0 && idx < kWave)) atomicAdd(&g_seg_stats[1 + 4 * round], 1u);
+              }
+#endif
+              if (idx >= 0 && idx < kWave) {
+                c = tab[idx];
+                continue;
+              }
+              if (round == 1 || n < 4u * kSegMin) {  // this segment sequentially from the true code
+                const unsigned se_s = min(sb_s + m, n);
+                const int wc = ob.code(sb_s);
+                ChainState st;
+                st.d = static_cast<float>(c) * g.tsd_scale + g.tsd_offset;
+                st.w = static_cast<float>(wc) * g.weight_scale + g.weight_offset;
+                st.rt = static_cast<float>(c);
+                st.rw = static_cast<float>(wc);
+                st.fixed = false;
+                chain_run<FAST>(g, maximum_weight, st, hv + sb_s, se_s - sb_s);
+                c = static_cast<uint32_t>(static_cast<int>(st.rt));
+                continue;
+              }
+              // first miss of round 0: the next round starts here, exactly
+              scratch[kSegFrom + h] = s;
+              scratch[kSegCur + h] = c;
+              scratch[kSegAgain] = 1u;
+              exact = false;
+              ca = static_cast<int>(c);
+            }
+            // approximate walk: nearest table entry + distance x the table's slope
+            const int idx = ca - lo_s;
+            const int ic = idx < 0 ? 0 : (idx > kWave - 1 ? kWave - 1 : idx);
+            const float slope = static_cast<float>(static_cast<int>(tab[kWave - 1]) - static_cast<int>(tab[0])) * (1.0f / (kWave - 1));
+            ca = static_cast<int>(tab[ic]) + static_cast<int>(rintf(static_cast<float>(idx - ic) * slope));
+            ca = ca < 1 ? 1 : (ca > 32767 ? 32767 : ca);
+            if (s + 1u < nseg) scratch[kSegLo + ubase + s + 1u] = static_cast<uint32_t>(ca - kSegHalf);
+          }
+          out = (c + kUpdateMarker) | (static_cast<uint32_t>(ob.code(n)) << 16);
+        }
+        if (exact) {
+          block[list[kSegVox + h]] = out;
+          list[kSegCode + h] = out;  // (a voxel applied in several chunks continues from here)
+          scratch[kSegDone + h] = 1u;
         }
       }
-      out = (c + kUpdateMarker) | (static_cast<uint32_t>(ob.code(n)) << 16);
     }
-    *cell = out;
+    if (round == 0) {
+      SEG_STAMP(4);
+      __syncthreads();
+      if (scratch[kSegAgain] == 0u) break;
+    }
   }
-  __syncthreads();
-}
-
-__device__ inline void seg_chains(const GridView& g, float maximum_weight, const uint32_t* vals, uint32_t* scratch,
-                                  unsigned H, uint32_t* block, unsigned tid) {
-  if (div_in_range_ok(g)) seg_chains_t<true>(g, maximum_weight, vals, scratch, H, block, tid);
-  else seg_chains_t<false>(g, maximum_weight, vals, scratch, H, block, tid);
+  SEG_STAMP(5);
+#ifdef HG_SEG_STATS
+  if (tid == 0) {
+    const unsigned long long dur = static_cast<unsigned long long>(seg_ts[5] - seg_ts[0]);
+    if (dur > atomicMax(&g_seg_longest, dur)) {
+      for (int k = 0; k < 6; ++k) g_seg_stamps[k] = seg_ts[k];
+      g_seg_stamps[6] = list[kSegCnt]; g_seg_stamps[7] = H + 100 * scratch[kSegAgain];
+    }
+  }
+#endif
 }
 
 }  // namespace hg

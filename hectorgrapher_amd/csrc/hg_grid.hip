@@ -331,7 +331,7 @@ int hg_ctx_destroy(hg_ctx* c) {
   for (DeviceBuffer* b : {&c->ws_points, &c->ws_scan_table, &c->ws_gate, &c->ws_counts,
                           &c->ws_offsets, &c->ws_keys_a, &c->ws_keys_b, &c->ws_vals_a,
                           &c->ws_vals_b, &c->ws_temp, &c->ws_misc, &c->ws_filter, &c->ws_jobs,
-                          &c->ws_keys_c, &c->ws_vals_c, &c->ws_offsets_b, &c->ws_sjobs, &c->ws_shadow,
+                          &c->ws_keys_c, &c->ws_vals_c, &c->ws_offsets_b, &c->ws_heavy, &c->ws_heavy_list, &c->ws_sjobs, &c->ws_shadow,
                           &c->ws_unwarp, &c->ws_unwarp_tab, &c->ws_unwarp_in})
     b->release();
   if (c->copy_stream) {

@@ -321,6 +321,11 @@ struct LevelIns {
   InsertParams p;
   int base[3];          // block coordinate the 32-bit keys are relative to
   const uint8_t* gate;  // insertion_ratio decimation mask or nullptr
+  // deferred long chains of the binned apply pass (k_bin_apply, "Long chains" there), or null: the ordered update
+  // values of the deferred voxels (bump-allocated through g.call[3]) and, per apply workgroup, its list of them
+  uint32_t* heavy_vals;
+  uint4* heavy_list;        // kHeavyPerWg entries {cell, offset, updates, -} per workgroup of the level's grid row
+  uint32_t heavy_capacity;  // values heavy_vals holds (>= the level's records of the call: nothing can overflow)
 };
 struct PyramidIns {
   LevelIns lv[kMaxInsLevels];
@@ -640,6 +645,14 @@ constexpr unsigned kSmallBinInKernel = 256;  // the same inside k_bin_apply
 #endif
   // bins from this size on head the work list (their slices carry the long chains)
 constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
+// HG_DEFER_LONG_CHAINS (off by default, see "Long chains" in bin_apply_body and DESIGN 3.1): compile the deferral of
+// long per-voxel chains and their segmented evaluation into k_bin_apply.
+#ifndef HG_HEAVY_MIN
+#define HG_HEAVY_MIN 512u
+#endif
+constexpr unsigned kHeavyMin = HG_HEAVY_MIN;      // updates of one voxel in one pass from which its chain is deferred
+constexpr unsigned kHeavyPerWg = 16;     // deferred voxels per apply workgroup (more: applied in place as before)
+constexpr unsigned kHeavyLdsVals = 8192; // update values the tail of k_bin_apply holds in LDS at a time
 
 enum : uint32_t { kFlagBinOverflow = 8u, kFlagWorkOverflow = 16u };
 
@@ -1415,6 +1428,7 @@ __device__ __forceinline__ void bin_offsets_body(const PyramidIns& P, const Leve
     // registration chain keeps them in k_bin_apply: a second kernel behind it costs more than it saves
     L.g.call[2] = min((P.slice_records >= 2048 || P.slice_records <= 0) ? s_large : s_work, L.g.work_capacity);
     L.g.call[1] = min(s_work, L.g.work_capacity);  // consumed by k_bin_apply
+    L.g.call[3] = 0;                               // values of deferred long chains (k_bin_apply)
     L.g.call[0] = 0;                               // next call collects from scratch
     unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
     if (P.shared) atomicAdd(upd, static_cast<unsigned long long>(s_base));
@@ -1715,11 +1729,32 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
   uint32_t* tv = sv;                  // their values: sv is free until the rank step
   // (the item path's few scalars live behind its arrays inside the pool, which the small-bin layout sizes:
   // 40 KiB in all, four workgroups per CU as far as LDS goes)
-  static_assert(kItemWords + 19u <= kPoolWords, "pool");
+  static_assert(kItemWords + 20u + 3u * kSegUnits <= kPoolWords, "pool");
+  static_assert(kBinThreads / kWave == static_cast<int>(kSegUnits), "seg_chains");
+  static_assert(kHeavyLdsVals + kSegWords + kSegListWords <= kPoolWords, "heavy tail");
   unsigned& s_hi = pool[kItemWords];
   unsigned& s_m = pool[kItemWords + 1];
   unsigned& s_big = pool[kItemWords + 2];
   unsigned* s_scan16 = pool + kItemWords + 3;
+  // Long chains. A voxel with hundreds or thousands of updates in one scan (next to the sensor, next to a wall) is a
+  // sequential chain of 0.061 us per update on ONE lane and used to be the end of the whole launch. Such voxels are
+  // not applied in their pass: the pass writes their ordered update values to device memory (heavy_vals) and notes
+  // them in the workgroup's list (heavy_list); when the workgroup has run out of work items it applies its
+  // deferred voxels by the segmented evaluation of hg_chain.h (seg_chains: eight wavefronts x 64 candidate start
+  // codes, bit-identical results, n / 8 steps instead of n). Behind the item loop, not inside it: there the code
+  // -- as much again as the rest of the kernel -- cost the ordinary path 27 to 44 spilled registers, inlined or
+  // called; here nothing else is live.
+  unsigned& s_nheavy = pool[kItemWords + 19];     // long chains of the running pass
+  uint32_t* def_b0 = pool + kItemWords + 20;      // per long chain of the pass: first value in sv,
+  uint32_t* def_cnt = def_b0 + kSegUnits;         //   number of updates,
+  uint32_t* def_off = def_cnt + kSegUnits;        //   offset of its values in heavy_vals
+  unsigned n_deferred = 0;                        // entries of this workgroup's list (uniform)
+#ifdef HG_DEFER_LONG_CHAINS
+  const bool defer_ok = L.heavy_vals != nullptr && div_in_range_ok(g);
+#else
+  constexpr bool defer_ok = false;  // (everything that hangs off it, the tail included, is compiled away)
+#endif
+  uint4* const my_heavy = defer_ok ? L.heavy_list + static_cast<size_t>(bx) * kHeavyPerWg : nullptr;
   const unsigned nwork = min(g.call[2], g.call[1]);  // the slices of large bins; whole bins: k_bin_apply_small
   const unsigned tid = threadIdx.x;
   for (unsigned wi = bx; wi < nwork; wi += gstride) {
@@ -1768,7 +1803,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
       asm volatile("" : "+v"(t2));
       base[tid] = t2 < 256u ? 0xFFFFFFFFu : 0u;
     }
-    if (tid == 0) { s_big = 0; s_m = 0; }
+    if (tid == 0) { s_big = 0; s_m = 0; s_nheavy = 0; }
     __syncthreads();
     // a whole bin that fits one pass: its records go straight into the LDS list (no filter, no buckets)
     const bool single = n <= static_cast<unsigned>(kBinCap) && s_bits == 0u;
@@ -1921,8 +1956,21 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
         const uint32_t seq_mask = (1u << kSeqBits) - 1u;
         const unsigned lo_v = voxel_of_l(lo);  // the voxel id as the records carry it
         uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + lo_v;
+        // (one long chain: deferred when there is room -- every round's sorted values go to heavy_vals in order --,
+        // else applied round by round by one lane as before)
         UnitChain chain;
-        if (tid == 0) chain.begin(g, *cell);
+        unsigned off_v = 0xFFFFFFFFu;
+        if (defer_ok && n_deferred < kHeavyPerWg) {
+          __syncthreads();
+          if (tid == 0) {
+            unsigned o = atomicAdd(&g.call[3], total_v);
+            if (o + total_v > L.heavy_capacity) o = 0xFFFFFFFFu;
+            s_hi = o;
+          }
+          __syncthreads();
+          off_v = s_hi;
+        }
+        if (off_v == 0xFFFFFFFFu && tid == 0) chain.begin(g, *cell);
         uint32_t cur_lo = 0;  // records with seq < cur_lo are applied (this form files a voxel under ONE l)
         unsigned* bucket = sv;            // 512 counters (sv is free until a round is sorted)
         unsigned* bucket_pre = sv + 512;  // their exclusive prefix
@@ -1980,13 +2028,22 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
           for (unsigned i = m + tid; i < m2; i += kBinThreads) gk[i] = 0xFFFFFFFFu;
           __syncthreads();
           bitonic_sort_kv(gk, gv, m2, tid);
-          if (tid == 0) chain.run(g, L.p.maximum_weight, gv, m);
+          if (off_v != 0xFFFFFFFFu) {
+            for (unsigned i = tid; i < m; i += kBinThreads) L.heavy_vals[off_v + done_v + i] = gv[i];
+          } else if (tid == 0) {
+            chain.run(g, L.p.maximum_weight, gv, m);
+          }
           __syncthreads();
           done_v += m;
           cur_lo = T;
           if (T > seq_mask) break;  // all seq values covered
         }
-        if (tid == 0) *cell = chain.end();
+        if (off_v != 0xFFFFFFFFu) {
+          if (tid == 0) my_heavy[n_deferred] = make_uint4(slot * kVoxelsPerBlock + lo_v, off_v, done_v, 0u);
+          ++n_deferred;
+        } else if (tid == 0) {
+          *cell = chain.end();
+        }
         hi = lo + 1;
       } else {
         cnt = base[hi - 1] + hist[hi - 1] - b_lo;
@@ -1996,6 +2053,31 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
         __syncthreads();
       }
       if (cnt) {
+        // owners of long chains put them on the pass's list (thread t < 512 / S owns voxel t of the slice: its buckets
+        // [t S, (t + 1) S) inside this pass) and reserve room for their values; the reservation's round trip runs
+        // behind the grouping and ranking below
+        const unsigned room = defer_ok ? min(kSegUnits, kHeavyPerWg - n_deferred) : 0u;
+        bool listed = false;
+        if (room) {
+          const unsigned l0 = max(lo, tid << s_bits), l1 = min(hi, (tid + 1u) << s_bits);
+          if (tid < per_slice && l0 < l1) {
+            const unsigned b0 = base[l0] - b_lo;
+            const unsigned mine = base[l1 - 1u] + hist[l1 - 1u] - b_lo - b0;
+            if (mine >= kHeavyMin) {
+              const unsigned e = atomicAdd(&s_nheavy, 1u);
+              if (e < room) {
+                unsigned off = atomicAdd(&g.call[3], mine);
+                unsigned keep = mine;
+                if (off + mine > L.heavy_capacity) { keep = 0u; off = 0u; }  // (cannot happen: capacity >= the level's records)
+                def_b0[e] = b0;
+                def_cnt[e] = keep;
+                def_off[e] = off;
+                my_heavy[n_deferred + e] = make_uint4(slot * kVoxelsPerBlock + voxel_of_l(l0), off, keep, 0u);
+                listed = keep != 0u;
+              }
+            }
+          }
+        }
         // group by voxel (arbitrary order inside a group)
         if (compact) {  // (one pass: lo = 0, hi = 512; the list is keyed by l already)
 #pragma unroll
@@ -2058,11 +2140,17 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
         BIN_STAMP(3);
         // one thread per voxel applies its updates in reference order; a wavefront that holds a
         // long chain is the critical path of the whole insert: give it issue priority
+        const unsigned heavy = min(s_nheavy, room);  // (uniform: written before the barriers above)
+        for (unsigned e = 0; e < heavy; ++e) {
+          const unsigned c = def_cnt[e], o = def_off[e], b = def_b0[e];
+          for (unsigned i = tid; i < c; i += kBinThreads) L.heavy_vals[o + i] = sv[b + i];
+        }
+        n_deferred += heavy;
         {
           // thread t < 512 / S owns voxel t of the slice: its buckets [t S, (t + 1) S) inside this pass
           const unsigned l0 = max(lo, tid << s_bits), l1 = min(hi, (tid + 1u) << s_bits);
           unsigned b0 = 0, mine = 0;
-          if (tid < per_slice && l0 < l1) {
+          if (tid < per_slice && l0 < l1 && !listed) {
             b0 = base[l0] - b_lo;
             mine = base[l1 - 1u] + hist[l1 - 1u] - b_lo - b0;
           }
@@ -2074,6 +2162,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
+        if (tid == 0) s_nheavy = 0;  // (the next pass of the item registers behind its cursor barrier)
         BIN_STAMP(4);
       }
       lo = hi;
@@ -2097,6 +2186,94 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
                                          pool + wave * kSmallWords);
     }
   }
+#ifdef HG_DEFER_LONG_CHAINS
+  if (n_deferred) {
+    // ---- the workgroup's deferred long chains ("Long chains" above) ----
+    // Up to eight voxels at a time whose values fit the LDS share the eight wavefronts (seg_chains hands out the
+    // segments in proportion to their lengths); a voxel with more values than that is applied chunk by chunk, its
+    // code handed on in the list. Everything below is derived from a copy of the thread index the optimiser
+    // cannot see through, or it hoists lane predicates of this tail into the kernel's prologue and spills them.
+    unsigned t2 = tid;
+    asm volatile("" : "+v"(t2));
+    uint32_t* const hvals = pool;
+    uint32_t* const hscratch = pool + kHeavyLdsVals;
+    uint32_t* const hlist = hscratch + kSegWords;
+#ifdef HG_BIN_STAMPS
+    if (threadIdx.x == 0 && bx < nwork) {
+      stamps[(static_cast<size_t>(order) * 4096 + bx) * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+      stamps[(static_cast<size_t>(order) * 4096 + 3072 + (bx & 1023u)) * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+      unsigned long long tot = 0;
+      for (unsigned q = 0; q < n_deferred; ++q) tot += my_heavy[q].z;
+      stamps[(static_cast<size_t>(order) * 4096 + bx) * 8 + 6] = static_cast<long long>(n_deferred) * 1000000ll + static_cast<long long>(tot);
+    }
+#endif
+    unsigned e = 0, chunk_done = 0;
+    while (e < n_deferred) {
+      __syncthreads();
+      if (t2 < kWave) {
+        // lanes 0..7 of the first wavefront read the next entries; the group is the longest prefix that fits
+        const bool have = t2 < kSegUnits && e + t2 < n_deferred;
+        uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+        if (have) ent = my_heavy[e + t2];
+        unsigned cnt_l = have ? ent.z : 0u, off_l = ent.y;
+        if (t2 == 0u) { cnt_l -= chunk_done; off_l += chunk_done; }
+        const bool first_chunked = __shfl(static_cast<int>(cnt_l), 0) > static_cast<int>(kHeavyLdsVals);
+        if (t2 == 0u && first_chunked) cnt_l = kHeavyLdsVals;
+        unsigned incl = cnt_l;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+          const unsigned t = static_cast<unsigned>(__shfl_up(static_cast<int>(incl), off));
+          if (t2 >= static_cast<unsigned>(off)) incl += t;
+        }
+        const bool in_group = have && incl <= kHeavyLdsVals && !(first_chunked && t2 > 0u);
+        const unsigned long long m = __ballot(in_group);
+        const unsigned H = static_cast<unsigned>(__builtin_ctzll(~m));  // leading entries that are in
+        if (t2 < H) {
+          hlist[kSegB0 + t2] = incl - cnt_l;
+          hlist[kSegCnt + t2] = cnt_l;
+          hlist[kSegVox + t2] = ent.x;
+          def_off[t2] = off_l;
+          if (!(t2 == 0u && chunk_done)) hlist[kSegCode + t2] = g.voxels[ent.x];  // (a chunked voxel continues from the list)
+        }
+        if (t2 == 0u) {
+          s_hi = H;
+          s_m = first_chunked ? 1u : 0u;
+        }
+      }
+      __syncthreads();
+#ifdef HG_BIN_STAMPS
+#define TAIL_STAMP(k) do { if (threadIdx.x == 0 && e == 0) stamps[(static_cast<size_t>(order) * 4096 + 3072 + (bx & 1023u)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TAIL_STAMP(k) do {} while (0)
+#endif
+      TAIL_STAMP(1);
+      const unsigned H = s_hi;
+      for (unsigned h = 0; h < H; ++h) {
+        const unsigned c = hlist[kSegCnt + h], o = def_off[h], b = hlist[kSegB0 + h];
+        for (unsigned i = t2; i < c; i += kBinThreads) hvals[b + i] = L.heavy_vals[o + i];
+      }
+      __syncthreads();
+      TAIL_STAMP(2);
+      __builtin_amdgcn_s_setprio(3);
+      seg_chains(chain_codec(g), L.p.maximum_weight, hvals, hlist, hscratch, g.voxels, H, 0u, t2);
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();
+      TAIL_STAMP(3);
+      if (s_m) {  // (uniform) the first entry is larger than the LDS: next chunk, or done with it
+        const unsigned total = my_heavy[e].z;
+        chunk_done += kHeavyLdsVals;
+        if (chunk_done >= total) { chunk_done = 0; ++e; }
+      } else {
+        e += H;
+        chunk_done = 0;
+      }
+    }
+    __syncthreads();
+#ifdef HG_BIN_STAMPS
+    if (threadIdx.x == 0 && bx < nwork) stamps[(static_cast<size_t>(order) * 4096 + bx) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
+  }
+#endif  // HG_DEFER_LONG_CHAINS
 }
 
 __global__ __launch_bounds__(kBinThreads, HG_APPLY_WAVES) void k_bin_apply(PyramidIns P, const uint32_t* __restrict__ rec_keys,
@@ -2312,6 +2489,34 @@ int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans,
   return HG_OK;
 }
 
+// Room for the deferred long chains of one apply launch over `P` (k_bin_apply, "Long chains"): per level one word
+// per record the level can hold (a record is deferred at most once, so the values cannot overflow) and the lists
+// of `grid_x` workgroups. `val_off` / `list_off`: this launch's share of the context's buffers, in values / entries
+// (several jobs in one launch); the caller has reserved ws_heavy / ws_heavy_list. HG_NO_DEFER=1 switches the
+// deferral off (every chain applied in its pass by one lane, as before round 5).
+bool heavy_enabled() {
+#ifdef HG_DEFER_LONG_CHAINS
+  static const bool on = [] { const char* e = getenv("HG_NO_DEFER"); return !(e && atoi(e)); }();
+  return on;
+#else
+  return false;
+#endif
+}
+void attach_heavy(hg_ctx* c, PyramidIns& P, size_t records_per_level, unsigned grid_x, size_t val_off, size_t list_off) {
+  for (int l = 0; l < P.levels; ++l) {
+    LevelIns& L = P.lv[l];
+    if (!heavy_enabled()) {
+      L.heavy_vals = nullptr;
+      L.heavy_list = nullptr;
+      L.heavy_capacity = 0;
+      continue;
+    }
+    L.heavy_vals = c->ws_heavy.as<uint32_t>() + val_off + records_per_level * l;
+    L.heavy_list = c->ws_heavy_list.as<uint4>() + list_off + static_cast<size_t>(grid_x) * kHeavyPerWg * l;
+    L.heavy_capacity = static_cast<uint32_t>(records_per_level);
+  }
+}
+
 // ---- binned path (single scan, unit weight) ------------------------------------------------
 // `pipe` >= 0: chunk number of a pipelined scan stream (several binned chunks in one call). The front
 // end (count, offsets, scatter) of chunk k runs on the context's stream, its apply pass on the apply
@@ -2357,6 +2562,12 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
   }
   if ((rc = buf_keys.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
   if ((rc = buf_vals.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
+  // (one buffer for both parities: the apply passes of a pipelined stream run one after the other on their stream)
+  if (heavy_enabled()) {
+    if ((rc = c->ws_heavy.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
+    if ((rc = c->ws_heavy_list.reserve(sizeof(uint4) * 1024u * kHeavyPerWg * P.levels)) != HG_OK) return rc;
+  }
+  attach_heavy(c, P, records_per_level, 1024u, 0, 0);
   const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
   if ((rc = c->ws_counts.reserve(sizeof(unsigned) * static_cast<size_t>(nwg_e) * kMaxInsLevels)) != HG_OK) return rc;
   if ((rc = c->ws_keys_b.reserve(sizeof(RunInfo) * run_info_units(n, nwg_e, P.levels))) != HG_OK) return rc;
@@ -2406,7 +2617,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
         double sum[5] = {0, 0, 0, 0, 0};
         int cnt = 0;
         long long last_end = 0; int last_i = -1;
-        for (int w = 0; w < 4096; ++w) {
+        for (int w = 0; w < 3072; ++w) {
           const long long* e = &h[(static_cast<size_t>(y) * 4096 + w) * 8];
           if (!e[0]) continue;
           ++cnt;
@@ -2416,7 +2627,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
         }
         {
           long long first = -1, lastend = 0, longest = 0; int li = -1;
-          for (int w = 0; w < 4096; ++w) {
+          for (int w = 0; w < 3072; ++w) {
             const long long* e = &h[(static_cast<size_t>(y) * 4096 + w) * 8];
             if (!e[0] || !e[5]) continue;
             if (first < 0 || e[0] < first) first = e[0];
@@ -2429,7 +2640,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
           // the 5 items that end last
           for (int rep = 0; rep < 5; ++rep) {
             long long best = 0; int bi = -1;
-            for (int w = 0; w < 4096; ++w) {
+            for (int w = 0; w < 3072; ++w) {
               const long long* q = &h[(static_cast<size_t>(y) * 4096 + w) * 8];
               if (q[0] && q[5] > best && q[5] < (rep ? lastend : lastend + 1)) { best = q[5]; bi = w; }
             }
@@ -2439,6 +2650,34 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
             lastend = best;
           }
         }
+        {
+          // deferred long chains: [7] tail start, [4] tail end (overwrites the item's chain stamp), [6] entries * 1e6 + values
+          int tails = 0; double tsum = 0; long long tmax = 0, tend = 0; long long tmax_info = 0;
+          const long long* tph = nullptr;
+          for (int w = 0; w < 3072; ++w) {
+            const long long* q = &h[(static_cast<size_t>(y) * 4096 + w) * 8];
+            if (!q[7]) continue;
+            ++tails; tsum += double(q[4] - q[7]);
+            if (q[4] - q[7] > tmax) { tmax = q[4] - q[7]; tmax_info = q[6]; tph = &h[(static_cast<size_t>(y) * 4096 + 3072 + (w & 1023)) * 8]; }
+            if (q[4] > tend) tend = q[4];
+          }
+          if (tails) fprintf(stderr, "   tails y=%d: %d workgroups, mean %.0f, longest %lld (entries %lld values %lld), last tail ends at %lld; longest's first group: entries %lld copy %lld seg %lld\n", y, tails,
+                             tsum / tails, tmax, tmax_info / 1000000ll, tmax_info % 1000000ll, tend - t0, tph ? tph[1] - tph[0] : 0, tph ? tph[2] - tph[1] : 0, tph ? tph[3] - tph[2] : 0);
+        }
+#ifdef HG_SEG_STATS
+        if (y == 0) {
+          unsigned st[8] = {0}, zero[8] = {0};
+          hipMemcpyFromSymbol(st, HIP_SYMBOL(hg::g_seg_stats), sizeof(st));
+          hipMemcpyToSymbol(HIP_SYMBOL(hg::g_seg_stats), zero, sizeof(zero));
+          fprintf(stderr, "   seg stats: lookups %u misses %u failed weight checks %u max |c - p| %u mean %.2f\n", st[0], st[1], st[2], st[3],
+                  st[0] ? double(st[4]) / st[0] : 0.0);
+          long long sp[8]; unsigned long long z = 0;
+          hipMemcpyFromSymbol(sp, HIP_SYMBOL(hg::g_seg_stamps), sizeof(sp));
+          hipMemcpyToSymbol(HIP_SYMBOL(hg::g_seg_longest), &z, sizeof(z));
+          fprintf(stderr, "   longest seg_chains call (x10ns): assign %lld affine+barrier %lld predict+chain(wave 0) %lld barrier %lld walk %lld; first voxel %lld values, %lld voxels\n",
+                  sp[1] - sp[0], sp[2] - sp[1], sp[3] - sp[2], sp[4] - sp[3], sp[5] - sp[4], sp[6], sp[7]);
+        }
+#endif
         fprintf(stderr, "bin y=%d items=%d mean cycles hist=%.0f group=%.0f rank=%.0f chain=%.0f; last item %d ends at %lld",
                 y, cnt, cnt ? sum[1] / cnt : 0, cnt ? sum[2] / cnt : 0, cnt ? sum[3] / cnt : 0, cnt ? sum[4] / cnt : 0, last_i, last_end - t0);
         if (last_i >= 0) {
@@ -2629,6 +2868,11 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
   if ((rc = c->ws_counts.reserve(sizeof(unsigned) * hit_words)) != HG_OK) return rc;
   if ((rc = c->ws_offsets.reserve(sizeof(uint4) * work_items)) != HG_OK) return rc;
   if ((rc = c->ws_jobs.reserve(table_bytes)) != HG_OK) return rc;
+  const unsigned apply_gx = count <= 2 ? 1024u : 512u;
+  if (heavy_enabled()) {
+    if ((rc = c->ws_heavy.reserve(sizeof(uint32_t) * rec_words)) != HG_OK) return rc;
+    if ((rc = c->ws_heavy_list.reserve(sizeof(uint4) * apply_gx * kHeavyPerWg * levels * count)) != HG_OK) return rc;
+  }
   size_t rec_off = 0, run_off = 0, hit_off = 0, work_off = 0;
   for (int j = 0; j < count; ++j) {
     InsertJob& J = jobs[j];
@@ -2642,6 +2886,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
     J.rec_vals = c->ws_vals_a.as<uint32_t>() + rec_off;
     J.runs = c->ws_keys_b.as<RunInfo>() + run_off;
     J.wg_hits = c->ws_counts.as<unsigned>() + hit_off;
+    const size_t heavy_off = rec_off;
     rec_off += static_cast<size_t>(nj) * kSlots * levels;
     run_off += run_info_units(nj, J.nwg, levels);
     hit_off += static_cast<size_t>(J.nwg) * kMaxInsLevels;
@@ -2667,6 +2912,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
       L.g.work = c->ws_offsets.as<uint4>() + work_off + per_level * l;
       L.g.work_capacity = static_cast<uint32_t>(per_level);
     }
+    attach_heavy(c, P, static_cast<size_t>(nj) * kSlots, apply_gx, heavy_off, static_cast<size_t>(apply_gx) * kHeavyPerWg * levels * j);
     work_off += per_level * levels;
   }
   const InsertJob* d_jobs = c->ws_jobs.as<InsertJob>();
@@ -2688,7 +2934,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
   {
     ProfScope ps(c, HG_K_APPLY, units * kSlots);
 #ifndef HG_BIN_STAMPS
-    hipLaunchKernelGGL(k_bin_apply_jobs, dim3(count <= 2 ? 1024 : 512, levels * count), dim3(kBinThreads), 0, s, d_jobs, count);
+    hipLaunchKernelGGL(k_bin_apply_jobs, dim3(apply_gx, levels * count), dim3(kBinThreads), 0, s, d_jobs, count);
 #endif
     if (count >= 4)  // as P.slice_records: throughput mode
       hipLaunchKernelGGL(k_bin_apply_small_jobs, dim3(512, count * levels), dim3(kSmallThreads), 0, s, d_jobs, levels);
@@ -2773,6 +3019,11 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   if ((rc = c->ws_counts.reserve(sizeof(unsigned) * hit_words)) != HG_OK) return rc;
   if ((rc = c->ws_sjobs.reserve(table_bytes)) != HG_OK) return rc;
   if ((rc = c->ws_shadow.reserve(sizeof(uint32_t) * shadow_words)) != HG_OK) return rc;
+  // (the apply passes run one after the other: they share one set of deferral buffers)
+  if (heavy_enabled()) {
+    if ((rc = c->ws_heavy.reserve(sizeof(uint32_t) * static_cast<size_t>(n_max) * kSlots * levels)) != HG_OK) return rc;
+    if ((rc = c->ws_heavy_list.reserve(sizeof(uint4) * 1024u * kHeavyPerWg * levels)) != HG_OK) return rc;
+  }
   {
     // bin counts and call counters are all-zero between calls of ONE layout (k_bin_offsets restores
     // that); bin offsets and touched lists keep their last values, so a call that lays the buffer out
@@ -2836,6 +3087,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
       L.g.bin_offset = base + max_pool;
       L.g.touched = base + 2u * max_pool;
     }
+    attach_heavy(c, P, static_cast<size_t>(nj) * kSlots, 1024u, 0, 0);
   }
   if (!P0.accumulate)  // hits and updates of this call start from zero; the jobs add to them
     for (int l = 0; l < levels; ++l)

@@ -94,6 +94,7 @@ struct hg_ctx {
   // second set of record / work-list buffers and the apply stream of the pipelined scan stream
   // (insert_chunk_binned with `pipe`): the front end of scan k + 1 runs next to the apply pass of scan k
   hg::DeviceBuffer ws_keys_c, ws_vals_c, ws_offsets_b;
+  hg::DeviceBuffer ws_heavy, ws_heavy_list;  // deferred long chains of the binned apply pass (hg_insert.hip)
   // grouped scan stream (insert_stream_grouped): job table of the whole call (pinned staging + device
   // copy; ev_sjobs marks the staging free again) and the per-scan bin arrays of the scans in flight
   hg::DeviceBuffer ws_sjobs, ws_shadow;

@@ -236,6 +236,70 @@ def test_sharded_offline_batch_driver_gloo_world2():
     assert got[0][6] == [[7, 7]] * 8
 
 
+class _UnevenEngine(_FakeEngine):
+    """Submaps of different sizes, as finished submaps are: submap j adds (j + l) % 4 blocks to level l per step --
+    so some (submap, level) grids stay EMPTY (zero blocks travel, the digest of an empty export still has to
+    match) -- and the block counts differ from rank to rank and from grid to grid."""
+
+    def step(self, i):
+        self.steps.append(i)
+        for j, pyr in zip(self.owned, self.pyramids):
+            for l, g in enumerate(pyr):
+                for b in range((j + l) % 4):
+                    row = np.full((1, 512), 1 + 1000 * j + 10 * i + l + 100000 * b, np.uint32)
+                    g.import_blocks(np.array([100 * j + 10 * i + b], np.uint64), row)
+
+
+def _uneven_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from hectorgrapher_amd import distributed as hgd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _UnevenEngine()
+    res = hgd.map_sharded(8, rank, world, eng, steps=3, warmup=1, barrier=dist.barrier, dist=dist)
+    gathered = hgd.gather_grids(eng.grids(), dist, rank, world, None, host=True)
+    chk = hgd.verify_gather(_FakeApi, None, eng.grids(), gathered, dist, rank, world)
+    out.put((rank, res["owned"], res["scans"], chk,
+             None if rank else [[int(k.shape[0]) for k, _ in row] for row in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_offline_batch_driver_gloo_world_4_and_8(world):
+    """The driver's 4- and 8-rank shapes of BASELINE configs[3] (8 submaps; at 8 ranks ONE submap per rank, the
+    shape `bench.py --gpus 8 --total-submaps 8` runs): shard(8, r, world), an all_gather of `world` count rows,
+    point-to-point transfers from every peer at once, grids without any block, uneven block counts -- and the
+    import / export check of all of it on rank 0."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {g[0]: g for g in (q.get(timeout=300) for _ in procs)}
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    per_rank = 8 // world
+    for r in range(world):
+        assert got[r][1] == list(range(r, 8, world)) and len(got[r][1]) == per_rank
+        assert got[r][2] == 8 * 3                      # whole-job scans of the timed region
+        if r:
+            assert got[r][3] is None and got[r][4] is None
+    chk = got[0][3]
+    steps = 4                                          # 1 warm-up + 3 timed
+    # what rank 0 must hold: for grid (k-th owned submap, level l) and source rank src the blocks of submap src + k * world
+    want = [[((src + k * world + l) % 4) * steps for src in range(world)] for k in range(per_rank) for l in range(2)]
+    assert got[0][4] == want
+    assert any(0 in row for row in want)               # (the empty grids are really there)
+    assert chk["ok"] and chk["ranks"] == world and chk["levels"] == 2 * per_rank
+    assert chk["blocks"] == sum(sum(row) for row in want)
+
+
 def test_map_sharded_hands_step_ranges_to_an_engine_that_runs_them_itself():
     """An engine that maps its submaps in host-thread groups (bench.py's offline-batch Engine) exposes
     run_steps(first, last): map_sharded hands it the warm-up range and the timed range instead of stepping."""

@@ -138,3 +138,32 @@ def test_offline_batch_command_full_size_two_ranks():
     solo = _offline_batch(1, {}, submaps=2, size=size, steps=2, cpu=True)
     par = solo["parity"]
     assert par and par["max_dt_m"] <= 1e-4 and par["max_dr_rad"] <= 1e-4 and par["same_iterations_and_termination"]
+
+
+def test_gpus_flag_line_carries_the_strong_scaling_leg():
+    """`bench.py --gpus N` (N > 1) is the command the driver's scaling step runs: besides the weak-scaling headline
+    (one independent submap per rank) the line must carry BASELINE configs[3] -- 8 submaps farmed to the N ranks in
+    the SAME process group, the gather of their blocks and its check -- and say how many ranks the process group
+    had. Two ranks on the test box's one GPU (gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HG_RANKS_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rings", "16", "--cols", "625", "--map-scans", "3", "--max-blocks", str(1 << 15)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["process_group"]["nranks"] == 2
+    assert out["config"]["gather_check"]["ok"] and out["config"]["gather_check"]["ranks"] == 2
+    leg = out["secondary"]["offline8"]
+    assert "error" not in leg, leg
+    assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["value"] > 0
+    assert leg["total_submaps"] == 8 and leg["submaps_per_gpu"] == 4
+    assert leg["process_group"]["nranks"] == 2
+    assert leg["gather_ms"] > 0
+    chk = leg["gather_check"]
+    assert chk["ok"] and chk["ranks"] == 2 and chk["levels"] == 3 * 4
