@@ -14,7 +14,7 @@ int main() {
     // a box room seen from a sensor moving along x: 16 rings x 360 columns
     for (int k = 0; k < 5; ++k) {
       sensor::TimedPointCloudData scan;
-      scan.time = 0.1 * k;
+      scan.time = 1000000 * static_cast<common::Time>(k);  // 0.1 s per scan, in ticks
       const float sx = 0.05f * k;
       for (int c = 0; c < 360; ++c)
         for (int r = 0; r < 16; ++r) {
@@ -31,9 +31,9 @@ int main() {
       auto result = builder.AddRangeData("lidar", scan);
       if (result) std::printf("scan %d pose %.4f %.4f %.4f\n", k, result->local_pose[0], result->local_pose[1], result->local_pose[2]);
     }
-    // the same trajectory through the sliding-window builder (OptimizingLocalTrajectoryBuilder
+    // the same trajectory through the sliding-window builder (SlidingWindowTrajectoryBuilder
     // shape): window of 3 control points, odometry with an alternating +-1 cm error
-    mapping::OptimizingLocalTrajectoryBuilder::Options wopt;
+    mapping::SlidingWindowTrajectoryBuilder::Options wopt;
     wopt.window = 3;
     // the sensor rests for the first two scans (the window's first state is fixed, with zero
     // velocity) and then moves at 0.5 m/s; the functor ties neighbouring velocities together (it reads
@@ -41,10 +41,10 @@ int main() {
     wopt.imu_translation_weight = 1.0;
     wopt.imu_velocity_weight = 0.01;
     wopt.imu_rotation_weight = 1.0;
-    mapping::OptimizingLocalTrajectoryBuilder wbuilder(&ctx, wopt);
+    mapping::SlidingWindowTrajectoryBuilder wbuilder(&ctx, wopt);
     for (int k = 0; k < 8; ++k) {
       sensor::TimedPointCloudData scan;
-      scan.time = 0.1 * k;
+      scan.time = 1000000 * static_cast<common::Time>(k);  // 0.1 s per scan, in ticks
       const float sx = 0.05f * (k > 0 ? k - 1 : 0);
       for (int c = 0; c < 360; ++c)
         for (int r = 0; r < 16; ++r) {
@@ -68,7 +68,7 @@ int main() {
       // control points are tied by PredictionImuPreintegrationCostFunctor blocks with velocity states
       for (int j = 0; j < 10; ++j) {
         sensor::ImuData imu;
-        imu.time = scan.time - 0.1 + 0.01 * (j + 1);
+        imu.time = scan.time - 1000000 + 100000 * (j + 1);
         imu.linear_acceleration = {{0.0, 0.0, 9.80665}};
         imu.angular_velocity = {{0.0, 0.0, 0.0}};
         wbuilder.AddImuData(imu);
@@ -83,8 +83,8 @@ int main() {
     // the pre-integration itself: 90 degrees about z in 1 s from a constant 100 Hz gyro
     {
       std::deque<sensor::ImuData> gyro;
-      for (int j = 0; j <= 100; ++j) gyro.push_back({0.01 * j, {{0.0, 0.0, 9.8}}, {{0.0, 0.0, 1.5707963267948966}}});
-      const std::array<double, 4> dq = mapping::IntegrateImuDeltaRotation(gyro, 0.0, 1.0);
+      for (int j = 0; j <= 100; ++j) gyro.push_back({100000 * static_cast<common::Time>(j), {{0.0, 0.0, 9.8}}, {{0.0, 0.0, 1.5707963267948966}}});
+      const std::array<double, 4> dq = mapping::IntegrateImuDeltaRotation(gyro, 0, common::FromSeconds(1.0));
       std::printf("imu delta rotation %.6f %.6f %.6f %.6f\n", dq[0], dq[1], dq[2], dq[3]);
     }
     // ActiveSubmaps3D: two live submaps, a new one every 3 insertions, the old one finished at 6

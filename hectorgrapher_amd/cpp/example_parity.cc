@@ -1,4 +1,4 @@
-// example_parity.cc — runs the OptimizingLocalTrajectoryBuilder-shaped adapter (hg_adapter.h) over a
+// example_parity.cc — runs the simplified sliding-window builder (SlidingWindowTrajectoryBuilder) of the adapter (hg_adapter.h) over a
 // deterministic trajectory and writes (1) every input it was fed, bit for bit, to a binary file and (2) the
 // window's solved poses, velocities and solver summaries with full precision to stdout, so that a test can
 // replay the same inputs through the CPU oracle with an independent statement of the window wiring
@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
   if (!f) return 2;
   try {
     Context ctx(0);
-    mapping::OptimizingLocalTrajectoryBuilder::Options opt;
+    mapping::SlidingWindowTrajectoryBuilder::Options opt;
     opt.window = 4;
     opt.resolutions = {0.10f, 0.20f};
     opt.max_blocks = 1u << 15;
@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     opt.imu_rotation_weight = 2.0;
     opt.odometry_translation_weight = 3.0;
     opt.odometry_rotation_weight = 5.0;
-    mapping::OptimizingLocalTrajectoryBuilder builder(&ctx, opt);
+    mapping::SlidingWindowTrajectoryBuilder builder(&ctx, opt);
     std::fwrite(&scans, sizeof(int), 1, f);
     for (int k = 0; k < scans; ++k) {
       // a box room with a pillar, seen from a sensor that rests for two scans, then moves 4 cm per scan along
@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
       const double step = k > 1 ? k - 1 : 0;
       const double sx = 0.04 * step, yaw = 0.005 * step;
       sensor::TimedPointCloudData scan;
-      scan.time = 0.1 * k;
+      scan.time = 1000000 * static_cast<common::Time>(k);  // 0.1 s per scan, in ticks
       for (int c = 0; c < 240; ++c)
         for (int r = 0; r < 12; ++r) {
           const double az = 6.283185307179586 * c / 240.0 + yaw, el = (-14.0 + 2.5 * r) * 0.017453292519943295;
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
       std::vector<sensor::ImuData> imu_batch;
       for (int j = 0; j < 10; ++j) {
         sensor::ImuData imu;
-        imu.time = scan.time - 0.1 + 0.01 * (j + 1);
+        imu.time = scan.time - 1000000 + 100000 * (j + 1);
         imu.linear_acceleration = {{0.0, 0.0, 9.80665}};
         imu.angular_velocity = {{0.0002, -0.0001, k > 1 ? 0.05 : 0.0}};
         builder.AddImuData(imu);
@@ -78,13 +78,13 @@ int main(int argc, char** argv) {
       }
       // the inputs of this step, bit for bit
       const int n = static_cast<int>(scan.ranges.size()), n_imu = static_cast<int>(imu_batch.size());
-      std::fwrite(&scan.time, sizeof(double), 1, f);
+      std::fwrite(&scan.time, sizeof(common::Time), 1, f);  // ticks
       std::fwrite(&n, sizeof(int), 1, f);
       std::fwrite(scan.ranges.data(), sizeof(float) * 4, n, f);
       std::fwrite(odom.pose.data(), sizeof(double), 7, f);
       std::fwrite(&n_imu, sizeof(int), 1, f);
       for (const auto& s : imu_batch) {
-        std::fwrite(&s.time, sizeof(double), 1, f);
+        std::fwrite(&s.time, sizeof(common::Time), 1, f);
         std::fwrite(s.angular_velocity.data(), sizeof(double), 3, f);
       }
       const int solves_before = builder.num_solves();

@@ -20,19 +20,19 @@ int main(int argc, char** argv) {
     mapping::HybridGridTSDF high(&ctx, res[0], 2.5f, 1000.f, 1u << 14), low(&ctx, res[1], 2.5f, 1000.f, 1u << 14);
     // four control points 50 ms apart on a gently curved path
     std::vector<Pose> poses;
-    std::vector<double> times;
+    std::vector<common::Time> times;
     for (int k = 0; k < 4; ++k) {
       const double yaw = 0.02 * k, roll = 0.003 * k * k;
       const double cy = std::cos(0.5 * yaw), sy = std::sin(0.5 * yaw), cr = std::cos(0.5 * roll), sr = std::sin(0.5 * roll);
       // q = q_yaw(z) * q_roll(x)
       poses.push_back(Pose{{0.05 * k, 0.02 * k - 0.001 * k * k, 0.004 * k, cy * cr, cy * sr, sy * sr, sy * cr}});
-      times.push_back(100.0 + 0.05 * k);
+      times.push_back(1000000000 + 500000 * static_cast<common::Time>(k));  // 100 s + 50 ms per control point, ticks
     }
     // two clouds of 16 rings x 180 columns swept over 70 ms each, seen from inside a box room; every 41st return NaN
     std::vector<sensor::TimedPointCloudData> clouds(2);
     const size_t rings = 16, cols = 180;
     for (int c = 0; c < 2; ++c) {
-      clouds[c].time = 100.0 + 0.01 + 0.07 * c;
+      clouds[c].time = 1000000000 + 100000 + 700000 * static_cast<common::Time>(c);
       clouds[c].origin = {{0.01f * c, -0.02f, 0.1f}};
       for (size_t col = 0; col < cols; ++col)
         for (size_t r = 0; r < rings; ++r) {
@@ -56,14 +56,14 @@ int main(int argc, char** argv) {
     const int n_cp = static_cast<int>(poses.size()), n_clouds = static_cast<int>(clouds.size());
     std::fwrite(&n_cp, sizeof(int), 1, f);
     for (int k = 0; k < n_cp; ++k) {
-      std::fwrite(&times[k], sizeof(double), 1, f);
+      std::fwrite(&times[k], sizeof(common::Time), 1, f);
       std::fwrite(poses[k].data(), sizeof(double), 7, f);
     }
     std::fwrite(submap_from_local.data(), sizeof(float), 7, f);
     std::fwrite(&n_clouds, sizeof(int), 1, f);
     for (const auto& c : clouds) {
       const int n = static_cast<int>(c.ranges.size());
-      std::fwrite(&c.time, sizeof(double), 1, f);
+      std::fwrite(&c.time, sizeof(common::Time), 1, f);
       std::fwrite(c.origin.data(), sizeof(float), 3, f);
       std::fwrite(&n, sizeof(int), 1, f);
       std::fwrite(c.ranges.data(), sizeof(float) * 4, n, f);

@@ -12,9 +12,12 @@
 //                                              (AddImuData / AddRangeData / AddOdometryData /
 //                                              MatchingResult / InsertionResult)
 //   hg_amd::mapping::OptimizingLocalTrajectoryBuilder
-//                                              mapping/internal/3d/optimizing_local_trajectory_builder.cc
-//                                              (sliding window: TSDF blocks :323-511, IMU pre-integration
-//                                              blocks with velocity states :928-1000, odometry :1009-1074)
+//                                              mapping/internal/3d/optimizing_local_trajectory_builder.cc in its
+//                                              own shape: control-point sampling :1162-1232, clouds bracketed and
+//                                              interpolated between control points :323-511, IMU pre-integration
+//                                              blocks with velocity states :928-1000, odometry blocks with adaptive
+//                                              weights :1009-1074, MaybeOptimize :1113-1413
+//   hg_amd::mapping::SlidingWindowTrajectoryBuilder   a simplified window (one control point per scan)
 // Header-only, C++11, no Eigen: poses are std::array<double, 7> (t xyz, q wxyz), points are
 // std::array<float, 3>. Errors throw hg_amd::Error (the reference CHECK-aborts instead).
 #ifndef HG_ADAPTER_H_
@@ -45,6 +48,15 @@ inline void Check(int rc, const char* what) {
 
 using Pose = std::array<double, 7>;  // t.x t.y t.z q.w q.x q.y q.z
 using Point = std::array<float, 3>;
+
+namespace common {
+// common::Time / common::Duration (common/time.h:36-42): universal time in 100 ns ticks, integers end to end --
+// every comparison of a scan's time with a control point's is exact, as in the reference.
+typedef int64_t Time;
+typedef int64_t Duration;
+inline Duration FromSeconds(double seconds) { return static_cast<int64_t>(seconds * 1e7); }  // duration_cast truncates (time.cc:30-33)
+inline double ToSeconds(Duration duration) { return static_cast<double>(duration) / 1e7; }   // (:35-38)
+}  // namespace common
 
 namespace transform {
 inline Pose Multiply(const Pose& a, const Pose& b) {  // Rigid3d operator* (rigid_transform.h:184-190)
@@ -79,6 +91,113 @@ inline std::array<float, 7> ToFloat(const Pose& p) {
   for (int i = 0; i < 7; ++i) f[i] = static_cast<float>(p[i]);
   return f;
 }
+// Rigid3f * Vector3f: Eigen's Quaternion<float>::_transformVector, then + translation (rigid_transform.h:193-197)
+inline Point TransformPoint(const std::array<float, 7>& p, const Point& v) {
+  const float qw = p[3], qx = p[4], qy = p[5], qz = p[6];
+  float ux = qy * v[2] - qz * v[1], uy = qz * v[0] - qx * v[2], uz = qx * v[1] - qy * v[0];
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const float cx = qy * uz - qz * uy, cy = qz * ux - qx * uz, cz = qx * uy - qy * ux;
+  const float rx = v[0] + qw * ux + cx, ry = v[1] + qw * uy + cy, rz = v[2] + qw * uz + cz;
+  return Point{{rx + p[0], ry + p[1], rz + p[2]}};
+}
+inline std::array<double, 3> Rotate(const std::array<double, 4>& q, const std::array<double, 3>& v) {  // Quaterniond * Vector3d
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double ux = y * v[2] - z * v[1], uy = z * v[0] - x * v[2], uz = x * v[1] - y * v[0];
+  const double tx = ux + ux, ty = uy + uy, tz = uz + uz;
+  return {{v[0] + w * tx + (y * tz - z * ty), v[1] + w * ty + (z * tx - x * tz), v[2] + w * tz + (x * ty - y * tx)}};
+}
+// transform::GetAngle (transform.h:34-37) and Eigen's angularDistance to the identity: 2 atan2(|vec|, |w|)
+inline double GetAngle(const Pose& p) {
+  return 2.0 * std::atan2(std::sqrt(p[4] * p[4] + p[5] * p[5] + p[6] * p[6]), std::abs(p[3]));
+}
+// InterpolateTransform (timestamped_transform.h:41-51): translation lerp, Eigen 3.3 QuaternionBase::slerp in double
+inline Pose InterpolateTransform(const Pose& a, const Pose& b, double factor) {
+  Pose r;
+  for (int k = 0; k < 3; ++k) r[k] = a[k] + (b[k] - a[k]) * factor;
+  const double one = 1.0 - std::numeric_limits<double>::epsilon();
+  const double d = (a[4] * b[4] + a[5] * b[5]) + (a[6] * b[6] + a[3] * b[3]);  // coeffs (x, y, z, w): pairwise sum
+  const double abs_d = std::abs(d);
+  double s0, s1;
+  if (abs_d >= one) {
+    s0 = 1.0 - factor;
+    s1 = factor;
+  } else {
+    const double theta = std::acos(abs_d), sin_theta = std::sin(theta);
+    s0 = std::sin((1.0 - factor) * theta) / sin_theta;
+    s1 = std::sin(factor * theta) / sin_theta;
+  }
+  if (d < 0.0) s1 = -s1;
+  for (int k = 3; k < 7; ++k) r[k] = s0 * a[k] + s1 * b[k];
+  return r;
+}
+inline Pose InterpolateTransform(const Pose& a, const Pose& b, common::Time time_a, common::Time time_b, common::Time time) {
+  if (!(time_a <= time && time <= time_b)) throw Error("InterpolateTransform: time outside the two transforms", HG_ERR_TIME);
+  const double duration = common::ToSeconds(time_b - time_a);
+  return InterpolateTransform(a, b, common::ToSeconds(time - time_a) / duration);  // (:59-62)
+}
+
+// transform::TransformInterpolationBuffer (transform_interpolation_buffer.cc:40-140): time-ordered transforms with
+// interpolated lookups; LookupUntilDelta is the ADAPTIVE control-point sampling's search.
+class TransformInterpolationBuffer {
+ public:
+  void Push(common::Time time, const Pose& transform) {
+    if (!entries_.empty() && time < latest_time()) throw Error("TransformInterpolationBuffer: new transform is older than latest", HG_ERR_INVALID);
+    entries_.push_back(Entry{time, transform});
+  }
+  bool empty() const { return entries_.empty(); }
+  common::Time earliest_time() const { return entries_.front().time; }
+  common::Time latest_time() const { return entries_.back().time; }
+  bool Has(common::Time time) const { return !entries_.empty() && earliest_time() <= time && time <= latest_time(); }
+  Pose Lookup(common::Time time) const {
+    if (!Has(time)) throw Error("TransformInterpolationBuffer: missing transform", HG_ERR_TIME);
+    size_t end = LowerBound(time);
+    if (entries_[end].time == time) return entries_[end].transform;
+    return InterpolateTransform(entries_[end - 1].transform, entries_[end].transform, entries_[end - 1].time, entries_[end].time, time);
+  }
+  common::Time LookupUntilDelta(common::Time start_time, double max_translation, double max_rotation, double max_duration,
+                                double* translation_ratio, double* rotation_ratio, double* time_ratio) const {
+    if (!Has(start_time)) throw Error("TransformInterpolationBuffer: missing transform", HG_ERR_TIME);
+    size_t candidate = LowerBound(start_time);
+    const Pose start_transform = entries_[candidate].time == start_time
+                                     ? entries_[candidate].transform
+                                     : InterpolateTransform(entries_[candidate - 1].transform, entries_[candidate].transform,
+                                                            entries_[candidate - 1].time, entries_[candidate].time, start_time);
+    double target_ratio = 1.0;
+    while (candidate + 1 < entries_.size()) {
+      const Pose delta = Multiply(Inverse(start_transform), entries_[candidate + 1].transform);
+      const double translation_distance = std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+      const double rotation_distance = std::abs(GetAngle(delta));
+      const double delta_time = std::abs(common::ToSeconds(entries_[candidate + 1].time - start_time));
+      ++candidate;
+      *translation_ratio = translation_distance / max_translation;
+      *rotation_ratio = rotation_distance / max_rotation;
+      *time_ratio = delta_time / max_duration;
+      target_ratio = std::max(*translation_ratio, std::max(*rotation_ratio, *time_ratio));
+      if (target_ratio >= 1.0) break;
+    }
+    const common::Duration delta_duration = entries_[candidate].time - start_time;
+    const common::Duration corrected = target_ratio > 1.0 ? common::FromSeconds(common::ToSeconds(delta_duration) / target_ratio)
+                                                          : delta_duration;
+    if (target_ratio > 1.0) {
+      *translation_ratio /= target_ratio;
+      *rotation_ratio /= target_ratio;
+      *time_ratio /= target_ratio;
+    }
+    return start_time + corrected;
+  }
+
+ private:
+  struct Entry { common::Time time; Pose transform; };
+  size_t LowerBound(common::Time time) const {  // first entry with entry.time >= time
+    size_t lo = 0, hi = entries_.size();
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (entries_[mid].time < time) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  }
+  std::deque<Entry> entries_;
+};
 }  // namespace transform
 
 namespace sensor {
@@ -88,12 +207,13 @@ struct RangeData {  // sensor/range_data.h:44-57 (misses are unused by the TSDF 
   size_t width = 0;
 };
 struct TimedPointCloudData {  // sensor/timed_point_cloud_data.h:27-32
-  double time = 0.0;
+  common::Time time = 0;
   Point origin{{0.f, 0.f, 0.f}};
-  std::vector<std::array<float, 4>> ranges;  // xyz + relative time
+  std::vector<std::array<float, 4>> ranges;  // xyz + time relative to `time`, seconds (TimedRangefinderPoint)
+  size_t width = 0;
 };
-struct OdometryData { double time; Pose pose; };
-struct ImuData { double time; std::array<double, 3> linear_acceleration, angular_velocity; };
+struct OdometryData { common::Time time; Pose pose; };
+struct ImuData { common::Time time; std::array<double, 3> linear_acceleration, angular_velocity; };
 }  // namespace sensor
 
 class Context {
@@ -393,8 +513,8 @@ class TsdfScanMatcher3D {
 // (front, back) are omitted. Times: universal 100 ns ticks for the cloud and control points, seconds
 // relative to the cloud for the returns (TimedRangefinderPoint::time). The subdivisions of this
 // cloud that share a control-point pair become one hg_problem_add_unwarped_block.
-inline int64_t FromSecondsTicks(double seconds) { return static_cast<int64_t>(seconds * 1e7); }  // common/time.cc:30-33
-inline double TicksToSeconds(int64_t ticks) { return static_cast<double>(ticks) / 1e7; }         // :35-38
+inline int64_t FromSecondsTicks(double seconds) { return common::FromSeconds(seconds); }  // common/time.cc:30-33
+inline double TicksToSeconds(int64_t ticks) { return common::ToSeconds(ticks); }         // :35-38
 
 inline void AddPerPointMatchingResiduals(hg_problem* problem, const std::vector<int>& pose_ids,
                                          const std::vector<int64_t>& control_times, int64_t cloud_time,
@@ -440,7 +560,7 @@ class LocalTrajectoryBuilder3D {
     std::vector<const HybridGridTSDF*> insertion_grids;
   };
   struct MatchingResult {
-    double time;
+    common::Time time;
     Pose local_pose;
     sensor::RangeData range_data_in_local;
     std::unique_ptr<const InsertionResult> insertion_result;  // nullptr if map update is disabled
@@ -542,11 +662,12 @@ class LocalTrajectoryBuilder3D {
 
 // use_per_point_unwarping, second half (optimizing_local_trajectory_builder.cc:1331-1379, then :1437-1440 and
 // submap_3d.cc:436-437): the clouds that leave the window are unwarped return by return with the window's solved
-// control poses and inserted, all on the device (hg_pyramid_insert_unwarped). Times in seconds as elsewhere in this
-// header; they become 100 ns ticks as common::FromSeconds makes them. control_poses.front() is optimized_pose.
+// control poses and inserted, all on the device (hg_pyramid_insert_unwarped). Times are common::Time ticks, as the
+// clouds and the control points carry them (a return on a control point's tick IS inside the window).
+// control_poses.front() is optimized_pose.
 inline void InsertUnwarped(const std::vector<HybridGridTSDF*>& grids, const hg_insert_opts& inserter,
                            const std::vector<sensor::TimedPointCloudData>& clouds, size_t width,
-                           const std::vector<Pose>& control_poses, const std::vector<double>& control_times,
+                           const std::vector<Pose>& control_poses, const std::vector<common::Time>& control_times,
                            const std::array<float, 7>* submap_from_local = nullptr, int insert_mode = HG_INSERT_EXACT) {
   if (grids.empty() || clouds.empty() || control_poses.size() < 2 || control_poses.size() != control_times.size())
     throw Error("InsertUnwarped: needs grids, clouds and at least two control points", HG_ERR_INVALID);
@@ -557,7 +678,7 @@ inline void InsertUnwarped(const std::vector<HybridGridTSDF*>& grids, const hg_i
   std::vector<float> points;
   for (const auto& c : clouds) {
     hg_timed_cloud t{};
-    t.time = static_cast<int64_t>(c.time * 1e7);
+    t.time = c.time;
     t.begin = points.size() / 4;
     t.count = c.ranges.size();
     for (int k = 0; k < 3; ++k) t.origin[k] = c.origin[k];
@@ -568,7 +689,7 @@ inline void InsertUnwarped(const std::vector<HybridGridTSDF*>& grids, const hg_i
   std::vector<int64_t> times;
   for (size_t k = 0; k < control_poses.size(); ++k) {
     poses.insert(poses.end(), control_poses[k].begin(), control_poses[k].end());
-    times.push_back(static_cast<int64_t>(control_times[k] * 1e7));
+    times.push_back(control_times[k]);
   }
   Check(hg_pyramid_insert_unwarped(pyr.data(), opts.data(), static_cast<int>(pyr.size()), points.data(), points.size() / 4,
                                    width, HG_HOST, table.data(), static_cast<int>(table.size()), poses.data(), times.data(),
@@ -584,17 +705,17 @@ inline void InsertUnwarped(const std::vector<HybridGridTSDF*>& grids, const hg_i
 // (transform/transform.h:121-135) -- with identity calibration. Host scalar code, as in the reference.
 // Returns (w, x, y, z). `imu` is ordered by time; samples before `start` other than the last one are
 // ignored, and without a sample at or before `start` the first sample is held.
-inline std::array<double, 4> IntegrateImuDeltaRotation(const std::deque<sensor::ImuData>& imu, double start,
-                                                       double end) {
+inline std::array<double, 4> IntegrateImuDeltaRotation(const std::deque<sensor::ImuData>& imu, common::Time start,
+                                                       common::Time end) {
   std::array<double, 4> q{{1.0, 0.0, 0.0, 0.0}};
   if (imu.empty() || !(start < end)) return q;
   size_t it = 0;
   while (it + 1 < imu.size() && imu[it + 1].time <= start) ++it;
-  double current = start;
+  common::Time current = start;
   while (current < end) {
-    const double next_imu = it + 1 < imu.size() ? imu[it + 1].time : std::numeric_limits<double>::infinity();
-    const double next = std::min(next_imu, end);
-    const double dt = next - current;
+    const common::Time next_imu = it + 1 < imu.size() ? imu[it + 1].time : std::numeric_limits<common::Time>::max();
+    const common::Time next = std::min(next_imu, end);
+    const double dt = common::ToSeconds(next - current);
     const double ax = imu[it].angular_velocity[0] * dt, ay = imu[it].angular_velocity[1] * dt,
                  az = imu[it].angular_velocity[2] * dt;
     double scale = 0.5, w = 1.0;
@@ -616,14 +737,14 @@ inline std::array<double, 4> IntegrateImuDeltaRotation(const std::deque<sensor::
   return q;
 }
 
-// OptimizingLocalTrajectoryBuilder-shaped driver (mapping/internal/3d/optimizing_local_trajectory_builder.cc):
-// a sliding window of control points is re-optimised on every scan — AddRangeData (:188-264) queues the
+// A SIMPLIFIED sliding-window driver (one control point per scan; the reference's own shape is
+// OptimizingLocalTrajectoryBuilder below): a sliding window of control points is re-optimised on every scan — AddRangeData (:188-264) queues the
 // cloud and adds a control point, MaybeOptimize (:1114-1413) builds one problem over the window (first
 // state constant :1268-1275, one TSDF block per scan :323-511, odometry blocks between neighbours
 // :1009-1074), solves it on the device, and the scans that leave the window are inserted into the map at
 // their optimised poses (:1332-1404). One control point per scan (the reference spaces them by
 // ct_window_rate and interpolates; that is hg_problem_add_block's pose_b / interpolation_ratio).
-class OptimizingLocalTrajectoryBuilder {
+class SlidingWindowTrajectoryBuilder {
  public:
   typedef LocalTrajectoryBuilder3D::MatchingResult MatchingResult;
   typedef LocalTrajectoryBuilder3D::InsertionResult InsertionResult;
@@ -636,7 +757,7 @@ class OptimizingLocalTrajectoryBuilder {
     double imu_translation_weight = 1.0, imu_velocity_weight = 1.0, imu_rotation_weight = 1.0;
   };
 
-  OptimizingLocalTrajectoryBuilder(Context* ctx, const Options& options) : ctx_(ctx), options_(options) {
+  SlidingWindowTrajectoryBuilder(Context* ctx, const Options& options) : ctx_(ctx), options_(options) {
     for (float r : options.resolutions)
       grids_.emplace_back(new HybridGridTSDF(ctx, r, options.relative_truncation_distance, options.maximum_weight,
                                              options.max_blocks));
@@ -644,7 +765,7 @@ class OptimizingLocalTrajectoryBuilder {
     hg_solver_default_opts(&solver_);
     solver_.max_num_iterations = options.max_num_iterations;
   }
-  ~OptimizingLocalTrajectoryBuilder() { if (problem_) hg_problem_destroy(problem_); }
+  ~SlidingWindowTrajectoryBuilder() { if (problem_) hg_problem_destroy(problem_); }
 
   // IMU samples are queued (oltb.cc:166-186); MaybeOptimize pre-integrates them between neighbouring
   // control points on the host and hands the delta rotation to hg_problem_add_imu_block (:968-1000)
@@ -680,7 +801,7 @@ class OptimizingLocalTrajectoryBuilder {
     // velocity of the new state: the translation of the predicted step over its duration (the
     // constant-velocity form of PredictStateOdom, oltb.cc:1641); zero for the first control point
     if (!window_.empty() && cp.time > window_.back().time)
-      for (int k = 0; k < 3; ++k) cp.velocity[k] = (cp.pose[k] - window_.back().pose[k]) / (cp.time - window_.back().time);
+      for (int k = 0; k < 3; ++k) cp.velocity[k] = (cp.pose[k] - window_.back().pose[k]) / common::ToSeconds(cp.time - window_.back().time);
     window_.push_back(std::move(cp));
 
     std::vector<hg_grid*> pyr;
@@ -703,7 +824,7 @@ class OptimizingLocalTrajectoryBuilder {
         const std::array<double, 4> dq = IntegrateImuDeltaRotation(imu_data_, window_[i - 1].time, window_[i].time);
         Check(hg_problem_add_imu_block(problem_, static_cast<int>(i) - 1, static_cast<int>(i),
                                        options_.imu_translation_weight, options_.imu_velocity_weight,
-                                       options_.imu_rotation_weight, window_[i].time - window_[i - 1].time, dq.data()),
+                                       options_.imu_rotation_weight, common::ToSeconds(window_[i].time - window_[i - 1].time), dq.data()),
               "hg_problem_add_imu_block");
         ++last_imu_blocks_;
       }
@@ -767,7 +888,7 @@ class OptimizingLocalTrajectoryBuilder {
 
  private:
   struct ControlPoint {
-    double time = 0;
+    common::Time time = 0;
     Pose pose, odom;
     std::array<double, 3> velocity{{0.0, 0.0, 0.0}};
     bool has_odom = false, inserted = false;
@@ -787,6 +908,622 @@ class OptimizingLocalTrajectoryBuilder {
   Pose last_inserted_pose_{{0, 0, 0, 1, 0, 0, 0}};
   sensor::OdometryData last_odom_{};
   bool have_odom_ = false, map_has_data_ = false;
+};
+
+
+// proto::TSDFRangeDataInserterOptions3D of the low-resolution inserter (trajectory_builder_3d.lua:94-109)
+inline hg_insert_opts DefaultLowResolutionTSDFInserterOptions() {
+  hg_insert_opts o = DefaultTSDFInserterOptions();
+  o.min_range = 1.0; o.max_range = 60.0; o.insertion_ratio = 0.1;
+  o.normal_computation_horizontal_stride = 20; o.normal_computation_vertical_stride = 4;
+  return o;
+}
+
+// =====================================================================================================
+// OptimizingLocalTrajectoryBuilder in the reference's own shape
+// (mapping/internal/3d/optimizing_local_trajectory_builder.cc, options of
+// configuration_files/trajectory_builder_3d.lua:18-31,56-60,120-146 with grid_type = "TSDF"):
+//   * control points are NOT the scans: CONSTANT sampling places one every ct_window_rate behind the odometry
+//     (:1169-1176), SYNCED_WITH_RANGE_DATA one per cloud (:1178-1187), ADAPTIVE by odometry motion (:1189-1232);
+//     a new control point is predicted from the odometry delta (PredictStateOdom :1596-1656);
+//   * every cloud is bracketed by the control points around its time and matched with an interpolation factor:
+//     a single-pose block when it sits exactly on one, a two-pose block otherwise (:323-364,:392-502), against the
+//     matching submap's two grids -- both clouds on the pyramid (use_multi_resolution_matching) or, the default, the
+//     high-resolution cloud on the high-resolution grid AND the low-resolution cloud on the low-resolution grid;
+//   * IMU pre-integration blocks with velocity states (:928-1000), odometry blocks from interpolated odometry
+//     lookups at the control points' times with the adaptive weights (:1009-1058);
+//   * the solve runs in the matching submap's frame (:1248,:1290), first control point constant (:1268-1275);
+//   * the clouds that fall out of the window are moved to the tracking frame of the front control point with the
+//     pose interpolated at their time (:1382-1404) -- or return by return (use_per_point_unwarping, :1331-1379,
+//     on the device) -- and inserted into the active submaps (:1437-1440, ActiveSubmaps3D above).
+// Outside (host-side and not on the TSDF path): PoseExtrapolator / ImuTracker (the initial
+// gravity orientation is an option here), IMU calibration, the RK4 integrator (an external library; Euler as
+// IntegrateImuWithTranslationEuler), the rotational scan matcher histogram, the debug logger.
+// =====================================================================================================
+struct State {  // mapping/internal/3d/state.h
+  std::array<double, 3> translation{{0, 0, 0}};
+  std::array<double, 4> rotation{{1, 0, 0, 0}};  // w x y z
+  std::array<double, 3> velocity{{0, 0, 0}};
+  Pose ToRigid() const { return Pose{{translation[0], translation[1], translation[2], rotation[0], rotation[1], rotation[2], rotation[3]}}; }
+};
+
+class OptimizingLocalTrajectoryBuilder {
+ public:
+  enum ControlPointSampling { CONSTANT = 0, SYNCED_WITH_RANGE_DATA = 1, ADAPTIVE = 2 };
+  struct AdaptiveVoxelFilterOptions { float max_length, min_num_points, max_range; };
+  struct Options {
+    // TRAJECTORY_BUILDER_3D (trajectory_builder_3d.lua:18-31,56-60)
+    float min_range = 1.f, max_range = 60.f;
+    int num_accumulated_range_data = 1;
+    float voxel_filter_size = 0.15f;
+    AdaptiveVoxelFilterOptions high_resolution_adaptive_voxel_filter{2.f, 150.f, 15.f};
+    AdaptiveVoxelFilterOptions low_resolution_adaptive_voxel_filter{4.f, 200.f, 60.f};
+    int max_num_iterations = 12;  // ceres_scan_matcher.ceres_solver_options
+    double motion_filter_max_time_seconds = 0.5, motion_filter_max_distance_meters = 0.1, motion_filter_max_angle_radians = 0.004;
+    ActiveSubmaps3D::Options submaps;  // grid_type = "TSDF"; the low-resolution inserter defaults are set below
+    // optimizing_local_trajectory_builder (:120-146)
+    double high_resolution_grid_weight = 1, low_resolution_grid_weight = 1;
+    double velocity_weight = 1, translation_weight = 1, rotation_weight = 1;
+    double odometry_translation_weight = 1, odometry_rotation_weight = 1;
+    double ct_window_horizon = 0.9, ct_window_rate = 0.1;
+    double initialization_duration = 3.0;
+    bool use_adaptive_odometry_weights = true;
+    bool use_per_point_unwarping = false;
+    bool use_multi_resolution_matching = false;
+    int num_points_per_subdivision = 4;
+    ControlPointSampling control_point_sampling = CONSTANT;
+    double sampling_max_delta_translation = 0.2, sampling_max_delta_rotation = 0.1;
+    double sampling_min_delta_time = 0.025, sampling_max_delta_time = 0.25;
+    bool velocity_in_state = true;
+    double odometry_translation_normalization = 2.0e-2, odometry_rotation_normalization = 1.0e-1;
+    // initialize_map_orientation_with_imu: the first control point's orientation is what the pose extrapolator's
+    // EstimateGravityOrientation returns (:271-276); the extrapolator stays with the caller, who hands it in
+    std::array<double, 4> initial_orientation{{1, 0, 0, 0}};
+    int insert_mode = HG_INSERT_EXACT;
+    Options() { submaps.low_resolution_inserter = DefaultLowResolutionTSDFInserterOptions(); }
+  };
+  struct ControlPoint {
+    common::Time time;
+    State state;
+    double dT, dR, dt;  // sampling ratios of the ADAPTIVE mode (diagnostic, as in the reference)
+  };
+  struct InsertionResult {
+    std::vector<Point> high_resolution_point_cloud, low_resolution_point_cloud;  // TrajectoryNode::Data (tracking frame)
+    std::vector<std::shared_ptr<Submap3D>> insertion_submaps;
+  };
+  struct MatchingResult {
+    common::Time time;
+    Pose local_pose;
+    sensor::RangeData range_data_in_local;
+    std::unique_ptr<const InsertionResult> insertion_result;
+  };
+
+  OptimizingLocalTrajectoryBuilder(Context* ctx, const Options& options)
+      : ctx_(ctx), options_(options), active_submaps_(ctx, options.submaps),
+        ct_window_horizon_(common::FromSeconds(options.ct_window_horizon)),
+        ct_window_rate_(common::FromSeconds(options.ct_window_rate)),
+        initialization_duration_(common::FromSeconds(options.initialization_duration)) {
+    Check(hg_problem_create(ctx->get(), &problem_), "hg_problem_create");
+    hg_solver_default_opts(&solver_);
+    solver_.max_num_iterations = options.max_num_iterations;
+  }
+  ~OptimizingLocalTrajectoryBuilder() { if (problem_) hg_problem_destroy(problem_); }
+  OptimizingLocalTrajectoryBuilder(const OptimizingLocalTrajectoryBuilder&) = delete;
+  OptimizingLocalTrajectoryBuilder& operator=(const OptimizingLocalTrajectoryBuilder&) = delete;
+
+  void AddImuData(const sensor::ImuData& imu_data) {  // (:153-168)
+    if (!have_imu_) {
+      initial_data_time_ = imu_data.time;
+      have_imu_ = true;
+    }
+    imu_data_.push_back(imu_data);
+  }
+  void AddOdometryData(const sensor::OdometryData& odometry_data) {  // (:170-186)
+    if (!have_imu_) return;                                          // "IMU not yet initialized."
+    if (!imu_data_.empty() && imu_data_.front().time >= odometry_data.time) return;  // dropped to maintain IMU consistency
+    odometer_data_.push_back(odometry_data);
+  }
+  void SetMapUpdateEnabled(bool enabled) { map_update_enabled_ = enabled; }
+  void UseScanMatching(bool use) { use_scan_matching_ = use; }
+
+  std::unique_ptr<MatchingResult> AddRangeData(const std::string& /*sensor_id*/,
+                                               const sensor::TimedPointCloudData& range_data_in_tracking) {  // (:188-264)
+    if (range_data_in_tracking.ranges.empty()) throw Error("AddRangeData: empty cloud", HG_ERR_INVALID);  // CHECK_GT(size, 0)
+    if (!have_imu_ || odometer_data_.empty()) return nullptr;
+    PointCloudSet set;
+    set.time = range_data_in_tracking.time;
+    set.origin = range_data_in_tracking.origin;
+    set.original_cloud = range_data_in_tracking.ranges;
+    set.width = range_data_in_tracking.width;
+    set.min_point_timestamp = std::numeric_limits<float>::max();
+    set.max_point_timestamp = std::numeric_limits<float>::min();  // (sic: the smallest positive float, :213)
+    for (const auto& hit : range_data_in_tracking.ranges) {
+      if (std::isnan(hit[0]) || std::isnan(hit[1]) || std::isnan(hit[2])) continue;
+      const float dx = hit[0] - set.origin[0], dy = hit[1] - set.origin[1], dz = hit[2] - set.origin[2];
+      const float range = std::sqrt(dx * dx + (dy * dy + dz * dz));  // Eigen's 3-term reduction x0 + (x1 + x2)
+      if (range >= options_.min_range && range <= options_.max_range) {
+        set.points.push_back(hit);
+        if (hit[3] > set.max_point_timestamp) set.max_point_timestamp = hit[3];
+        if (hit[3] < set.min_point_timestamp) set.min_point_timestamp = hit[3];
+      }
+    }
+    if (initial_data_time_ > set.StartTime()) return nullptr;           // "Not enough data, skipping this cloud."
+    if (odometer_data_.front().time > set.StartTime()) return nullptr;  // "Not enough odom data, ..."
+    AdaptiveVoxelFilterOptions high = options_.high_resolution_adaptive_voxel_filter;
+    high.min_num_points = high.min_num_points / options_.num_accumulated_range_data;
+    AdaptiveFilter(high, set.points, &set.high_resolution_filtered_points, &set.high_resolution_filtered_times);
+    AdaptiveVoxelFilterOptions low = options_.low_resolution_adaptive_voxel_filter;
+    low.min_num_points = low.min_num_points / options_.num_accumulated_range_data;
+    AdaptiveFilter(low, set.points, &set.low_resolution_filtered_points, &set.low_resolution_filtered_times);
+    point_cloud_data_.push_back(std::move(set));
+    return MaybeOptimize(range_data_in_tracking.time);
+  }
+
+  // ---- what the parity tests and a curious host look at ----
+  const std::deque<ControlPoint>& control_points() const { return control_points_; }
+  size_t num_queued_clouds() const { return point_cloud_data_.size(); }
+  const hg_solver_summary& last_summary() const { return last_summary_; }
+  int num_optimizations() const { return num_optimizations_; }
+  int num_insertions() const { return num_insertions_; }
+  // the TSDF blocks of the last solve: {cloud size, control point a, control point b or -1, interpolation factor, level set}
+  struct BlockInfo { size_t points; int pose_a, pose_b; double factor; int grid; };  // grid: 0 high, 1 low, 2 pyramid
+  const std::vector<BlockInfo>& last_blocks() const { return last_blocks_; }
+  int last_num_residuals() const { return last_num_residuals_; }  // of the last solve: TSDF returns + 9 per IMU + 6 per odometry block
+  int last_odometry_blocks() const { return last_odometry_blocks_; }
+  int last_imu_blocks() const { return last_imu_blocks_; }
+  const ActiveSubmaps3D& active_submaps() const { return active_submaps_; }
+
+ private:
+  struct PointCloudSet {  // (optimizing_local_trajectory_builder.h:96-116)
+    common::Time time;
+    Point origin;
+    std::vector<std::array<float, 4>> points, original_cloud;
+    std::vector<Point> high_resolution_filtered_points, low_resolution_filtered_points;  // positions (what the matching reads)
+    std::vector<float> high_resolution_filtered_times, low_resolution_filtered_times;     // their TimedRangefinderPoint::time
+    size_t width;
+    float min_point_timestamp, max_point_timestamp;
+    common::Time StartTime() const { return time + common::FromSeconds(min_point_timestamp); }
+    common::Time EndTime() const { return time + common::FromSeconds(max_point_timestamp); }
+  };
+
+  // sensor::AdaptiveVoxelFilter(options).Filter(TimedPointCloud) on the device
+  void AdaptiveFilter(const AdaptiveVoxelFilterOptions& o, const std::vector<std::array<float, 4>>& cloud,
+                      std::vector<Point>* xyz, std::vector<float>* times) const {
+    xyz->clear();
+    times->clear();
+    if (cloud.empty()) return;
+    std::vector<uint32_t> keep(cloud.size());
+    size_t n = 0;
+    Check(hg_adaptive_voxel_filter(ctx_->get(), o.max_length, o.min_num_points, o.max_range, cloud[0].data(), cloud.size(), 4,
+                                   HG_HOST, keep.data(), &n), "hg_adaptive_voxel_filter");
+    xyz->resize(n);
+    times->resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      (*xyz)[i] = Point{{cloud[keep[i]][0], cloud[keep[i]][1], cloud[keep[i]][2]}};
+      (*times)[i] = cloud[keep[i]][3];
+    }
+  }
+
+  transform::TransformInterpolationBuffer OdometryBuffer() const {
+    transform::TransformInterpolationBuffer buffer;
+    for (const auto& o : odometer_data_) buffer.Push(o.time, o.pose);
+    return buffer;
+  }
+
+  // PredictState = PredictStateOdom (:1516-1521, :1596-1656): the odometry delta between the two times, applied as the
+  // reference applies it (delta = current^-1 * previous, sic)
+  State PredictStateOdom(const State& start_state, common::Time start_time, common::Time end_time) const {
+    {  // (:1599-1603: the walk back through the IMU queue only CHECKs that a sample at or before start_time exists)
+      size_t it = imu_data_.size() - 1;
+      while (imu_data_[it].time > start_time) {
+        if (it == 0) throw Error("PredictStateOdom: no IMU sample at or before the start time", HG_ERR_TIME);
+        --it;
+      }
+    }
+    const transform::TransformInterpolationBuffer buffer = OdometryBuffer();
+    const common::Time earliest = buffer.earliest_time(), latest = buffer.latest_time();
+    auto lookup = [&](common::Time t) {
+      if (buffer.Has(t)) return buffer.Lookup(t);
+      return t < earliest ? buffer.Lookup(earliest) : buffer.Lookup(latest);
+    };
+    const Pose previous = lookup(start_time), current = lookup(end_time);
+    const Pose delta = transform::Multiply(transform::Inverse(current), previous);
+    const double delta_time_seconds = common::ToSeconds(end_time - start_time);
+    State out;
+    for (int k = 0; k < 3; ++k) {
+      out.translation[k] = start_state.translation[k] + delta[k];
+      out.velocity[k] = (1.0 / delta_time_seconds) * delta[k];
+    }
+    // start_rotation * delta_pose.rotation(): a plain quaternion product (no normalisation)
+    const double w = start_state.rotation[0], x = start_state.rotation[1], y = start_state.rotation[2], z = start_state.rotation[3];
+    out.rotation = {{w * delta[3] - x * delta[4] - y * delta[5] - z * delta[6], w * delta[4] + x * delta[3] + y * delta[6] - z * delta[5],
+                     w * delta[5] + y * delta[3] + z * delta[4] - x * delta[6], w * delta[6] + z * delta[3] + x * delta[5] - y * delta[4]}};
+    return out;
+  }
+
+  void AddControlPoint(common::Time t, double dT = 0.0, double dR = 0.0, double dt = 0.0) {  // (:266-321)
+    ControlPoint cp{t, State(), dT, dR, dt};
+    if (control_points_.empty()) {
+      cp.state.rotation = options_.initial_orientation;
+    } else if (active_submaps_.submaps().empty()) {
+      cp.state = control_points_.back().state;
+    } else {
+      cp.state = PredictStateOdom(control_points_.back().state, control_points_.back().time, t);
+    }
+    control_points_.push_back(cp);
+  }
+
+  void TransformStates(const Pose& transform) {  // (:1097-1111)
+    const std::array<double, 4> q{{transform[3], transform[4], transform[5], transform[6]}};
+    for (ControlPoint& cp : control_points_) {
+      const Pose np = transform::Multiply(transform, cp.state.ToRigid());
+      const std::array<double, 3> nv = transform::Rotate(q, cp.state.velocity);
+      cp.state.translation = {{np[0], np[1], np[2]}};
+      cp.state.rotation = {{np[3], np[4], np[5], np[6]}};
+      cp.state.velocity = nv;
+    }
+  }
+
+  void RemoveObsoleteSensorData() {  // (:1076-1095)
+    if (control_points_.empty()) return;
+    while (!point_cloud_data_.empty() && control_points_.size() > 1 &&
+           ct_window_horizon_ < control_points_.back().time - control_points_.front().time &&
+           control_points_[1].time < point_cloud_data_.front().StartTime())
+      control_points_.pop_front();
+    while (imu_data_.size() > 1 && imu_data_[1].time <= control_points_.front().time) imu_data_.pop_front();
+    while (odometer_data_.size() > 1 && odometer_data_[1].time <= control_points_.front().time) odometer_data_.pop_front();
+  }
+
+  // ---- the residual blocks of one solve ----
+  void AddScanBlock(const std::vector<Point>& cloud, hg_grid* const* grids, int levels, bool multi_res, double weight,
+                    int a, int b, double factor, int grid_tag) {
+    Check(hg_problem_add_block(problem_, cloud[0].data(), cloud.size(), HG_HOST, grids, levels, multi_res ? 1 : 0,
+                               weight / std::sqrt(static_cast<double>(cloud.size())), a, b, factor), "hg_problem_add_block");
+    last_blocks_.push_back(BlockInfo{cloud.size(), a, b, factor, grid_tag});
+  }
+  void AddPerScanMatchingResiduals(Submap3D* matching_submap) {  // (:323-511)
+    hg_grid* high = matching_submap->high_resolution_hybrid_grid().get();
+    hg_grid* low = matching_submap->low_resolution_hybrid_grid().get();
+    hg_grid* pyramid[2] = {high, low};
+    size_t next = 0;
+    for (const PointCloudSet& set : point_cloud_data_) {
+      if (set.time > control_points_.back().time) break;
+      while (control_points_[next].time <= set.time) {
+        if (next + 1 == control_points_.size()) break;
+        ++next;
+      }
+      if (next == 0 || !(control_points_[next - 1].time <= set.time && control_points_[next].time >= set.time))
+        throw Error("AddPerScanMatchingResiduals: a cloud lies outside the control points", HG_ERR_TIME);  // CHECKs :335-337
+      const int a = static_cast<int>(next) - 1, b = static_cast<int>(next);
+      const double duration = common::ToSeconds(control_points_[next].time - control_points_[next - 1].time);
+      const double factor = common::ToSeconds(set.time - control_points_[next - 1].time) / duration;
+      if (options_.use_multi_resolution_matching) {
+        if (options_.high_resolution_grid_weight > 0.0 && !set.high_resolution_filtered_points.empty()) {
+          if (factor == 0.0 || factor == 1.0)
+            AddScanBlock(set.high_resolution_filtered_points, pyramid, 2, true, options_.high_resolution_grid_weight,
+                         factor == 0.0 ? a : b, -1, 0.0, 2);
+          else
+            AddScanBlock(set.high_resolution_filtered_points, pyramid, 2, true, options_.high_resolution_grid_weight, a, b, factor, 2);
+        }
+        continue;
+      }
+      const bool on_prev = control_points_[next - 1].time == set.time, on_next = control_points_[next].time == set.time;
+      if (options_.high_resolution_grid_weight > 0.0 && !set.high_resolution_filtered_points.empty()) {
+        if (on_prev) AddScanBlock(set.high_resolution_filtered_points, &high, 1, false, options_.high_resolution_grid_weight, a, -1, 0.0, 0);
+        else if (on_next) AddScanBlock(set.high_resolution_filtered_points, &high, 1, false, options_.high_resolution_grid_weight, b, -1, 0.0, 0);
+        else AddScanBlock(set.high_resolution_filtered_points, &high, 1, false, options_.high_resolution_grid_weight, a, b, factor, 0);
+      }
+      if (options_.low_resolution_grid_weight > 0.0 && !set.low_resolution_filtered_points.empty()) {
+        if (on_prev) AddScanBlock(set.low_resolution_filtered_points, &low, 1, false, options_.low_resolution_grid_weight, a, -1, 0.0, 1);
+        else if (on_next) AddScanBlock(set.low_resolution_filtered_points, &low, 1, false, options_.low_resolution_grid_weight, b, -1, 0.0, 1);
+        else AddScanBlock(set.low_resolution_filtered_points, &low, 1, false, options_.low_resolution_grid_weight, a, b, factor, 1);
+      }
+    }
+  }
+  // use_per_point_unwarping (:513-683): the high-resolution cloud in subdivisions of num_points_per_subdivision returns,
+  // each interpolated at its own time (on the pyramid, or on the high-resolution grid); without the pyramid the
+  // low-resolution cloud as well, return by return on the low-resolution grid (:622-683)
+  void AddPerPointResiduals(Submap3D* matching_submap) {
+    hg_grid* high = matching_submap->high_resolution_hybrid_grid().get();
+    hg_grid* low = matching_submap->low_resolution_hybrid_grid().get();
+    hg_grid* pyramid[2] = {high, low};
+    std::vector<int> ids(control_points_.size());
+    std::vector<int64_t> times(control_points_.size());
+    for (size_t i = 0; i < control_points_.size(); ++i) { ids[i] = static_cast<int>(i); times[i] = control_points_[i].time; }
+    for (const PointCloudSet& set : point_cloud_data_) {
+      if (set.high_resolution_filtered_points.empty()) continue;
+      if (options_.use_multi_resolution_matching)
+        scan_matching::AddPerPointMatchingResiduals(problem_, ids, times, set.time, set.high_resolution_filtered_points,
+                                                    set.high_resolution_filtered_times, pyramid, 2, true,
+                                                    options_.high_resolution_grid_weight, options_.num_points_per_subdivision);
+      else
+        scan_matching::AddPerPointMatchingResiduals(problem_, ids, times, set.time, set.high_resolution_filtered_points,
+                                                    set.high_resolution_filtered_times, &high, 1, false,
+                                                    options_.high_resolution_grid_weight, options_.num_points_per_subdivision);
+    }
+    if (!options_.use_multi_resolution_matching && options_.low_resolution_grid_weight > 0)
+      for (const PointCloudSet& set : point_cloud_data_) {
+        if (set.low_resolution_filtered_points.empty()) continue;
+        scan_matching::AddPerPointMatchingResiduals(problem_, ids, times, set.time, set.low_resolution_filtered_points,
+                                                    set.low_resolution_filtered_times, &low, 1, false,
+                                                    options_.low_resolution_grid_weight, 1);
+      }
+  }
+  void AddIMUResiduals() {  // (:928-1007), imu_cost_term = PREINTEGRATION
+    last_imu_blocks_ = 0;
+    if (options_.translation_weight == 0.0 && options_.velocity_weight == 0.0 && options_.rotation_weight == 0.0) return;
+    if (!options_.velocity_in_state) throw Error("IMU residuals require velocity_in_state", HG_ERR_INVALID);  // CHECK :937
+    {  // (:971-975) a sample at or before the first control point must exist
+      size_t it = imu_data_.size() - 1;
+      while (imu_data_[it].time > control_points_.front().time) {
+        if (it == 0) throw Error("AddIMUResiduals: no IMU sample at or before the first control point", HG_ERR_TIME);
+        --it;
+      }
+    }
+    for (size_t i = 1; i < control_points_.size(); ++i) {
+      const std::array<double, 4> dq = IntegrateImuDeltaRotation(imu_data_, control_points_[i - 1].time, control_points_[i].time);
+      Check(hg_problem_add_imu_block(problem_, static_cast<int>(i) - 1, static_cast<int>(i), options_.translation_weight,
+                                     options_.velocity_weight, options_.rotation_weight,
+                                     common::ToSeconds(control_points_[i].time - control_points_[i - 1].time), dq.data()),
+            "hg_problem_add_imu_block");
+      ++last_imu_blocks_;
+    }
+  }
+  void AddOdometryResiduals() {  // (:1009-1074)
+    last_odometry_blocks_ = 0;
+    if (odometer_data_.size() <= 1) return;
+    const transform::TransformInterpolationBuffer buffer = OdometryBuffer();
+    for (size_t i = 1; i < control_points_.size(); ++i) {
+      if (!(buffer.earliest_time() <= control_points_[i - 1].time && control_points_[i].time <= buffer.latest_time())) continue;
+      const Pose previous = buffer.Lookup(control_points_[i - 1].time), current = buffer.Lookup(control_points_[i].time);
+      const Pose delta = transform::Multiply(transform::Inverse(current), previous);
+      const double delta_time = common::ToSeconds(control_points_[i].time - control_points_[i - 1].time);
+      double translation_weight = options_.odometry_translation_weight, rotation_weight = options_.odometry_rotation_weight;
+      if (options_.use_adaptive_odometry_weights) {
+        const double translation_distance = std::abs(std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]));
+        const double rotation_distance = std::abs(transform::GetAngle(delta));  // angularDistance(Identity)
+        translation_weight = options_.odometry_translation_weight /
+                             std::sqrt(translation_distance + options_.odometry_translation_normalization * delta_time);
+        rotation_weight = options_.odometry_rotation_weight /
+                          std::sqrt(rotation_distance + options_.odometry_rotation_normalization * delta_time);
+      }
+      Check(hg_problem_add_odometry_block(problem_, static_cast<int>(i) - 1, static_cast<int>(i), translation_weight,
+                                          rotation_weight, delta.data()), "hg_problem_add_odometry_block");
+      ++last_odometry_blocks_;
+    }
+  }
+
+  std::unique_ptr<MatchingResult> MaybeOptimize(common::Time time) {  // (:1113-1413)
+    if (time - initial_data_time_ < initialization_duration_) return nullptr;
+    if (odometer_data_.size() < 2) return nullptr;
+    if (control_points_.empty()) AddControlPoint(std::max(initial_data_time_, odometer_data_.front().time));
+    bool added_control_point = false;
+    switch (options_.control_point_sampling) {
+      case CONSTANT:
+        while (control_points_.back().time + ct_window_rate_ < odometer_data_.back().time) {
+          AddControlPoint(control_points_.back().time + ct_window_rate_);
+          added_control_point = true;
+        }
+        break;
+      case SYNCED_WITH_RANGE_DATA:
+        for (const PointCloudSet& set : point_cloud_data_)
+          if (control_points_.back().time < set.time && set.time < imu_data_.back().time) {
+            AddControlPoint(set.time);
+            added_control_point = true;
+          }
+        break;
+      case ADAPTIVE: {
+        const transform::TransformInterpolationBuffer buffer = OdometryBuffer();
+        common::Time candidate_time = control_points_.back().time;
+        while (candidate_time < buffer.latest_time()) {
+          double translation_ratio = 0.0, rotation_ratio = 0.0, time_ratio = 0.0;
+          candidate_time = buffer.LookupUntilDelta(control_points_.back().time, options_.sampling_max_delta_translation,
+                                                   options_.sampling_max_delta_rotation, options_.sampling_max_delta_time,
+                                                   &translation_ratio, &rotation_ratio, &time_ratio);
+          if (common::ToSeconds(candidate_time - control_points_.back().time) < options_.sampling_min_delta_time)
+            candidate_time = control_points_.back().time + common::FromSeconds(options_.sampling_min_delta_time);
+          if (candidate_time < buffer.latest_time()) {
+            AddControlPoint(candidate_time, translation_ratio, rotation_ratio, time_ratio);
+            added_control_point = true;
+          }
+        }
+        break;
+      }
+    }
+    if (!added_control_point) return nullptr;
+
+    if (!active_submaps_.submaps().empty()) {
+      Submap3D* matching_submap = active_submaps_.submaps().front().get();
+      const Pose inv = transform::Inverse(matching_submap->local_pose());
+      // "We assume the map is always aligned with the direction of gravity" (:1243-1244, isApprox(Identity, 1e-8))
+      if (!(std::abs(std::abs(inv[3]) - 1.0) < 1e-8)) throw Error("matching submap is rotated against the local frame", HG_ERR_UNSUPPORTED);
+      TransformStates(inv);
+      Check(hg_problem_reset(problem_), "hg_problem_reset");
+      last_blocks_.clear();
+      for (size_t i = 0; i < control_points_.size(); ++i) {
+        const bool constant = i == 0;  // (:1268-1275)
+        const Pose p = control_points_[i].state.ToRigid();
+        Check(hg_problem_add_pose(problem_, p.data(), constant), "hg_problem_add_pose");
+        if (options_.velocity_in_state)
+          Check(hg_problem_set_velocity(problem_, static_cast<int>(i), control_points_[i].state.velocity.data(), constant),
+                "hg_problem_set_velocity");
+      }
+      if (use_scan_matching_) {
+        if (options_.use_per_point_unwarping) AddPerPointResiduals(matching_submap);
+        else AddPerScanMatchingResiduals(matching_submap);
+      }
+      AddIMUResiduals();
+      AddOdometryResiduals();
+      last_num_residuals_ = hg_problem_num_residuals(problem_);
+      Check(hg_problem_solve(problem_, &solver_, &last_summary_), "hg_problem_solve");
+      ++num_optimizations_;
+      for (size_t i = 0; i < control_points_.size(); ++i) {
+        Pose p;
+        Check(hg_problem_get_pose(problem_, static_cast<int>(i), p.data()), "hg_problem_get_pose");
+        control_points_[i].state.translation = {{p[0], p[1], p[2]}};
+        control_points_[i].state.rotation = {{p[3], p[4], p[5], p[6]}};
+        if (options_.velocity_in_state)
+          Check(hg_problem_get_velocity(problem_, static_cast<int>(i), control_points_[i].state.velocity.data()), "hg_problem_get_velocity");
+      }
+      TransformStates(matching_submap->local_pose());
+    }
+
+    const Pose optimized_pose = control_points_.front().state.ToRigid();
+    const common::Time time_optimized_pose = control_points_.front().time;
+    const Pose optimized_inverse = transform::Inverse(optimized_pose);
+    sensor::RangeData accumulated;  // accumulated_range_data_in_tracking
+    accumulated.width = point_cloud_data_.front().width;
+    if (active_submaps_.submaps().empty()) {
+      // "To initialize the empty map we add all available range data assuming zero motion." (:1301-1330; the clouds stay queued)
+      size_t it = 0;
+      for (const PointCloudSet& set : point_cloud_data_) {
+        if (!(set.time < control_points_.back().time)) continue;
+        while (control_points_[it].time <= set.time) ++it;
+        if (it == 0 || it >= control_points_.size()) throw Error("initialisation: a cloud lies outside the control points", HG_ERR_TIME);
+        const Pose cloud_pose = transform::InterpolateTransform(control_points_[it - 1].state.ToRigid(), control_points_[it].state.ToRigid(),
+                                                                control_points_[it - 1].time, control_points_[it].time, set.time);
+        const std::array<float, 7> tf = transform::ToFloat(transform::Multiply(optimized_inverse, cloud_pose));
+        for (const auto& p : set.original_cloud) accumulated.returns.push_back(transform::TransformPoint(tf, Point{{p[0], p[1], p[2]}}));
+        accumulated.origin = transform::TransformPoint(tf, set.origin);
+      }
+    } else if (options_.use_per_point_unwarping) {
+      return UnwarpAndInsert(time_optimized_pose, optimized_pose);
+    } else {
+      if (!(control_points_.front().time <= point_cloud_data_.front().time))
+        throw Error("the oldest cloud is older than the window", HG_ERR_TIME);  // CHECK :1381
+      while (!point_cloud_data_.empty() &&
+             ct_window_horizon_ - ct_window_rate_ < control_points_.back().time - point_cloud_data_.front().time) {
+        while (control_points_[1].time < point_cloud_data_.front().time) control_points_.pop_front();
+        const Pose cloud_pose = transform::InterpolateTransform(control_points_[0].state.ToRigid(), control_points_[1].state.ToRigid(),
+                                                                control_points_[0].time, control_points_[1].time,
+                                                                point_cloud_data_.front().time);
+        const std::array<float, 7> tf = transform::ToFloat(transform::Multiply(optimized_inverse, cloud_pose));
+        for (const auto& p : point_cloud_data_.front().points)
+          accumulated.returns.push_back(transform::TransformPoint(tf, Point{{p[0], p[1], p[2]}}));
+        accumulated.origin = transform::TransformPoint(tf, point_cloud_data_.front().origin);
+        point_cloud_data_.pop_front();
+      }
+    }
+    RemoveObsoleteSensorData();
+    return AddAccumulatedRangeData(time_optimized_pose, optimized_pose, accumulated);
+  }
+
+  // (:1415-1470) voxel filter and adaptive filters for the trajectory node, range data to the local frame, insertion
+  std::unique_ptr<MatchingResult> AddAccumulatedRangeData(common::Time time, const Pose& optimized_pose,
+                                                          const sensor::RangeData& range_data_in_tracking) {
+    if (range_data_in_tracking.returns.empty()) return nullptr;
+    const std::vector<Point> filtered = sensor::VoxelFilter(ctx_, options_.voxel_filter_size).Filter(range_data_in_tracking.returns);
+    if (filtered.empty()) return nullptr;
+    std::unique_ptr<MatchingResult> result(new MatchingResult);
+    result->time = time;
+    result->local_pose = optimized_pose;
+    const std::array<float, 7> to_local = transform::ToFloat(optimized_pose);  // TransformTimedRangeData(range_data_in_tracking, ...): unfiltered
+    result->range_data_in_local.width = range_data_in_tracking.width;
+    result->range_data_in_local.origin = transform::TransformPoint(to_local, range_data_in_tracking.origin);
+    result->range_data_in_local.returns.reserve(range_data_in_tracking.returns.size());
+    for (const Point& p : range_data_in_tracking.returns) result->range_data_in_local.returns.push_back(transform::TransformPoint(to_local, p));
+    std::unique_ptr<InsertionResult> insertion(new InsertionResult);
+    {
+      const AdaptiveVoxelFilterOptions& h = options_.high_resolution_adaptive_voxel_filter;
+      insertion->high_resolution_point_cloud = sensor::AdaptiveVoxelFilter(ctx_, h.max_length, h.min_num_points, h.max_range).Filter(filtered);
+      if (insertion->high_resolution_point_cloud.empty()) return nullptr;  // "Dropped empty high resolution point cloud data."
+      const AdaptiveVoxelFilterOptions& l = options_.low_resolution_adaptive_voxel_filter;
+      insertion->low_resolution_point_cloud = sensor::AdaptiveVoxelFilter(ctx_, l.max_length, l.min_num_points, l.max_range).Filter(filtered);
+      if (insertion->low_resolution_point_cloud.empty()) return nullptr;
+    }
+    // InsertIntoSubmap (:1472-1514)
+    if (MotionFilterIsSimilar(time, optimized_pose)) return result;  // insertion_result stays null
+    // gravity_alignment = optimized_pose.rotation(); local_from_gravity_aligned = pose.rotation() * gravity_alignment.inverse()
+    const Pose rot{{0, 0, 0, optimized_pose[3], optimized_pose[4], optimized_pose[5], optimized_pose[6]}};
+    const Pose lfg = transform::Multiply(rot, transform::Inverse(rot));
+    if (map_update_enabled_) active_submaps_.InsertData(result->range_data_in_local, {{lfg[3], lfg[4], lfg[5], lfg[6]}});
+    ++num_insertions_;
+    insertion->insertion_submaps = active_submaps_.submaps();
+    result->insertion_result = std::move(insertion);
+    return result;
+  }
+
+  // use_per_point_unwarping (:1331-1379): the clouds that leave are unwarped return by return on the device with the
+  // window's control poses and go into every live submap from there (no host copy of the unwarped cloud)
+  std::unique_ptr<MatchingResult> UnwarpAndInsert(common::Time time, const Pose& optimized_pose) {
+    if (!(control_points_.front().time <= point_cloud_data_.front().StartTime()))
+      throw Error("the oldest cloud starts before the window", HG_ERR_TIME);  // CHECK :1333-1334
+    std::vector<hg_timed_cloud> table;
+    std::vector<float> points;
+    size_t width = point_cloud_data_.front().width;
+    while (!point_cloud_data_.empty() && ct_window_horizon_ < control_points_.back().time - point_cloud_data_.front().StartTime() &&
+           control_points_.back().time > point_cloud_data_.front().EndTime()) {
+      const PointCloudSet& set = point_cloud_data_.front();
+      hg_timed_cloud t{};
+      t.time = set.time;
+      t.begin = points.size() / 4;
+      t.count = set.points.size();
+      for (int k = 0; k < 3; ++k) t.origin[k] = set.origin[k];
+      table.push_back(t);
+      for (const auto& p : set.points) points.insert(points.end(), p.begin(), p.end());
+      point_cloud_data_.pop_front();
+    }
+    std::vector<double> poses;
+    std::vector<int64_t> times;
+    for (const ControlPoint& cp : control_points_) {
+      const Pose p = cp.state.ToRigid();
+      poses.insert(poses.end(), p.begin(), p.end());
+      times.push_back(cp.time);
+    }
+    RemoveObsoleteSensorData();
+    if (points.empty()) return nullptr;
+    std::unique_ptr<MatchingResult> result(new MatchingResult);
+    result->time = time;
+    result->local_pose = optimized_pose;
+    if (MotionFilterIsSimilar(time, optimized_pose) || !map_update_enabled_) return result;
+    // frame 1 = range_data_in_local on the device; every live submap then takes it with its own frame change
+    result->range_data_in_local.returns.resize(points.size() / 4);
+    Check(hg_unwarp_range_data(ctx_->get(), points.data(), points.size() / 4, HG_HOST, table.data(), static_cast<int>(table.size()),
+                               poses.data(), times.data(), static_cast<int>(times.size()), 1, nullptr,
+                               result->range_data_in_local.returns[0].data(), result->range_data_in_local.origin.data()),
+          "hg_unwarp_range_data");
+    result->range_data_in_local.width = width;
+    const Pose rot{{0, 0, 0, optimized_pose[3], optimized_pose[4], optimized_pose[5], optimized_pose[6]}};
+    const Pose lfg = transform::Multiply(rot, transform::Inverse(rot));
+    active_submaps_.InsertData(result->range_data_in_local, {{lfg[3], lfg[4], lfg[5], lfg[6]}});
+    ++num_insertions_;
+    std::unique_ptr<InsertionResult> insertion(new InsertionResult);
+    insertion->insertion_submaps = active_submaps_.submaps();
+    result->insertion_result = std::move(insertion);
+    return result;
+  }
+
+  bool MotionFilterIsSimilar(common::Time time, const Pose& pose) {  // (mapping/internal/motion_filter.cc:40-58)
+    ++motion_total_;
+    if (motion_total_ > 1 && time - motion_last_time_ <= common::FromSeconds(options_.motion_filter_max_time_seconds)) {
+      const double dx = pose[0] - motion_last_pose_[0], dy = pose[1] - motion_last_pose_[1], dz = pose[2] - motion_last_pose_[2];
+      if (std::sqrt(dx * dx + dy * dy + dz * dz) <= options_.motion_filter_max_distance_meters &&
+          transform::GetAngle(transform::Multiply(transform::Inverse(pose), motion_last_pose_)) <= options_.motion_filter_max_angle_radians)
+        return true;
+    }
+    motion_last_time_ = time;
+    motion_last_pose_ = pose;
+    return false;
+  }
+
+  Context* ctx_;
+  Options options_;
+  ActiveSubmaps3D active_submaps_;
+  common::Duration ct_window_horizon_, ct_window_rate_, initialization_duration_;
+  hg_problem* problem_ = nullptr;
+  hg_solver_opts solver_;
+  hg_solver_summary last_summary_{};
+  common::Time initial_data_time_ = 0;
+  bool have_imu_ = false, map_update_enabled_ = true, use_scan_matching_ = true;
+  std::deque<sensor::ImuData> imu_data_;
+  std::deque<sensor::OdometryData> odometer_data_;
+  std::deque<PointCloudSet> point_cloud_data_;
+  std::deque<ControlPoint> control_points_;
+  std::vector<BlockInfo> last_blocks_;
+  int last_odometry_blocks_ = 0, last_imu_blocks_ = 0, last_num_residuals_ = 0, num_optimizations_ = 0, num_insertions_ = 0;
+  int motion_total_ = 0;
+  common::Time motion_last_time_ = 0;
+  Pose motion_last_pose_{{0, 0, 0, 1, 0, 0, 0}};
 };
 
 }  // namespace mapping

@@ -146,9 +146,9 @@ def _imu_delta_rotation(imu, start, end):
         it += 1
     cur = start
     while cur < end:
-        nxt_imu = imu[it + 1][0] if it + 1 < len(imu) else float("inf")
+        nxt_imu = imu[it + 1][0] if it + 1 < len(imu) else (1 << 62)
         nxt = min(nxt_imu, end)
-        a = np.asarray(imu[it][1]) * (nxt - cur)
+        a = np.asarray(imu[it][1]) * ((nxt - cur) / 1e7)   # common::ToSeconds of a tick difference
         sq = float(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
         scale, w = 0.5, 1.0
         if sq > 1e-8:
@@ -164,7 +164,8 @@ def _imu_delta_rotation(imu, start, end):
 
 
 def test_cpp_window_builder_against_oracle(tmp_path):
-    """The C++ OptimizingLocalTrajectoryBuilder-shaped adapter (cpp/hg_adapter.h) against the CPU oracle: the
+    """The simplified sliding-window builder of the adapter (cpp/hg_adapter.h: SlidingWindowTrajectoryBuilder, one
+    control point per scan; the reference's own shape is tested in tests/test_gpu_cpp_oltb.py) against the CPU oracle: the
     example dumps every input it feeds the adapter; this test states the window wiring a second time --
     range crop (oltb.cc:214-227), prediction from the odometry delta, first control point constant with its
     velocity (:1268-1275), IMU pre-integration blocks between neighbours (:928-1000), one multi-resolution scan
@@ -208,15 +209,16 @@ def test_cpp_window_builder_against_oracle(tmp_path):
     off += 4
     steps = []
     for _ in range(n_scans):
-        (t,) = struct.unpack_from("d", raw, off); off += 8
+        (t,) = struct.unpack_from("q", raw, off); off += 8   # common::Time ticks
         (n,) = struct.unpack_from("i", raw, off); off += 4
         pts = np.frombuffer(raw, np.float32, n * 4, off).reshape(n, 4).copy(); off += 16 * n
         odom = np.frombuffer(raw, np.float64, 7, off).copy(); off += 56
         (n_imu,) = struct.unpack_from("i", raw, off); off += 4
         imu = []
         for _ in range(n_imu):
-            vals = np.frombuffer(raw, np.float64, 4, off).copy(); off += 32
-            imu.append((float(vals[0]), vals[1:4]))
+            (ti,) = struct.unpack_from("q", raw, off); off += 8
+            vals = np.frombuffer(raw, np.float64, 3, off).copy(); off += 24
+            imu.append((int(ti), vals))
         steps.append((t, pts, odom, imu))
     # the window builder over the oracle (options of example_parity.cc)
     res = [0.10, 0.20]
@@ -234,7 +236,7 @@ def test_cpp_window_builder_against_oracle(tmp_path):
         else:
             cp["pose"] = _pose_mul(window[-1]["pose"], _pose_mul(_pose_inv(window[-1]["odom"]), odom))
             if t > window[-1]["time"]:
-                cp["vel"] = (cp["pose"][:3] - window[-1]["pose"][:3]) / (t - window[-1]["time"])
+                cp["vel"] = (cp["pose"][:3] - window[-1]["pose"][:3]) / ((t - window[-1]["time"]) / 1e7)
         window.append(cp)
         solved = 0
         if map_has_data:
@@ -245,7 +247,7 @@ def test_cpp_window_builder_against_oracle(tmp_path):
                 pr.set_velocity(i, c["vel"], first)
             for i in range(1, len(window)):
                 dq = _imu_delta_rotation(imu_all, window[i - 1]["time"], window[i]["time"])
-                pr.add_imu_block(i - 1, i, w_imu[0], w_imu[1], w_imu[2], window[i]["time"] - window[i - 1]["time"], dq)
+                pr.add_imu_block(i - 1, i, w_imu[0], w_imu[1], w_imu[2], (window[i]["time"] - window[i - 1]["time"]) / 1e7, dq)
             for i in range(1 if len(window) > 1 else 0, len(window)):
                 c = window[i]["cloud"]
                 pr.add_block(c, grids, 1.0 / np.sqrt(float(len(c))), i, multi_res=True)
@@ -312,18 +314,18 @@ def test_cpp_insert_unwarped_against_oracle(tmp_path):
     (n_cp,) = struct.unpack_from("i", raw, off); off += 4
     times, poses = [], []
     for _ in range(n_cp):
-        (t,) = struct.unpack_from("d", raw, off); off += 8
+        (t,) = struct.unpack_from("q", raw, off); off += 8   # common::Time ticks
         poses.append(np.frombuffer(raw, np.float64, 7, off).copy()); off += 56
-        times.append(int(t * 1e7))  # static_cast<int64_t>(seconds * 1e7), as the adapter
+        times.append(int(t))
     submap = np.frombuffer(raw, np.float32, 7, off).copy(); off += 28
     (n_clouds,) = struct.unpack_from("i", raw, off); off += 4
     clouds = []
     for _ in range(n_clouds):
-        (t,) = struct.unpack_from("d", raw, off); off += 8
+        (t,) = struct.unpack_from("q", raw, off); off += 8
         origin = np.frombuffer(raw, np.float32, 3, off).copy(); off += 12
         (n,) = struct.unpack_from("i", raw, off); off += 4
         pts = np.frombuffer(raw, np.float32, n * 4, off).reshape(n, 4).copy(); off += 16 * n
-        clouds.append((int(t * 1e7), origin, pts))
+        clouds.append((int(t), origin, pts))
     assert any(np.isnan(c[2][:, 1]).any() for c in clouds)
     poses = np.asarray(poses)
     xyz, origin, ok = po.unwarp_range_data(np.asarray(times, np.int64), poses, clouds)
