@@ -54,3 +54,54 @@ def test_subdivision_time_adds_the_two_point_times_in_float():
     subs = api.per_point_subdivisions(np.array([a, b], np.float32), t0, control, 2)
     want = api.to_seconds(t0 + as_float - control[0]) / api.to_seconds(control[1] - control[0])
     assert subs == [(0, 2, 0, 1, want)]
+
+
+def test_cpp_adapter_host_functions_against_oracle_and_python_statement():
+    """The host-only pieces of cpp/hg_adapter.h that the reference-shaped OptimizingLocalTrajectoryBuilder stands on
+    -- InterpolateTransform (timestamped_transform.h:41-65, Eigen slerp), TransformInterpolationBuffer::Lookup /
+    LookupUntilDelta (transform_interpolation_buffer.cc:55-125: the ADAPTIVE control-point sampling) and the
+    pre-integrated IMU rotation (imu_integration.h:99-131) -- against the oracle's InterpolateTransform (pinned by the
+    reference's own 21-factor test) and the Python statement of the same functions (tests/oltb_replay.py). No GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import pyoracle as po
+    import oltb_replay as rp
+    cpp = os.path.join(root, "hectorgrapher_amd", "cpp")
+    exe = os.path.join(cpp, "example_host_logic")
+    src = os.path.join(cpp, "example_host_logic.cc")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(cpp, "hg_adapter.h"))):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", src, "-L" + os.path.join(root, "hectorgrapher_amd"), "-lhg_mi355x",
+                               "-Wl,-rpath," + os.path.join(root, "hectorgrapher_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    odom, imu, lookups, untils, deltas = [], [], [], [], []
+    for line in out.stdout.splitlines():
+        f = line.split()
+        if f[0] == "odom":
+            odom.append((int(f[1]), np.array([float(x) for x in f[2:]])))
+        elif f[0] == "imu":
+            imu.append((int(f[1]), np.array([float(x) for x in f[2:]])))
+        elif f[0] == "lookup":
+            lookups.append((int(f[1]), np.array([float(x) for x in f[2:]])))
+        elif f[0] == "until":
+            untils.append((int(f[1]), [float(x) for x in f[2:5]], int(f[6]), [float(x) for x in f[7:10]]))
+        elif f[0] == "imu_delta":
+            deltas.append((int(f[1]), int(f[2]), np.array([float(x) for x in f[3:]])))
+    assert len(odom) == 40 and len(imu) == 80 and len(lookups) == 5 and len(untils) == 12 and len(deltas) == 4
+    buf = rp.InterpolationBuffer(po, odom)
+    for t, pose in lookups:
+        np.testing.assert_allclose(pose, buf.lookup(t), rtol=0, atol=1e-15)
+    assert any(t not in buf.times for t, _ in lookups) and any(t in buf.times for t, _ in lookups)
+    capped = 0
+    for t, lim, cand, ratios in untils:
+        c, tr, rr, dr = buf.lookup_until_delta(t, lim[0], lim[1], lim[2])
+        assert c == cand, (t, lim, c, cand)              # integer ticks: exactly
+        np.testing.assert_allclose(ratios, [tr, rr, dr], rtol=1e-12, atol=1e-15)
+        capped += max(ratios) > 1.0 - 1e-12
+    assert capped >= 9                                   # translation, rotation and time each decide some of them
+    for a, b, q in deltas:
+        np.testing.assert_allclose(q, rp.imu_delta_rotation(imu, a, b), rtol=0, atol=1e-15)
