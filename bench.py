@@ -36,6 +36,8 @@ def parse_args():
     ap.add_argument("--map-scans", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads of the all-cores CPU baseline of the batch workloads (default: every core, at most 64)")
     ap.add_argument("--max-blocks", type=int, default=1 << 18)
     ap.add_argument("--window", type=int, default=10, help="control points of --workload window")
     ap.add_argument("--no-window-unwarp", action="store_true",
@@ -98,6 +100,62 @@ def make_scans(rings, cols, first, count, stream_base):
         pts = synth.generate_scan(pose, rings, cols, stream=stream_base + k)
         out.append((pose, pts))
     return out
+
+
+def cpu_threads(args):
+    """Host threads of the all-cores CPU legs: every core, bounded (a GPU box has hundreds; each thread builds a
+    map of its own)."""
+    cores = os.cpu_count() or 1
+    want = getattr(args, "cpu_threads", 0)
+    return max(1, min(cores, want if want > 0 else 64))
+
+
+def all_cores_baseline(args, prepare, work, units_per_thread, what):
+    """the batch configurations' CPU figure with every core busy -- one INDEPENDENT unit (its own
+    submap) per host thread, all threads at once (ctypes drops the GIL inside the oracle). prepare() builds a thread's
+    state untimed, work(state) is what is timed, from the moment all threads are ready until the last one is done."""
+    import threading
+    T = cpu_threads(args)
+    ready = threading.Barrier(T + 1)
+    errors, ends = [], []
+
+    def run():
+        try:
+            state = prepare()
+            ready.wait()
+            work(state)
+            ends.append(time.perf_counter())
+        except BaseException as e:  # surfaced below
+            errors.append(e)
+            try:
+                ready.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run) for _ in range(T)]
+    for t in threads:
+        t.start()
+    try:
+        ready.wait()
+    except threading.BrokenBarrierError:
+        pass
+    t0 = time.perf_counter()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    elapsed = max(ends) - t0
+    return {"value": T * units_per_thread / elapsed, "cores": T, "cores_available": os.cpu_count(),
+            "sample": "%s; one per host thread, %d threads at once, oracle -O3" % (what, T)}
+
+
+def oracle_map(po, synth, map_scans):
+    og = [po.Grid(r) for r in RESOLUTIONS]
+    for pose, pts in map_scans:
+        loc = synth.transform_points(pose, pts)
+        for g in og:
+            g.insert(pose[:3], loc)
+    return og
 
 
 def cpu_baseline(args, map_scans, query_scans, gpu_steps):
@@ -547,16 +605,26 @@ def run_window(args):
     builds = [window_prepare(problem, specs[s], d_scans[s:s + n_cp - 1], grids, n_pts, args.rings) for s in range(total)]
 
     leaving = [api.RangeData([0, 0, 0], d_scans[s], width=args.rings) for s in range(total)]
-    # Per-point unwarping of the scan that leaves the window (use_per_point_unwarping, oltb.cc:1331-1379):
-    # control point i of window s sits at time (first + i) * 0.1 s; the leaving scan belongs to control
-    # point 1 and its returns carry per-point times (all 0 here: the synthetic scans are taken from a
-    # standing sensor, so any spread would smear the map; every return still runs the whole fp64
-    # interpolation chain between control points 0 and 1). --no-window-unwarp inserts at control point 1's pose.
+    # Per-point unwarping of the scan that leaves the window (use_per_point_unwarping, oltb.cc:1331-1379): control
+    # point i of window s sits at time (first + i) * 0.1 s; the leaving scan belongs to control point 1. Its
+    # insertion copy is taken by a MOVING sensor (round 5): the columns are stamped over a 0.1 s sweep from 60 ms
+    # before to 40 ms behind control point 1 and measured from the pose the trajectory has at that time
+    # (synth.generate_swept_scan), so the returns fall between control points 0..1 AND 1..2 -- two control-point
+    # pairs, every return its own interpolation factor -- and only the unwarping puts them where the map expects
+    # them. (The matching blocks keep the standing-sensor scans.) --no-window-unwarp inserts at control point 1's pose.
     unwarp = not args.no_window_unwarp
     cp_dt = 1_000_000  # 0.1 s in ticks, the delta_time of the IMU blocks
-    d_timed = None
+    d_timed = timed_host = None
     if unwarp:
-        d_timed = [torch.cat([d, torch.zeros((d.shape[0], 1), dtype=d.dtype, device=dev)], 1).contiguous() for d in d_scans[:total]]
+        col_t = np.linspace(-0.06, 0.04, args.cols).astype(np.float32)
+        pt_t = np.repeat(col_t, args.rings)[:, None]
+        timed_host = []
+        for s_ in range(total):
+            k1 = args.map_scans + s_
+            swept = synth.generate_swept_scan(lambda c: synth.pose_k(k1 + float(col_t[c]) / 0.1), args.rings, args.cols,
+                                              stream=args.map_scans + s_)
+            timed_host.append(np.ascontiguousarray(np.concatenate([swept, pt_t], 1), np.float32))
+        d_timed = [torch.from_numpy(t).to(dev) for t in timed_host]
     torch.cuda.synchronize()
 
     def control_times(s):
@@ -615,8 +683,7 @@ def run_window(args):
             """Insertion of the scan leaving window w at the window's `poses`, as the GPU step does it."""
             if unwarp:
                 ct = control_times(w)
-                timed = np.concatenate([scans[w], np.zeros((len(scans[w]), 1), np.float32)], 1)
-                xyz, origin, ok = po.unwarp_range_data(ct, poses, [(int(ct[1]), [0, 0, 0], timed)])
+                xyz, origin, ok = po.unwarp_range_data(ct, poses, [(int(ct[1]), [0, 0, 0], timed_host[w])])
                 assert ok
                 opt = np.asarray(poses[0], np.float64).astype(np.float32)  # optimized_pose.cast<float>() (:1437-1440)
                 xyz = po.transform_points(opt, xyz)
@@ -667,7 +734,8 @@ def run_window(args):
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "window: %d control points (81 free columns at 10), %d multi-res scan blocks + IMU/odometry blocks per solve, exact insert of the scan leaving the window%s"
-                               % (n_cp, n_cp - 1, " after per-point unwarping on the device (hg_register_scan_unwarped)" if unwarp else ""),
+                               % (n_cp, n_cp - 1, " after per-point unwarping on the device (hg_register_scan_unwarped): the leaving scan is taken by a moving sensor, its "
+                                  "columns stamped over a 0.1 s sweep across control point 1, so its returns interpolate between two control-point pairs" if unwarp else ""),
                    "mean_lm_iterations": float(np.mean(its)),
                    "problem_build": "pre-marshalled C-ABI calls per window (window_prepare); initial guesses from the synthetic ground truth + a fixed perturbation, not from the previous solve",
                    "unwarp_ms_per_call": (prof["unwarp"][1] / max(1, prof["unwarp"][0])) if unwarp else None},
@@ -789,6 +857,17 @@ def run_window_batch(args):
             raise SystemExit("bench.py: parity gate failed, GPU and oracle window poses differ: %r" % (parity,))
         base = {"value": 1.0 / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
                 "sample": "1 window of the same workload (solve %d iterations + insert), oracle -O3 1 thread" % so.num_iterations}
+
+        def one_window(state):  # the first window of a submap of its own: solve + insert
+            pr_ = po.Problem()
+            window_problem(pr_, synth, args.map_scans - 1, n_cp, sub["scans"][0:n_cp - 1], state, n_pts)
+            pr_.solve()
+            e_ = pr_.get_pose(1)
+            l_ = synth.transform_points(e_, sub["scans"][0])
+            for g_ in state:
+                g_.insert(e_[:3].astype(np.float32), l_)
+        base["all_cores"] = all_cores_baseline(args, lambda: oracle_map(po, synth, sub["map"]), one_window, 1,
+                                               "1 window step (solve + insert) of an independent submap")
     n_launch = max(1, prof["residuals"][0])
     avg_ms = prof["residuals"][1] / n_launch
     share = min(1.0, sum(evals) / n_launch) if evals else 1.0
@@ -992,6 +1071,14 @@ def run_match_batch(args):
         lbar = pb / max(1, lk)
         base = {"value": n_cpu / (time.perf_counter() - t1), "unit": "matches/s", "cores": 1, "kind": "port",
                 "sample": "%d matches of the same workload, oracle -O3 1 thread" % n_cpu}
+
+        def some_matches(state):  # (matches only read the map: the threads share the one built above)
+            for (pose_, pts_, _, guess_) in queries[:n_cpu]:
+                pr_ = po.Problem()
+                i_ = pr_.add_pose(guess_)
+                pr_.add_block(pts_, og, scale, i_, multi_res=True)
+                pr_.solve()
+        base["all_cores"] = all_cores_baseline(args, lambda: None, some_matches, n_cpu, "%d independent matches against the map" % n_cpu)
         parity = {"max_dt_m": max_dt, "max_dr_rad": max_dr, "matches": n_cpu, "tolerance": 1e-4,
                   "same_iterations_and_termination": bool(same_flow),
                   "step": "matches 0..%d of the last timed step (batch of %d, %d-pt scans)" % (n_cpu - 1, B, n_pts)}
@@ -1067,6 +1154,21 @@ def oracle_replay_submap(args, stream_base, steps0, scale, total):
         raise SystemExit("bench.py: parity gate failed, GPU and oracle poses of the replayed submap differ: %r" % (parity,))
     base = {"value": n_cpu / cpu_s, "unit": "scans/s", "cores": 1, "kind": "port",
             "sample": "%d registration steps of one submap (match + 3-level insert), oracle -O3 1 thread" % n_cpu}
+    map_scans = make_scans(args.rings, args.cols, 0, args.map_scans, stream_base)
+
+    def some_steps(state):  # the same steps on a submap of the thread's own
+        for i in range(args.warmup, args.warmup + n_cpu):
+            pose_, pts_ = q0[i]
+            pr_ = po.Problem()
+            pi_ = pr_.add_pose(synth.pose_mul(pose_, synth.perturbation()))
+            pr_.add_block(pts_, state, scale, pi_, multi_res=True)
+            pr_.solve()
+            at_ = pr_.get_pose(pi_)
+            loc_ = synth.transform_points(at_, pts_)
+            for g_ in state:
+                g_.insert(at_[:3].astype(np.float32), loc_)
+    base["all_cores"] = all_cores_baseline(args, lambda: oracle_map(po, synth, map_scans), some_steps, n_cpu,
+                                           "%d registration steps of an independent submap" % n_cpu)
     return base, parity
 
 
@@ -1147,7 +1249,7 @@ def run_offline_batch(args, out_fd=None, group=None):
             self.ins = [api.TSDFRangeDataInserter3D() for _ in RESOLUTIONS]
             self.owned = owned
             self.pyramids, self.queries, self.guesses, self.problems = [], [], [], []
-            self.steps0, self.errs, self.its = {}, [], []
+            self.steps0, self.errs, self.its, self.evals = {}, [], [], 0
             for j in owned:
                 sb = 100000 * (j + 1)  # PRNG streams of submap j (the same submaps whatever G is)
                 grids = [api.HybridGridTSDF(self.ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
@@ -1163,6 +1265,11 @@ def run_offline_batch(args, out_fd=None, group=None):
 
         def step(self, i):
             n, k = len(self.problems), i % distinct
+            # kernel durations by HIP events on every prof_every-th timed step (an event pair serialises the stream)
+            sampling = args.prof_every > 0 and i >= args.warmup and (i - args.warmup) % args.prof_every == 0
+            if i == args.warmup:
+                self.ctx.prof_reset()
+            self.ctx.prof_enable(sampling)
             for j in range(n):
                 p = self.problems[j]
                 p.reset()
@@ -1176,6 +1283,8 @@ def run_offline_batch(args, out_fd=None, group=None):
                 for j in range(n):
                     self.errs.append(float(np.linalg.norm(poses[j][:3] - self.queries[j][k][0][:3])))
                     self.its.append(summ[j].num_iterations)
+                    if sampling:
+                        self.evals += summ[j].num_cost_evaluations
 
         def grids(self):
             return [g for pyr in self.pyramids for g in pyr]
@@ -1270,6 +1379,18 @@ def run_offline_batch(args, out_fd=None, group=None):
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     mean_err, mean_its = float(acc[0] / acc[2]), float(acc[1] / acc[2])
     pg_info = process_group_info(dist)
+    # the residual family of this rank (dominant kernel of the batched step): launches, time, evaluating problems
+    res_launches = res_ms = 0.0
+    ins_ms_total, ins_calls = 0.0, 0
+    evals = 0
+    for g in eng.groups:
+        pr_ = g.ctx.prof_read()
+        g.ctx.prof_enable(False)
+        res_launches += pr_["residuals"][0]
+        res_ms += pr_["residuals"][1]
+        ins_ms_total += sum(pr_[k][1] for k in ("ray_count", "scan", "ray_expand", "apply"))
+        ins_calls += pr_["apply"][0]
+        evals += g.evals
     for g in eng.groups:  # the maps of this leg are done with (a caller's group goes on)
         for gr in g.grids():
             gr.close()
@@ -1283,6 +1404,22 @@ def run_offline_batch(args, out_fd=None, group=None):
     if not args.no_cpu_baseline and world == 1:
         base, parity = oracle_replay_submap(args, 100000 * (res["owned"][0] + 1), eng.steps0, scale, total)
     per_rank = len(res["owned"])
+    roofline = None
+    if res_launches > 0:
+        lbar = base["mean_levels_probed"] if base and base.get("mean_levels_probed") else 4.0 / 3.0
+        avg_ms = res_ms / res_launches
+        # a launch of a group evaluates the group's problems that are still running: algorithmic bytes per launch =
+        # (evaluating problems per launch) x N x (12 + 32 Lbar)
+        per_launch = evals / res_launches
+        bytes_per_launch = per_launch * n_pts * (12.0 + 32.0 * lbar)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None,
+                    "kernel": "k_tsdf_residuals_single_batch" if per_rank > 1 else "k_tsdf_residuals_single",
+                    "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "problems_evaluating_per_launch": per_launch, "mean_levels_probed": lbar,
+                    "insert_ms_per_call": ins_ms_total / max(1, ins_calls),
+                    "hip_event_sampling": "every %d-th timed step of rank 0's groups" % max(1, args.prof_every)}
     out = {
         "metric": "scans/s (offline batch mapping: %d independent submaps x %d scans, 100k-pt scans, 3-res TSDF registration)" % (S, steps),
         "value": value, "unit": "scans/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -1298,7 +1435,7 @@ def run_offline_batch(args, out_fd=None, group=None):
                    "mean_lm_iterations": mean_its, "mean_pose_error_m": mean_err,
                    "resident_voxel_gib_per_gpu": per_rank * len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30,
                    "gather_ms": gather_ms, "gather_check": gather_check, "process_group": pg_info},
-        "roofline": None, "parity": parity, "cpu_baseline": base,
+        "roofline": roofline, "parity": parity, "cpu_baseline": base,
         "gpu_over_cpu": value / base["value"] if base else None,
     }
     if dist is not None and own_group:
@@ -1483,6 +1620,9 @@ def secondary_workloads(args):
                          "frac": roof.get("frac"), "kernel": roof.get("kernel"), "avg_launch_ms": roof.get("avg_launch_ms"),
                          "parity_ok": None if ok is None else bool(ok), "parity": par or None,
                          "wall_s": round(time.perf_counter() - t0, 2)}
+            if r.get("cpu_baseline"):
+                out[name]["cpu_baseline"] = r["cpu_baseline"]
+                out[name]["gpu_over_cpu"] = r["value"] / r["cpu_baseline"]["value"]
             cfg = r.get("config") or {}
             for k in ("gather_ms", "gather_check", "process_group", "voxel_working_set_mib", "room_copies"):
                 if cfg.get(k) is not None:

@@ -129,6 +129,47 @@ def generate_scan(pose_tq, rings, cols, seed=42, stream=0, noise_sigma=0.01):
     return (d_s * rng[:, None]).astype(np.float32)
 
 
+def raycast_from(origins, dirs):
+    """raycast with an origin per ray: (N, 3) origins, (N, 3) unit directions (a sensor that moves while it sweeps)."""
+    to = dirs * RAY_LENGTH
+    ratio = np.ones(len(dirs))
+    lo = ROOM_MIN - origins
+    hi = ROOM_MIN + ROOM_SIZE - origins
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for a in range(3):
+            pos = to[:, a] > 0
+            neg = to[:, a] < 0
+            ratio = np.where(pos, np.minimum(ratio, hi[:, a] / to[:, a]), ratio)
+            ratio = np.where(neg, np.minimum(ratio, lo[:, a] / to[:, a]), ratio)
+    aa = np.einsum("ij,ij->i", to, to)
+    for c, r in SPHERES:
+        oc = origins - c
+        beta = np.einsum("ij,ij->i", to, oc)
+        cc = np.einsum("ij,ij->i", oc, oc) - r * r
+        disc = beta * beta - aa * cc
+        ok = disc >= 0
+        sol = (-beta - np.sqrt(np.where(ok, disc, 0.0))) / aa
+        ok &= sol >= 0
+        ratio = np.where(ok, np.minimum(ratio, sol), ratio)
+    return ratio * RAY_LENGTH
+
+
+def generate_swept_scan(pose_of_column, rings, cols, seed=42, stream=0, noise_sigma=0.01):
+    """A scan taken by a MOVING sensor: column c is measured from pose_of_column(c) (t xyz, q wxyz) and returned in
+    that pose's sensor frame, as a spinning lidar delivers it -- what per-point unwarping exists for. (N, 3) float32,
+    azimuth-major like generate_scan."""
+    d_s = directions(rings, cols)
+    poses = np.array([pose_of_column(c) for c in range(cols)], np.float64)   # (cols, 7)
+    d_w = np.empty_like(d_s)
+    origins = np.repeat(poses[:, :3], rings, axis=0)
+    for c in range(cols):
+        d_w[c * rings:(c + 1) * rings] = quat_rotate(poses[c, 3:], d_s[c * rings:(c + 1) * rings])
+    rng = raycast_from(origins, d_w)
+    if noise_sigma > 0:
+        rng = rng + noise_sigma * _normal(len(rng), seed, stream)
+    return (d_s * rng[:, None]).astype(np.float32)
+
+
 CONFIGS = {"10k": (16, 625), "100k": (50, 2000), "1k": (8, 128), "4k": (16, 256)}
 
 
