@@ -819,9 +819,24 @@ __device__ inline WgTable* wg_table(const RunInfo* runs, unsigned n, unsigned nw
 // Bodies of the four kernels of the binned path, shared by the single-pyramid launches (pyramid in
 // the kernel arguments) and the batched launches (a table of jobs in device memory, one job = one
 // pyramid with its own scan: hg_register_scan_batch). `bx` of `nbx` = workgroup index inside the job.
+#ifdef HG_COUNT_STAMPS
+// diagnostics: wall time (s_memrealtime, 10 ns) the wavefronts of k_bin_count* spend per phase, summed over all
+// wavefronts: [0] ray set-up (point load), [1] direct-slot key loads, [2] hash path (probe / insert / publish),
+// [3] LDS aggregation + barrier, [4] bin reservation (returning atomics), [5] tables, run info, touched list;
+// [6] wavefronts, [7] wavefronts that entered the hash path, [8] runs resolved by the hash path
+__device__ unsigned long long g_count_stamps[16];
+#define COUNT_STAMP(k) do { const long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&g_count_stamps[k], static_cast<unsigned long long>(now_ - cs_t)); cs_t = now_; } while (0)
+#else
+#define COUNT_STAMP(k) do {} while (0)
+#endif
 __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelIns& L, int level, unsigned bx, unsigned nbx,
                                                const ScanTable* scans, uint32_t n_scans, const float* xyz,
                                                unsigned n, RunInfo* runs, unsigned* wg_hits) {
+#ifdef HG_COUNT_STAMPS
+  long long cs_t = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63u) == 0) atomicAdd(&g_count_stamps[6], 1ull);
+#endif
   const unsigned i = xcd_chunk(bx, nbx) * 256u + threadIdx.x;  // see hg_device.h
   const int lane = threadIdx.x & (kWave - 1);
   WgTable* const tab = wg_table(runs, n, nbx, P.levels, level, bx);
@@ -852,23 +867,61 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
   // (k_bin_count_jobs on maps in HBM: 85 % of its wave cycles waiting). All loads of the wave in flight
   // together; the hash path only for blocks that are new or live in the overflow area. (A block's key word is
   // set before its hash entry is published: seeing it is enough, the pool slot is pre-zeroed.)
-  unsigned long long entry[kMaxRuns];
+  COUNT_STAMP(0);
+  unsigned long long entry[kMaxRuns], tent[kMaxRuns];
   uint32_t slot[kMaxRuns], dslot[kMaxRuns];
+  // A grid with blocks in the overflow area (a map wider than its direct window, or several maps folded into one
+  // pool) finds those through the hash table. Round 5: their FIRST probe is issued together with the direct-slot
+  // loads of all runs -- one round trip for a block wherever it lives, where the hash path used to start (one run
+  // after the other, each probe awaited) only after the direct check had come back: on a stream over 400 room
+  // copies half of the wavefronts' time (in-kernel stamps). Grids without overflow blocks skip it.
+  const bool overflowed = __hip_atomic_load(&L.g.counters[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
     dslot[k] = (k < nr) ? direct_slot(L.g, run_key[k]) : 0u;
     entry[k] = (k < nr) ? __hip_atomic_load(&L.g.block_keys[dslot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
   }
+  if (overflowed) {
+#pragma unroll
+    for (int k = 0; k < kMaxRuns; ++k)
+      tent[k] = (k < nr) ? __hip_atomic_load(&L.g.table[hash_key(run_key[k]) & L.g.table_mask], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT)
+                         : 0ull;
+  } else {
+#pragma unroll
+    for (int k = 0; k < kMaxRuns; ++k) tent[k] = 0ull;
+  }
+#ifdef HG_COUNT_STAMPS
+  {
+    bool miss = false;
+    unsigned nmiss = 0;
+    for (int k = 0; k < kMaxRuns; ++k)
+      if (k < nr && entry[k] != run_key[k] + 1ull &&
+          !((tent[k] >> 24) == run_key[k] + 1ull && static_cast<uint32_t>(tent[k] & 0xFFFFFFu) != kSlotPending)) { miss = true; ++nmiss; }
+    COUNT_STAMP(1);
+    const unsigned long long mm = __ballot(miss);
+    if (mm && (threadIdx.x & 63u) == 0) atomicAdd(&g_count_stamps[7], 1ull);
+    {  // (one atomic per wavefront: per-lane atomics on one word would be the measurement)
+      unsigned tot = nmiss;
+      for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+      if (tot && (threadIdx.x & 63u) == 0) atomicAdd(&g_count_stamps[8], static_cast<unsigned long long>(tot));
+    }
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < kMaxRuns; ++k) {
     slot[k] = 0xFFFFFFFFu;
     if (k < nr) {
-      if (entry[k] == run_key[k] + 1ull)
+      const unsigned long long tag = run_key[k] + 1ull;
+      if (entry[k] == tag)
         slot[k] = dslot[k];
+      else if ((tent[k] >> 24) == tag && static_cast<uint32_t>(tent[k] & 0xFFFFFFu) != kSlotPending)
+        slot[k] = static_cast<uint32_t>(tent[k] & 0xFFFFFFu);
       else
         slot[k] = insert_block_shared(L.g, run_key[k]);
     }
   }
+  COUNT_STAMP(2);
   // Record ranges inside the bins: the runs of the WORKGROUP are added up per block in an LDS hash
   // table (one LDS atomic per run: it returns the run's offset inside the workgroup's share, in any
   // order -- the order of the records inside a bin is free, the apply pass orders them by seq), then ONE
@@ -903,6 +956,7 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
     }
   }
   __syncthreads();
+  COUNT_STAMP(3);
   // one returning device-scope atomic per occupied entry, all of a thread's in flight together
   uint32_t e_key[kTable / 256u], e_base[kTable / 256u];
 #pragma unroll
@@ -924,6 +978,7 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
       if (e_base[j] == 0u) { first_pos[kMaxRuns + j] = atomicAdd(&s_first, 1u); first_slot[kMaxRuns + j] = e_key[j] - 1u; }
     }
   }
+  COUNT_STAMP(4);
   const unsigned long long m = __ballot(hit);
   if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
   __syncthreads();
@@ -943,6 +998,7 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
 #pragma unroll
   for (int j = 0; j < kMaxRuns + static_cast<int>(kTable / 256u); ++j)
     if (first_pos[j] != kNone) L.g.touched[s_first_base + first_pos[j]] = first_slot[j];
+  COUNT_STAMP(5);
 }
 
 
@@ -3130,6 +3186,20 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
     }
     HG_HIP_CHECK(hipGetLastError());
   }
+#ifdef HG_COUNT_STAMPS
+  {
+    HG_HIP_CHECK(hipStreamSynchronize(s));
+    unsigned long long st[16], zero[16] = {0};
+    HG_HIP_CHECK(hipMemcpyFromSymbol(st, HIP_SYMBOL(hg::g_count_stamps), sizeof(st)));
+    HG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(hg::g_count_stamps), zero, sizeof(zero)));
+    const double tot = double(st[0] + st[1] + st[2] + st[3] + st[4] + st[5]);
+    if (tot > 0)
+      fprintf(stderr, "k_bin_count_jobs phases, share of wavefront wall time: ray %.1f%%  key loads %.1f%%  hash path %.1f%%  "
+              "LDS aggregation %.1f%%  bin atomics %.1f%%  tables %.1f%%; %.2f us per wavefront; %llu wavefronts, %.1f%% entered the hash path, "
+              "%llu runs through it\n", 100 * st[0] / tot, 100 * st[1] / tot, 100 * st[2] / tot, 100 * st[3] / tot, 100 * st[4] / tot,
+              100 * st[5] / tot, tot * 0.01 / double(st[6] ? st[6] : 1), st[6], 100.0 * st[7] / double(st[6] ? st[6] : 1), st[8]);
+  }
+#endif
   return HG_OK;
 }
 
