@@ -603,9 +603,12 @@ __device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offs
   return r;
 }
 
+#ifdef HG_DIAG_LEVELS
+__device__ unsigned long long g_diag_levels[8];  // wavefronts, all-finest wavefronts, lanes, finest lanes, wavefronts with <= 4 others
+#endif
 template <int LEVELS, bool SHARE>
 __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& raw, double x, double y,
-                                        double z, bool* ok) {
+                                        double z, bool* ok, bool pred_fast = false) {
   // a coordinate this large has no cell; NaN passes and indexes cell 0 like the general path
   const bool usable = !(fabs(x) >= 1e30 || fabs(y) >= 1e30 || fabs(z) >= 1e30);
   LevelPin lp[LEVELS];
@@ -634,6 +637,17 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   *ok = dp.ok;
   if (!dp.ok) return {0.0, 0.0, 0.0, 0.0};  // wave-uniform: the caller takes the general path
   DirectFetch f[LEVELS];
+  // Staged lookup (round 5; SHARE = the batched kernel, which is bound by vector issue and the L1, not by latency):
+  // 78 % of the returns of the bench scene stop at the finest level. A tile that is PREDICTED to hold only such
+  // returns (pred_fast: the level partition below put them first) sets up, loads and interpolates ONE level; the
+  // finest level's words are awaited, and only when a lane turns out to need more (a wave-uniform branch on a
+  // ballot: the pose has moved since the partition) the wavefront goes on to the coarser levels -- a second round
+  // trip, rare. Tiles that are not predicted fast take the plain order: all levels in one round trip. Same voxels,
+  // same selection, same arithmetic per lane: bit-identical residuals. (Without the prediction -- every wavefront
+  // staged, 37 % of them fast with the scan's structure in the lane order -- the second round trip of the other 63 %
+  // eats the gain: 143.5 -> 141 us per launch of 64 matches; with all lanes forced to one level the pass takes 107.)
+  constexpr bool kStaged = SHARE && LEVELS > 1;
+  bool staged_fast = false;
   {
     // p / res per level and axis. SHARE (the batched kernel, bound by instruction issue): when every level's
     // resolution is the one before doubled (0.05 / 0.10 / 0.20 m: the same mantissa), the quotient of level l
@@ -655,11 +669,32 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
         float q[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) q[a] = cell_quotient_fast(p[a], r0, rr);
+        bool level0_done = false;
+        if constexpr (kStaged) {
+          if (pred_fast) {  // (wave-uniform)
+            direct_setup(lp[0], x, y, z, q, dp.min_b[0], usable, f[0]);
+            direct_load(lp[0], f[0]);
+            direct_merge(f[0]);
+            const bool v0 = (multi != 0) & f[0].in & all_weights_valid(f[0].code);
+            staged_fast = __ballot(!v0) == 0ull;
+            level0_done = true;
+#ifdef HG_DIAG_LEVELS
+            if ((threadIdx.x & 63u) == 0) {
+              atomicAdd(&g_diag_levels[5], 1ull);
+              if (!staged_fast) atomicAdd(&g_diag_levels[6], 1ull);
+              atomicAdd(&g_diag_levels[7], static_cast<unsigned long long>(__popcll(__ballot(!v0))));
+            }
+#endif
+          }
+        }
+        if (!staged_fast) {
 #pragma unroll
-        for (int l = 0; l < LEVELS; ++l) {
-          const float scale = 1.0f / static_cast<float>(1 << l);
-          const float ql[3] = {q[0] * scale, q[1] * scale, q[2] * scale};
-          direct_setup(lp[l], x, y, z, ql, dp.min_b[l], usable, f[l]);
+          for (int l = 0; l < LEVELS; ++l) {
+            if (l == 0 && level0_done) continue;
+            const float scale = 1.0f / static_cast<float>(1 << l);
+            const float ql[3] = {q[0] * scale, q[1] * scale, q[2] * scale};
+            direct_setup(lp[l], x, y, z, ql, dp.min_b[l], usable, f[l]);
+          }
         }
       } else {
         const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
@@ -683,10 +718,15 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   BODY_STAMP(1);
   BODY_STAMP(2);
   ISA_MARK("cells+addresses|loads");
+  if (!staged_fast) {  // (wave-uniform; always taken by the kernels that are not staged)
+    const bool have0 = kStaged && pred_fast;  // the finest level is already in (its lanes turned out to need more)
 #pragma unroll
-  for (int l = 0; l < LEVELS; ++l) direct_load(lp[l], f[l]);
+    for (int l = 0; l < LEVELS; ++l)
+      if (!(l == 0 && have0)) direct_load(lp[l], f[l]);
 #pragma unroll
-  for (int l = 0; l < LEVELS; ++l) direct_merge(f[l]);
+    for (int l = 0; l < LEVELS; ++l)
+      if (!(l == 0 && have0)) direct_merge(f[l]);
+  }
   BODY_STAMP(3);
   ISA_MARK("loads|select");
   if (!multi) {
@@ -716,24 +756,40 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
 #pragma unroll
   for (int c = 0; c < 8; ++c) code[c] = f[0].code[c];
   float res = lp[0].res, tsd_scale = lp[0].tsd_scale, tsd_offset = lp[0].tsd_offset;
-  bool found = false;
+  bool found = staged_fast;  // (every lane's finest level is valid: nothing to select)
+  if (!staged_fast) {
 #pragma unroll
-  for (int l = 0; l < LEVELS; ++l) {
-    // valid: inside the window (outside it no block exists: the voxels read as unknown, whatever the
-    // toroidal slot holds) and all 8 weights non-zero
-    const bool valid = f[l].in & all_weights_valid(f[l].code);
-    if (l > 0) {
-      const bool take = !found && valid;
+    for (int l = 0; l < LEVELS; ++l) {
+      // valid: inside the window (outside it no block exists: the voxels read as unknown, whatever the
+      // toroidal slot holds) and all 8 weights non-zero
+      const bool valid = f[l].in & all_weights_valid(f[l].code);
+      if (l > 0) {
+        const bool take = !found && valid;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) code[c] = take ? f[l].code[c] : code[c];
+        for (int c = 0; c < 8; ++c) code[c] = take ? f[l].code[c] : code[c];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) c3[a] = take ? f[l].c[a] : c3[a];
-      res = take ? lp[l].res : res;
-      tsd_scale = take ? lp[l].tsd_scale : tsd_scale;
-      tsd_offset = take ? lp[l].tsd_offset : tsd_offset;
+        for (int a = 0; a < 3; ++a) c3[a] = take ? f[l].c[a] : c3[a];
+        res = take ? lp[l].res : res;
+        tsd_scale = take ? lp[l].tsd_scale : tsd_scale;
+        tsd_offset = take ? lp[l].tsd_offset : tsd_offset;
+      }
+      found = found || valid;
     }
-    found = found || valid;
   }
+#ifdef HG_DIAG_LEVELS
+  {
+    // wavefronts whose active lanes all stop at the finest level / lanes that do
+    const bool v0 = f[0].in & all_weights_valid(f[0].code);
+    const unsigned long long act = __ballot(true), m0 = __ballot(v0);
+    if ((threadIdx.x & 63u) == static_cast<unsigned>(__ffsll(static_cast<long long>(act)) - 1)) {
+      atomicAdd(&g_diag_levels[0], 1ull);
+      atomicAdd(&g_diag_levels[1], m0 == act ? 1ull : 0ull);
+      atomicAdd(&g_diag_levels[2], static_cast<unsigned long long>(__popcll(act)));
+      atomicAdd(&g_diag_levels[3], static_cast<unsigned long long>(__popcll(m0)));
+      atomicAdd(&g_diag_levels[4], __popcll(act & ~m0) <= 4 ? 1ull : 0ull);
+    }
+  }
+#endif
   ISA_MARK("select|interpolation");
   const D3 r = interp_all_valid(res, tsd_scale, tsd_offset, c3, code, x, y, z);
   ISA_MARK("interpolation|row");
@@ -828,7 +884,8 @@ __device__ __attribute__((noinline)) D3 pyramid_tsd_general(const PyramidView* p
 }
 
 template <bool SHARE = false>
-__device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, double x, double y, double z) {
+__device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, double x, double y, double z,
+                                 bool pred_fast = false) {
   const int levels = pv.multi_res ? pv.levels : 1;
   bool ok;
   D3 r;
@@ -838,11 +895,15 @@ __device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, do
   if (ok) return r;
   return pyramid_tsd_general(pv.self_mem, x, y, z);
 #endif
+#ifdef HG_FORCE_L1  // (timing experiment only: every lookup stops at the finest level -- wrong results)
+  r = pyramid_tsd_direct<1, SHARE>(pv, raw, x, y, z, &ok);
+  if (ok) return r;
+#endif
   switch (levels) {  // wave-uniform
-    case 1: r = pyramid_tsd_direct<1, SHARE>(pv, raw, x, y, z, &ok); break;
-    case 2: r = pyramid_tsd_direct<2, SHARE>(pv, raw, x, y, z, &ok); break;
-    case 3: r = pyramid_tsd_direct<3, SHARE>(pv, raw, x, y, z, &ok); break;
-    default: r = pyramid_tsd_direct<4, SHARE>(pv, raw, x, y, z, &ok); break;
+    case 1: r = pyramid_tsd_direct<1, SHARE>(pv, raw, x, y, z, &ok, pred_fast); break;
+    case 2: r = pyramid_tsd_direct<2, SHARE>(pv, raw, x, y, z, &ok, pred_fast); break;
+    case 3: r = pyramid_tsd_direct<3, SHARE>(pv, raw, x, y, z, &ok, pred_fast); break;
+    default: r = pyramid_tsd_direct<4, SHARE>(pv, raw, x, y, z, &ok, pred_fast); break;
   }
   if (ok) return r;
   return pyramid_tsd_general(pv.self_mem, x, y, z);
@@ -858,7 +919,8 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
 // QuaternionBase::_transformVector, then + translation (rigid_transform.h:193-197).
 template <bool SHARE = false>
 __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRaw& dp, const double* t,
-                                           const double* q, const double* v, double scaling, double* row8) {
+                                           const double* q, const double* v, double scaling, double* row8,
+                                           bool pred_fast = false) {
   const double qw = q[0];
   const double u[3] = {q[1], q[2], q[3]};
   double uv[3], c2[3];
@@ -869,7 +931,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRa
   const double wy = (v[1] + qw * uv[1] + c2[1]) + t[1];
   const double wz = (v[2] + qw * uv[2] + c2[2]) + t[2];
   ISA_MARK("transform|cells+addresses");
-  const D3 tsd = pyramid_tsd<SHARE>(pv, dp, wx, wy, wz);
+  const D3 tsd = pyramid_tsd<SHARE>(pv, dp, wx, wy, wz, pred_fast);
   const double r = scaling * tsd.a;
   const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
   // d world / d q = [uv | qw duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v). Written out per k with
@@ -1004,7 +1066,8 @@ __device__ __forceinline__ void tsdf_residuals_body(
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
     double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64], unsigned wg,
     const double* pose_tq = nullptr /* the transform when it does not come from xf (first launch) */,
-    unsigned width = 0, unsigned tiles = 1 /* tiles of THREADS returns per workgroup (the batched kernel) */) {
+    unsigned width = 0, unsigned tiles = 1 /* tiles of THREADS returns per workgroup (the batched kernel) */,
+    unsigned fast_n = 0 /* the first fast_n returns are expected to stop at the finest level (level partition) */) {
   const ScanOrder order = make_scan_order(n, width);
   const unsigned first_i0 = wg * tiles * THREADS + threadIdx.x;
   BODY_STAMP(0);
@@ -1043,7 +1106,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
     }
     if (i0 < n) {
       // (THREADS == 256: the batched kernel)
-      return_row<THREADS == 256>(pv, dp, tq, tq + 3, vc, scaling, row8);
+      return_row<THREADS == 256>(pv, dp, tq, tq + 3, vc, scaling, row8, i0 - threadIdx.x + THREADS <= fast_n);
       if (residuals) residuals[i_cur] = row8[7];
     }
     if (tile > 0) wave_sync();  // the operand reads of the tile before are done
@@ -3791,6 +3854,7 @@ struct SingleJob {
   unsigned width;     // returns per column of the structured scan, or 0 (scan_index)
   unsigned tiles;     // tiles of kBatchThreads returns per workgroup
   unsigned pad;
+  const unsigned* fast_n;  // level partition: returns at the front of xyz that stopped at the finest level, or null
 };
 
 // Throughput form: the residual pass of all problems in one launch WITHOUT the LM step in its tail
@@ -3813,7 +3877,132 @@ __global__ __launch_bounds__(THREADS, HG_BATCH_WAVES) void k_tsdf_residuals_sing
   tsdf_residuals_body<THREADS>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
                                      reinterpret_cast<double (*)[kWave][8]>(smem),
                                      reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
-                                     xcd_chunk(blockIdx.x, J.num_wg), nullptr, J.width, J.tiles);
+                                     xcd_chunk(blockIdx.x, J.num_wg), nullptr, J.width, J.tiles,
+                                     J.fast_n ? *J.fast_n : 0u);
+}
+
+// ------------------------------------------------------------------------------------------
+// Level partition (round 5). The batched residual pass is bound by vector issue and the L1, and most of both is
+// spent on pyramid levels most returns never use: a return takes the first level whose 8 voxels are all known
+// (interpolated_multi_resolution_tsdf.h:99-106), and 78 % of the returns of the bench scene find it at the finest
+// one. Which returns do is a property of the map and the pose, stable over a solve (the pose moves by centimetres),
+// but they are scattered over the wavefronts (37 % of them hold no other lane). Before a batch of solves the returns
+// of every problem are therefore SORTED by that property at the initial pose -- three small launches for the whole
+// batch: classify (one finest-level lookup per return), scan of the per-workgroup counts, stable scatter of the
+// coordinates into a buffer of the problem -- and the residual kernel treats the leading tiles as "expected to stop
+// at the finest level" (pred_fast in pyramid_tsd_direct). A permutation of the returns: the normal equations are the
+// same sums in another order (results to rounding, as for the structured lane order); deterministic.
+// ------------------------------------------------------------------------------------------
+struct PartJob {
+  PyramidView pv;
+  const float* xyz;      // the block's cloud
+  float* out;            // the same returns, those that stop at the finest level first (both groups in lane order)
+  unsigned char* flags;  // per return (in lane order): stops at the finest level
+  unsigned* counts;      // per workgroup of 256 returns: how many do (k_level_scan: their exclusive prefix); [nwg] total
+  const BlockXform* xf;  // the transform the returns are classified at: the candidate the solve evaluates next
+  unsigned n, nwg, width, pad;
+};
+__global__ __launch_bounds__(256) void k_level_classify(const PartJob* __restrict__ jobs) {
+  const PartJob& J = jobs[blockIdx.y];
+  if (blockIdx.x >= J.nwg) return;
+  const ScanOrder order = make_scan_order(J.n, J.width);
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+  double v[3];
+  load_point(J.xyz, scan_index(order, i0 < J.n ? i0 : 0u), v);
+  const DirectRaw raw = direct_issue(J.pv);
+  const LevelPin lp = pin_level(J.pv.level[0]);
+  // directly addressable? (as pyramid_tsd_direct; a pool that is not sends every lookup through the general path,
+  // which has no staged form: nothing is expected fast)
+  const su8 w = raw.w[0];
+  bool lok = w[0] == 0u;
+  uint32_t min_b[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lok = lok & ((w[4 + a] - w[1 + a]) < (1u << lp.bits[a]));
+    min_b[a] = w[1 + a];
+  }
+  double tq[7];
+  load_transform_uniform(J.xf->t, tq);
+  bool fast = false;
+  if (lok && i0 < J.n) {
+    // the world point as return_row forms it
+    const double qw = tq[3];
+    const double u[3] = {tq[4], tq[5], tq[6]};
+    double uv[3], c2[3];
+    cross3(u, v, uv);
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    cross3(u, uv, c2);
+    const double x = (v[0] + qw * uv[0] + c2[0]) + tq[0];
+    const double y = (v[1] + qw * uv[1] + c2[1]) + tq[1];
+    const double z = (v[2] + qw * uv[2] + c2[2]) + tq[2];
+    const bool usable = !(fabs(x) >= 1e30 || fabs(y) >= 1e30 || fabs(z) >= 1e30);
+    const float p[3] = {static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)};
+    const float rr = refined_rcp(lp.res);
+    const float q[3] = {cell_quotient_fast(p[0], lp.res, rr), cell_quotient_fast(p[1], lp.res, rr), cell_quotient_fast(p[2], lp.res, rr)};
+    DirectFetch f;
+    direct_setup(lp, x, y, z, q, min_b, usable, f);
+    direct_load(lp, f);
+    direct_merge(f);
+    fast = f.in & all_weights_valid(f.code);
+  }
+  if (i0 < J.n) J.flags[i0] = fast ? 1 : 0;
+  __shared__ unsigned s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const unsigned long long m = __ballot(fast);
+  if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&s_cnt, static_cast<unsigned>(__popcll(m)));
+  __syncthreads();
+  if (threadIdx.x == 0) J.counts[blockIdx.x] = s_cnt;
+}
+__global__ __launch_bounds__(1024) void k_level_scan(const PartJob* __restrict__ jobs) {
+  const PartJob& J = jobs[blockIdx.x];
+  __shared__ unsigned s_wave[16], s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (unsigned base = 0; base < J.nwg; base += 1024u) {
+    const unsigned i = base + threadIdx.x;
+    const unsigned v = i < J.nwg ? J.counts[i] : 0u;
+    unsigned incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = static_cast<unsigned>(__shfl_up(static_cast<int>(incl), off));
+      if (lane >= static_cast<unsigned>(off)) incl += t;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned before = s_carry;
+    for (unsigned k = 0; k < wave; ++k) before += s_wave[k];
+    if (i < J.nwg) J.counts[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023u) s_carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) J.counts[J.nwg] = s_carry;
+}
+__global__ __launch_bounds__(256) void k_level_scatter(const PartJob* __restrict__ jobs) {
+  const PartJob& J = jobs[blockIdx.y];
+  if (blockIdx.x >= J.nwg) return;
+  const ScanOrder order = make_scan_order(J.n, J.width);
+  const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
+  const bool in = i0 < J.n;
+  const bool fast = in && J.flags[i0] != 0;
+  __shared__ unsigned s_fast[4], s_slow[4];
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long mf = __ballot(fast), ms = __ballot(in && !fast);
+  if (lane == 0) { s_fast[wave] = static_cast<unsigned>(__popcll(mf)); s_slow[wave] = static_cast<unsigned>(__popcll(ms)); }
+  __syncthreads();
+  unsigned bf = 0, bs = 0;
+  for (unsigned k = 0; k < wave; ++k) { bf += s_fast[k]; bs += s_slow[k]; }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned fast_before = J.counts[blockIdx.x], total_fast = J.counts[J.nwg];
+  if (in) {
+    const unsigned pos = fast ? fast_before + bf + static_cast<unsigned>(__popcll(mf & below))
+                              : total_fast + (blockIdx.x * 256u - fast_before) + bs + static_cast<unsigned>(__popcll(ms & below));
+    typedef float f3 __attribute__((ext_vector_type(3), aligned(4)));
+    const f3 pt = *reinterpret_cast<const __attribute__((address_space(1))) f3*>(as_global(J.xyz) + 12ull * scan_index(order, i0));
+    *reinterpret_cast<__attribute__((address_space(1))) f3*>(const_cast<__attribute__((address_space(1))) char*>(as_global(J.out)) + 12ull * pos) = pt;
+  }
 }
 // Uploads every problem's solver head from its mailbox and prepares its first transform (k_lm
 // MODE_PREPARE for all problems of a batch in one launch).
@@ -3965,6 +4154,7 @@ struct hg_problem {
   unsigned* d_ticket = nullptr;
   BlockXform* d_xf = nullptr;
   DeviceBuffer partials, residuals;
+  DeviceBuffer part_xyz, part_flags, part_counts;  // level partition of the block's cloud (batched single-pose solves)
   bool solve_pending = false;
   PyramidView* d_pv = nullptr;  // per block: its pyramid in device memory (PyramidView::self_mem)
   PyramidView* h_pv = nullptr;  // pinned staging = what d_pv holds (re-uploaded only when it changes)
@@ -4428,6 +4618,9 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->h_pv) (void)hipHostFree(p->h_pv);
   if (p->h_eval) (void)hipHostFree(p->h_eval);
   p->partials.release();
+  p->part_xyz.release();
+  p->part_flags.release();
+  p->part_counts.release();
   p->residuals.release();
   delete p;
   return HG_OK;
@@ -5130,6 +5323,50 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   SingleJob* jobs = static_cast<SingleJob*>(c->pinned_jobs);
   unsigned max_wg = 0;
   unsigned long long units = 0;
+  // Level partition (see k_level_classify): worth its three launches and one finest-level lookup per return once the
+  // batch is large enough to be bound by throughput (HG_PARTITION_MIN problems, default 48: 64 matches 27.3k -> 29.4k
+  // matches/s, 32 and 16 even; 0 switches it off)
+  static const int part_min = std::getenv("HG_PARTITION_MIN") ? std::atoi(std::getenv("HG_PARTITION_MIN")) : 48;
+  bool partition = part_min > 0 && count >= part_min;
+  for (int i = 0; i < count && partition; ++i) {
+    const PyramidView& pv = problems[i]->h_pv[0];
+    if (!(pv.multi_res && pv.levels >= 2)) partition = false;
+  }
+  PartJob* pjobs = nullptr;
+  unsigned max_pwg = 0;
+  if (partition) {
+    // (the job tables of the partition live behind the SingleJob table in the same pinned staging / device buffer)
+    const size_t need = 2 * sizeof(SingleJob) * static_cast<size_t>(count) + sizeof(PartJob) * static_cast<size_t>(count) + 192;
+    if (c->jobs_capacity < need) {
+      if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
+      c->pinned_jobs = nullptr;
+      c->jobs_capacity = 0;
+      const size_t cap = std::max<size_t>(kBatchGroup, count) * (2 * sizeof(SingleJob) + sizeof(PartJob)) + 192;
+      HG_HIP_CHECK(hipHostMalloc(&c->pinned_jobs, cap));
+      c->jobs_capacity = cap;
+      jobs = static_cast<SingleJob*>(c->pinned_jobs);
+    }
+    pjobs = reinterpret_cast<PartJob*>(reinterpret_cast<char*>(jobs) + ((sizeof(SingleJob) * static_cast<size_t>(count) + 63) & ~size_t(63)));
+    for (int i = 0; i < count; ++i) {
+      hg_problem* p = problems[i];
+      const BlockInfo& bi = p->h_state.h.blocks[0];
+      PartJob& Q = pjobs[i];
+      std::memset(&Q, 0, sizeof(Q));
+      Q.pv = p->h_pv[0];
+      Q.xyz = p->blocks[0].d_xyz;
+      Q.n = bi.n;
+      Q.nwg = (bi.n + 255u) / 256u;
+      Q.width = p->blocks[0].width;
+      if ((rc = p->part_xyz.reserve(static_cast<size_t>(bi.n) * 12u)) != HG_OK) return rc;
+      if ((rc = p->part_flags.reserve(bi.n)) != HG_OK) return rc;
+      if ((rc = p->part_counts.reserve((static_cast<size_t>(Q.nwg) + 1u) * sizeof(unsigned))) != HG_OK) return rc;
+      Q.out = p->part_xyz.as<float>();
+      Q.flags = p->part_flags.as<unsigned char>();
+      Q.counts = p->part_counts.as<unsigned>();
+      Q.xf = p->d_xf;
+      max_pwg = std::max(max_pwg, Q.nwg);
+    }
+  }
   for (int i = 0; i < count; ++i) {
     hg_problem* p = problems[i];
     const LmHead& S = p->h_state.h;
@@ -5138,6 +5375,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     std::memset(&J, 0, sizeof(J));
     J.pv = p->h_pv[0];  // built by upload_state; also resident at p->d_pv (self_mem)
     J.xyz = p->blocks[0].d_xyz;
+    J.fast_n = nullptr;
     J.xf = p->d_xf;
     // the batched pass has its own workgroup size; several tiles per workgroup once the batch fills the chip more
     // than once (64 matches of 100k returns: 25.5k / 27.5k / 28.3k / 27.9k matches/s at 1 / 2 / 4 / 8 tiles; 32: 22.7k /
@@ -5157,11 +5395,42 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     max_wg = std::max(max_wg, J.num_wg);
     units += bi.n;
   }
-  if ((rc = c->ws_misc.reserve(sizeof(SingleJob) * count)) != HG_OK) return rc;
-  HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs, sizeof(SingleJob) * count, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_lm_prepare_batch, dim3(count), dim3(kLmBlock), 0, s, static_cast<const SingleJob*>(c->ws_misc.ptr));
+  // device tables: [SingleJob x count | PartJob x count | SingleJob x count over the partitioned clouds]
+  const size_t single_bytes = (sizeof(SingleJob) * static_cast<size_t>(count) + 63) & ~size_t(63);
+  const size_t part_bytes = (sizeof(PartJob) * static_cast<size_t>(count) + 63) & ~size_t(63);
+  const SingleJob* d_jobs = nullptr;
+  const SingleJob* d_jobs_part = nullptr;
+  const PartJob* d_pjobs = nullptr;
+  {
+    size_t table_bytes = sizeof(SingleJob) * static_cast<size_t>(count);
+    if (partition) {
+      // the third table: the same jobs over the partitioned clouds (lane order already in the copy)
+      SingleJob* jobs2 = reinterpret_cast<SingleJob*>(reinterpret_cast<char*>(jobs) + single_bytes + part_bytes);
+      for (int i = 0; i < count; ++i) {
+        jobs2[i] = jobs[i];
+        jobs2[i].xyz = problems[i]->part_xyz.as<float>();
+        jobs2[i].fast_n = problems[i]->part_counts.as<unsigned>() + pjobs[i].nwg;
+        jobs2[i].width = 0u;
+      }
+      table_bytes = single_bytes + part_bytes + sizeof(SingleJob) * static_cast<size_t>(count);
+    }
+    if ((rc = c->ws_misc.reserve(table_bytes)) != HG_OK) return rc;
+    HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs, table_bytes, hipMemcpyHostToDevice, s));
+    d_jobs = static_cast<const SingleJob*>(c->ws_misc.ptr);
+    if (partition) {
+      d_pjobs = reinterpret_cast<const PartJob*>(static_cast<const char*>(c->ws_misc.ptr) + single_bytes);
+      d_jobs_part = reinterpret_cast<const SingleJob*>(static_cast<const char*>(c->ws_misc.ptr) + single_bytes + part_bytes);
+    }
+  }
+  hipLaunchKernelGGL(k_lm_prepare_batch, dim3(count), dim3(kLmBlock), 0, s, d_jobs);
   HG_HIP_CHECK(hipGetLastError());
   const int max_it = problems[0]->h_state.h.opt.max_num_iterations;
+  // The returns are classified at the candidate the solve evaluates THIRD: the first two steps take the pose from
+  // the initial guess (centimetres off) to within a millimetre of where it ends, and a return on the edge of the
+  // finest level's known voxels changes sides with every voxel the pose moves -- classified at the guess itself,
+  // 35 % of the wavefronts that were expected fast held such a lane a few iterations later and paid the second
+  // round trip. HG_PARTITION_AT overrides the iteration.
+  static const int part_at = std::getenv("HG_PARTITION_AT") ? std::atoi(std::getenv("HG_PARTITION_AT")) : 2;
   // (Round 4, measured and dropped: the batch cut in two halves on two streams, the second one residual pass behind
   // the first, so that one half's step kernel -- `count` workgroups on an otherwise idle chip, 10 us per iteration
   // against 22 us of residual pass for eight 100k-point scans -- would run under the other half's residual pass.
@@ -5170,14 +5439,19 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   // 10.20k scans/s for eight submaps, no gain at 16 or 64.)
   {
     ProfScope group(c, HG_K_RESIDUALS, units * (max_it + 1), static_cast<unsigned>(max_it + 1), true);
+    const SingleJob* table = d_jobs;
     for (int it = 0; it <= max_it; ++it) {
+      if (partition && it == std::min(part_at, max_it)) {
+        hipLaunchKernelGGL(k_level_classify, dim3(max_pwg, count), dim3(256), 0, s, d_pjobs);
+        hipLaunchKernelGGL(k_level_scan, dim3(count), dim3(1024), 0, s, d_pjobs);
+        hipLaunchKernelGGL(k_level_scatter, dim3(max_pwg, count), dim3(256), 0, s, d_pjobs);
+        table = d_jobs_part;
+      }
       // (a direct-only kernel at 117 VGPRs with a general-only twin launched behind it was measured 3-5 %
       // slower than this one at 144 VGPRs with the general path as a cold call: the window test up
       // front and the second launch cost more than the fourth wavefront per SIMD brings)
-      hipLaunchKernelGGL(k_tsdf_residuals_single_batch<kBatchThreads>, dim3(max_wg, count), dim3(kBatchThreads), 0, s,
-                         static_cast<const SingleJob*>(c->ws_misc.ptr));
-      hipLaunchKernelGGL(k_lm_single_batch, dim3(count), dim3(kEvalThreads), 0, s,
-                         static_cast<const SingleJob*>(c->ws_misc.ptr));
+      hipLaunchKernelGGL(k_tsdf_residuals_single_batch<kBatchThreads>, dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
+      hipLaunchKernelGGL(k_lm_single_batch, dim3(count), dim3(kEvalThreads), 0, s, table);
     }
   }
   HG_HIP_CHECK(hipGetLastError());
@@ -5221,6 +5495,19 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     const int r2 = hg_problem_fetch(problems[i], summaries ? summaries + i : nullptr);
     if (r2 != HG_OK) rc = r2;
   }
+#if defined(HG_DIAG_LEVELS) && !defined(HG_BIG)
+  {
+    unsigned long long st[8], zero[8] = {0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(hg::g_diag_levels), sizeof(st));
+    hipMemcpyToSymbol(HIP_SYMBOL(hg::g_diag_levels), zero, sizeof(zero));
+    if (st[0])
+      fprintf(stderr, "levels: %llu wavefronts, %.1f%% with every lane at the finest level, %.1f%% with at most 4 lanes beyond it; "
+              "%.1f%% of the lanes at the finest level; wavefronts predicted fast %llu, of which %.1f%% fell back (%.2f lanes each)\n",
+              st[0], 100.0 * st[1] / st[0], 100.0 * st[4] / st[0], 100.0 * st[3] / st[2], st[5], st[5] ? 100.0 * st[6] / st[5] : 0.0,
+              st[6] ? double(st[7]) / st[6] : 0.0);
+  }
+#endif
   return rc;
 }
 
