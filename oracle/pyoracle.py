@@ -10,14 +10,19 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libhg_oracle.so")
+# HG_ORACLE_SANITIZE=1: the same sources built with -fsanitize=undefined, aborting on the first finding
+# (oracle/Makefile: libhg_oracle_ubsan.so; tests/test_oracle_kat.py::test_oracle_under_ubsan runs the known-answer
+# tests, an insert, a solve and the unwarping through it)
+_SAN = os.environ.get("HG_ORACLE_SANITIZE") == "1"
+_LIB_NAME = "libhg_oracle_ubsan.so" if _SAN else "libhg_oracle.so"
+_LIB_PATH = os.path.join(_HERE, _LIB_NAME)
 
 
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("hg_oracle.hpp", "hg_oracle_capi.cc")):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libhg_oracle.so"],
+        subprocess.check_call(["make", "-C", _HERE, "-B", _LIB_NAME],
                               stdout=subprocess.DEVNULL)
     return _LIB_PATH
 

@@ -347,3 +347,58 @@ def test_lm_reaches_the_minimum_an_independent_solver_finds(po):
     assert abs(summ.final_cost - ref.cost) <= 1e-2 * summ.initial_cost
     assert np.abs(tq[:3] - solved[:3]).max() < 3e-3
     assert min(np.abs(tq[3:] - solved[3:]).max(), np.abs(tq[3:] + solved[3:]).max()) < 3e-3
+
+
+def test_oracle_under_ubsan():
+    """Sanitizers run on the CPU build only: the oracle restatement compiled with -fsanitize=undefined
+    (-fno-sanitize-recover: any finding aborts) runs this file's known-answer tests, the ray-walk identities and a
+    small insert + two-pose solve -- signed overflow, bad shifts, out-of-range float-to-int conversions, misaligned
+    or null accesses and array bounds in the codec, the tree, the ray walk, the Jet arithmetic and the solver would
+    end the subprocess with a sanitizer report."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HG_ORACLE_SANITIZE="1")
+    code = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "oracle")); sys.path.insert(0, %r)
+import numpy as np
+import pyoracle as po
+assert po.lib()._name.endswith("libhg_oracle_ubsan.so")
+from hectorgrapher_amd import synth
+grids = [po.Grid(r) for r in (0.05, 0.10, 0.20)]
+for k in range(3):
+    pose = synth.pose_k(k)
+    pts = synth.generate_scan(pose, 8, 128, stream=k)
+    loc = synth.transform_points(pose, pts)
+    for g in grids:
+        g.insert(pose[:3], loc, width=8)
+pr = po.Problem()
+a = pr.add_pose(synth.pose_k(2), True)
+b = pr.add_pose(synth.pose_mul(synth.pose_k(3), synth.perturbation()))
+pts = synth.generate_scan(synth.pose_k(3), 8, 128, stream=3)
+pr.add_block(pts, grids, 1.0 / np.sqrt(len(pts)), b, multi_res=True)
+pr.add_block(pts, [grids[1]], 0.5 / np.sqrt(len(pts)), a, b, 0.7)
+pr.set_velocity(a, [0, 0, 0], True); pr.set_velocity(b, [0.1, 0, 0])
+pr.add_odometry_block(a, b, 2.0, 3.0, synth.pose_mul(synth.pose_inverse(synth.pose_k(3)), synth.pose_k(2)))
+pr.add_imu_block(a, b, 1.0, 1.0, 1.0, 0.1, [1.0, 0.0, 0.0, 0.0])
+s = pr.solve()
+assert s.num_iterations >= 1
+ijk, t, w = grids[0].export()
+assert len(t) > 1000
+ct = np.array([0, 1000000, 2000000], np.int64)
+cp = np.array([synth.pose_k(0), synth.pose_k(1), synth.pose_k(2)])
+tp = np.concatenate([pts, np.linspace(0.0, 0.19, len(pts), dtype=np.float32)[:, None]], 1)
+xyz, org, ok = po.unwarp_range_data(ct, cp, [(0, [0, 0, 0], tp)])
+assert ok
+print("ubsan ok", s.num_iterations, len(t))
+""" % (root, root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ubsan ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+    assert "runtime error" not in out.stderr, out.stderr[-3000:]
+    # and the reference's known-answer vectors through the sanitized build
+    kat = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_oracle_kat.py"), "-q", "-x",
+                          "-k", "not ubsan", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert kat.returncode == 0, (kat.stdout[-1500:], kat.stderr[-1500:])
+    assert "runtime error" not in kat.stderr
