@@ -52,6 +52,9 @@ def parse_args():
                          "on a centred square lattice), so that the blocks the stream touches outgrow the 256 MB Infinity Cache "
                          "(SURVEY 8d: B = 500 with an HBM-resident working set); 1 = the single room")
     ap.add_argument("--batch", type=int, default=8, help="--workload match_batch: independent matches per call")
+    ap.add_argument("--batches-in-flight", type=int, default=2,
+                    help="--workload match_batch: sets of problem handles the search keeps; 2 = build batch k + 1 while "
+                         "batch k runs (hg_problem_solve_batch_async), 1 = one blocking call per batch")
     ap.add_argument("--insert-mode", default="exact", choices=["exact", "fast"],
                     help="exact = voxel codes bit-identical to the reference (default, headline); fast = "
                          "HG_INSERT_FAST tolerance mode (order-free sums, one quantisation per call) for "
@@ -1009,22 +1012,47 @@ def run_match_batch(args):
         queries.append((pose, pts, torch.from_numpy(pts).to(dev), synth.pose_mul(pose, synth.perturbation())))
     torch.cuda.synchronize()
     scale = 1.0 / np.sqrt(float(n_pts))
-    problems = [api.Problem(ctx) for _ in range(B)]
+    # --batches-in-flight 2 (default): the search keeps two sets of problem handles; while the device solves batch k the
+    # host builds batch k + 1 on the other set and enqueues it (hg_problem_solve_batch_async), then fetches batch k --
+    # the device does not wait for the host between batches. 1 = hg_problem_solve_batch, one batch at a time.
+    depth = max(1, args.batches_in_flight)
+    sets = [[api.Problem(ctx) for _ in range(B)] for _ in range(depth)]
+    problems = sets[0]
     stats = {"its": [], "evals": 0}
+    flight = []  # (set index, sampled)
 
-    def step(sample):
-        for p, (_, _, d, guess) in zip(problems, queries):
-            p.reset()
-            i = p.add_pose(guess)
-            p.add_block(d, grids, scale, i, multi_res=True, width=args.rings)
-        summ = api.solve_batch(problems)
+    def collect():
+        k, sample = flight.pop(0)
+        summ = api.fetch_batch(sets[k])
         stats["its"].append(np.mean([s_.num_iterations for s_ in summ]))
         stats["last"] = summ
+        stats["last_set"] = k
         if sample:
             stats["evals"] += sum(s_.num_cost_evaluations for s_ in summ)
 
-    for _ in range(args.warmup):
-        step(False)
+    def step(sample, number):
+        k = number % depth
+        for p, (_, _, d, guess) in zip(sets[k], queries):
+            p.reset()
+            i = p.add_pose(guess)
+            p.add_block(d, grids, scale, i, multi_res=True, width=args.rings)
+        if depth == 1:
+            summ = api.solve_batch(sets[k])
+            stats["its"].append(np.mean([s_.num_iterations for s_ in summ]))
+            stats["last"] = summ
+            stats["last_set"] = k
+            if sample:
+                stats["evals"] += sum(s_.num_cost_evaluations for s_ in summ)
+            return
+        api.solve_batch_async(sets[k])
+        flight.append((k, sample))
+        if len(flight) >= depth:
+            collect()
+
+    for w in range(max(args.warmup, depth)):  # (every set of handles has allocated its buffers)
+        step(False, w)
+    while flight:
+        collect()
     stats = {"its": [], "evals": 0}
     ctx.prof_reset()
     ctx.synchronize()
@@ -1032,9 +1060,12 @@ def run_match_batch(args):
     for i in range(args.steps):
         sampling = args.prof_every > 0 and i % args.prof_every == 0
         ctx.prof_enable(sampling)
-        step(sampling)
+        step(sampling, i)
+    while flight:
+        collect()
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
+    problems = sets[stats["last_set"]]
     prof = ctx.prof_read()
     ctx.prof_enable(False)
     errs = [float(np.linalg.norm(p.get_pose(0)[:3] - q[0][:3])) for p, q in zip(problems, queries)]
@@ -1097,7 +1128,11 @@ def run_match_batch(args):
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "match_batch: %d independent single-pose multi-res LM matches per call "
-                               "(hg_problem_solve_batch), %d-pt scans, no insertion" % (B, n_pts),
+                               "(%s), %d-pt scans, no insertion" % (
+                                   B, "hg_problem_solve_batch" if depth == 1 else
+                                   "hg_problem_solve_batch_async + hg_problem_fetch, %d batches in flight: the host builds "
+                                   "the next batch while the device solves this one" % depth, n_pts),
+                   "batches_in_flight": depth,
                    "mean_lm_iterations": float(np.mean(stats["its"])), "mean_pose_error_m": float(np.mean(errs))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_tsdf_residuals_single_batch",

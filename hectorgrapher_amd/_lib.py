@@ -33,7 +33,7 @@ SYMBOLS = [
     "hg_problem_add_odometry_block", "hg_problem_add_imu_block", "hg_problem_add_block",
     "hg_problem_add_unwarped_block", "hg_problem_set_block_width",
     "hg_problem_num_residuals", "hg_problem_num_columns", "hg_problem_evaluate",
-    "hg_solver_default_opts", "hg_problem_solve", "hg_problem_solve_batch", "hg_problem_solve_async", "hg_problem_fetch",
+    "hg_solver_default_opts", "hg_problem_solve", "hg_problem_solve_batch", "hg_problem_solve_batch_async", "hg_problem_solve_async", "hg_problem_fetch",
     "hg_register_scan", "hg_register_scan_mode", "hg_register_scan_batch", "hg_register_scan_sequence", "hg_match_evaluate", "hg_match_solve",
     "hg_pyramid_insert_unwarped", "hg_unwarp_range_data", "hg_unwarp_last_device", "hg_unwarp_status", "hg_register_scan_unwarped",
 ]
@@ -201,6 +201,7 @@ def load():
     L.hg_solver_default_opts.argtypes = [P(SolverOpts)]
     L.hg_problem_solve.argtypes = [vp, P(SolverOpts), P(SolverSummary)]
     L.hg_problem_solve_batch.argtypes = [vp, i32, P(SolverOpts), vp]
+    L.hg_problem_solve_batch_async.argtypes = [vp, i32, P(SolverOpts)]
     L.hg_problem_solve_async.argtypes = [vp, P(SolverOpts)]
     L.hg_problem_fetch.argtypes = [vp, P(SolverSummary)]
     L.hg_register_scan.argtypes = [vp, P(SolverOpts), i32, vp, vp, i32, vp, vp, sz, sz, i32, vp,

@@ -651,6 +651,28 @@ def solve_batch(problems, **kw):
     return list(summ)
 
 
+def solve_batch_async(problems, **kw):
+    """hg_problem_solve_batch_async: the enqueue-only form of solve_batch. The host is free while the batch runs
+    (build and enqueue the next batch on another set of problems); collect with fetch_batch(problems)."""
+    L = _lib.load()
+    o = SolverOpts()
+    L.hg_solver_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    n = len(problems)
+    arr = (C.c_void_p * n)(*[p._h for p in problems])
+    check(L.hg_problem_solve_batch_async(arr, n, C.byref(o)), "hg_problem_solve_batch_async")
+
+
+def fetch_batch(problems):
+    """hg_problem_fetch on every problem of a batch enqueued by solve_batch_async. Returns the summaries."""
+    L = _lib.load()
+    summ = (SolverSummary * len(problems))()
+    for i, p in enumerate(problems):
+        check(L.hg_problem_fetch(p._h, C.byref(summ[i])), "hg_problem_fetch")
+    return list(summ)
+
+
 def register_scan(problem, pose_index, inserters, range_data, grids, **solver_kw):
     """One registration step on the device (hg_register_scan_mode): solve `problem`, then insert
     `range_data` (tracking frame) into `grids` at the solved pose, in the mode of inserters[0]

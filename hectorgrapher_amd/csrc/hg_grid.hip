@@ -359,6 +359,8 @@ int hg_ctx_destroy(hg_ctx* c) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->flag_words) (void)hipHostFree(const_cast<uint32_t*>(c->flag_words));
   if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
+  for (hipEvent_t e : c->ev_jobs)
+    if (e) (void)hipEventDestroy(e);
   if (c->ev_lazy_batch) (void)hipEventDestroy(c->ev_lazy_batch);
   if (c->pinned_ijobs) (void)hipHostFree(c->pinned_ijobs);
   if (c->pinned_sjobs) (void)hipHostFree(c->pinned_sjobs);

@@ -130,7 +130,9 @@ struct hg_ctx {
   std::vector<const volatile unsigned long long*> lazy_batch_flags;
   std::vector<unsigned long long> lazy_batch_seqs;
   hipEvent_t ev_lazy_batch = nullptr;
-  size_t jobs_capacity = 0;
+  size_t jobs_capacity = 0;       // bytes of ONE slot of pinned_jobs: a ring of kJobSlots slots (jobs_staging, hg_match.hip)
+  unsigned jobs_slot = 0;
+  hipEvent_t ev_jobs[4] = {nullptr, nullptr, nullptr, nullptr};  // slot's copy to the device has been read
   void* pinned_ijobs = nullptr;  // pinned staging of a batched insertion's job table
   size_t ijobs_capacity = 0;
   // Sticky error flags that insert calls without a stats read-back leave for the host

@@ -606,7 +606,10 @@ __device__ inline D3 interp_all_valid(float res, float tsd_scale, float tsd_offs
 #ifdef HG_DIAG_LEVELS
 __device__ unsigned long long g_diag_levels[8];  // wavefronts, all-finest wavefronts, lanes, finest lanes, wavefronts with <= 4 others
 #endif
-template <int LEVELS, bool SHARE>
+// SHARE: 0 = the latency-bound kernels, 1 = the batched kernel (shared division), 2 = the batched kernel over a
+// level-partitioned cloud (staged lookup; its own instantiation, so that batches without a partition keep the code
+// they had: the staged form costs them 1.5 % per launch)
+template <int LEVELS, int SHARE>
 __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& raw, double x, double y,
                                         double z, bool* ok, bool pred_fast = false) {
   // a coordinate this large has no cell; NaN passes and indexes cell 0 like the general path
@@ -646,7 +649,7 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   // same selection, same arithmetic per lane: bit-identical residuals. (Without the prediction -- every wavefront
   // staged, 37 % of them fast with the scan's structure in the lane order -- the second round trip of the other 63 %
   // eats the gain: 143.5 -> 141 us per launch of 64 matches; with all lanes forced to one level the pass takes 107.)
-  constexpr bool kStaged = SHARE && LEVELS > 1;
+  constexpr bool kStaged = SHARE == 2 && LEVELS > 1;
   bool staged_fast = false;
   {
     // p / res per level and axis. SHARE (the batched kernel, bound by instruction issue): when every level's
@@ -883,7 +886,7 @@ __device__ __attribute__((noinline)) D3 pyramid_tsd_general(const PyramidView* p
   return r;
 }
 
-template <bool SHARE = false>
+template <int SHARE = 0>
 __device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, double x, double y, double z,
                                  bool pred_fast = false) {
   const int levels = pv.multi_res ? pv.levels : 1;
@@ -917,7 +920,7 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
 
 // One return at transform (t, q): row8 = [d r / d(t, q) (7) | r]. The world point follows Eigen's
 // QuaternionBase::_transformVector, then + translation (rigid_transform.h:193-197).
-template <bool SHARE = false>
+template <int SHARE = 0>
 __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRaw& dp, const double* t,
                                            const double* q, const double* v, double scaling, double* row8,
                                            bool pred_fast = false) {
@@ -1060,7 +1063,7 @@ __device__ inline void load_transform_uniform(const double* tq, double* out7) {
 }
 
 // residuals of one block at its current transform + 36 partial sums per workgroup
-template <int THREADS = kEvalThreads>
+template <int THREADS = kEvalThreads, int SHARE = (THREADS == 256 ? 1 : 0)>
 __device__ __forceinline__ void tsdf_residuals_body(
     const PyramidView& pv, const float* __restrict__ xyz, unsigned n, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials,
@@ -1106,7 +1109,7 @@ __device__ __forceinline__ void tsdf_residuals_body(
     }
     if (i0 < n) {
       // (THREADS == 256: the batched kernel)
-      return_row<THREADS == 256>(pv, dp, tq, tq + 3, vc, scaling, row8, i0 - threadIdx.x + THREADS <= fast_n);
+      return_row<SHARE>(pv, dp, tq, tq + 3, vc, scaling, row8, i0 - threadIdx.x + THREADS <= fast_n);
       if (residuals) residuals[i_cur] = row8[7];
     }
     if (tile > 0) wave_sync();  // the operand reads of the tile before are done
@@ -3867,14 +3870,14 @@ struct SingleJob {
 #ifndef HG_BATCH_WAVES
 #define HG_BATCH_WAVES 4
 #endif
-template <int THREADS>
+template <int THREADS, bool STAGED>
 __global__ __launch_bounds__(THREADS, HG_BATCH_WAVES) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
   const SingleJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.num_wg) return;
   if (J.G->h.done) return;
   const PyramidView& pv = J.pv;
   __shared__ __align__(16) unsigned char smem[(THREADS / kWave) * (kWave * 8 + 64) * sizeof(double)];
-  tsdf_residuals_body<THREADS>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
+  tsdf_residuals_body<THREADS, STAGED ? 2 : 1>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
                                      reinterpret_cast<double (*)[kWave][8]>(smem),
                                      reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
                                      xcd_chunk(blockIdx.x, J.num_wg), nullptr, J.width, J.tiles,
@@ -5170,6 +5173,33 @@ static void window_jobs_iteration(hg_ctx* c, const WindowJob* d_jobs) {
 }
 // Behind a batched solve of general problems: returns once every problem has terminated on the device or all
 // launches are enqueued (see solve_settle).
+// Pinned staging of a batched solve's job table: a ring of kJobSlots slots, so that a batch can be enqueued while the
+// table copies of the batches before it are still waiting in the stream (hg_problem_solve_batch_async: the caller
+// builds batch k + 1 while batch k runs). A slot is handed out again only after its copy has been read (ev_jobs).
+constexpr unsigned kJobSlots = 4;
+static int jobs_staging(hg_ctx* c, size_t bytes, void** out, unsigned* slot) {
+  if (c->jobs_capacity < bytes) {
+    // (growing: no copy may be reading the old ring)
+    HG_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
+    c->pinned_jobs = nullptr;
+    c->jobs_capacity = 0;
+    const size_t one = kBatchGroup * std::max(2 * sizeof(SingleJob) + sizeof(PartJob), sizeof(WindowJob)) + 256;
+    const size_t cap = (std::max(one, bytes) + 255) & ~size_t(255);
+    HG_HIP_CHECK(hipHostMalloc(&c->pinned_jobs, cap * kJobSlots));
+    c->jobs_capacity = cap;
+  }
+  *slot = c->jobs_slot++ % kJobSlots;
+  if (c->ev_jobs[*slot]) HG_HIP_CHECK(hipEventSynchronize(c->ev_jobs[*slot]));
+  *out = static_cast<char*>(c->pinned_jobs) + static_cast<size_t>(*slot) * c->jobs_capacity;
+  return HG_OK;
+}
+static int jobs_staging_sent(hg_ctx* c, unsigned slot) {  // behind the hipMemcpyAsync that reads the slot
+  if (!c->ev_jobs[slot]) HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_jobs[slot], hipEventDisableTiming));
+  HG_HIP_CHECK(hipEventRecord(c->ev_jobs[slot], c->stream));
+  return HG_OK;
+}
+
 static int batch_settle(hg_ctx* c) {
   if (!c || c->lazy_batch_left <= 0) return HG_OK;
   const WindowJob* d_jobs = static_cast<const WindowJob*>(c->ws_misc.ptr);
@@ -5242,15 +5272,10 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   if (!batchable && windows) {
     // window batch: k_lm / k_window_residuals over a table of problems (grid row = problem)
     const size_t bytes = static_cast<size_t>(count) * sizeof(WindowJob);
-    if (c->jobs_capacity < bytes) {
-      if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
-      c->pinned_jobs = nullptr;
-      c->jobs_capacity = 0;
-      const size_t cap = std::max<size_t>(kBatchGroup * std::max(sizeof(SingleJob), sizeof(WindowJob)), bytes);
-      HG_HIP_CHECK(hipHostMalloc(&c->pinned_jobs, cap));
-      c->jobs_capacity = cap;
-    }
-    WindowJob* jobs = static_cast<WindowJob*>(c->pinned_jobs);
+    void* staging = nullptr;
+    unsigned slot = 0;
+    if ((rc = jobs_staging(c, bytes, &staging, &slot)) != HG_OK) return rc;
+    WindowJob* jobs = static_cast<WindowJob*>(staging);
     unsigned max_plain = 0, max_unwarp = 0;
     unsigned long long units_plain = 0, units_unwarp = 0;
     for (int i = 0; i < count; ++i) {
@@ -5281,6 +5306,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     if ((rc = c->ws_misc.reserve(bytes)) != HG_OK) return rc;
     const WindowJob* d_jobs = static_cast<const WindowJob*>(c->ws_misc.ptr);
     HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs, bytes, hipMemcpyHostToDevice, s));
+    if ((rc = jobs_staging_sent(c, slot)) != HG_OK) return rc;
     hipLaunchKernelGGL(k_lm_jobs, dim3(count), dim3(kLmBlock), 0, s, d_jobs, static_cast<int>(MODE_PREPARE));
     HG_HIP_CHECK(hipGetLastError());
     const int max_it = problems[0]->h_state.h.opt.max_num_iterations;
@@ -5310,17 +5336,13 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     return HG_OK;
   }
   if (!batchable) return HG_OK;
-  // job table: pinned staging owned by the context (the previous batch has been fetched, so its copy
-  // has completed), one asynchronous copy, no stream synchronisation
-  if (c->jobs_capacity < static_cast<size_t>(count) * sizeof(SingleJob)) {
-    if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
-    c->pinned_jobs = nullptr;
-    c->jobs_capacity = 0;
-    const size_t cap = std::max<size_t>(kBatchGroup, count) * sizeof(SingleJob);
-    HG_HIP_CHECK(hipHostMalloc(&c->pinned_jobs, cap));
-    c->jobs_capacity = cap;
-  }
-  SingleJob* jobs = static_cast<SingleJob*>(c->pinned_jobs);
+  // job tables: one slot of the context's pinned staging ring, one asynchronous copy, no stream synchronisation
+  void* staging = nullptr;
+  unsigned slot = 0;
+  if ((rc = jobs_staging(c, 2 * sizeof(SingleJob) * static_cast<size_t>(count) + sizeof(PartJob) * static_cast<size_t>(count) + 192,
+                         &staging, &slot)) != HG_OK)
+    return rc;
+  SingleJob* jobs = static_cast<SingleJob*>(staging);
   unsigned max_wg = 0;
   unsigned long long units = 0;
   // Level partition (see k_level_classify): worth its three launches and one finest-level lookup per return once the
@@ -5335,17 +5357,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   PartJob* pjobs = nullptr;
   unsigned max_pwg = 0;
   if (partition) {
-    // (the job tables of the partition live behind the SingleJob table in the same pinned staging / device buffer)
-    const size_t need = 2 * sizeof(SingleJob) * static_cast<size_t>(count) + sizeof(PartJob) * static_cast<size_t>(count) + 192;
-    if (c->jobs_capacity < need) {
-      if (c->pinned_jobs) (void)hipHostFree(c->pinned_jobs);
-      c->pinned_jobs = nullptr;
-      c->jobs_capacity = 0;
-      const size_t cap = std::max<size_t>(kBatchGroup, count) * (2 * sizeof(SingleJob) + sizeof(PartJob)) + 192;
-      HG_HIP_CHECK(hipHostMalloc(&c->pinned_jobs, cap));
-      c->jobs_capacity = cap;
-      jobs = static_cast<SingleJob*>(c->pinned_jobs);
-    }
+    // (the job tables of the partition live behind the SingleJob table in the same staging slot / device buffer)
     pjobs = reinterpret_cast<PartJob*>(reinterpret_cast<char*>(jobs) + ((sizeof(SingleJob) * static_cast<size_t>(count) + 63) & ~size_t(63)));
     for (int i = 0; i < count; ++i) {
       hg_problem* p = problems[i];
@@ -5416,6 +5428,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     }
     if ((rc = c->ws_misc.reserve(table_bytes)) != HG_OK) return rc;
     HG_HIP_CHECK(hipMemcpyAsync(c->ws_misc.ptr, jobs, table_bytes, hipMemcpyHostToDevice, s));
+    if ((rc = jobs_staging_sent(c, slot)) != HG_OK) return rc;
     d_jobs = static_cast<const SingleJob*>(c->ws_misc.ptr);
     if (partition) {
       d_pjobs = reinterpret_cast<const PartJob*>(static_cast<const char*>(c->ws_misc.ptr) + single_bytes);
@@ -5450,7 +5463,10 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
       // (a direct-only kernel at 117 VGPRs with a general-only twin launched behind it was measured 3-5 %
       // slower than this one at 144 VGPRs with the general path as a cold call: the window test up
       // front and the second launch cost more than the fourth wavefront per SIMD brings)
-      hipLaunchKernelGGL(k_tsdf_residuals_single_batch<kBatchThreads>, dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
+      if (table == d_jobs_part)
+        hipLaunchKernelGGL((k_tsdf_residuals_single_batch<kBatchThreads, true>), dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
+      else
+        hipLaunchKernelGGL((k_tsdf_residuals_single_batch<kBatchThreads, false>), dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
       hipLaunchKernelGGL(k_lm_single_batch, dim3(count), dim3(kEvalThreads), 0, s, table);
     }
   }
@@ -5481,6 +5497,10 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     return HG_OK;
   }
   bool batched = false;
+  // HG_HOST_TIMES=1: where the host spends the call (stderr; enqueue = uploads + tables + launches, first fetch =
+  // the wait for the device)
+  static const bool host_times = std::getenv("HG_HOST_TIMES") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
   int rc = solve_batch_enqueue(problems, count, opts, &batched);
   if (rc != HG_OK) return rc;
   if (!batched) {
@@ -5490,10 +5510,19 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
     }
     return HG_OK;
   }
+  const auto t_enqueued = std::chrono::steady_clock::now();
   if ((rc = batch_settle(problems[0]->ctx)) != HG_OK) return rc;
+  auto t_first = t_enqueued;
   for (int i = 0; i < count; ++i) {
     const int r2 = hg_problem_fetch(problems[i], summaries ? summaries + i : nullptr);
     if (r2 != HG_OK) rc = r2;
+    if (i == 0) t_first = std::chrono::steady_clock::now();
+  }
+  if (host_times) {
+    const auto t_end = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::duration d) { return std::chrono::duration<double, std::micro>(d).count(); };
+    fprintf(stderr, "hg_problem_solve_batch(%d): enqueue %.1f us, settle + first fetch %.1f us, other fetches %.1f us\n", count,
+            us(t_enqueued - t_begin), us(t_first - t_enqueued), us(t_end - t_first));
   }
 #if defined(HG_DIAG_LEVELS) && !defined(HG_BIG)
   {
@@ -5509,6 +5538,29 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
   }
 #endif
   return rc;
+}
+
+int hg_problem_solve_batch_async(hg_problem* const* problems, int count, const hg_solver_opts* opts) {
+  if (!problems || count < 1) return HG_ERR_INVALID;
+  if (count > kBatchGroup) {
+    for (int i0 = 0; i0 < count; i0 += kBatchGroup) {
+      const int rc = hg_problem_solve_batch_async(problems + i0, std::min(kBatchGroup, count - i0), opts);
+      if (rc != HG_OK) return rc;
+    }
+    return HG_OK;
+  }
+  bool batched = false;
+  int rc = solve_batch_enqueue(problems, count, opts, &batched);
+  if (rc != HG_OK) return rc;
+  if (!batched) {
+    // other shapes: each problem's own enqueue-only solve, one behind the other in the context's stream
+    for (int i = 0; i < count; ++i)
+      if ((rc = hg_problem_solve_async(problems[i], opts)) != HG_OK) return rc;
+    return HG_OK;
+  }
+  // windows sharing their launches hold their last iterations back in a state the context has once: settled here
+  // (the call then returns when the windows are nearly solved; single-pose batches return at once)
+  return batch_settle(problems[0]->ctx);
 }
 
 int hg_register_scan_batch(hg_problem* const* problems, int count, const hg_solver_opts* sopts,

@@ -381,6 +381,13 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
  * solved poses live in device memory only. */
 int hg_problem_solve_async(hg_problem* p, const hg_solver_opts* opts);
 int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary);
+/* Enqueue-only form of hg_problem_solve_batch (= this call, then hg_problem_fetch on every problem). The host is
+ * free while the batch runs: a constraint search builds the problems of batch k + 1 (another set of hg_problem
+ * handles) and enqueues them while batch k is being solved, then fetches batch k -- the device never waits for the
+ * host between batches. Any number of batches may be in flight; a problem must be fetched before it is reset or
+ * solved again. Batches of general (window-shaped) problems return when their solve is nearly finished (their last
+ * iterations are enqueued on demand), single-pose batches at once. */
+int hg_problem_solve_batch_async(hg_problem* const* problems, int count, const hg_solver_opts* opts);
 /* One registration step (what OptimizingLocalTrajectoryBuilder::AddRangeData does with a scan,
  * optimizing_local_trajectory_builder.cc:1283 then :1437-1499): solve the prepared problem, then
  * insert `xyz` — given in the frame of pose `pose_index` (tracking frame), `origin` likewise —

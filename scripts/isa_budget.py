@@ -13,7 +13,7 @@ Usage: python3 scripts/isa_budget.py [out.json]      (needs hipcc; no GPU)
 import json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN2hg29k_tsdf_residuals_single_batchILi256EEEvPKNS_9SingleJobE"
+KERNEL = "_ZN2hg29k_tsdf_residuals_single_batchILi256ELb0EEEvPKNS_9SingleJobE"
 
 
 def classify(op):

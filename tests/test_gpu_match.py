@@ -633,6 +633,62 @@ def test_solve_batch_with_several_tiles_per_workgroup(po, hg, ctx, count):
         assert np.abs(pr.get_pose(i) - batch[j].get_pose(0)).max() < 1e-9
 
 
+def test_solve_batch_async_keeps_several_batches_in_flight(po, hg, ctx):
+    """hg_problem_solve_batch_async: three batches (50 problems -- the level partition is on --, 9 and 5, the last one
+    with a two-pose problem that makes it fall back to per-problem enqueues) are enqueued one behind the other before
+    any of them is fetched, twice over so that the job-table staging ring wraps; every problem ends where
+    hg_problem_solve_batch put it (bitwise: same launches, same order of sums)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    res = (0.05, 0.10, 0.20)
+    grids = [hg.HybridGridTSDF(ctx, r, max_blocks=1 << 16) for r in res]
+    for k in range(4):
+        pose = synth.pose_k(k)
+        loc = synth.transform_points(pose, synth.generate_scan(pose, 32, 900, stream=k))
+        for g in grids:
+            hg.TSDFRangeDataInserter3D().Insert(hg.RangeData(pose[:3], loc), g)
+    shapes = [(8, 25), (16, 64), (16, 65), (8, 257), (4, 513), (32, 33), (2, 1025), (1, 255), (8, 129), (3, 683)]
+    cases = []
+    for j in range(64):
+        rings, cols = shapes[j % len(shapes)]
+        pose = synth.pose_k(4 + j % 3)
+        pts = synth.generate_scan(pose, rings, cols, stream=900 + j)
+        cases.append((torch.from_numpy(pts).to(dev), len(pts), synth.pose_mul(pose, synth.perturbation())))
+
+    def build(lo, hi, with_two_pose=False):
+        ps = []
+        for d, n, guess in cases[lo:hi]:
+            p = hg.Problem(ctx)
+            i = p.add_pose(guess)
+            p.add_block(d, grids, 1.0 / np.sqrt(n), i, multi_res=True)
+            ps.append(p)
+        if with_two_pose:
+            p2 = hg.Problem(ctx)
+            a_ = p2.add_pose(cases[0][2], True)
+            b_ = p2.add_pose(cases[1][2])
+            p2.add_block(cases[0][0], grids, 1e-2, a_, b_, 0.4, multi_res=True)
+            ps.append(p2)
+        return ps
+
+    cuts = [(0, 50, False), (50, 59, False), (59, 63, True)]
+    ref = [build(*c) for c in cuts]
+    s_ref = [hg.solve_batch(b) for b in ref]
+    for _ in range(2):
+        flight = [build(*c) for c in cuts]
+        for b in flight:
+            hg.solve_batch_async(b)
+        s_flight = [hg.fetch_batch(b) for b in flight]
+        for rb, fb, rs, fs in zip(ref, flight, s_ref, s_flight):
+            for rp, fp, a, b in zip(rb, fb, rs, fs):
+                for i in range(2 if rp is rb[-1] and len(rb) == 5 else 1):
+                    assert np.array_equal(rp.get_pose(i), fp.get_pose(i))
+                assert (a.num_iterations, a.termination_type, a.termination_reason, a.final_cost) == \
+                       (b.num_iterations, b.termination_type, b.termination_reason, b.final_cost)
+    # a problem that has not been fetched cannot be fetched twice
+    with pytest.raises(Exception):
+        hg.fetch_batch(flight[1][:1])
+
+
 def test_register_scan_batch_equals_individual_registrations(po, hg, ctx):
     """hg_register_scan_batch: the registration step of several independent submaps with shared
     launches (batched matcher + insert kernels over a table of pyramids) gives every submap what
