@@ -165,7 +165,7 @@ struct LmHead {
   // (SURVEY 8a16). The factorisation then runs block by block in registers (cholesky_solve_btd).
   int btd_groups;
   int btd_uniform;  // 6 or 9: every group has that many columns and the band holds the full coupling of neighbours
-  int btd_cr;       // 1: uniform groups are factorised by cyclic reduction over the workgroup (0: HG_LM_BTD_CHAIN=1)
+  int btd_cr;       // uniform groups: 2 twisted factorisation (two wavefronts, from both ends), 1 cyclic reduction over the workgroup, 0 chain in one wavefront
   int btd_start[kMaxPoses + 1];
   int btd_size[kMaxPoses + 1];
   SmallBlockDev small[kMaxSmall];
@@ -217,8 +217,8 @@ struct LmState {
   alignas(16) unsigned short gather_h[kHCap][kGatherMax];
   alignas(16) unsigned short gather_g[kMaxCols][kGatherMax];
 #ifdef HG_BIG
-  double A[kHCap + 1];                 // the scaled system / its factor (LDS in the plain build)
-  double cr_ws[kCrStride * kMaxPoses];  // cyclic-reduction workspace
+  alignas(16) double A[kHCap + 2];     // the scaled system / its factor (LDS in the plain build), + dump slot + padding
+  alignas(16) double cr_ws[kCrStride * kMaxPoses];  // cyclic-reduction workspace
 #endif
 };
 
@@ -1658,7 +1658,7 @@ struct LmShared {
   double A[kHCap + 1];    // + a dump slot for predicated-off stores of the block solver
   double rhs[kMaxCols], y[kMaxCols];
   double invd[kMaxCols];  // reciprocals of the Cholesky diagonal
-  double loc[kMaxBlocks][kLoc];         // local normal equations of the TSDF blocks (k_window_residuals tail)
+  alignas(16) double loc[kMaxBlocks][kLoc];  // local normal equations of the TSDF blocks (k_window_residuals tail)
   double small[kMaxSmall][kSmallLoc];   // the same of the odometry / IMU blocks (lower triangle, row-major)
   LmTables T;
   double red[kMaxPoses + 8];  // per-pose partial results (+ scalar slots)
@@ -2416,6 +2416,9 @@ __device__ __forceinline__ bool cholesky_solve_cr(int W, const double* A, const 
   return ok && *ok_flag != 0;
 }
 
+#include "hg_btd.h"  // cholesky_solve_twisted
+static_assert(kTwWs <= kCrStride, "the twisted factorisation shares the cyclic-reduction workspace");
+
 // Small systems: every lane factorises its own register copy (no LDS round trips, no barriers);
 // left-looking term order; one reciprocal per column instead of a division per entry.
 template <int N>
@@ -2569,11 +2572,25 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
     // uniform 6 / 9-column groups, three or more of them: cyclic reduction over all wavefronts
     const bool use_cr = h.btd_groups >= 3 && (h.btd_uniform == 9 || h.btd_uniform == 6) && h.btd_cr != 0 &&
                         (h.btd_groups + 1) / 2 <= static_cast<int>(blockDim.x) / kWave;
-    if (use_cr) {
+    const bool use_tw = h.btd_groups >= 2 && h.btd_groups <= 9 && (h.btd_uniform == 9 || h.btd_uniform == 6) &&
+                        h.btd_cr == 2 && static_cast<int>(blockDim.x) >= 8 * kWave;
+    if (use_tw) {
+#ifdef HG_BIG
+      double* ws = S.A + (kHCap + 2);  // LmState::cr_ws follows A
+#else
+      double* ws = &S.loc[0][0];  // (the local systems were consumed by the assembly)
+#endif
+      if (h.btd_uniform == 9)
+        cholesky_solve_twisted<9>(W, (lds_f64*)S.A, (lds_f64*)S.rhs, (lds_f64*)h.step, (lds_f64*)ws, h.btd_groups,
+                                  (lds_i32*)&S.solve_ok);
+      else
+        cholesky_solve_twisted<6>(W, (lds_f64*)S.A, (lds_f64*)S.rhs, (lds_f64*)h.step, (lds_f64*)ws, h.btd_groups,
+                                  (lds_i32*)&S.solve_ok);
+    } else if (use_cr) {
 #ifdef HG_BIG
       double* ws = S.small ? nullptr : nullptr;
-      ws = S.A + (kHCap + 1);  // LmState::cr_ws follows A
-      static_assert(offsetof(LmState, cr_ws) == offsetof(LmState, A) + sizeof(double) * (kHCap + 1), "cr_ws behind A");
+      ws = S.A + (kHCap + 2);  // LmState::cr_ws follows A
+      static_assert(offsetof(LmState, cr_ws) == offsetof(LmState, A) + sizeof(double) * (kHCap + 2), "cr_ws behind A");
 #else
       double* ws = &S.loc[0][0];  // (the local systems were consumed by the assembly)
       static_assert(sizeof(S.loc) + sizeof(S.small) >= sizeof(double) * kCrStride * kMaxPoses, "cyclic-reduction workspace");
@@ -4332,7 +4349,9 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       bool uni = (mb == 6 || mb == 9) && bw >= 2 * mb - 1;
       for (int g = 1; g < groups; ++g) uni = uni && S.btd_size[g] == mb;
       if (uni && std::getenv("HG_LM_BTD_GENERIC") == nullptr) S.btd_uniform = mb;
-      S.btd_cr = std::getenv("HG_LM_BTD_CHAIN") == nullptr ? 1 : 0;
+      // 2: twisted factorisation from both ends of the chain (up to nine groups: the default shape), 1: cyclic reduction
+      // over the workgroup (long chains, or HG_LM_BTD_CR=1), 0: the chain in one wavefront (HG_LM_BTD_CHAIN=1)
+      S.btd_cr = std::getenv("HG_LM_BTD_CHAIN") != nullptr ? 0 : (std::getenv("HG_LM_BTD_CR") != nullptr || groups > 9) ? 1 : 2;
     }
     if (!ok) {
       std::memset(S.btd_start, 0, sizeof(S.btd_start));
@@ -5101,6 +5120,17 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
   fprintf(stderr, " [load]%lld", S.stamps[0] - S.stamps[8]);
   for (int i = 1; i < 8; ++i) fprintf(stderr, " [%d]%lld", i, S.stamps[i] - S.stamps[i - 1]);
   fprintf(stderr, " | solve: factor %lld forward %lld backward %lld", S.stamps[9] - S.stamps[4], S.stamps[10] - S.stamps[9], S.stamps[5] - S.stamps[10]);
+#if !defined(HG_BIG) && HG_LM_STAMPS >= 2
+  {
+    long long tw[64];
+    (void)hipMemcpyFromSymbol(tw, HIP_SYMBOL(g_tw_stamps), sizeof(tw));
+    fprintf(stderr, "\n  twisted: entry %lld, elimination slots %lld %lld %lld %lld, middle %lld, unwinding slots %lld %lld %lld %lld",
+            tw[1] - tw[0], tw[2] - tw[1], tw[3] - tw[2], tw[4] - tw[3], tw[5] - tw[4], tw[20] - tw[5], tw[21] - tw[20], tw[22] - tw[21],
+            tw[23] - tw[22], tw[24] - tw[23]);
+    fprintf(stderr, "; slot 0 of wavefront 0: to step %lld, loads %lld + %lld, columns %lld, X store %lld, Schur %lld, to barrier %lld",
+            tw[30] - tw[1], tw[31] - tw[30], tw[35] - tw[31], tw[32] - tw[35], tw[33] - tw[32], tw[34] - tw[33], tw[2] - tw[34]);
+  }
+#endif
   fprintf(stderr, "\n");
 #endif
   for (int i = 0; i < S.num_poses; ++i) {
