@@ -33,6 +33,9 @@ __device__ long long g_tw_stamps[64];
 #define TW_STAMP(i) do {} while (0)
 #define TW_STAMP_DEP(i, val) do {} while (0)
 #endif
+#ifndef HG_TW_SKIP
+#define HG_TW_SKIP 0  // scripts/tw_bench.hip: bit 0 skip the Schur update, 1 the column loop, 2 the X / y stores, 3 the backsolve, 4 t
+#endif
 #ifndef HG_TW_CUT
 #define HG_TW_CUT 0  // scripts/tw_bench.hip: leave the solve at point 1 .. 4 (timing by elimination; wrong results)
 #endif
@@ -92,11 +95,16 @@ __device__ HG_TW_ATTR bool cholesky_solve_twisted(int W, lds_f64* A, lds_f64* b,
       for (int k = 0; k < MB; ++k) X[k] = px[k * sx];
     }
     bool ok = true;
+    if (!(HG_TW_SKIP & 2))
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
       const double d = L[j][j];
       ok = ok && d > 0.0 && d < 1e300;
-      const double r = rsqrt(d);
+      // 1 / sqrt(d): the hardware estimate (2^-26) and one Newton step -- (1 - 1.5 e^2) / sqrt(d), two units in the
+      // last place -- in four dependent operations; the library call is ten with its second-order term and its
+      // special cases (d is positive and finite here, or the solve is reported as failed)
+      const double y0 = __builtin_amdgcn_rsq(d);
+      const double r = fma(y0, fma(-(d * y0), 0.5 * y0, 0.5), y0);
       L[j][j] = r;
 #pragma unroll
       for (int i = j + 1; i < MB; ++i) L[i][j] *= r;
@@ -109,7 +117,7 @@ __device__ HG_TW_ATTR bool cholesky_solve_twisted(int W, lds_f64* A, lds_f64* b,
       }
     }
     if (!ok && lane == 0) *ok_flag = 0;
-    if (lane <= MB && (coupled || lane == MB)) {
+    if (!(HG_TW_SKIP & 4) && lane <= MB && (coupled || lane == MB)) {
       lds_f64* px = lane < MB ? A + eb + lane * si : ydst;
       const int sx = lane < MB ? sk : 1;
 #pragma unroll
@@ -118,6 +126,7 @@ __device__ HG_TW_ATTR bool cholesky_solve_twisted(int W, lds_f64* A, lds_f64* b,
   };
   // x = L^-T t in every lane, in place
   auto backsolve = [&](double (&tt)[MB]) {
+    if (!(HG_TW_SKIP & 8))
 #pragma unroll
     for (int k = MB - 1; k >= 0; --k) {
       tt[k] *= L[k][k];
@@ -155,7 +164,7 @@ __device__ HG_TW_ATTR bool cholesky_solve_twisted(int W, lds_f64* A, lds_f64* b,
       // Schur update of the neighbour: D_n -= X X^T, b_n -= X y, in one pass: y is row MB of X (lanes TRI .. pair it
       // with the rows of X). The upper chain's last step leaves its share for the middle group in U: the lower
       // chain's last step may be updating that block in the same slot.
-      if (lane < TRI + MB) {
+      if (!(HG_TW_SKIP & 1) && lane < TRI + MB) {
         const bool isb = lane >= TRI;
         const int r = isb ? MB : er, c = isb ? lane - TRI : ec;
         const lds_f64* pr = isb ? ty : A + eb + r * si;
@@ -208,7 +217,7 @@ __device__ HG_TW_ATTR bool cholesky_solve_twisted(int W, lds_f64* A, lds_f64* b,
     if (mine) {
       double tt[MB];
       lds_f64* tw = ty + 10;
-      if (lane < MB) {
+      if (!(HG_TW_SKIP & 16) && lane < MB) {
         double t0 = ty[lane], t1 = 0.0;  // (two chains)
 #pragma unroll
         for (int i = 0; i < MB; ++i) {

@@ -1659,7 +1659,7 @@ struct LmShared {
   double rhs[kMaxCols], y[kMaxCols];
   double invd[kMaxCols];  // reciprocals of the Cholesky diagonal
   alignas(16) double loc[kMaxBlocks][kLoc];  // local normal equations of the TSDF blocks (k_window_residuals tail)
-  double small[kMaxSmall][kSmallLoc];   // the same of the odometry / IMU blocks (lower triangle, row-major)
+  alignas(16) double small[kMaxSmall][kSmallLoc];   // the same of the odometry / IMU blocks (lower triangle, row-major)
   LmTables T;
   double red[kMaxPoses + 8];  // per-pose partial results (+ scalar slots)
   int solve_ok;           // wavefront 0's factorisation succeeded
@@ -2852,6 +2852,163 @@ __device__ __forceinline__ void assemble_gathered(LmShared& S, const LmState* G,
   __syncthreads();
 }
 
+#ifndef HG_BIG
+// What a step's thread asks of device memory before it knows the problem's shape (round 5): its words of the head, its
+// entries of H, the gather lists of its entries of the candidate's normal equations and its share of the blocks'
+// local systems (written by the residual launch in front; how many blocks there are comes as a kernel argument) --
+// ONE round trip at kernel entry. The local systems are staged in LDS (coalesced 16-byte loads) and the entries
+// gathered from there: gathered straight from device memory, 20k scattered 8-byte loads went through the CU's one
+// address unit at ~4 lanes a cycle (8.3k cycles behind the head: in-kernel stamps); the step used to walk through
+// five dependent round trips (head, H, lists, values, cost terms; head + H + assembly 12.9k cycles).
+// Covers the first kPre * blockDim entries (2048: the LDS-resident build holds 3240; the rest take the plain loops).
+constexpr int kPre = 4;
+constexpr int kStageLoc = (kMaxBlocks * kLoc / 2 + kLmBlock - 1) / kLmBlock;        // 16-byte loads per thread: every block
+constexpr int kStageSmall = (kMaxSmall * kSmallLoc / 2 + kLmBlock - 1) / kLmBlock;
+static_assert(kLoc % 2 == 0 && kSmallLoc % 2 == 0, "local systems are staged in 16-byte pieces");
+typedef unsigned short hg_us8 __attribute__((ext_vector_type(kGatherMax)));
+typedef double hg_d2 __attribute__((ext_vector_type(2)));
+struct LmPrefetch {
+  unsigned long long head[(sizeof(LmHead) / 8 + kLmBlock - 1) / kLmBlock];
+  double H[kPre];
+  hg_us8 at_h[kPre];
+  hg_us8 at_g;
+  hg_d2 loc[kStageLoc], small[kStageSmall];
+};
+__device__ __forceinline__ void lm_prefetch(LmPrefetch& P, const LmState* G, const double* loc_sums, const SmallOut* small_out,
+                                            unsigned nb, unsigned ns) {
+  const unsigned tid = threadIdx.x;
+  constexpr unsigned kWords = sizeof(LmHead) / 8;
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
+#pragma unroll
+  for (unsigned u = 0; u < sizeof(P.head) / 8; ++u) {
+    const unsigned i = tid + u * kLmBlock;
+    P.head[u] = src[i < kWords ? i : 0u];
+  }
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const unsigned idx = tid + u * kLmBlock;  // < kPre * kLmBlock <= kHCap: always inside the arrays
+    P.H[u] = G->H[idx];
+    P.at_h[u] = *reinterpret_cast<const hg_us8*>(&G->gather_h[idx][0]);
+  }
+  P.at_g = *reinterpret_cast<const hg_us8*>(&G->gather_g[tid < kMaxCols ? tid : 0][0]);
+  const hg_d2* l2 = reinterpret_cast<const hg_d2*>(loc_sums);
+  const hg_d2* s2 = reinterpret_cast<const hg_d2*>(small_out);
+  const unsigned nl = nb * (kLoc / 2), nsm = ns * (kSmallLoc / 2);
+#pragma unroll
+  for (int u = 0; u < kStageLoc; ++u) {
+    const unsigned i = tid + u * kLmBlock;
+    if (i < nl) P.loc[u] = l2[i];
+  }
+#pragma unroll
+  for (int u = 0; u < kStageSmall; ++u) {
+    const unsigned i = tid + u * kLmBlock;
+    if (i < nsm) P.small[u] = s2[i];
+  }
+}
+static_assert(kPre * kLmBlock <= kHCap, "prefetched entries lie inside the band storage");
+
+// the staged local systems to LDS (before the barrier behind the head)
+__device__ __forceinline__ void lm_stage(LmShared& S, const LmPrefetch& P, unsigned nb, unsigned ns) {
+  const unsigned tid = threadIdx.x;
+  hg_d2* l2 = reinterpret_cast<hg_d2*>(&S.loc[0][0]);
+  hg_d2* s2 = reinterpret_cast<hg_d2*>(&S.small[0][0]);
+  const unsigned nl = nb * (kLoc / 2), nsm = ns * (kSmallLoc / 2);
+#pragma unroll
+  for (int u = 0; u < kStageLoc; ++u) {
+    const unsigned i = tid + u * kLmBlock;
+    if (i < nl) l2[i] = P.loc[u];
+  }
+#pragma unroll
+  for (int u = 0; u < kStageSmall; ++u) {
+    const unsigned i = tid + u * kLmBlock;
+    if (i < nsm) s2[i] = P.small[u];
+  }
+}
+
+// assemble_gathered with the lists in registers and the local systems in LDS (same order of the sums per entry)
+__device__ __forceinline__ void assemble_prefetched(LmShared& S, const LmPrefetch& P, const LmState* G) {
+  LmHead& h = S.h;
+  const int n = h.ncols, W = h.bw + 1, nW = n * W;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const double* locf = &S.loc[0][0];
+  const double* smallf = &S.small[0][0];
+  auto fetch = [&](unsigned short at, bool live) {
+    const bool on = live && at != 0xFFFFu;
+    const bool sm = at >= kGatherSmallBase;
+    const double* src = sm ? smallf : locf;
+    const unsigned o = on ? (sm ? at - kGatherSmallBase : at) : 0u;
+    const double v = src[o];
+    return on ? v : 0.0;
+  };
+  // contributions k0 .. k1 - 1 of every entry of this thread, all reads in flight; the lists are packed from the front,
+  // so the later groups are skipped when no thread of the wavefront has that many
+  double v[kPre + 1];
+#pragma unroll
+  for (int u = 0; u <= kPre; ++u) v[u] = 0.0;
+  bool live[kPre + 1];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) live[u] = tid + u * kLmBlock < nW;
+  live[kPre] = tid < n;
+  auto group = [&](int k0, int k1) {
+    double t[kPre + 1][kGatherMax];
+#pragma unroll
+    for (int u = 0; u <= kPre; ++u)
+#pragma unroll
+      for (int k = k0; k < k1; ++k) t[u][k] = fetch(u < kPre ? P.at_h[u][k] : P.at_g[k], live[u]);
+#pragma unroll
+    for (int u = 0; u <= kPre; ++u)
+#pragma unroll
+      for (int k = k0; k < k1; ++k) v[u] += t[u][k];
+  };
+  auto any_at = [&](int k) {
+    bool a = live[kPre] && P.at_g[k] != 0xFFFFu;
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) a = a || (live[u] && P.at_h[u][k] != 0xFFFFu);
+    return __ballot(a) != 0ull;
+  };
+  constexpr int kFirst = kGatherMax < 4 ? kGatherMax : 4;
+  group(0, kFirst);
+#pragma unroll
+  for (int k0 = kFirst; k0 < kGatherMax; k0 += 2) {
+    if (!any_at(k0)) break;  // (wave-uniform)
+    group(k0, k0 + 2 < kGatherMax ? k0 + 2 : kGatherMax);
+  }
+  // the blocks' r^T r: one term per lane of wavefront 0 (lane-strided beyond 64 blocks), added by a butterfly
+  const int nb = h.num_blocks, ns = h.num_small;
+  if (tid < kWave) {
+    double term = 0.0;
+    for (int k = tid; k < nb + ns; k += kWave) {
+      const bool tsdf = k < nb;
+      const bool on = tsdf ? h.blocks[k].active != 0 : h.small[k - nb].active != 0;
+      const double c = tsdf ? locf[k * kLoc + 90] : smallf[(k - nb) * kSmallLoc + kSmallTri + 18];
+      term += on ? c : 0.0;
+    }
+    const double cost = wave_sum(term);
+    if (tid == 0) h.cand_cost = 0.5 * cost;
+  }
+#pragma unroll
+  for (int u = 0; u < kPre; ++u)
+    if (live[u]) S.Hc[tid + u * kLmBlock] = v[u];
+  if (live[kPre]) h.gc[tid] = v[kPre];
+  // (entries beyond the prefetched ones: lists from device memory, contributions from LDS)
+  for (int idx = tid + kPre * kLmBlock; idx < nW; idx += nthreads) {
+    const hg_us8 at = *reinterpret_cast<const hg_us8*>(&G->gather_h[idx][0]);
+    double w = 0.0;
+#pragma unroll
+    for (int k = 0; k < kGatherMax; ++k) w += fetch(at[k], true);
+    S.Hc[idx] = w;
+  }
+  for (int i = tid + kLmBlock; i < n; i += nthreads) {
+    const hg_us8 at = *reinterpret_cast<const hg_us8*>(&G->gather_g[i][0]);
+    double w = 0.0;
+#pragma unroll
+    for (int k = 0; k < kGatherMax; ++k) w += fetch(at[k], true);
+    h.gc[i] = w;
+  }
+  __syncthreads();
+}
+#endif
+
 // Transforms of every block at the candidate (thread b: block b), written straight to device memory
 // for the next residual launch. Only the structural non-zeros of M are filled by prepare_block.
 __device__ __forceinline__ void prepare_all(const LmHead& h, BlockXform* xf) {
@@ -2968,7 +3125,7 @@ __device__ __forceinline__ void build_tables(LmShared& S, LmState* G) {
 // state machine.
 __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* loc_sums,
                         const SmallOut* small_out, int mode, const PinBox* host_up = nullptr,
-                        unsigned up_words = 0) {
+                        unsigned up_words = 0, unsigned stage = 0 /* TSDF blocks | odometry / IMU blocks << 16, or 0: unknown */) {
   const int tid = threadIdx.x, nthreads = blockDim.x;
 #ifdef HG_LM_STAMPS
   const long long t_entry = __builtin_amdgcn_s_memtime();
@@ -2984,6 +3141,12 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
     S.Tp = &G->T;
   }
   __syncthreads();
+#endif
+#ifndef HG_BIG
+  LmPrefetch pre;
+  const unsigned st_nb = stage & 0xFFFFu, st_ns = stage >> 16;
+  const bool prefetched = mode != MODE_PREPARE && blockDim.x == kLmBlock && stage != 0u && st_nb <= kMaxBlocks && st_ns <= kMaxSmall;
+  if (prefetched) lm_prefetch(pre, G, loc_sums, small_out, st_nb, st_ns);
 #endif
   if (mode == MODE_PREPARE && host_up) {
     // zero-copy upload: scatter the non-zero words the host left in the mailbox
@@ -3003,12 +3166,25 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
     for (int u = 0; u < kUp; ++u)
       if (idx[u] < sizeof(LmHead) / 8) dst[idx[u]] = val[u];
   } else {
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(&S.h);
-    for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
+#ifndef HG_BIG
+    if (prefetched) {
+#pragma unroll
+      for (unsigned u = 0; u < sizeof(pre.head) / 8; ++u) {
+        const unsigned i = threadIdx.x + u * kLmBlock;
+        if (i < sizeof(LmHead) / 8) dst[i] = pre.head[u];
+      }
+      lm_stage(S, pre, st_nb, st_ns);
+    } else
+#endif
+    {
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
+      for (unsigned i = threadIdx.x; i < sizeof(LmHead) / 8; i += blockDim.x) dst[i] = src[i];
+    }
   }
   __syncthreads();
   LmHead& h = S.h;
+  if (mode == MODE_STEP && h.done) return;  // (uniform; the kernels look before the call when they cannot prefetch)
   const int n = h.ncols, nW = n * (h.bw + 1);
 #ifdef HG_LM_STAMPS
   if (threadIdx.x == 0) {
@@ -3032,12 +3208,24 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
   // blocks on a pair of control points -- stages the local systems and the tables and searches per entry
   const bool gathered = G->T.pair_overflow == 0;  // uniform
 #ifndef HG_BIG
-  if (h.phase != PHASE_INIT)
-    for (int i = tid; i < nW; i += nthreads) S.H[i] = G->H[i];
+  if (h.phase != PHASE_INIT) {
+    if (prefetched) {
+#pragma unroll
+      for (int u = 0; u < kPre; ++u)
+        if (tid + u * kLmBlock < nW) S.H[tid + u * kLmBlock] = pre.H[u];
+      for (int i = tid + kPre * kLmBlock; i < nW; i += nthreads) S.H[i] = G->H[i];
+    } else {
+      for (int i = tid; i < nW; i += nthreads) S.H[i] = G->H[i];
+    }
+  }
 #endif
   if (gathered) {
     HG_STAMP(S, 1);
-    assemble_gathered(S, G, loc_sums, small_out);
+#ifndef HG_BIG
+    if (prefetched) assemble_prefetched(S, pre, G);
+    else
+#endif
+      assemble_gathered(S, G, loc_sums, small_out);
   } else {
 #ifndef HG_BIG
     double* dst = &S.loc[0][0];
@@ -3164,6 +3352,9 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
   HG_STAMP(S, 6);
   if (!h.done) prepare_all(h, xf);
   HG_STAMP(S, 7);
+#ifdef HG_LM_STAMPS
+  __syncthreads();  // (the stamp is in the head the threads store below)
+#endif
   // store the head and (if it changed) H
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
@@ -4116,7 +4307,8 @@ struct WindowJob {
   unsigned* tickets;
   double* loc;
   const PinBox* box;
-  unsigned up_words, pad;
+  unsigned up_words;
+  unsigned stage;  // TSDF blocks | odometry / IMU blocks << 16 (lm_step's prefetch), or 0
 };
 template <bool UNWARP>
 __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals_jobs(
@@ -4131,21 +4323,32 @@ __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k
 __global__ __launch_bounds__(kLmBlock) void k_lm_jobs(const WindowJob* __restrict__ jobs, int mode) {
   __shared__ LmShared S;
   const WindowJob& J = jobs[blockIdx.x];
-  if (mode == MODE_STEP && J.G->h.done) return;
-  lm_step(S, J.G, J.xf, J.loc, J.small_out, mode, mode == MODE_PREPARE ? J.box : nullptr, J.up_words);
+  if (mode == MODE_STEP && J.stage == 0u && J.G->h.done) return;  // (with the counts known the step itself looks, behind its prefetch)
+  lm_step(S, J.G, J.xf, J.loc, J.small_out, mode, mode == MODE_PREPARE ? J.box : nullptr, J.up_words, J.stage);
 }
 
 __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
                                                  const SmallOut* small_out, int mode,
-                                                 const PinBox* host_up, unsigned up_words) {
+                                                 const PinBox* host_up, unsigned up_words, unsigned stage) {
   __shared__ LmShared S;
-  if (mode == MODE_STEP && G->h.done) return;
-  lm_step(S, G, xf, partials, small_out, mode, host_up, up_words);
+  if (mode == MODE_STEP && stage == 0u && G->h.done) return;
+  lm_step(S, G, xf, partials, small_out, mode, host_up, up_words, stage);
 }
 
 HG_CAP_NS_CLOSE
 
 using namespace hg;
+
+// what lm_step's prefetch stages: TSDF blocks | odometry / IMU blocks << 16 (0 = none: the step finds out itself)
+static unsigned lm_stage_counts(const LmHead& S) {
+#ifdef HG_BIG
+  (void)S;
+  return 0u;
+#else
+  if (S.num_blocks < 0 || S.num_blocks > kMaxBlocks || S.num_small < 0 || S.num_small > kMaxSmall) return 0u;
+  return static_cast<unsigned>(S.num_blocks) | (static_cast<unsigned>(S.num_small) << 16);
+#endif
+}
 
 struct hg_problem {
   hg_ctx* ctx = nullptr;
@@ -4500,7 +4703,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
   if (with_lm) {
     ProfScope ps(p->ctx, HG_K_LM, 1);
     hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc),
-                       p->d_small, MODE_STEP, static_cast<const PinBox*>(nullptr), 0u);
+                       p->d_small, MODE_STEP, static_cast<const PinBox*>(nullptr), 0u, lm_stage_counts(p->h_state.h));
     HG_HIP_CHECK(hipGetLastError());
   }
   return HG_OK;
@@ -4923,11 +5126,11 @@ int hg_problem_evaluate(hg_problem* p, double* cost, double* residuals, double* 
     if (rc != HG_OK) return rc;
     d_res = p->residuals.as<double>();
   }
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_PREPARE, p->d_box, p->up_words, 0u);
   HG_HIP_CHECK(hipGetLastError());
   rc = launch_eval(p, d_res, false);
   if (rc != HG_OK) return rc;
-  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_ASSEMBLE, static_cast<const PinBox*>(nullptr), 0u);
+  hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_ASSEMBLE, static_cast<const PinBox*>(nullptr), 0u, 0u);
   HG_HIP_CHECK(hipGetLastError());
   HG_HIP_CHECK(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(LmState), hipMemcpyDeviceToHost, s));
   if (d_res) HG_HIP_CHECK(hipMemcpyAsync(residuals, d_res, sizeof(double) * nres, hipMemcpyDeviceToHost, s));
@@ -4973,7 +5176,7 @@ static int solve_async_impl(hg_problem* p, const hg_solver_opts* opts, bool lazy
                              S0.blocks[0].active && S0.num_small == 0 && p->num_eval < 2 &&
                              !std::getenv("HG_PREPARE_KERNEL");
   if (!first_uploads) {
-    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_PREPARE, p->d_box, p->up_words);
+    hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_PREPARE, p->d_box, p->up_words, 0u);
     HG_HIP_CHECK(hipGetLastError());
   }
   // the launches of the single-pose registration step are back-to-back: one event pair brackets all
@@ -5328,6 +5531,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
       J.loc = p->d_loc;
       J.box = p->d_box;
       J.up_words = p->up_words;
+      J.stage = lm_stage_counts(S);
       max_plain = std::max(max_plain, J.wg_plain + J.num_small);
       max_unwarp = std::max(max_unwarp, J.wg_unwarp);
       for (int b = 0; b < S.num_blocks; ++b)
