@@ -41,7 +41,7 @@ __device__ long long g_tw_stamps[64];
 #endif
 constexpr int kTwWs = 46 + 10 + 46 + 180;
 #ifndef HG_TW_ATTR
-#define HG_TW_ATTR __attribute__((noinline))
+#define HG_TW_ATTR __forceinline__
 #endif
 #ifndef HG_TW_UPSHIFT
 #define HG_TW_UPSHIFT 2

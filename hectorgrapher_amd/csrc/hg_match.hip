@@ -1646,6 +1646,9 @@ struct LmShared {
   LmTables* Tp;
   double red[kMaxPoses + 8];
   int solve_ok;
+  int h_changed;
+  LmState* step_G;        // what lm_back needs of lm_front's arguments (nothing stays live in the kernel across the calls)
+  BlockXform* step_xf;
 };
 #define LM_T(S) (*(S).Tp)
 typedef double lds_f64;  // the block solvers take generic pointers here (A is in device memory)
@@ -1663,9 +1666,15 @@ struct LmShared {
   LmTables T;
   double red[kMaxPoses + 8];  // per-pose partial results (+ scalar slots)
   int solve_ok;           // wavefront 0's factorisation succeeded
+  int h_changed;          // this step replaced H (stored back at its end)
+  LmState* step_G;        // what lm_back needs of lm_front's arguments (nothing stays live in the kernel across the calls:
+  BlockXform* step_xf;    // the copies of the arguments it kept in vector registers were spilled and reloaded around them)
 };
 #define LM_T(S) ((S).T)
 #endif
+// ONE instance for the kernels that run the general step and for the functions they call (lm_front / lm_back): at
+// file scope, so that the functions address it as LDS without a generic pointer
+__shared__ LmShared g_lm_shared;
 constexpr int kRedScalar = kMaxPoses + 5;  // slot of S.red that carries a scalar between barriers
 
 __device__ inline double readlane_f64(double v, int lane) {
@@ -2511,11 +2520,18 @@ __device__ __forceinline__ double gradient_max_norm(LmShared& S) {
 // or terminates. Workgroup-wide: every thread evaluates the (uniform) predicates from the head in
 // LDS, thread 0 updates its scalars between barriers, the loops over the matrix are spread over all
 // threads; the factorisation itself runs in wavefront 0.
-__device__ __forceinline__ void compute_next_candidate(LmShared& S) {
+// (Round 5: in three pieces. The factorisation is the only part of a step that needs the whole register file, and
+// inside one function with the rest of the step either its state or the step's loop invariants went to scratch memory
+// -- or, as a function of its own, its 31 callee-saved registers did, whose reload alone cost 1.9 us per step. Now the
+// kernel body holds nothing but attempt_solve; what comes before and behind it are the functions lm_front / lm_back.)
+// attempt_begin: FinalizeIterationAndCheckIfMinimizerCanContinue, the LM diagonal, the scaled system. False: the
+// solve has terminated. attempt_solve: the factorisation. attempt_end: model cost change, step validity, the candidate;
+// true: the step was invalid, the radius has been reduced -- begin again.
+__device__ __forceinline__ bool attempt_begin(LmShared& S) {
   LmHead& h = S.h;
   const int n = h.ncols, W = h.bw + 1;
   const int tid = threadIdx.x, nthreads = blockDim.x;
-  while (true) {
+  {
     __syncthreads();
     // FinalizeIterationAndCheckIfMinimizerCanContinue (all threads evaluate the same predicates)
     const bool stop_iter = h.iteration >= h.opt.max_num_iterations;
@@ -2536,7 +2552,7 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
     }
     if (stop_iter || stop_grad || stop_rad) {
       __syncthreads();
-      return;
+      return false;
     }
     if (!reuse) {
       for (int k = tid; k < n; k += nthreads) {
@@ -2569,6 +2585,15 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
     for (int a = tid; a < n; a += nthreads) S.rhs[a] = h.g[a] * h.scale[a];
     __syncthreads();
     HG_STAMP(S, 4);
+  }
+  return true;
+}
+
+__device__ __forceinline__ void attempt_solve(LmShared& S) {
+  LmHead& h = S.h;
+  const int n = h.ncols, W = h.bw + 1;
+  const int tid = threadIdx.x;
+  {
     // uniform 6 / 9-column groups, three or more of them: cyclic reduction over all wavefronts
     const bool use_cr = h.btd_groups >= 3 && (h.btd_uniform == 9 || h.btd_uniform == 6) && h.btd_cr != 0 &&
                         (h.btd_groups + 1) / 2 <= static_cast<int>(blockDim.x) / kWave;
@@ -2623,39 +2648,32 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
     }
     HG_STAMP(S, 5);
     __syncthreads();
+  }
+}
+
+__device__ __forceinline__ bool attempt_end(LmShared& S) {
+  LmHead& h = S.h;
+  const int n = h.ncols;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  {
     bool valid = S.solve_ok != 0;
     double mcc = 0.0;
     if (valid) {
-      __syncthreads();
-      for (int k = tid; k < n; k += nthreads) h.step[k] = -h.step[k];
-      __syncthreads();
-      // model_cost_change = -(step.J^T r + step^T J^T J step / 2) on the scaled system: thread a forms
-      // term a, wavefront 0 adds the terms (lane-strided partial sums, then a butterfly)
-      // (row a of the band is cut into kSplit runs of columns summed by different threads and added in run
-      // order: the 81 rows of a window alone would leave 430 of the 512 threads idle behind 35 dependent
-      // LDS round trips each. A holds the consumed factor by now and serves as scratch.)
-      constexpr int kSplit = 4;
-      for (int t = tid; t < n * kSplit; t += nthreads) {
-        const int a = t / kSplit, part = t - a * kSplit;
-        const int b0 = max(0, a - (W - 1)), b1 = min(n - 1, a + (W - 1));
-        const int len = b1 - b0 + 1, per = (len + kSplit - 1) / kSplit;
-        const int lo = b0 + part * per, hi = min(b1, lo + per - 1);
-        double row = 0.0;
-        for (int b = lo; b <= hi; ++b) row += band_get(S.H, a, b, W) * h.scale[a] * h.scale[b] * h.step[b];
-        S.A[t] = row;
-      }
-      __syncthreads();
-      for (int a = tid; a < n; a += nthreads) {
-        double row = 0.0;
-#pragma unroll
-        for (int part = 0; part < kSplit; ++part) row += S.A[a * kSplit + part];
-        S.y[a] = h.step[a] * (h.g[a] * h.scale[a]) + 0.5 * (h.step[a] * row);
-      }
-      __syncthreads();
+      // model_cost_change = -(step . g_s + step . H_s step / 2) on the scaled system, step = -y. y solves
+      // (H_s + D) y = g_s with D the LM diagonal the system was built with, so H_s step = -g_s - D step and the value is
+      // sum_a step_a (D_a step_a - g_s,a) / 2: one pass over the columns in wavefront 0 (lane-strided partial sums,
+      // then a butterfly) where the band matrix-vector product took four barriers and 35 dependent LDS round trips per
+      // row (mcc + candidate 8.4k cycles -> DESIGN.md 3.3). Equal to the product form up to the residual of the solve.
       if (tid < kLmThreads) {
+        const double radius = h.radius;
         double part = 0.0;
-        for (int a = tid; a < n; a += kLmThreads) part += S.y[a];
-        const double m = -wave_sum(part);
+        for (int a = tid; a < n; a += kLmThreads) {
+          const double st = -h.step[a];
+          h.step[a] = st;
+          const double lm = sqrt(h.diagonal[a] / radius);
+          part += 0.5 * (st * (lm * lm * st - h.g[a] * h.scale[a]));
+        }
+        const double m = wave_sum(part);
         if (tid == 0) S.red[kRedScalar] = m;
       }
       __syncthreads();
@@ -2676,8 +2694,7 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
         }
       }
       __syncthreads();
-      if (fail) return;
-      continue;
+      return !fail;
     }
     if (tid == 0) {
       h.reuse_diagonal = 1;
@@ -2687,7 +2704,7 @@ __device__ __forceinline__ void compute_next_candidate(LmShared& S) {
     for (int k = tid; k < n; k += nthreads) h.delta[k] = h.step[k] * h.scale[k];
     __syncthreads();
     pose_plus(h, h.x, h.delta, h.cand);
-    return;
+    return false;
   }
 }
 
@@ -3123,9 +3140,60 @@ __device__ __forceinline__ void build_tables(LmShared& S, LmState* G) {
 // One LM iteration by the calling workgroup: loads the solver head, the blocks' local systems
 // (written by the tails of k_window_residuals and by the odometry / IMU wavefronts) and advances the
 // state machine.
-__device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf, const double* loc_sums,
-                        const SmallOut* small_out, int mode, const PinBox* host_up = nullptr,
-                        unsigned up_words = 0, unsigned stage = 0 /* TSDF blocks | odometry / IMU blocks << 16, or 0: unknown */) {
+// The end of a step: transforms of the candidate for the next residual launch, the head (and H, if it changed) back to
+// device memory, the mailbox when the solve has terminated. Workgroup-wide.
+__device__ __forceinline__ void lm_finish(LmShared& S, LmState* G, BlockXform* xf) {
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  LmHead& h = S.h;
+  __syncthreads();
+  HG_STAMP(S, 6);
+#ifdef HG_LM_STAMPS
+  if (threadIdx.x == 0 && S.h.stamps[15]) S.h.stamps[12] = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (!h.done) prepare_all(h, xf);
+  HG_STAMP(S, 7);
+#ifdef HG_LM_STAMPS
+  __syncthreads();  // (the stamp is in the head the threads store below)
+#endif
+  // store the head and (if it changed) H
+  {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&G->h);
+    for (unsigned i = tid; i < sizeof(LmHead) / 8; i += nthreads) dst[i] = src[i];
+  }
+#ifndef HG_BIG
+  if (S.h_changed) {
+    const int nW = h.ncols * (h.bw + 1);
+    for (int i = tid; i < nW; i += nthreads) G->H[i] = S.H[i];
+  }
+#endif
+  if (h.done && h.box) {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&h.box->h);
+    for (unsigned i = tid; i < sizeof(LmHead) / 8; i += nthreads) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      *reinterpret_cast<volatile unsigned long long*>(&h.box->flag) = h.seq;
+      __threadfence_system();
+    }
+  }
+}
+
+// A step up to its first factorisation (or all of MODE_PREPARE / MODE_ASSEMBLE). True: the scaled system stands in
+// S.A / S.rhs -- attempt_solve, then lm_back. A function of its own (see attempt_begin); its state lives in g_lm_shared.
+// (The pointers are typed as device memory: a function cannot infer that from its callers as a kernel does, and
+// generic pointers made every access a flat operation, which counts against the LDS counter as well.)
+#define HG_GLOBAL __attribute__((address_space(1)))
+__device__ __attribute__((noinline)) bool lm_front(HG_GLOBAL LmState* G1, HG_GLOBAL BlockXform* xf1, const HG_GLOBAL double* loc1,
+                        const HG_GLOBAL SmallOut* small1, int mode, const HG_GLOBAL PinBox* up1,
+                        unsigned up_words, unsigned stage /* TSDF blocks | odometry / IMU blocks << 16, or 0: unknown */) {
+  LmState* G = (LmState*)G1;
+  BlockXform* xf = (BlockXform*)xf1;
+  const double* loc_sums = (const double*)loc1;
+  const SmallOut* small_out = (const SmallOut*)small1;
+  const PinBox* host_up = (const PinBox*)up1;
+  LmShared& S = g_lm_shared;
   const int tid = threadIdx.x, nthreads = blockDim.x;
 #ifdef HG_LM_STAMPS
   const long long t_entry = __builtin_amdgcn_s_memtime();
@@ -3184,7 +3252,7 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
   }
   __syncthreads();
   LmHead& h = S.h;
-  if (mode == MODE_STEP && h.done) return;  // (uniform; the kernels look before the call when they cannot prefetch)
+  if (mode == MODE_STEP && h.done) return false;  // (uniform; the kernels look before the call when they cannot prefetch)
   const int n = h.ncols, nW = n * (h.bw + 1);
 #ifdef HG_LM_STAMPS
   if (threadIdx.x == 0) {
@@ -3201,9 +3269,12 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
     }
     prepare_all(h, xf);
     build_tables(S, G);
-    return;
+    return false;
   }
   HG_STAMP(S, 0);
+#ifdef HG_LM_STAMPS
+  if (threadIdx.x == 0 && S.h.stamps[15]) S.h.stamps[11] = __builtin_amdgcn_s_memrealtime();
+#endif
   // H at x; the assembly gathers from device memory through the static lists, or -- more than kPairMax
   // blocks on a pair of control points -- stages the local systems and the tables and searches per entry
   const bool gathered = G->T.pair_overflow == 0;  // uniform
@@ -3253,9 +3324,10 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
 #endif
     for (int i = tid; i < n; i += nthreads) G->h.gc[i] = h.gc[i];
     if (tid == 0) G->h.cand_cost = h.cand_cost;
-    return;
+    return false;
   }
   bool h_changed = false;
+  bool solve = false;
   if (h.phase == PHASE_INIT) {
     // IterationZero: EvaluateGradientAndJacobian at x (= cand)
     for (int i = tid; i < nW; i += nthreads) S.H[i] = S.Hc[i];
@@ -3275,7 +3347,7 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
       h.phase = PHASE_CANDIDATE;
     }
     h_changed = true;
-    compute_next_candidate(S);
+    solve = attempt_begin(S);
   } else {
     // candidate evaluated: ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful
     // (every thread evaluates the same scalars from the head in LDS)
@@ -3345,38 +3417,49 @@ __device__ __forceinline__ void lm_step(LmShared& S, LmState* G, BlockXform* xf,
           h.reuse_diagonal = 1;
         }
       }
-      compute_next_candidate(S);
+      solve = attempt_begin(S);
     }
   }
-  __syncthreads();
-  HG_STAMP(S, 6);
-  if (!h.done) prepare_all(h, xf);
-  HG_STAMP(S, 7);
-#ifdef HG_LM_STAMPS
-  __syncthreads();  // (the stamp is in the head the threads store below)
-#endif
-  // store the head and (if it changed) H
-  {
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&G->h);
-    for (unsigned i = tid; i < sizeof(LmHead) / 8; i += nthreads) dst[i] = src[i];
+  if (tid == 0) {  // (uniform; read behind barriers)
+    S.h_changed = h_changed ? 1 : 0;
+    S.step_G = G;
+    S.step_xf = xf;
   }
-#ifndef HG_BIG
-  if (h_changed)
-    for (int i = tid; i < nW; i += nthreads) G->H[i] = S.H[i];
-#else
-  (void)h_changed;
-#endif
-  if (h.done && h.box) {
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&S.h);
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&h.box->h);
-    for (unsigned i = tid; i < sizeof(LmHead) / 8; i += nthreads) dst[i] = src[i];
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) {
-      *reinterpret_cast<volatile unsigned long long*>(&h.box->flag) = h.seq;
-      __threadfence_system();
-    }
+  if (!solve) lm_finish(S, G, xf);
+  return solve;
+}
+
+// A step behind a factorisation. True: the step was invalid and the system has been rebuilt with a smaller radius --
+// attempt_solve again.
+__device__ __attribute__((noinline)) bool lm_back() {
+  LmShared& S = g_lm_shared;
+  LmState* G = (LmState*)(HG_GLOBAL LmState*)S.step_G;
+  BlockXform* xf = (BlockXform*)(HG_GLOBAL BlockXform*)S.step_xf;
+  bool again = attempt_end(S);
+  if (again) again = attempt_begin(S);
+  if (!again) lm_finish(S, G, xf);
+  return again;
+}
+
+// Invalid steps (the rare path: the first factorisation of a step is in the kernel body, straight-line -- in a loop
+// there its addresses and lane indices were hoisted in front of the loop and spilled): factorise again until a step is
+// valid or the solve gives up.
+__device__ __attribute__((noinline)) void lm_retry() {
+  bool again = true;
+  while (again) {  // (uniform)
+    attempt_solve(g_lm_shared);
+    again = lm_back();
+  }
+}
+
+// MODE_PREPARE / MODE_ASSEMBLE / one LM step, for the kernels
+__device__ __forceinline__ void lm_step(LmState* G, BlockXform* xf, const double* loc_sums, const SmallOut* small_out, int mode,
+                                        const PinBox* host_up = nullptr, unsigned up_words = 0, unsigned stage = 0) {
+  bool solve = lm_front((HG_GLOBAL LmState*)G, (HG_GLOBAL BlockXform*)xf, (const HG_GLOBAL double*)loc_sums,
+                        (const HG_GLOBAL SmallOut*)small_out, mode, (const HG_GLOBAL PinBox*)host_up, up_words, stage);
+  if (solve) {  // (uniform)
+    attempt_solve(g_lm_shared);
+    if (lm_back()) lm_retry();
   }
 }
 
@@ -4218,9 +4301,8 @@ __global__ __launch_bounds__(256) void k_level_scatter(const PartJob* __restrict
 // Uploads every problem's solver head from its mailbox and prepares its first transform (k_lm
 // MODE_PREPARE for all problems of a batch in one launch).
 __global__ __launch_bounds__(kLmBlock) void k_lm_prepare_batch(const SingleJob* __restrict__ jobs) {
-  __shared__ LmShared S;
   const SingleJob& J = jobs[blockIdx.x];
-  lm_step(S, J.G, const_cast<BlockXform*>(J.xf), J.partials, nullptr, MODE_PREPARE, J.box, J.up_words);
+  lm_step(J.G, const_cast<BlockXform*>(J.xf), J.partials, nullptr, MODE_PREPARE, J.box, J.up_words);
 }
 __global__ __launch_bounds__(kEvalThreads) void k_lm_single_batch(const SingleJob* __restrict__ jobs) {
   const SingleJob& J = jobs[blockIdx.x];
@@ -4321,18 +4403,16 @@ __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k
                       J.xf, J.partials, J.small_out, tsdf_wg, small, J.tickets, J.loc, blockIdx.x);
 }
 __global__ __launch_bounds__(kLmBlock) void k_lm_jobs(const WindowJob* __restrict__ jobs, int mode) {
-  __shared__ LmShared S;
   const WindowJob& J = jobs[blockIdx.x];
   if (mode == MODE_STEP && J.stage == 0u && J.G->h.done) return;  // (with the counts known the step itself looks, behind its prefetch)
-  lm_step(S, J.G, J.xf, J.loc, J.small_out, mode, mode == MODE_PREPARE ? J.box : nullptr, J.up_words, J.stage);
+  lm_step(J.G, J.xf, J.loc, J.small_out, mode, mode == MODE_PREPARE ? J.box : nullptr, J.up_words, J.stage);
 }
 
 __global__ __launch_bounds__(kLmBlock) void k_lm(LmState* G, BlockXform* xf, const double* partials,
                                                  const SmallOut* small_out, int mode,
                                                  const PinBox* host_up, unsigned up_words, unsigned stage) {
-  __shared__ LmShared S;
   if (mode == MODE_STEP && stage == 0u && G->h.done) return;
-  lm_step(S, G, xf, partials, small_out, mode, host_up, up_words, stage);
+  lm_step(G, xf, partials, small_out, mode, host_up, up_words, stage);
 }
 
 HG_CAP_NS_CLOSE
@@ -5322,7 +5402,8 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
   fprintf(stderr, "lm stamps (cycles of the last step):");
   fprintf(stderr, " [load]%lld", S.stamps[0] - S.stamps[8]);
   for (int i = 1; i < 8; ++i) fprintf(stderr, " [%d]%lld", i, S.stamps[i] - S.stamps[i - 1]);
-  fprintf(stderr, " | solve: factor %lld forward %lld backward %lld", S.stamps[9] - S.stamps[4], S.stamps[10] - S.stamps[9], S.stamps[5] - S.stamps[10]);
+  fprintf(stderr, " | stamps 0 -> 6: %lld ticks of s_memtime in %lld x 10 ns of s_memrealtime = %.3f ticks per ns", S.stamps[6] - S.stamps[0],
+          S.stamps[12] - S.stamps[11], double(S.stamps[6] - S.stamps[0]) / (10.0 * double(S.stamps[12] - S.stamps[11])));
 #if !defined(HG_BIG) && HG_LM_STAMPS >= 2
   {
     long long tw[64];

@@ -31,7 +31,7 @@ constexpr int kMaxN = 81, kMaxW = 18;
 
 template <int MB>
 __global__ __launch_bounds__(512) void k_bench(const double* A0, const double* b0, double* x_out, int groups, int reps,
-                                               int solve, int* ok_out) {
+                                               int solve, int* ok_out, long long* first) {
   __shared__ __align__(16) double A[kMaxN * kMaxW + 2];
   __shared__ __align__(16) double Ap[kMaxN * kMaxW + 2];
   __shared__ __align__(16) double b[kMaxN], bp[kMaxN], x[kMaxN];
@@ -46,12 +46,23 @@ __global__ __launch_bounds__(512) void k_bench(const double* A0, const double* b
     for (int i = threadIdx.x; i < nW; i += blockDim.x) A[i] = Ap[i];
     for (int i = threadIdx.x; i < n; i += blockDim.x) b[i] = bp[i];
     __syncthreads();
+#ifdef TW_EVICT_ICACHE
+    {  // 96 KB of straight-line code between the solves: the solve's code is not in the instruction cache when it starts,
+       // as in k_lm, which runs once per launch behind a residual kernel (the time is in the solve = 0 run as well)
+      float ev = static_cast<float>(r);
+      asm volatile(".rept 12288\n v_add_f32 %0, %0, %0\n .endr" : "+v"(ev));
+      if (ev == 123.456f) x[0] = ev;
+    }
+    __syncthreads();
+#endif
+    const long long t0 = r < 8 ? __builtin_amdgcn_s_memtime() : 0;
     if (solve) {
       const bool good = hg::cholesky_solve_twisted<MB>(W, (hg::lds_f64*)A, (hg::lds_f64*)b, (hg::lds_f64*)x, (hg::lds_f64*)ws, groups,
                                                       (hg::lds_i32*)&ok);
       all_ok &= good ? 1 : 0;
     }
     __syncthreads();
+    if (r < 8 && threadIdx.x == 0) first[r] = __builtin_amdgcn_s_memtime() - t0;  // (cold instruction cache: the first solve)
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) x_out[i] = x[i];
   if (threadIdx.x == 0) *ok_out = all_ok;
@@ -106,6 +117,8 @@ int main(int argc, char** argv) {
   }
   double *dA, *db, *dx;
   int* dok;
+  long long* dfirst;
+  (void)hipMalloc(&dfirst, 64);
   (void)hipMalloc(&dA, band.size() * 8);
   (void)hipMalloc(&db, n * 8);
   (void)hipMalloc(&dx, n * 8);
@@ -117,7 +130,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {  // (the last of three runs counts)
       (void)hipDeviceSynchronize();
       const auto t0 = std::chrono::steady_clock::now();
-      hipLaunchKernelGGL(k_bench<9>, dim3(1), dim3(512), 0, 0, dA, db, dx, groups, reps, solve, dok);
+      hipLaunchKernelGGL(k_bench<9>, dim3(1), dim3(512), 0, 0, dA, db, dx, groups, reps, solve, dok, dfirst);
       (void)hipDeviceSynchronize();
       ms[solve] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -131,6 +144,9 @@ int main(int argc, char** argv) {
     err = std::max(err, std::fabs(xg[i] - xr[i]));
     nrm = std::max(nrm, std::fabs(xr[i]));
   }
+  long long first[8];
+  (void)hipMemcpy(first, dfirst, 64, hipMemcpyDeviceToHost);
+  printf("first solves of the launch (s_memtime ticks, incl. ~2 stamps): %lld %lld %lld %lld %lld\n", first[0], first[1], first[2], first[3], first[7]);
   int clk_khz = 0;
   (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
   const double us = (ms[1] - ms[0]) * 1e3 / reps;
