@@ -2508,11 +2508,17 @@ __device__ __forceinline__ double gradient_max_norm(LmShared& S) {
     }
     S.red[p] = m;
   }
+  // the maximum over the control points: one butterfly in wavefront 0 per 64 of them (a maximum does not depend on the
+  // order), one barrier instead of two and a loop over the poses in every thread
+  if (threadIdx.x < kWave) {
+    wave_sync();  // (control point p's thread is lane p of this wavefront when p < 64)
+    double m = 0.0;
+    for (int p = threadIdx.x; p < h.num_poses; p += kWave) m = fmax(m, S.red[p]);
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if (threadIdx.x == 0) S.red[kRedScalar + 1] = m;
+  }
   __syncthreads();
-  double m = 0.0;
-  for (int p = 0; p < h.num_poses; ++p) m = fmax(m, S.red[p]);
-  __syncthreads();  // S.red may be rewritten
-  return m;
+  return S.red[kRedScalar + 1];
 }
 
 // LevenbergMarquardtStrategy::ComputeStep + TrustRegionMinimizer::ComputeTrustRegionStep,
@@ -2554,16 +2560,11 @@ __device__ __forceinline__ bool attempt_begin(LmShared& S) {
       __syncthreads();
       return false;
     }
-    if (!reuse) {
-      for (int k = tid; k < n; k += nthreads) {
-        const double sd = S.H[band_index(k, k, W)] * h.scale[k] * h.scale[k];
-        h.diagonal[k] = fmin(fmax(sd, h.opt.min_lm_diagonal), h.opt.max_lm_diagonal);
-      }
-    }
-    __syncthreads();
     {
-      // A = scaled H + LM diagonal; rows walked without an integer division per entry
+      // A = scaled H + LM diagonal; rows walked without an integer division per entry. The thread of a diagonal entry
+      // also renews the LM diagonal of its column when it is not reused (a pass and a barrier of its own before)
       const double radius = h.radius;
+      const double dmin = h.opt.min_lm_diagonal, dmax = h.opt.max_lm_diagonal;
       int a = tid / W, c = tid - a * W;
       const int da = nthreads / W, dc = nthreads - da * W;
       for (int idx = tid; idx < n * W; idx += nthreads) {
@@ -2572,7 +2573,12 @@ __device__ __forceinline__ bool attempt_begin(LmShared& S) {
         if (b >= 0) {
           v = S.H[idx] * h.scale[a] * h.scale[b];
           if (a == b) {
-            const double lm = sqrt(h.diagonal[a] / radius);
+            double dg = h.diagonal[a];
+            if (!reuse) {
+              dg = fmin(fmax(v, dmin), dmax);  // (v = H_aa scale_a scale_a: the same product)
+              h.diagonal[a] = dg;
+            }
+            const double lm = sqrt(dg / radius);
             v += lm * lm;
           }
         }
@@ -2654,7 +2660,7 @@ __device__ __forceinline__ void attempt_solve(LmShared& S) {
 __device__ __forceinline__ bool attempt_end(LmShared& S) {
   LmHead& h = S.h;
   const int n = h.ncols;
-  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int tid = threadIdx.x;
   {
     bool valid = S.solve_ok != 0;
     double mcc = 0.0;
@@ -2701,8 +2707,15 @@ __device__ __forceinline__ bool attempt_end(LmShared& S) {
       h.invalid_steps = 0;
       h.model_cost_change = mcc;
     }
-    for (int k = tid; k < n; k += nthreads) h.delta[k] = h.step[k] * h.scale[k];
-    __syncthreads();
+    // delta = step * scale: control point p's thread writes the columns it is about to read in pose_plus (no pass and
+    // barrier of their own)
+    if (tid < h.num_poses) {
+      const int p = tid;
+      if (!h.constant[p])
+        for (int k = 0; k < 6; ++k) h.delta[h.col[p] + k] = h.step[h.col[p] + k] * h.scale[h.col[p] + k];
+      if (h.vfree[p])
+        for (int k = 0; k < 3; ++k) h.delta[h.vcol[p] + k] = h.step[h.vcol[p] + k] * h.scale[h.vcol[p] + k];
+    }
     pose_plus(h, h.x, h.delta, h.cand);
     return false;
   }
@@ -2892,7 +2905,7 @@ struct LmPrefetch {
   hg_d2 loc[kStageLoc], small[kStageSmall];
 };
 __device__ __forceinline__ void lm_prefetch(LmPrefetch& P, const LmState* G, const double* loc_sums, const SmallOut* small_out,
-                                            unsigned nb, unsigned ns) {
+                                            unsigned nb, unsigned ns, unsigned nw) {
   const unsigned tid = threadIdx.x;
   constexpr unsigned kWords = sizeof(LmHead) / 8;
   const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&G->h);
@@ -2904,8 +2917,13 @@ __device__ __forceinline__ void lm_prefetch(LmPrefetch& P, const LmState* G, con
 #pragma unroll
   for (int u = 0; u < kPre; ++u) {
     const unsigned idx = tid + u * kLmBlock;  // < kPre * kLmBlock <= kHCap: always inside the arrays
-    P.H[u] = G->H[idx];
-    P.at_h[u] = *reinterpret_cast<const hg_us8*>(&G->gather_h[idx][0]);
+    if (u * kLmBlock < nw) {  // (uniform: a round of entries the band does not have is not asked for)
+      P.H[u] = G->H[idx];
+      P.at_h[u] = *reinterpret_cast<const hg_us8*>(&G->gather_h[idx][0]);
+    } else {
+      P.H[u] = 0.0;
+      P.at_h[u] = static_cast<unsigned short>(0xFFFFu);
+    }
   }
   P.at_g = *reinterpret_cast<const hg_us8*>(&G->gather_g[tid < kMaxCols ? tid : 0][0]);
   const hg_d2* l2 = reinterpret_cast<const hg_d2*>(loc_sums);
@@ -2969,13 +2987,17 @@ __device__ __forceinline__ void assemble_prefetched(LmShared& S, const LmPrefetc
   auto group = [&](int k0, int k1) {
     double t[kPre + 1][kGatherMax];
 #pragma unroll
-    for (int u = 0; u <= kPre; ++u)
+    for (int u = 0; u <= kPre; ++u) {
+      if (u < kPre && u * kLmBlock >= nW) continue;  // (uniform: a round of entries the band does not have)
 #pragma unroll
       for (int k = k0; k < k1; ++k) t[u][k] = fetch(u < kPre ? P.at_h[u][k] : P.at_g[k], live[u]);
+    }
 #pragma unroll
-    for (int u = 0; u <= kPre; ++u)
+    for (int u = 0; u <= kPre; ++u) {
+      if (u < kPre && u * kLmBlock >= nW) continue;
 #pragma unroll
       for (int k = k0; k < k1; ++k) v[u] += t[u][k];
+    }
   };
   auto any_at = [&](int k) {
     bool a = live[kPre] && P.at_g[k] != 0xFFFFu;
@@ -3187,7 +3209,7 @@ __device__ __forceinline__ void lm_finish(LmShared& S, LmState* G, BlockXform* x
 #define HG_GLOBAL __attribute__((address_space(1)))
 __device__ __attribute__((noinline)) bool lm_front(HG_GLOBAL LmState* G1, HG_GLOBAL BlockXform* xf1, const HG_GLOBAL double* loc1,
                         const HG_GLOBAL SmallOut* small1, int mode, const HG_GLOBAL PinBox* up1,
-                        unsigned up_words, unsigned stage /* TSDF blocks | odometry / IMU blocks << 16, or 0: unknown */) {
+                        unsigned up_words, unsigned stage /* lm_stage_counts(), or 0: unknown */) {
   LmState* G = (LmState*)G1;
   BlockXform* xf = (BlockXform*)xf1;
   const double* loc_sums = (const double*)loc1;
@@ -3212,9 +3234,9 @@ __device__ __attribute__((noinline)) bool lm_front(HG_GLOBAL LmState* G1, HG_GLO
 #endif
 #ifndef HG_BIG
   LmPrefetch pre;
-  const unsigned st_nb = stage & 0xFFFFu, st_ns = stage >> 16;
+  const unsigned st_nb = stage & 0xFFu, st_ns = (stage >> 8) & 0xFFu, st_nw = stage >> 16;
   const bool prefetched = mode != MODE_PREPARE && blockDim.x == kLmBlock && stage != 0u && st_nb <= kMaxBlocks && st_ns <= kMaxSmall;
-  if (prefetched) lm_prefetch(pre, G, loc_sums, small_out, st_nb, st_ns);
+  if (prefetched) lm_prefetch(pre, G, loc_sums, small_out, st_nb, st_ns, st_nw);
 #endif
   if (mode == MODE_PREPARE && host_up) {
     // zero-copy upload: scatter the non-zero words the host left in the mailbox
@@ -3365,16 +3387,22 @@ __device__ __attribute__((noinline)) bool lm_front(HG_GLOBAL LmState* G1, HG_GLO
       S.red[p] = dn;
       S.A[p] = pn;  // (A is free until the next solve)
     }
-    __syncthreads();
-    double sn = 0.0, xn = 0.0;
-#pragma unroll
-    for (int p = 0; p < kMaxPoses; ++p) {
-      const double dn = S.red[p], pn = S.A[p];
-      sn += p < h.num_poses ? dn : 0.0;
-      xn += p < h.num_poses ? pn : 0.0;
+    // the two sums over the control points, in control-point order as before, by lane 0 of wavefront 0 (whose lanes
+    // are the threads above: kMaxPoses <= 64) instead of by every thread behind a barrier of its own
+    if (tid == 0) {
+      wave_sync();
+      double sn0 = 0.0, xn0 = 0.0;
+      for (int p = 0; p < h.num_poses; ++p) {
+        sn0 += S.red[p];
+        xn0 += S.A[p];
+      }
+      S.red[kRedScalar + 2] = sn0;
+      S.A[kMaxPoses] = xn0;
     }
-    sn = sqrt(sn);
-    xn = sqrt(xn);
+    static_assert(kMaxPoses <= kWave, "the per-pose threads of a step sit in one wavefront");
+    __syncthreads();
+    const double sn = sqrt(S.red[kRedScalar + 2]);
+    const double xn = sqrt(S.A[kMaxPoses]);
     const double cost_change = h.x_cost - h.cand_cost;
     const bool ptol = sn <= h.opt.parameter_tolerance * (xn + h.opt.parameter_tolerance);
     const bool ftol = fabs(cost_change) <= h.opt.function_tolerance * h.x_cost;
@@ -4390,7 +4418,7 @@ struct WindowJob {
   double* loc;
   const PinBox* box;
   unsigned up_words;
-  unsigned stage;  // TSDF blocks | odometry / IMU blocks << 16 (lm_step's prefetch), or 0
+  unsigned stage;  // lm_stage_counts(): what lm_step's prefetch needs to know, or 0
 };
 template <bool UNWARP>
 __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals_jobs(
@@ -4419,14 +4447,17 @@ HG_CAP_NS_CLOSE
 
 using namespace hg;
 
-// what lm_step's prefetch stages: TSDF blocks | odometry / IMU blocks << 16 (0 = none: the step finds out itself)
+// what lm_step's prefetch needs to know before the head is there: TSDF blocks | odometry / IMU blocks << 8 | band
+// entries << 16 (0 = nothing: the step finds out itself)
 static unsigned lm_stage_counts(const LmHead& S) {
 #ifdef HG_BIG
   (void)S;
   return 0u;
 #else
   if (S.num_blocks < 0 || S.num_blocks > kMaxBlocks || S.num_small < 0 || S.num_small > kMaxSmall) return 0u;
-  return static_cast<unsigned>(S.num_blocks) | (static_cast<unsigned>(S.num_small) << 16);
+  const unsigned nW = static_cast<unsigned>(S.ncols) * static_cast<unsigned>(S.bw + 1);
+  if (S.num_blocks > 255 || S.num_small > 255 || nW > 0xFFFFu) return 0u;
+  return static_cast<unsigned>(S.num_blocks) | (static_cast<unsigned>(S.num_small) << 8) | (nW << 16);
 #endif
 }
 
