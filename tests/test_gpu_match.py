@@ -430,14 +430,17 @@ def test_window_of_ten_control_points(po, hg, ctx, maps):
 
 
 @pytest.mark.parametrize("velocities", [True, False])
-@pytest.mark.parametrize("path", ["cyclic_reduction", "btd_chain", "btd_padded", "band"])
+@pytest.mark.parametrize("path", ["twisted", "cyclic_reduction", "btd_chain", "btd_padded", "band"])
 def test_window_linear_solver_paths(po, hg, ctx, maps, path, velocities, monkeypatch):
-    """The factorisations of the window's normal equations -- block cyclic reduction over the workgroup
+    """The factorisations of the window's normal equations -- the twisted block factorisation from both ends of the
+    chain with a wavefront per group (the default up to nine groups), block cyclic reduction over the workgroup
     (uniform 9- or 6-column groups), the block chain in one wavefront (registers, forward pass folded in),
     the padded block form, the band Cholesky -- give the oracle's solve: same iterations, poses within
     tolerance. With velocities: 9-column groups (pose + velocity, IMU blocks); without: 6-column groups
     coupled by two-pose scan blocks. (The environment switches are read at every solve.)"""
-    if path == "btd_chain":
+    if path == "cyclic_reduction":
+        monkeypatch.setenv("HG_LM_BTD_CR", "1")
+    elif path == "btd_chain":
         monkeypatch.setenv("HG_LM_BTD_CHAIN", "1")
     elif path == "btd_padded":
         monkeypatch.setenv("HG_LM_BTD_GENERIC", "1")
