@@ -1234,10 +1234,13 @@ template <int N> __device__ inline DJ<N> dj_acos(const DJ<N>& f) {
 
 // QuaternionParameterization (Ceres 1.13 local_parameterization.cc)
 __device__ inline void quaternion_plus(const double* x, const double* delta, double* out) {
+#pragma clang fp contract(fast)  // (LM side only: no discrete decision downstream; see lm_step_single)
   const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
   if (nd > 0.0) {
-    const double sbd = sin(nd) / nd;
-    const double q0 = cos(nd), q1 = sbd * delta[0], q2 = sbd * delta[1], q3 = sbd * delta[2];
+    double sn, q0;
+    sincos(nd, &sn, &q0);  // (one argument reduction for both)
+    const double sbd = sn / nd;
+    const double q1 = sbd * delta[0], q2 = sbd * delta[1], q3 = sbd * delta[2];
     out[0] = q0 * x[0] - q1 * x[1] - q2 * x[2] - q3 * x[3];
     out[1] = q0 * x[1] + q1 * x[0] + q2 * x[3] - q3 * x[2];
     out[2] = q0 * x[2] - q1 * x[3] + q2 * x[0] + q3 * x[1];
