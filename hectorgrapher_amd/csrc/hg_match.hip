@@ -994,6 +994,45 @@ __device__ inline void store_partial(double* p, double v) {
 __device__ inline double load_partial(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Round 5, the single-pose chain: partial sums that are their own flag (cdna_hip_programming.md Guideline 16, R2:
+// "the data IS the flag"). A double travels as two 8-byte granules {tag = this launch's epoch, 32 bits of the value},
+// each written by ONE aligned 8-byte write-through store; the reader re-reads a granule until its tag is the epoch.
+// No acknowledgement wait, no ticket, no reload behind the ticket: the hand-over was store drain (0.7 us) + returning
+// atomic (0.8 us) + loads (1.2 us) per launch, now it is the visibility of the last workgroup's stores plus the
+// re-read that sees them. Epochs count launches per problem (never 0, never reused: the buffer starts zeroed).
+__device__ inline void store_partial_tagged(unsigned long long* g, double v, unsigned epoch) {
+  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v));
+  const unsigned long long tag = static_cast<unsigned long long>(epoch) << 32;
+  __hip_atomic_store(g, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// both granules of a double by ONE 16-byte load around the L1 (each 8-byte half is a granule of its own, validated by
+// its own tag; two 8-byte loads per double made the first sweep twice as long -- 8-byte accesses run at 0.54-0.70x the
+// 16-byte rate). Fourteen loads and their wait in ONE asm statement: the compiler knows nothing of an asm load's
+// latency, so no result may leave the statement before the wait. (A buffer load with the sc1 bit through
+// __builtin_amdgcn_raw_buffer_load_b128 never saw the tags: measured, dropped.)
+typedef unsigned long long hg_u64x2 __attribute__((ext_vector_type(2)));
+constexpr int kSweep = 14;
+__device__ __forceinline__ void load_granule_pairs(hg_u64x2 (&v)[kSweep], const unsigned long long* const (&g)[kSweep]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %14, off sc1\n global_load_dwordx4 %1, %15, off sc1\n"
+      "global_load_dwordx4 %2, %16, off sc1\n global_load_dwordx4 %3, %17, off sc1\n"
+      "global_load_dwordx4 %4, %18, off sc1\n global_load_dwordx4 %5, %19, off sc1\n"
+      "global_load_dwordx4 %6, %20, off sc1\n global_load_dwordx4 %7, %21, off sc1\n"
+      "global_load_dwordx4 %8, %22, off sc1\n global_load_dwordx4 %9, %23, off sc1\n"
+      "global_load_dwordx4 %10, %24, off sc1\n global_load_dwordx4 %11, %25, off sc1\n"
+      "global_load_dwordx4 %12, %26, off sc1\n global_load_dwordx4 %13, %27, off sc1\n"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+        "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13])
+      : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(g[8]), "v"(g[9]), "v"(g[10]),
+        "v"(g[11]), "v"(g[12]), "v"(g[13])
+      : "memory");
+}
+__device__ inline hg_u64x2 load_granule_pair(const unsigned long long* g) {  // (the re-reads: two 8-byte loads)
+  return hg_u64x2{__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                  __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+}
 
 // Which return a lane takes. The vector L1 prices a gather by the distinct 128-byte lines the four lanes of
 // every aligned quad touch (scripts/tcp_bench.hip: one cycle per line and quad, no merging beyond adjacent
@@ -1070,7 +1109,8 @@ __device__ __forceinline__ void tsdf_residuals_body(
     double* __restrict__ residuals, double (*xs)[kWave][8], double (*cs)[64], unsigned wg,
     const double* pose_tq = nullptr /* the transform when it does not come from xf (first launch) */,
     unsigned width = 0, unsigned tiles = 1 /* tiles of THREADS returns per workgroup (the batched kernel) */,
-    unsigned fast_n = 0 /* the first fast_n returns are expected to stop at the finest level (level partition) */) {
+    unsigned fast_n = 0 /* the first fast_n returns are expected to stop at the finest level (level partition) */,
+    unsigned epoch = 0 /* != 0: the partial sums go out as tagged granules (store_partial_tagged), `partials` = the granule buffer */) {
   const ScanOrder order = make_scan_order(n, width);
   const unsigned first_i0 = wg * tiles * THREADS + threadIdx.x;
   BODY_STAMP(0);
@@ -1168,7 +1208,10 @@ __device__ __forceinline__ void tsdf_residuals_body(
     double s = 0.0;
 #pragma unroll
     for (int wv = 0; wv < THREADS / kWave; ++wv) s += cs[wv][a * 8 + b] + xs[wv][0][a * 8 + b];
-    store_partial(&partials[static_cast<size_t>(wg) * kAcc + threadIdx.x], s);
+    if (epoch != 0u)  // (uniform)
+      store_partial_tagged(reinterpret_cast<unsigned long long*>(partials) + (static_cast<size_t>(wg) * kAcc + threadIdx.x) * 2, s, epoch);
+    else
+      store_partial(&partials[static_cast<size_t>(wg) * kAcc + threadIdx.x], s);
   }
   BODY_STAMP(5);
   ISA_MARK("tile|exit");
@@ -3512,7 +3555,8 @@ __device__ inline int b6(int i, int j) { return i * 6 + 5 - (i - j); }  // band_
 
 template <bool FIRST = false>
 __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, BlockXform* xf, const double* partials,
-                               unsigned num_wg, const PinBox* host_up = nullptr, unsigned up_words = 0) {
+                               unsigned num_wg, const PinBox* host_up = nullptr, unsigned up_words = 0,
+                               unsigned epoch = 0 /* != 0: `partials` holds tagged granules of this epoch */) {
   // (Round 5: multiply-adds of this function are fused -- the file is compiled -ffp-contract=off for the voxel lookups,
   // whose discrete decisions need the reference's roundings; nothing in the LM step takes one, and the tail is a chain
   // of dependent fp64 operations: 14.7 -> 14.0 us per launch together with the right-looking factorisation below.)
@@ -3553,15 +3597,58 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
     if (j < stripes) {
       double acc = 0.0;
       const double* p = partials + k;
-      for (unsigned w = j; w < num_wg; w += 16 * stripes) {
-        double v[16];
+      if (epoch != 0u) {  // (uniform) tagged granules: re-read what has not arrived yet
+        const unsigned long long* gp = reinterpret_cast<const unsigned long long*>(partials) + 2 * k;
+        for (unsigned w = j; w < num_wg; w += kSweep * stripes) {
+          hg_u64x2 gr[kSweep];
+          const unsigned long long* ga[kSweep];
+          const unsigned long long none = static_cast<unsigned long long>(epoch) << 32;  // (reads as 0.0)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const unsigned idx = w + u * stripes;
-          v[u] = idx < num_wg ? load_partial(&p[static_cast<size_t>(idx) * kAcc]) : 0.0;
+          for (int u = 0; u < kSweep; ++u) {
+            const unsigned idx = w + u * stripes;
+            ga[u] = gp + static_cast<size_t>(idx < num_wg ? idx : 0u) * (2 * kAcc);
+          }
+          load_granule_pairs(gr, ga);  // (as 8-byte loads: 3927 against 4065 scans/s)
+#pragma unroll
+          for (int u = 0; u < kSweep; ++u)
+            if (w + u * stripes >= num_wg) gr[u] = hg_u64x2{none, none};
+          bool pending = true;
+          unsigned long long t_first = 0;
+          for (unsigned spins = 0; pending; ++spins) {
+            pending = false;
+#pragma unroll
+            for (int u = 0; u < kSweep; ++u) {
+              if (static_cast<unsigned>(gr[u].x >> 32) != epoch || static_cast<unsigned>(gr[u].y >> 32) != epoch) {
+                gr[u] = load_granule_pair(ga[u]);
+                pending = true;
+              }
+            }
+            if (pending && spins == 0u) t_first = __builtin_amdgcn_s_memrealtime();
+            if (pending && (spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_first > 200000000ull) {
+              // (two seconds of polling -- s_memrealtime counts 100 MHz -- cannot happen: every workgroup of the launch
+              // runs, the others never wait for this one) the sum becomes NaN and the step is reported as failed
+              // instead of spinning for ever
+              gr[0] = hg_u64x2{0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull};
+#pragma unroll
+              for (int u = 1; u < kSweep; ++u) gr[u] = hg_u64x2{none, none};
+              break;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kSweep; ++u)
+            acc += __longlong_as_double(static_cast<long long>((gr[u].y << 32) | (gr[u].x & 0xFFFFFFFFull)));
         }
+      } else {
+        for (unsigned w = j; w < num_wg; w += 16 * stripes) {
+          double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += v[u];
+          for (int u = 0; u < 16; ++u) {
+            const unsigned idx = w + u * stripes;
+            v[u] = idx < num_wg ? load_partial(&p[static_cast<size_t>(idx) * kAcc]) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += v[u];
+        }
       }
       scratch[j * kAcc + k] = acc;
     }
@@ -4110,7 +4197,8 @@ template <int THREADS, bool FIRST = false>
 __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* __restrict__ xyz, unsigned n,
                                             unsigned width, double scaling, const BlockXform* __restrict__ xf,
                                             double* __restrict__ partials, LmState* G, unsigned* ticket,
-                                            unsigned wg_index, unsigned num_wg, const FirstUpload* up = nullptr) {
+                                            unsigned wg_index, unsigned num_wg, unsigned epoch,
+                                            const FirstUpload* up = nullptr) {
   if (!FIRST && G->h.done) return;
 #ifdef HG_EVAL_STAMPS
   const int eval_it = G->h.iteration;
@@ -4123,8 +4211,19 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
   tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, partials, nullptr,
                                reinterpret_cast<double (*)[kWave][8]>(smem),
                                reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
-                               xcd_chunk(wg_index, num_wg), FIRST ? up->pose : nullptr, width);
+                               xcd_chunk(wg_index, num_wg), FIRST ? up->pose : nullptr, width, 1, 0, epoch);
   EVAL_STAMP(1);
+  if (epoch != 0u) {
+    // tagged partial sums (store_partial_tagged): workgroup 0 runs the LM step and waits for the granules themselves
+    // (the workgroup launched last instead: 3753 against 3790-3830 scans/s)
+    if (wg_index != 0u) return;
+    __syncthreads();  // (ends this workgroup's use of the tiles in smem)
+    EVAL_STAMP(2);
+    lm_step_single<FIRST>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), partials, num_wg,
+                          FIRST ? up->box : nullptr, FIRST ? up->up_words : 0u, epoch);
+    EVAL_STAMP(3);
+    return;
+  }
   __shared__ int s_last;
   // hand-over of the partials without fences: sc1 stores drained here, one counted arrival per
   // workgroup behind the barrier, sc1 loads in the tail (store_partial / load_partial)
@@ -4146,15 +4245,15 @@ __device__ __forceinline__ void single_eval(const PyramidView& pv, const float* 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single(
     PyramidView pv, const float* __restrict__ xyz, unsigned n, unsigned width, double scaling,
-    const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket) {
-  single_eval<THREADS>(pv, xyz, n, width, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x);
+    const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket, unsigned epoch) {
+  single_eval<THREADS>(pv, xyz, n, width, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x, epoch);
 }
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_first(
     PyramidView pv, const float* __restrict__ xyz, unsigned n, unsigned width, double scaling,
     const BlockXform* __restrict__ xf, double* __restrict__ partials, LmState* G, unsigned* ticket,
-    FirstUpload up) {
-  single_eval<THREADS, true>(pv, xyz, n, width, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x, &up);
+    FirstUpload up, unsigned epoch) {
+  single_eval<THREADS, true>(pv, xyz, n, width, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x, epoch, &up);
 }
 
 // Several INDEPENDENT single-pose problems per launch (blockIdx.y = problem): each keeps its own
@@ -4487,6 +4586,8 @@ struct hg_problem {
   // device state
   LmState* d_state = nullptr;
   unsigned* d_ticket = nullptr;
+  hg::DeviceBuffer granules;   // tagged partial sums of the single-pose chain (store_partial_tagged)
+  unsigned epoch = 0;          // launches of that chain so far
   BlockXform* d_xf = nullptr;
   DeviceBuffer partials, residuals;
   DeviceBuffer part_xyz, part_flags, part_counts;  // level partition of the block's cloud (batched single-pose solves)
@@ -4763,6 +4864,21 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
     const PyramidView& pv = p->h_pv[0];
     (void)hb;
     ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n, 1, !p->prof_grouped);
+    // partial sums as tagged granules (HG_TICKET_HANDOVER=1: the acknowledged stores + ticket of rounds 1-4)
+    static const bool tagged = std::getenv("HG_TICKET_HANDOVER") == nullptr;
+    double* sums = p->partials.as<double>();
+    unsigned epoch = 0;
+    if (tagged) {
+      const size_t need = static_cast<size_t>(bi.num_wg) * kAcc * 2 * sizeof(unsigned long long);
+      if (p->granules.bytes < need) {
+        const int rc = p->granules.reserve(need);
+        if (rc != HG_OK) return rc;
+        HG_HIP_CHECK(hipMemsetAsync(p->granules.ptr, 0, p->granules.bytes, s));  // (no tag equals an epoch: epochs start at 1)
+      }
+      sums = p->granules.as<double>();
+      epoch = ++p->epoch;
+      if (epoch == 0u) epoch = ++p->epoch;
+    }
     if (first) {
       FirstUpload up;
       std::memcpy(up.pose, S.cand[0], sizeof(up.pose));
@@ -4770,10 +4886,10 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
       up.up_words = p->up_words;
       up.pad = 0;
       hipLaunchKernelGGL(k_tsdf_residuals_single_first<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
-                         hb.d_xyz, bi.n, hb.width, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket, up);
+                         hb.d_xyz, bi.n, hb.width, bi.scaling, p->d_xf, sums, p->d_state, p->d_ticket, up, epoch);
     } else {
       hipLaunchKernelGGL(k_tsdf_residuals_single<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv,
-                         hb.d_xyz, bi.n, hb.width, bi.scaling, p->d_xf, p->partials.as<double>(), p->d_state, p->d_ticket);
+                         hb.d_xyz, bi.n, hb.width, bi.scaling, p->d_xf, sums, p->d_state, p->d_ticket, epoch);
     }
     HG_HIP_CHECK(hipGetLastError());
     return HG_OK;
@@ -4955,6 +5071,7 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->h_pv) (void)hipHostFree(p->h_pv);
   if (p->h_eval) (void)hipHostFree(p->h_eval);
   p->partials.release();
+  p->granules.release();
   p->part_xyz.release();
   p->part_flags.release();
   p->part_counts.release();
