@@ -216,3 +216,26 @@ def test_register_scan_batch_of_100k_point_scans_against_oracle(po, hg, ctx):
             g.status()
             for x, y in zip(o.export(), g.export()):
                 assert np.array_equal(x, y)
+
+
+def test_both_hand_overs_of_the_partial_sums_pass_the_bench_gate():
+    """The single-pose chain hands its partial sums to the LM tail as tagged granules (round 5) or, with
+    HG_TICKET_HANDOVER=1, by acknowledged stores and a ticket (rounds 1 - 4). The switch is read once per process, so
+    each form runs the headline command in a process of its own: bench.py aborts unless the first timed steps equal the
+    oracle's (poses within 1e-4 m / 1e-4 rad, same iterations and termination), and the two forms must agree with
+    each other far below that."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for env_extra in ({}, {"HG_TICKET_HANDOVER": "1"}):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-scans", "2",
+                              "--no-secondary", "--host-steps", "0"], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    for d in lines:
+        assert d["parity"]["same_iterations_and_termination"] and d["parity"]["max_dt_m"] < 1e-9
+    assert abs(lines[0]["config"]["mean_pose_error_m"] - lines[1]["config"]["mean_pose_error_m"]) < 1e-9
