@@ -4520,8 +4520,13 @@ struct WindowJob {
   unsigned up_words;
   unsigned stage;  // lm_stage_counts(): what lm_step's prefetch needs to know, or 0
 };
+#ifndef HG_WINDOW_JOBS_WAVES
+// (the same body lands at 125 VGPRs in k_window_residuals and at 164 here under the budget of three workgroups per CU:
+// with the budget of four -- 128 VGPRs, a few spills -- eight windows per call run 2417 -> 2496 scans/s)
+#define HG_WINDOW_JOBS_WAVES 4
+#endif
 template <bool UNWARP>
-__global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_WAVES) void k_window_residuals_jobs(
+__global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_JOBS_WAVES) void k_window_residuals_jobs(
     const WindowJob* __restrict__ jobs) {
   const WindowJob& J = jobs[blockIdx.y];
   // the odometry / IMU blocks ride on the per-scan launch
