@@ -5907,13 +5907,12 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   hipLaunchKernelGGL(k_lm_prepare_batch, dim3(count), dim3(kLmBlock), 0, s, d_jobs);
   HG_HIP_CHECK(hipGetLastError());
   const int max_it = problems[0]->h_state.h.opt.max_num_iterations;
-  // The returns are classified at the candidate the solve evaluates SECOND: the first step takes the pose from the
-  // initial guess (centimetres off) most of the way to where it ends, and a return on the edge of the finest level's
-  // known voxels changes sides with every voxel the pose moves -- classified at the guess itself, 35 % of the
-  // wavefronts that were expected fast held such a lane a few iterations later and paid the second round trip; at the
-  // third candidate 4 %, but one more launch runs unpartitioned (156 against 114 us): 36.16k against 35.99k
-  // matches/s for the second. HG_PARTITION_AT overrides the iteration.
-  static const int part_at = std::getenv("HG_PARTITION_AT") ? std::atoi(std::getenv("HG_PARTITION_AT")) : 1;
+  // The returns are classified at the candidate the solve evaluates THIRD: the first two steps take the pose from
+  // the initial guess (centimetres off) to within a millimetre of where it ends, and a return on the edge of the
+  // finest level's known voxels changes sides with every voxel the pose moves -- classified at the guess itself,
+  // 35 % of the wavefronts that were expected fast held such a lane a few iterations later and paid the second
+  // round trip. HG_PARTITION_AT overrides the iteration.
+  static const int part_at = std::getenv("HG_PARTITION_AT") ? std::atoi(std::getenv("HG_PARTITION_AT")) : 2;
   // (Round 4, measured and dropped: the batch cut in two halves on two streams, the second one residual pass behind
   // the first, so that one half's step kernel -- `count` workgroups on an otherwise idle chip, 10 us per iteration
   // against 22 us of residual pass for eight 100k-point scans -- would run under the other half's residual pass.
