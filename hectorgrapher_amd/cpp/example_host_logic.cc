@@ -44,5 +44,64 @@ int main() {
     const std::array<double, 4> q = mapping::IntegrateImuDeltaRotation(imu, sp[0], sp[1]);
     std::printf("imu_delta %lld %lld %.17g %.17g %.17g %.17g\n", static_cast<long long>(sp[0]), static_cast<long long>(sp[1]), q[0], q[1], q[2], q[3]);
   }
+  // --- the reference's own known-answer tests for these two pieces, run through the adapter ---
+  // transform/transform_interpolation_buffer_test.cc:29-45 (testHas)
+  {
+    transform::TransformInterpolationBuffer b;
+    const Pose identity{{0, 0, 0, 1, 0, 0, 0}};
+    std::printf("kat_has %d", b.Has(50) ? 1 : 0);
+    b.Push(50, identity);
+    std::printf(" %d %d %d", b.Has(25) ? 1 : 0, b.Has(50) ? 1 : 0, b.Has(75) ? 1 : 0);
+    b.Push(100, identity);
+    std::printf(" %d %d %d %d %d %lld %lld\n", b.Has(25) ? 1 : 0, b.Has(50) ? 1 : 0, b.Has(75) ? 1 : 0, b.Has(100) ? 1 : 0,
+                b.Has(125) ? 1 : 0, static_cast<long long>(b.earliest_time()), static_cast<long long>(b.latest_time()));
+  }
+  // :47-65 (testLookup): identity at 50, translation (10, 10, 10) * Rz(2 rad) at 100, looked up at 75
+  {
+    transform::TransformInterpolationBuffer b;
+    b.Push(50, Pose{{0, 0, 0, 1, 0, 0, 0}});
+    b.Push(100, Pose{{10., 10., 10., std::cos(1.0), 0, 0, std::sin(1.0)}});
+    const Pose p = b.Lookup(75);
+    std::printf("kat_lookup %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+  }
+  // :67-74 (testLookupSingleTransform)
+  {
+    transform::TransformInterpolationBuffer b;
+    b.Push(75, Pose{{0, 0, 0, 1, 0, 0, 0}});
+    const Pose p = b.Lookup(75);
+    std::printf("kat_single %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+  }
+  // mapping/internal/3d/imu_integration_test.cc:30-58 (ZeroIntegration): 101 zero samples one second apart
+  {
+    std::deque<sensor::ImuData> d;
+    common::Time t = 0;
+    d.push_back(sensor::ImuData{t, {{0, 0, 0}}, {{0, 0, 0}}});
+    for (int i = 0; i < 100; ++i) {
+      t += common::FromSeconds(1);
+      d.push_back(sensor::ImuData{t, {{0, 0, 0}}, {{0, 0, 0}}});
+    }
+    size_t it = d.size() - 1;
+    while (d[it].time > 0) --it;
+    const mapping::IntegrateImuWithTranslationResult r = mapping::IntegrateImuWithTranslationEuler(d, 0, t, &it);
+    std::printf("kat_imu_zero %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", r.delta_velocity[0], r.delta_velocity[1],
+                r.delta_velocity[2], r.delta_translation[0], r.delta_translation[1], r.delta_translation[2], r.delta_rotation[0],
+                r.delta_rotation[1], r.delta_rotation[2], r.delta_rotation[3]);
+  }
+  // :60-116 (ConstantAcceleration): (0, 0, 9.80665) at 100 Hz, integrated from 0 to every sample time
+  {
+    std::deque<sensor::ImuData> d;
+    common::Time t = 0;
+    d.push_back(sensor::ImuData{t, {{0, 0, 9.80665}}, {{0, 0, 0}}});
+    for (int i = 0; i < 1000; ++i) {
+      t += common::FromSeconds(0.01);
+      d.push_back(sensor::ImuData{t, {{0, 0, 9.80665}}, {{0, 0, 0}}});
+      size_t it = d.size() - 1;
+      while (d[it].time > 0) --it;
+      const mapping::IntegrateImuWithTranslationResult r = mapping::IntegrateImuWithTranslationEuler(d, 0, t, &it);
+      std::printf("kat_imu_const %lld %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", static_cast<long long>(t),
+                  r.delta_velocity[0], r.delta_velocity[1], r.delta_velocity[2], r.delta_translation[0], r.delta_translation[1],
+                  r.delta_translation[2], r.delta_rotation[0], r.delta_rotation[1], r.delta_rotation[2], r.delta_rotation[3]);
+    }
+  }
   return 0;
 }

@@ -698,26 +698,32 @@ inline void InsertUnwarped(const std::vector<HybridGridTSDF*>& grids, const hg_i
         "hg_pyramid_insert_unwarped");
 }
 
-// Pre-integrated rotation between two control points, the only part of the pre-integration result
-// PredictionImuPreintegrationCostFunctor reads (prediction_imu_preintegration_cost_functor.h:81-84):
-// the rotation recurrence of IntegrateImuWithTranslationEuler (imu_integration.h:99-131) --
-// piecewise-constant angular velocity, delta_rotation *= AngleAxisVectorToRotationQuaternion(w * dt)
-// (transform/transform.h:121-135) -- with identity calibration. Host scalar code, as in the reference.
-// Returns (w, x, y, z). `imu` is ordered by time; samples before `start` other than the last one are
-// ignored, and without a sample at or before `start` the first sample is held.
-inline std::array<double, 4> IntegrateImuDeltaRotation(const std::deque<sensor::ImuData>& imu, common::Time start,
-                                                       common::Time end) {
-  std::array<double, 4> q{{1.0, 0.0, 0.0, 0.0}};
-  if (imu.empty() || !(start < end)) return q;
-  size_t it = 0;
-  while (it + 1 < imu.size() && imu[it + 1].time <= start) ++it;
-  common::Time current = start;
-  while (current < end) {
-    const common::Time next_imu = it + 1 < imu.size() ? imu[it + 1].time : std::numeric_limits<common::Time>::max();
-    const common::Time next = std::min(next_imu, end);
+// IntegrateImuWithTranslationEuler (imu_integration.h:99-154) with identity calibration: piecewise-constant samples,
+// per step delta_rotation *= AngleAxisVectorToRotationQuaternion(w dt) (transform/transform.h:121-135),
+// delta_velocity += delta_rotation * (a dt) (Eigen's _transformVector), delta_translation += delta_velocity dt.
+// `*it` is the reference's iterator: the last sample at or before start_time on entry (its CHECKs are exceptions here),
+// advanced past every sample the integration consumes. Host scalar code, as in the reference. Pinned by the
+// reference's own known answers, imu_integration_test.cc:30-120 (tests/test_host_logic.py).
+struct IntegrateImuWithTranslationResult {
+  std::array<double, 3> delta_translation{{0.0, 0.0, 0.0}};
+  std::array<double, 4> delta_rotation{{1.0, 0.0, 0.0, 0.0}};  // (w, x, y, z)
+  std::array<double, 3> delta_velocity{{0.0, 0.0, 0.0}};
+};
+inline IntegrateImuWithTranslationResult IntegrateImuWithTranslationEuler(const std::deque<sensor::ImuData>& imu,
+                                                                          common::Time start_time, common::Time end_time,
+                                                                          size_t* it) {
+  if (!(start_time <= end_time)) throw Error("IntegrateImuWithTranslationEuler: start_time > end_time", HG_ERR_INVALID);
+  if (*it >= imu.size() || imu[*it].time > start_time) throw Error("IntegrateImuWithTranslationEuler: no sample at or before start_time", HG_ERR_TIME);
+  if (*it + 1 < imu.size() && !(imu[*it + 1].time > start_time)) throw Error("IntegrateImuWithTranslationEuler: iterator is not the last sample before start_time", HG_ERR_TIME);
+  IntegrateImuWithTranslationResult result;
+  std::array<double, 4>& q = result.delta_rotation;
+  common::Time current = start_time;
+  while (current < end_time) {
+    const common::Time next_imu = *it + 1 < imu.size() ? imu[*it + 1].time : std::numeric_limits<common::Time>::max();
+    const common::Time next = std::min(next_imu, end_time);
     const double dt = common::ToSeconds(next - current);
-    const double ax = imu[it].angular_velocity[0] * dt, ay = imu[it].angular_velocity[1] * dt,
-                 az = imu[it].angular_velocity[2] * dt;
+    const double ax = imu[*it].angular_velocity[0] * dt, ay = imu[*it].angular_velocity[1] * dt,
+                 az = imu[*it].angular_velocity[2] * dt;
     double scale = 0.5, w = 1.0;
     const double sq = ax * ax + ay * ay + az * az;
     if (sq > 1e-8) {  // kCutoffAngle: linearised below
@@ -731,10 +737,37 @@ inline std::array<double, 4> IntegrateImuDeltaRotation(const std::deque<sensor::
                                    q[0] * y + q[2] * w + q[3] * x - q[1] * z,
                                    q[0] * z + q[3] * w + q[1] * y - q[2] * x}};
     q = r;
+    // delta_velocity += delta_rotation * (linear_acceleration * dt): uv = 2 (q.vec x v), v + w uv + q.vec x uv
+    const double vx = imu[*it].linear_acceleration[0] * dt, vy = imu[*it].linear_acceleration[1] * dt,
+                 vz = imu[*it].linear_acceleration[2] * dt;
+    double ux = q[2] * vz - q[3] * vy, uy = q[3] * vx - q[1] * vz, uz = q[1] * vy - q[2] * vx;
+    ux += ux; uy += uy; uz += uz;
+    result.delta_velocity[0] += vx + q[0] * ux + (q[2] * uz - q[3] * uy);
+    result.delta_velocity[1] += vy + q[0] * uy + (q[3] * ux - q[1] * uz);
+    result.delta_velocity[2] += vz + q[0] * uz + (q[1] * uy - q[2] * ux);
+    for (int k = 0; k < 3; ++k) result.delta_translation[k] += result.delta_velocity[k] * dt;
     current = next;
-    if (current == next_imu) ++it;
+    if (current == next_imu) ++*it;
   }
-  return q;
+  return result;
+}
+
+// Pre-integrated rotation between two control points, the only part of the pre-integration result
+// PredictionImuPreintegrationCostFunctor reads (prediction_imu_preintegration_cost_functor.h:81-84).
+// Returns (w, x, y, z). `imu` is ordered by time; samples before `start` other than the last one are
+// ignored, and without a sample at or before `start` the first sample is held (the window's first control point may
+// precede the first IMU sample; the reference CHECKs there).
+inline std::array<double, 4> IntegrateImuDeltaRotation(const std::deque<sensor::ImuData>& imu, common::Time start,
+                                                       common::Time end) {
+  if (imu.empty() || !(start < end)) return std::array<double, 4>{{1.0, 0.0, 0.0, 0.0}};
+  size_t it = 0;
+  while (it + 1 < imu.size() && imu[it + 1].time <= start) ++it;
+  if (imu[it].time > start) {  // (it == 0) hold the first sample from `start` on
+    std::deque<sensor::ImuData> held = imu;
+    held[0].time = start;
+    return IntegrateImuWithTranslationEuler(held, start, end, &it).delta_rotation;
+  }
+  return IntegrateImuWithTranslationEuler(imu, start, end, &it).delta_rotation;
 }
 
 // A SIMPLIFIED sliding-window driver (one control point per scan; the reference's own shape is

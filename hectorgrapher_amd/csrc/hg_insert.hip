@@ -73,6 +73,18 @@ __device__ inline uint32_t find_scan(const ScanTable* scans, uint32_t n_scans, u
   return lo;
 }
 
+// The scan of return i inside a workgroup whose first return is wg_first (uniform). The returns of a workgroup almost
+// always belong to one scan, so the search runs on the uniform index -- scalar loads through the scalar cache,
+// and the table entry arrives in scalar registers -- and only lanes beyond that scan's end search for themselves.
+// (Per lane, the binary search was three dependent vector loads in front of everything else a count or scatter
+// workgroup does: k_bin_count of an eight-scan chunk 10.6 us per scan against 6.7 with the scan as a kernel argument.)
+__device__ inline ScanTable scan_lookup(const ScanTable* scans, uint32_t n_scans, unsigned long long i, unsigned long long wg_first) {
+  const uint32_t k = __builtin_amdgcn_readfirstlane(find_scan(scans, n_scans, wg_first));
+  ScanTable sc = scans[k];
+  if (k + 1u < n_scans && i >= scans[k + 1u].begin) sc = scans[find_scan(scans, n_scans, i)];
+  return sc;
+}
+
 // Gates of Insert (:703-716) and the setup of InsertHit (:294-317).
 __device__ inline Ray ray_setup(const GridView& g, const InsertParams& p, const ScanTable& sc,
                                 const float* xyz, unsigned long long i, const uint8_t* gate) {
@@ -185,6 +197,11 @@ __device__ inline Ray ray_setup(const GridView& g, const InsertParams& p, const 
 }
 
 // tsd and weight of the update of cell (cx, cy, cz) along ray r (:318-342).
+// UNIT: the caller has established weight_function_epsilon >= 1 (the binned paths): tsd / tau >= -1 >= -epsilon for the
+// clamped tsd (a correctly rounded quotient of |a| <= |b| never exceeds 1), so the weight is 1 and neither the division
+// nor the comparison is evaluated. APPROX (tolerance mode only): the distance by the hardware's square root estimate
+// (1 ulp) instead of the correctly rounded one.
+template <bool UNIT = false, bool APPROX = false>
 __device__ inline void ray_sample_cell(const GridView& g, const InsertParams& p, const Ray& r,
                                        int cx, int cy, int cz, float& tsd, float& weight);
 __device__ inline void ray_sample(const GridView& g, const InsertParams& p, const Ray& r, int pos,
@@ -195,6 +212,7 @@ __device__ inline void ray_sample(const GridView& g, const InsertParams& p, cons
   cz = r.bz + static_cast<int>(roundf(static_cast<float>(r.dz) * fp / fn));
   ray_sample_cell(g, p, r, cx, cy, cz, tsd, weight);
 }
+template <bool UNIT, bool APPROX>
 __device__ inline void ray_sample_cell(const GridView& g, const InsertParams& p, const Ray& r,
                                        int cx, int cy, int cz, float& tsd, float& weight) {
   const float ccx = static_cast<float>(cx) * g.resolution;
@@ -207,8 +225,10 @@ __device__ inline void ray_sample_cell(const GridView& g, const InsertParams& p,
     tsd = clampf(r.ndir * (dx * r.nx + (dy * r.ny + dz * r.nz)), -tau, tau);
     return;
   }
-  const float dist = norm3(ccx - r.ox, ccy - r.oy, ccz - r.oz);
+  const float ex = ccx - r.ox, ey = ccy - r.oy, ez = ccz - r.oz;
+  const float dist = APPROX ? __builtin_amdgcn_sqrtf(ex * ex + (ey * ey + ez * ez)) : norm3(ex, ey, ez);
   tsd = clampf(r.range - dist, -tau, tau);
+  if (UNIT) return;
   const float normalized = tsd / tau;
   if (normalized < -p.epsilon) {
     // :333-340, evaluated in double as std::exp/std::pow promote
@@ -850,7 +870,7 @@ __device__ __forceinline__ void bin_count_body(const PyramidIns& P, const LevelI
   if (i < n) {
     // a chunk of several scans: returns are concatenated in scan order, so seq = i * 8 + sample is the
     // reference's update order across the whole chunk
-    const ScanTable sc = scans ? scans[find_scan(scans, n_scans, i)] : scan_of(P);
+    const ScanTable sc = scans ? scan_lookup(scans, n_scans, i, xcd_chunk(bx, nbx) * 256u) : scan_of(P);
     const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
     hit = r.valid && r.n + 1 <= kSlots;
     if (r.valid && !hit) atomicOr(&L.g.counters[1], kFlagStride);
@@ -1227,6 +1247,47 @@ __device__ inline double fast_survival(const GridView& g, uint32_t code, double 
   return A;
 }
 
+// The same product for the bins' apply pass (round 6), where the Gamma-function form above was most of the kernel
+// (240 VGPRs, two lgamma pairs + exp + pow in fp64 per touched voxel). With alpha = (c0 - 1) / step and
+// beta = alpha + 1 + delta, delta = 1 / (kw step) - 1 (-0.0071 for maximum weight 1000: the stored weight of an
+// update is 1.0071, not 1), the growth phase is
+//   prod_{j<n} (alpha + j) / (beta + j) = alpha / (alpha + n) * [G(a + delta) / G(a)] / [G(b + delta) / G(b)],
+//   a = alpha + 1, b = alpha + n + 1 (G = Gamma), and log(G(x + delta) / G(x)) = delta psi(x) + delta^2 / 2 psi'(x) + O(delta^3)
+// with the asymptotic digamma / trigamma series (x >= 1; error < 3e-3 in psi at x = 1, times delta: < 3e-5 in A, a
+// tsd code is 3e-5 of the range, and far less for the x >= 2 every weight after the first update has).
+// The saturated phase is exp((m - n) log(wmax / (wmax + 1))). fp32 throughout: the relative error of A stays
+// below 1e-6, the updates' mean and the blend are formed in fp64 by the caller as before.
+__device__ inline float fast_survival_f(const GridView& g, uint32_t code, unsigned m, float log_q_sat, uint32_t* code_out) {
+#pragma clang fp contract(fast)
+  const int step = static_cast<int>(roundf(g.weight_resolution));
+  const int c0 = static_cast<int>(code & 0x7FFFu) == 0 ? 1 : static_cast<int>(code & 0x7FFFu);
+  const unsigned grow_all = c0 >= 32767 ? 0u : static_cast<unsigned>((32767 - c0 + step - 1) / step);
+  const unsigned n = min(m, grow_all);
+  const unsigned long long c_end = static_cast<unsigned long long>(c0) + static_cast<unsigned long long>(step) * m;
+  *code_out = static_cast<uint32_t>(c_end < 32767ull ? c_end : 32767ull);
+  float A = 1.0f;
+  if (n > 0u) {
+    if (c0 == 1) {
+      A = 0.0f;  // weight 0: the first update replaces the value
+    } else {
+      const float fstep = static_cast<float>(step);
+      const float alpha = static_cast<float>(c0 - 1) / fstep;
+      const float delta = 1.0f / (g.weight_scale * fstep) - 1.0f;
+      const float fn = static_cast<float>(n);
+      const float a = alpha + 1.0f, b = alpha + fn + 1.0f;
+      const float ra = 1.0f / a, rb = 1.0f / b;
+      const float ra2 = ra * ra, rb2 = rb * rb;
+      // psi(a) - psi(b), psi'(a) - psi'(b)
+      const float dpsi = __logf(a * rb) - 0.5f * (ra - rb) - (1.0f / 12.0f) * (ra2 - rb2) + (1.0f / 120.0f) * (ra2 * ra2 - rb2 * rb2);
+      const float dtri = (ra - rb) + 0.5f * (ra2 - rb2) + (1.0f / 6.0f) * (ra2 * ra - rb2 * rb);
+      const float x = delta * dpsi + 0.5f * delta * delta * dtri;
+      A = alpha / (alpha + fn) * __expf(x);
+    }
+  }
+  if (m > n) A *= __expf(static_cast<float>(m - n) * log_q_sat);
+  return A;
+}
+
 // Same quantities by walking the weight sequence update by update: for weight resolutions whose
 // fraction is too close to one half for the closed form above (not the case for the defaults).
 __device__ inline double fast_survival_walk(const GridView& g, float maxw, uint32_t code, double m, uint32_t* code_out) {
@@ -1503,6 +1564,9 @@ __global__ __launch_bounds__(1024) void k_bin_offsets_jobs(const InsertJob* __re
   bin_offsets_body(J.P, L, blockIdx.x % levels, J.records_per_level);
 }
 
+// FAST (tolerance mode on the bins, k_fast_bin_apply): one word per record, voxel | units << 9 with the sample's
+// tsd + tau in units of 2 tau / (2^23 - 1) -- the order of a voxel's updates does not matter there, so no seq.
+template <bool FAST = false>
 __device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, const LevelIns& L, int level, unsigned bx, unsigned nbx,
                                                  const ScanTable* scans, uint32_t n_scans, const float* xyz,
                                                  unsigned n, const RunInfo* runs, uint32_t* rec_keys,
@@ -1524,7 +1588,7 @@ __device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, const Leve
   }
   __syncthreads();
   if ((info.run[0] | info.run[1] | info.run[2] | info.run[3]) == 0u) return;
-  const ScanTable sc = scans ? scans[find_scan(scans, n_scans, i)] : scan_of(P);
+  const ScanTable sc = scans ? scan_lookup(scans, n_scans, i, xcd_chunk(bx, nbx) * 256u) : scan_of(P);
   const Ray r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
   // One pass over the sample positions for all lanes (the per-run loops made a wavefront walk
   // every run as long as its longest lane: ~10-12 sample evaluations where 8 suffice). The runs of a ray
@@ -1557,9 +1621,16 @@ __device__ __forceinline__ void bin_scatter_body(const PyramidIns& P, const Leve
     }
     if (!in) continue;
     float tsd, w;
-    ray_sample_cell(L.g, L.p, r, cx, cy, cz, tsd, w);
-    rec_keys[at + pos] = (voxel_in_block(cx, cy, cz) << kSeqBits) | (i * kSlots + pos);
-    rec_vals[at + pos] = __float_as_uint(tsd);
+    ray_sample_cell<true, FAST>(L.g, L.p, r, cx, cy, cz, tsd, w);  // (unit weights: a condition of the binned paths)
+    if (FAST) {
+      const float tau = L.p.truncation_distance;
+      const float to_units = static_cast<float>(kFastUnits) / (tau + tau);
+      const unsigned units = min(static_cast<unsigned>(__float2int_rn((tsd + tau) * to_units)), kFastUnits);
+      rec_keys[at + pos] = voxel_in_block(cx, cy, cz) | (units << 9);
+    } else {
+      rec_keys[at + pos] = (voxel_in_block(cx, cy, cz) << kSeqBits) | (i * kSlots + pos);
+      rec_vals[at + pos] = __float_as_uint(tsd);
+    }
   }
 }
 
@@ -1573,6 +1644,175 @@ __global__ __launch_bounds__(256) void k_bin_scatter_jobs(const InsertJob* __res
   if (blockIdx.x >= J.nwg) return;
   const LevelIns L = J.P.lv[blockIdx.y % levels];
   bin_scatter_body(J.P, L, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.rec_keys, J.rec_vals);
+}
+
+// ==========================================================================================
+// Tolerance path on the bins (round 6; replaces k_fast_accumulate's one device-scope 64-bit atomic per distinct
+// voxel of a workgroup). Same semantics -- the updates a voxel receives in one chunk of a call are summed as
+// integers and applied once in closed form -- but the sums are formed where they cost nothing:
+//   k_bin_count          (the exact path's) block runs, block slots, bin reservations
+//   k_fast_offsets       per level: exclusive scan of the touched bins; ONE apply item per bin, bins beyond
+//                        kFastItemRecords records cut into parts by RECORD range (no order to keep)
+//   k_fast_scatter       one 4-byte record per sample: voxel | units << 9
+//   k_fast_bin_apply     per item: the records stream in coalesced, an LDS tile of 512 x {count << 44 | sum} takes
+//                        them by LDS atomics, one closed-form UpdateCell per touched voxel, 2 KiB block read and
+//                        written once. Parts of a cut bin leave their tiles in a scratch area; the part that
+//                        arrives last (a ticket per bin) adds them up and applies.
+// No accumulator array (8 B per voxel of the pool), no global atomics on voxels.
+// ==========================================================================================
+constexpr unsigned kFastItemRecords = 8192;  // records of one apply item (32 per thread)
+constexpr unsigned kFastApplyThreads = 256;
+constexpr unsigned kFastMaxParts = 256;      // parts of one bin (8 bits in the item)
+
+// Tiles of the parts of cut bins: per level `tile_capacity` tiles of 512 x u64 behind each other.
+struct FastScratch {
+  unsigned long long* tiles;
+  unsigned tile_capacity;  // per level
+};
+
+// grid (levels), 1024 threads. Work item {slot | part << 24, first record, records | (parts - 1) << 24, first tile
+// of the bin}.
+__global__ __launch_bounds__(1024) void k_fast_offsets(PyramidIns P, unsigned records_per_level, FastScratch fs) {
+  const int level = blockIdx.x;
+  const LevelIns& L = P.lv[level];
+  __shared__ unsigned s_scan[16];
+  __shared__ unsigned s_base, s_work, s_tiles;
+  const unsigned nt = L.g.call[0];
+  if (threadIdx.x == 0) { s_base = 0; s_work = 0; s_tiles = 0; }
+  __syncthreads();
+  for (unsigned c0 = 0; c0 < nt; c0 += 1024u) {
+    const unsigned i = c0 + threadIdx.x;
+    const unsigned slot = i < nt ? L.g.touched[i] : 0u;
+    const unsigned cnt = i < nt ? L.g.bin_count[slot] : 0u;
+    unsigned chunk_total = 0;
+    const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
+    const unsigned bin_off = static_cast<unsigned>(level) * records_per_level + s_base + excl;
+    if (i < nt) {
+      L.g.bin_offset[slot] = bin_off;
+      L.g.bin_count[slot] = 0;  // the apply pass counts the arrivals of a cut bin's parts here and leaves 0 behind
+    }
+    unsigned parts = cnt ? 1u : 0u;
+    unsigned per_part = cnt;
+    if (cnt > kFastItemRecords) {
+      parts = min((cnt + kFastItemRecords - 1u) / kFastItemRecords, kFastMaxParts);
+      per_part = (cnt + parts - 1u) / parts;
+    }
+    const unsigned w0 = reserve_items(&s_work, parts);
+    const unsigned t0 = reserve_items(&s_tiles, parts > 1u ? parts : 0u);
+    bool fits = w0 + parts <= L.g.work_capacity && (parts <= 1u || t0 + parts <= fs.tile_capacity);
+    if (parts && !fits) atomicOr(&L.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes both from the records
+    for (unsigned k = 0; fits && k < parts; ++k) {
+      const unsigned b = k * per_part, e = min(cnt, b + per_part);
+      L.g.work[w0 + k] = make_uint4(slot | (k << 24), bin_off + b, (e - b) | ((parts - 1u) << 24),
+                                    static_cast<unsigned>(level) * fs.tile_capacity + t0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += chunk_total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    L.g.call[1] = min(s_work, L.g.work_capacity);
+    L.g.call[0] = 0;  // next call collects from scratch
+    unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
+    if (P.shared) atomicAdd(upd, static_cast<unsigned long long>(s_base));
+    else *upd = s_base + (P.accumulate ? *upd : 0ull);  // U of this call
+    publish_flags(P, level);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fast_scatter(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
+                                                      const float* xyz, unsigned n, const RunInfo* runs, uint32_t* recs) {
+  bin_scatter_body<true>(P, P.lv[blockIdx.y], blockIdx.y, blockIdx.x, gridDim.x, scans, n_scans, xyz, n, runs, recs, nullptr);
+}
+
+// grid (G, levels), 256 threads, two voxels per thread.
+__global__ __launch_bounds__(kFastApplyThreads) void k_fast_bin_apply(PyramidIns P, const uint32_t* __restrict__ recs,
+                                                                     FastScratch fs) {
+  const LevelIns& L = P.lv[blockIdx.y];
+  const GridView& g = L.g;
+  const unsigned n_items = g.call[1];
+  const double tau = static_cast<double>(L.p.truncation_distance);
+  const double unit = (tau + tau) / static_cast<double>(kFastUnits);
+  const float maxw = L.p.maximum_weight;
+  const float frac = g.weight_resolution - floorf(g.weight_resolution);
+  const bool closed_form = fabsf(frac - 0.5f) > 0.05f && g.weight_resolution >= 1.0f && maxw == g.max_weight;
+  // log(wmax / (wmax + 1)): the share of a saturated voxel's value that survives one update
+  const float wmax = 32766.f * g.weight_scale;
+  const float log_q_sat = static_cast<float>(log(static_cast<double>(wmax) / (static_cast<double>(wmax) + 1.0)));
+  __shared__ unsigned long long s_acc[kVoxelsPerBlock];
+  __shared__ int s_last;
+  const unsigned t = threadIdx.x;
+  for (unsigned w = blockIdx.x; w < n_items; w += gridDim.x) {
+    const uint4 item = g.work[w];
+    const uint32_t slot = item.x & 0xFFFFFFu, part = item.x >> 24;
+    const unsigned cnt = item.z & 0xFFFFFFu, parts = (item.z >> 24) + 1u;
+    const uint32_t* __restrict__ r = recs + item.y;
+    s_acc[t] = 0ull;
+    s_acc[t + kFastApplyThreads] = 0ull;
+    __syncthreads();
+    // records: eight loads of a thread in flight, then their LDS atomics
+    for (unsigned b = 0; b < cnt; b += 8u * kFastApplyThreads) {
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned j = b + k * kFastApplyThreads + t;
+        v[k] = j < cnt ? r[j] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned j = b + k * kFastApplyThreads + t;
+        if (j < cnt) atomicAdd(&s_acc[v[k] & 511u], (1ull << kFastCountShift) | static_cast<unsigned long long>(v[k] >> 9));
+      }
+    }
+    __syncthreads();
+    unsigned long long a[2] = {s_acc[t], s_acc[t + kFastApplyThreads]};
+    if (parts > 1u) {
+      // a part of a cut bin: the tile goes to the scratch area (write-through, drained before the arrival is
+      // counted: the hand-over of hg_match.hip's partial sums); the last part to arrive sums all of them
+      unsigned long long* tiles = fs.tiles + static_cast<size_t>(item.w) * kVoxelsPerBlock;
+      unsigned long long* mine = tiles + static_cast<size_t>(part) * kVoxelsPerBlock;
+      __hip_atomic_store(mine + t, a[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + t + kFastApplyThreads, a[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        const unsigned arrived = atomicAdd(&g.bin_count[slot], 1u);
+        s_last = arrived == parts - 1u ? 1 : 0;
+        if (s_last) g.bin_count[slot] = 0u;  // ready for the next call's count pass
+      }
+      __syncthreads();
+      const bool last = s_last != 0;
+      if (last) {
+        a[0] = 0ull;
+        a[1] = 0ull;
+        for (unsigned q = 0; q < parts; ++q) {
+          const unsigned long long* tq = tiles + static_cast<size_t>(q) * kVoxelsPerBlock;
+          a[0] += __hip_atomic_load(tq + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          a[1] += __hip_atomic_load(tq + t + kFastApplyThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      __syncthreads();  // (s_last and s_acc are reused by the next item)
+      if (!last) continue;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (a[h] == 0ull) continue;
+      const double m = static_cast<double>(a[h] >> kFastCountShift);
+      const double sum = static_cast<double>(a[h] & ((1ull << kFastCountShift) - 1ull)) * unit - m * tau;
+      const double mean = sum / m;
+      uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + t + h * kFastApplyThreads;
+      const uint32_t code = *cell;
+      const double d0 = static_cast<double>(value_to_tsd(g, code & 0xFFFFu));
+      uint32_t wcode;
+      const double A = closed_form ? static_cast<double>(fast_survival_f(g, code >> 16, static_cast<unsigned>(a[h] >> kFastCountShift), log_q_sat, &wcode))
+                                   : fast_survival_walk(g, maxw, code >> 16, m, &wcode);
+      // every update is a convex combination, so the m updates carry the weight 1 - A together; they enter at
+      // their mean (their individual shares depend on the arrival order)
+      const double d = d0 * A + mean * (1.0 - A);
+      *cell = (tsd_to_value(g, static_cast<float>(d)) | kUpdateMarker) | (wcode << 16);
+    }
+    // (a thread clears and re-reads only its own two words of s_acc: no barrier needed before the next item)
+  }
 }
 
 // Bitonic sort of m (power of two) key/value pairs in LDS by all kBinThreads threads. Keys are
@@ -2776,7 +3016,70 @@ int ensure_accumulators(hg_grid* grid) {
 }
 
 // ---- tolerance path (HG_INSERT_FAST, unit weight) -------------------------------------------
-int insert_chunk_fast(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans, uint32_t n_scans,
+// Tolerance path on the bins (k_fast_offsets ... k_fast_bin_apply). One chunk = up to 2^20 - 1 returns of one or
+// several scans: the scans of a chunk share their bins, so a voxel's updates of the whole chunk are applied once.
+int insert_chunk_fast(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_scans, uint32_t n_scans,
+                      const float* d_xyz, unsigned long long n, bool want_stats) {
+  hipStream_t s = c->stream;
+  const unsigned records_per_level = static_cast<unsigned>(n) * kSlots;
+  PyramidIns P = P_in;
+  for (int l = 0; l < P.levels; ++l) P.lv[l].g.call = P.lv[l].g.counters + 16;
+  int rc;
+  {
+    size_t max_pool = 0;
+    for (int l = 0; l < P.levels; ++l) max_pool = std::max<size_t>(max_pool, P.lv[l].g.max_blocks);
+    // one item per touched bin plus the extra parts of cut bins (fewer than records / kFastItemRecords)
+    const size_t per_level = std::min<size_t>(static_cast<size_t>(n) * kMaxRuns, max_pool) +
+                             records_per_level / kFastItemRecords + 64u;
+    if ((rc = c->ws_offsets.reserve(sizeof(uint4) * per_level * P.levels)) != HG_OK) return rc;
+    for (int l = 0; l < P.levels; ++l) {
+      P.lv[l].g.work = c->ws_offsets.as<uint4>() + per_level * l;
+      P.lv[l].g.work_capacity = static_cast<uint32_t>(per_level);
+    }
+  }
+  // a cut bin of cnt records has ceil(cnt / kFastItemRecords) <= cnt / kFastItemRecords + 1 < 2 cnt / kFastItemRecords parts
+  FastScratch fs;
+  fs.tile_capacity = 2u * (records_per_level / kFastItemRecords) + 64u;
+  if ((rc = c->ws_vals_a.reserve(sizeof(unsigned long long) * kVoxelsPerBlock * fs.tile_capacity * P.levels)) != HG_OK) return rc;
+  fs.tiles = c->ws_vals_a.as<unsigned long long>();
+  const size_t slots = static_cast<size_t>(records_per_level) * P.levels;
+  if ((rc = c->ws_keys_a.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
+  const unsigned nwg_e = static_cast<unsigned>((n + 255) / 256);
+  if ((rc = c->ws_counts.reserve(sizeof(unsigned) * static_cast<size_t>(nwg_e) * kMaxInsLevels)) != HG_OK) return rc;
+  if ((rc = c->ws_keys_b.reserve(sizeof(RunInfo) * run_info_units(n, nwg_e, P.levels))) != HG_OK) return rc;
+  unsigned* wg_hits = c->ws_counts.as<unsigned>();
+  uint32_t* recs = c->ws_keys_a.as<uint32_t>();
+  RunInfo* runs = c->ws_keys_b.as<RunInfo>();
+  {
+    ProfScope ps(c, HG_K_RAY_COUNT, n * P.levels);
+    hipLaunchKernelGGL(k_bin_count, dim3(nwg_e, P.levels), dim3(256), 0, s, P, d_scans, n_scans, d_xyz,
+                       static_cast<unsigned>(n), runs, wg_hits);
+  }
+  {
+    ProfScope ps(c, HG_K_SCAN, P.levels);
+    hipLaunchKernelGGL(k_fast_offsets, dim3(P.levels), dim3(1024), 0, s, P, records_per_level, fs);
+  }
+  {
+    ProfScope ps(c, HG_K_RAY_EXPAND, n * P.levels);
+    hipLaunchKernelGGL(k_fast_scatter, dim3(nwg_e, P.levels), dim3(256), 0, s, P, d_scans, n_scans, d_xyz,
+                       static_cast<unsigned>(n), runs, recs);
+  }
+  {
+    ProfScope ps(c, HG_K_APPLY, slots);
+    hipLaunchKernelGGL(k_fast_bin_apply, dim3(1024, P.levels), dim3(kFastApplyThreads), 0, s, P, recs, fs);
+  }
+  HG_HIP_CHECK(hipGetLastError());
+  if (want_stats) {
+    // hits from the per-workgroup counts; updates were written by k_fast_offsets
+    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, nullptr, 0u);
+    HG_HIP_CHECK(hipGetLastError());
+  }
+  return HG_OK;
+}
+
+// The round-2 form (one device-scope atomic per distinct voxel of a workgroup into an 8-byte accumulator per voxel of
+// the pool), kept for comparison: HG_FAST_ATOMICS=1.
+int insert_chunk_fast_atomics(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans, uint32_t n_scans,
                       const float* d_xyz, unsigned long long n, bool want_stats) {
   hipStream_t s = c->stream;
   int rc;
@@ -3011,6 +3314,30 @@ namespace {
 // 29 us (groups of 8). Running the next group's front end NEXT TO the apply passes (second stream,
 // also with the front end confined to half of the CUs by a CU mask) was measured and dropped: the
 // apply pass slows down 2.5x under the front end's atomics and scattered writes, no net gain.
+// Pinned staging of a call's table (job table of a grouped stream, scan table of a multi-scan call): the previous
+// call's copy must have left it; the caller records ev_sjobs behind its own copy (stage_commit).
+int stage_table(hg_ctx* c, size_t table_bytes, void** out) {
+  if (c->sjobs_pending) {
+    HG_HIP_CHECK(hipEventSynchronize(c->ev_sjobs));  // the previous call's table copy has left the staging
+    c->sjobs_pending = false;
+  }
+  if (!c->ev_sjobs) HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sjobs, hipEventDisableTiming));
+  if (c->sjobs_capacity < table_bytes) {
+    if (c->pinned_sjobs) (void)hipHostFree(c->pinned_sjobs);
+    c->pinned_sjobs = nullptr;
+    c->sjobs_capacity = 0;
+    HG_HIP_CHECK(hipHostMalloc(&c->pinned_sjobs, table_bytes + table_bytes / 2));
+    c->sjobs_capacity = table_bytes + table_bytes / 2;
+  }
+  *out = c->pinned_sjobs;
+  return HG_OK;
+}
+int stage_commit(hg_ctx* c) {
+  HG_HIP_CHECK(hipEventRecord(c->ev_sjobs, c->stream));
+  c->sjobs_pending = true;
+  return HG_OK;
+}
+
 int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins, const float* d_xyz,
                           const uint64_t* scan_offsets, size_t n_scans, const float* poses_tq,
                           bool want_stats) {
@@ -3026,19 +3353,9 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   int rc;
   // job table staging
   const size_t table_bytes = static_cast<size_t>(count) * sizeof(InsertJob);
-  if (c->sjobs_pending) {
-    HG_HIP_CHECK(hipEventSynchronize(c->ev_sjobs));  // the previous call's table copy has left the staging
-    c->sjobs_pending = false;
-  }
-  if (!c->ev_sjobs) HG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sjobs, hipEventDisableTiming));
-  if (c->sjobs_capacity < table_bytes) {
-    if (c->pinned_sjobs) (void)hipHostFree(c->pinned_sjobs);
-    c->pinned_sjobs = nullptr;
-    c->sjobs_capacity = 0;
-    HG_HIP_CHECK(hipHostMalloc(&c->pinned_sjobs, table_bytes + table_bytes / 2));
-    c->sjobs_capacity = table_bytes + table_bytes / 2;
-  }
-  InsertJob* jobs = static_cast<InsertJob*>(c->pinned_sjobs);
+  void* staged = nullptr;
+  if ((rc = stage_table(c, table_bytes, &staged)) != HG_OK) return rc;
+  InsertJob* jobs = static_cast<InsertJob*>(staged);
   // workspace sizes: the largest group decides
   size_t max_pool = 0, max_blocks = 0;
   for (int l = 0; l < levels; ++l) {
@@ -3150,8 +3467,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
       HG_HIP_CHECK(hipMemsetAsync(P0.lv[l].g.counters + 2, 0, 4 * sizeof(uint32_t), s));
   const InsertJob* d_jobs = c->ws_sjobs.as<InsertJob>();
   HG_HIP_CHECK(hipMemcpyAsync(c->ws_sjobs.ptr, jobs, table_bytes, hipMemcpyHostToDevice, s));
-  HG_HIP_CHECK(hipEventRecord(c->ev_sjobs, s));
-  c->sjobs_pending = true;
+  if ((rc = stage_commit(c)) != HG_OK) return rc;
   for (int g0 = 0; g0 < count; g0 += group) {
     const int gn = std::min(group, count - g0);
     unsigned max_nwg = 0;
@@ -3298,13 +3614,15 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     if (opts[l].num_free_space_voxels > 0 || !(opts[l].relative_truncation_distance <= 3.0)) fixed_ok = false;
     if (!(static_cast<float>(opts[l].weight_function_epsilon) >= 1.0f)) unit_weight = false;
   }
+  const char* fa_env = getenv("HG_FAST_ATOMICS");
+  const bool fast_atomics = fa_env && fa_env[0] == '1';
   if (mode == HG_INSERT_FAST) {
     if (!fixed_ok || !unit_weight) {
       set_last_error("HG_INSERT_FAST needs unit update weights (weight_function_epsilon >= 1), no free-space "
                      "voxels and relative_truncation_distance <= 3");
       return HG_ERR_UNSUPPORTED;
     }
-    for (int l = 0; l < levels; ++l) {
+    for (int l = 0; l < levels && fast_atomics; ++l) {
       const int rc = ensure_accumulators(grids[l]);
       if (rc != HG_OK) return rc;
     }
@@ -3384,42 +3702,69 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     }
   }
   int pipe_chunks = 0;
-  while (s0 < n_scans && rc == HG_OK) {
-    size_t s1 = s0;
-    unsigned long long pts = 0;
-    table.clear();
-    // Exact binned path: one pass takes whole scans up to 2^17 returns together (a scan of up to
-    // 2^20 - 1 returns on its own: the 23-bit seq of its records). Several small scans share their
-    // launches; larger chunks were measured slower (ten 100k-point scans per pass: 187 us per scan in
-    // the apply kernel against 100 us scan by scan) because every slice of a bin reads the whole bin
-    // and voxels beyond one LDS pass are applied in rounds, both of which grow with the chunk.
-    const unsigned long long chunk_cap = (binned_ok && !fast) ? (1ull << 17) : kMaxChunkPoints;
-    while (s1 < n_scans && (s1 == s0 || pts + (scan_offsets[s1 + 1] - scan_offsets[s1]) <= chunk_cap)) {
-      ScanTable t;
-      t.begin = scan_offsets[s1] - scan_offsets[s0];
-      t.count = scan_offsets[s1 + 1] - scan_offsets[s1];
-      std::memcpy(t.origin, origins + 3 * s1, sizeof(t.origin));
-      if (poses_tq) std::memcpy(t.pose, poses_tq + 7 * s1, sizeof(t.pose));
-      else std::memset(t.pose, 0, sizeof(t.pose));
-      table.push_back(t);
-      pts += scan_offsets[s1 + 1] - scan_offsets[s1];
-      ++s1;
+  // The chunks of the call (whole scans up to chunk_cap returns) and ONE table of all scans, every entry relative to its
+  // chunk's first return. Exact binned path: one pass takes whole scans up to 2^17 returns together (a scan of up to
+  // 2^20 - 1 returns on its own: the 23-bit seq of its records). Several small scans share their launches; larger
+  // chunks were measured slower (ten 100k-point scans per pass: 187 us per scan in the apply kernel against 100 us
+  // scan by scan) because every slice of a bin reads the whole bin and voxels beyond one LDS pass are applied in
+  // rounds, both of which grow with the chunk. The tolerance mode has neither: its chunks are as large as the
+  // 20-bit update count of a voxel allows. The table travels through the context's pinned staging once per call
+  // (round 6; an upload and a stream synchronisation per chunk before).
+  const unsigned long long chunk_cap = (binned_ok && !fast) ? (1ull << 17) : kMaxChunkPoints;
+  struct Chunk { size_t s0, s1; unsigned long long pts; };
+  std::vector<Chunk> chunks;
+  const ScanTable* d_table = nullptr;
+  if (s0 < n_scans && rc == HG_OK) {
+    void* staged = nullptr;
+    if ((rc = stage_table(c, sizeof(ScanTable) * n_scans, &staged)) != HG_OK) return rc;
+    ScanTable* tab = static_cast<ScanTable*>(staged);
+    size_t a = s0;
+    bool multi = false;
+    // (tolerance mode: chunks of about equal size -- 32 scans of 100k returns go as 4 x 8, not 10 + 10 + 10 + 2:
+    // the launches of a chunk of two cost nearly those of ten)
+    unsigned long long cap = chunk_cap;
+    if (fast && n_total > chunk_cap) {
+      const unsigned long long k = (n_total + chunk_cap - 1) / chunk_cap;
+      cap = std::min(chunk_cap, (n_total + k - 1) / k + n_total / std::max<unsigned long long>(1, n_scans) / 2);
     }
-    if (pts > 0) {
-      const ScanTable* d_scans = nullptr;
-      if (table.size() > 1 || !fixed_ok) {
-        if ((rc = c->ws_scan_table.reserve(sizeof(ScanTable) * table.size())) != HG_OK) return rc;
-        HG_HIP_CHECK(hipMemcpyAsync(c->ws_scan_table.ptr, table.data(), sizeof(ScanTable) * table.size(),
-                                    hipMemcpyHostToDevice, s));
-        HG_HIP_CHECK(hipStreamSynchronize(s));  // `table` is reused by the next chunk
-        d_scans = c->ws_scan_table.as<ScanTable>();
-        if (d_origin)  // the origin the unwarping left in device memory replaces the host's guess
-          HG_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(c->ws_scan_table.ptr) + offsetof(ScanTable, origin), d_origin,
-                                      3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    while (a < n_scans) {
+      size_t b = a;
+      unsigned long long pts = 0;
+      while (b < n_scans && (b == a || pts + (scan_offsets[b + 1] - scan_offsets[b]) <= cap)) {
+        ScanTable& t = tab[b];
+        t.begin = scan_offsets[b] - scan_offsets[a];
+        t.count = scan_offsets[b + 1] - scan_offsets[b];
+        std::memcpy(t.origin, origins + 3 * b, sizeof(t.origin));
+        if (poses_tq) std::memcpy(t.pose, poses_tq + 7 * b, sizeof(t.pose));
+        else std::memset(t.pose, 0, sizeof(t.pose));
+        pts += scan_offsets[b + 1] - scan_offsets[b];
+        ++b;
       }
+      chunks.push_back({a, b, pts});
+      multi = multi || b - a > 1;
+      a = b;
+    }
+    table.assign(tab, tab + n_scans);
+    if (multi || !fixed_ok) {
+      if ((rc = c->ws_scan_table.reserve(sizeof(ScanTable) * n_scans)) != HG_OK) return rc;
+      HG_HIP_CHECK(hipMemcpyAsync(c->ws_scan_table.ptr, tab, sizeof(ScanTable) * n_scans, hipMemcpyHostToDevice, s));
+      if ((rc = stage_commit(c)) != HG_OK) return rc;
+      d_table = c->ws_scan_table.as<ScanTable>();
+      if (d_origin)  // (single-scan calls only) the origin the unwarping left in device memory replaces the host's guess
+        HG_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(c->ws_scan_table.ptr) + offsetof(ScanTable, origin), d_origin,
+                                    3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  for (size_t ci = 0; ci < chunks.size() && rc == HG_OK; ++ci) {
+    s0 = chunks[ci].s0;
+    const size_t s1 = chunks[ci].s1;
+    const unsigned long long pts = chunks[ci].pts;
+    const size_t tsize = s1 - s0;
+    if (pts > 0) {
+      const ScanTable* d_scans = (tsize > 1 || !fixed_ok) ? d_table + s0 : nullptr;
       const unsigned long long first = scan_offsets[s0] - scan_offsets[0];
       PyramidIns Pc = P;
-      Pc.scan0 = table[0];
+      Pc.scan0 = table[s0];
       Pc.accumulate = chunk_launched ? 1 : 0;  // counters restart with the first chunk that runs
       chunk_launched = true;
       for (int l = 0; l < levels; ++l)
@@ -3429,28 +3774,27 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
           set_last_error("HG_INSERT_FAST: a single scan is limited to 2^20 - 1 returns");
           return HG_ERR_UNSUPPORTED;
         }
-        rc = insert_chunk_fast(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts,
-                               stats != nullptr);
+        rc = (fast_atomics ? insert_chunk_fast_atomics : insert_chunk_fast)(c, Pc, d_scans, static_cast<uint32_t>(tsize),
+                                                                           d_xyz + 3 * first, pts, stats != nullptr);
       } else if (binned_ok && pts < (1ull << 20)) {
-        rc = insert_chunk_binned(c, Pc, table.size() > 1 ? d_scans : nullptr, static_cast<uint32_t>(table.size()),
+        rc = insert_chunk_binned(c, Pc, tsize > 1 ? d_scans : nullptr, static_cast<uint32_t>(tsize),
                                  d_xyz + 3 * first, pts, stats != nullptr, pipelined ? pipe_chunks : -1);
         if (pipelined && rc == HG_OK) ++pipe_chunks;
       } else if (fixed_ok) {
         const bool ws = stats != nullptr;
         if (key32 && unit_weight)
-          rc = insert_chunk_fixed<uint32_t, uint32_t>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
+          rc = insert_chunk_fixed<uint32_t, uint32_t>(c, Pc, d_scans, static_cast<uint32_t>(tsize), d_xyz + 3 * first, pts, ws);
         else if (key32)
-          rc = insert_chunk_fixed<uint32_t, unsigned long long>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
+          rc = insert_chunk_fixed<uint32_t, unsigned long long>(c, Pc, d_scans, static_cast<uint32_t>(tsize), d_xyz + 3 * first, pts, ws);
         else if (unit_weight)
-          rc = insert_chunk_fixed<unsigned long long, uint32_t>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
+          rc = insert_chunk_fixed<unsigned long long, uint32_t>(c, Pc, d_scans, static_cast<uint32_t>(tsize), d_xyz + 3 * first, pts, ws);
         else
-          rc = insert_chunk_fixed<unsigned long long, unsigned long long>(c, Pc, d_scans, static_cast<uint32_t>(table.size()), d_xyz + 3 * first, pts, ws);
+          rc = insert_chunk_fixed<unsigned long long, unsigned long long>(c, Pc, d_scans, static_cast<uint32_t>(tsize), d_xyz + 3 * first, pts, ws);
       } else {
-        rc = insert_chunk_compact(grids[0], Pc.lv[0].p, d_scans, static_cast<uint32_t>(table.size()),
+        rc = insert_chunk_compact(grids[0], Pc.lv[0].p, d_scans, static_cast<uint32_t>(tsize),
                                   d_xyz + 3 * first, pts, Pc.lv[0].gate, Pc.accumulate == 0);
       }
     }
-    s0 = s1;
   }
   if (pipe_chunks > 0)  // later work on the context's stream is ordered after the last apply pass
     HG_HIP_CHECK(hipStreamWaitEvent(s, c->ev_apply[(pipe_chunks - 1) & 1], 0));

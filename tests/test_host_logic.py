@@ -105,3 +105,58 @@ def test_cpp_adapter_host_functions_against_oracle_and_python_statement():
     assert capped >= 9                                   # translation, rotation and time each decide some of them
     for a, b, q in deltas:
         np.testing.assert_allclose(q, rp.imu_delta_rotation(imu, a, b), rtol=0, atol=1e-15)
+
+
+def _host_logic_lines():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = os.path.join(root, "hectorgrapher_amd", "cpp")
+    exe = os.path.join(cpp, "example_host_logic")
+    src = os.path.join(cpp, "example_host_logic.cc")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(cpp, "hg_adapter.h"))):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", src, "-L" + os.path.join(root, "hectorgrapher_amd"), "-lhg_mi355x",
+                               "-Wl,-rpath," + os.path.join(root, "hectorgrapher_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    return [line.split() for line in out.stdout.splitlines()]
+
+
+def _angular_distance_to_identity(q):
+    return 2.0 * np.arccos(min(1.0, abs(q[0]) / np.linalg.norm(q)))
+
+
+def test_cpp_transform_interpolation_buffer_reference_kat():
+    """The adapter's transform::TransformInterpolationBuffer through the reference's own test vectors,
+    transform/transform_interpolation_buffer_test.cc:29-74 (testHas, testLookup, testLookupSingleTransform; IsNearly 1e-6)."""
+    lines = {f[0]: f[1:] for f in _host_logic_lines() if f[0].startswith("kat_")}
+    # testHas: empty buffer, one entry at 50, then a second at 100; earliest / latest time
+    assert [int(x) for x in lines["kat_has"]] == [0, 0, 1, 0, 0, 1, 1, 1, 0, 50, 100]
+    # testLookup: halfway between identity and T(10, 10, 10) * Rz(2): T(5, 5, 5) * Rz(1)
+    p = np.array([float(x) for x in lines["kat_lookup"]])
+    np.testing.assert_allclose(p[:3], [5.0, 5.0, 5.0], rtol=0, atol=1e-6)
+    want = np.array([np.cos(0.5), 0.0, 0.0, np.sin(0.5)])
+    assert np.abs(p[3:] - want).max() < 1e-6 or np.abs(p[3:] + want).max() < 1e-6
+    # testLookupSingleTransform
+    np.testing.assert_allclose([float(x) for x in lines["kat_single"]], [0, 0, 0, 1, 0, 0, 0], rtol=0, atol=1e-6)
+
+
+def test_cpp_imu_euler_integration_reference_kat():
+    """The adapter's mapping::IntegrateImuWithTranslationEuler (which its IMU pre-integration blocks stand on) through the
+    reference's own known answers, mapping/internal/3d/imu_integration_test.cc:30-120: zero integration over 100 s,
+    and constant acceleration (0, 0, 9.80665) at 100 Hz from 0 to every sample time: |dv - t g| < 1e-8,
+    |dp - 0.5 t^2 g| < 10 t, rotation = identity to 1e-8 (kPrecision)."""
+    rows = _host_logic_lines()
+    zero = [np.array([float(x) for x in f[1:]]) for f in rows if f[0] == "kat_imu_zero"]
+    assert len(zero) == 1
+    assert np.linalg.norm(zero[0][0:3]) < 1e-8 and np.linalg.norm(zero[0][3:6]) < 1e-8
+    assert _angular_distance_to_identity(zero[0][6:10]) < 1e-8
+    const = [(int(f[1]), np.array([float(x) for x in f[2:]])) for f in rows if f[0] == "kat_imu_const"]
+    assert len(const) == 1000
+    g = np.array([0.0, 0.0, 9.80665])
+    for ticks, r in const:
+        t = api.to_seconds(ticks)
+        assert np.linalg.norm(r[0:3] - t * g) < 1e-8
+        assert np.linalg.norm(r[3:6] - 0.5 * t * t * g) < t * 10
+        assert _angular_distance_to_identity(r[6:10]) < 1e-8
+    assert const[-1][0] == 1000 * api.from_seconds(0.01)
