@@ -52,6 +52,10 @@ def parse_args():
                          "on a centred square lattice), so that the blocks the stream touches outgrow the 256 MB Infinity Cache "
                          "(SURVEY 8d: B = 500 with an HBM-resident working set); 1 = the single room")
     ap.add_argument("--batch", type=int, default=8, help="--workload match_batch: independent matches per call")
+    ap.add_argument("--batch-maps", type=int, default=1,
+                    help="--workload match_batch: identical copies of the map; consecutive batches of a handle set are matched "
+                         "against different copies (a constraint search changes submaps from batch to batch: every problem's "
+                         "pyramid description is uploaded again)")
     ap.add_argument("--batches-in-flight", type=int, default=2,
                     help="--workload match_batch: sets of problem handles the search keeps; 2 = build batch k + 1 while "
                          "batch k runs (hg_problem_solve_batch_async), 1 = one blocking call per batch")
@@ -70,6 +74,8 @@ def parse_args():
                          "submaps on a context of its own (0 = 2 from eight owned submaps on, else 1)")
     ap.add_argument("--batch-threads", type=int, default=1,
                     help="--workload register_batch: host threads, each with its own context (stream) and an equal share of the submaps")
+    ap.add_argument("--no-persistent-solve", action="store_true",
+                    help="headline: a launch per evaluation instead of the persistent single-launch solve")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default workload: skip the bounded runs of the secondary workloads (match_batch 64, "
                          "register_batch 8, insert_stream 32, window) that fill the `secondary` object")
@@ -1022,11 +1028,14 @@ def run_match_batch(args):
     n_pts = args.rings * args.cols
     B = args.batch
     map_scans = make_scans(args.rings, args.cols, 0, args.map_scans, 0)
-    grids = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
-    inserters = [api.TSDFRangeDataInserter3D() for _ in grids]
-    for pose, pts in map_scans:
-        api.insert_pyramid(inserters, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
-                           pose_tq=pose.astype(np.float32))
+    pyramids = []
+    for _ in range(max(1, args.batch_maps)):
+        grids = [api.HybridGridTSDF(ctx, r, max_blocks=args.max_blocks) for r in RESOLUTIONS]
+        inserters = [api.TSDFRangeDataInserter3D() for _ in grids]
+        for pose, pts in map_scans:
+            api.insert_pyramid(inserters, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids,
+                               pose_tq=pose.astype(np.float32))
+        pyramids.append(grids)
     # queries around the mapped stretch of the trajectory
     queries = []
     for j in range(B):
@@ -1056,10 +1065,11 @@ def run_match_batch(args):
 
     def step(sample, number):
         k = number % depth
+        target = pyramids[(number + number // depth) % len(pyramids)]  # (a handle set meets the copies in turn)
         for p, (_, _, d, guess) in zip(sets[k], queries):
             p.reset()
             i = p.add_pose(guess)
-            p.add_block(d, grids, scale, i, multi_res=True, width=args.rings)
+            p.add_block(d, target, scale, i, multi_res=True, width=args.rings)
         if depth == 1:
             summ = api.solve_batch(sets[k])
             stats["its"].append(np.mean([s_.num_iterations for s_ in summ]))
@@ -1156,7 +1166,7 @@ def run_match_batch(args):
                                    B, "hg_problem_solve_batch" if depth == 1 else
                                    "hg_problem_solve_batch_async + hg_problem_fetch, %d batches in flight: the host builds "
                                    "the next batch while the device solves this one" % depth, n_pts),
-                   "batches_in_flight": depth,
+                   "batches_in_flight": depth, "map_copies": len(pyramids),
                    "mean_lm_iterations": float(np.mean(stats["its"])), "mean_pose_error_m": float(np.mean(errs))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_tsdf_residuals_single_batch",
@@ -1722,6 +1732,13 @@ def run(args, out_fd=None):
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     ctx = api.Context(local_rank)
+    # The single-pose solve as ONE persistent launch (hg_ctx_set_option "persistent_solve", off by default in the
+    # library: the launch needs the GPU to itself, include/hg_mi355x.h). Here the process owns its GPU: one rank per
+    # device, no --submaps siblings; ranks that share a device in the one-GPU tests keep a launch per evaluation.
+    persistent = (not args.no_persistent_solve and args.submap_index < 0 and os.environ.get("HG_RANKS_SHARE_GPU") != "1")
+    if persistent:
+        ctx.set_option("persistent_solve", 1)
+    persistent = bool(ctx.get_option("persistent_solve"))
     n_pts = args.rings * args.cols
 
     # independent submap per rank: rank r uses PRNG streams offset by 1000*r
@@ -1917,11 +1934,13 @@ def run(args, out_fd=None):
     ins_bytes_per_launch = 12.0 * stats["N_in"] + 8.0 * stats["U"]  # summed over the 3 levels
     # a solve enqueues max_num_iterations + 1 launches; those after termination exit at once and move
     # no data, so the per-launch average is scaled by the share of launches that evaluated
-    active_share = min(1.0, stats["evals"] / n_resid) if n_resid else 1.0
+    # (persistent solve: ONE launch per solve that runs all of its evaluations, so the share is the number of
+    # evaluations per launch; rocprofv3 then shows k_tsdf_residuals_single_persist<512> with the solve's duration)
+    active_share = (stats["evals"] / n_resid if persistent else min(1.0, stats["evals"] / n_resid)) if n_resid else 1.0
     res_bytes_per_launch = n_pts * (12.0 + 32.0 * lbar) * active_share
     fam = {
         "insert(expand+sort+alloc+apply, 3 levels fused)": (t_insert / max(1, n_insert_calls), ins_bytes_per_launch, t_insert),
-        "k_tsdf_residuals": (t_resid / max(1, n_resid), res_bytes_per_launch, t_resid),  # rocprof: k_tsdf_residuals_single<512>
+        "k_tsdf_residuals": (t_resid / max(1, n_resid), res_bytes_per_launch, t_resid),  # rocprof: k_tsdf_residuals_single<512> / _single_persist<512>
     }
     dom = max(fam, key=lambda k: fam[k][2])
     avg_ms, bytes_per, _ = fam[dom]
@@ -1968,7 +1987,9 @@ def run(args, out_fd=None):
                                       "and per_kernel_ms_total does not add up to ms_per_step (rocprofv3 trace: profiles/r05_trace_gaps.txt)"
                                       % (max(1, args.prof_every), args.steps, 5 * max(1, args.prof_every)),
                 "build": {"version": api._lib.load().hg_version().decode(), "csrc_sha16": build_digest},
-                "residual_launches_evaluating": active_share}
+                "residual_launches_evaluating": active_share,
+                "solve_form": ("persistent: one k_tsdf_residuals_single_persist<512> launch per solve, %.1f evaluations each"
+                               % active_share) if persistent else "one k_tsdf_residuals_single<512> launch per evaluation"}
 
     out = {
         "metric": "scans/s (100k-pt scan, 3-res TSDF registration)" + (

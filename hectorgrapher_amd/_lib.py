@@ -22,7 +22,7 @@ ERRORS = {-1: "HG_ERR_INVALID", -2: "HG_ERR_NO_DEVICE", -3: "HG_ERR_HIP", -4: "H
 
 # Every symbol include/hg_mi355x.h declares.
 SYMBOLS = [
-    "hg_ctx_create", "hg_ctx_destroy", "hg_ctx_synchronize", "hg_ctx_stream", "hg_last_error",
+    "hg_ctx_create", "hg_ctx_destroy", "hg_ctx_synchronize", "hg_ctx_set_option", "hg_ctx_get_option", "hg_ctx_stream", "hg_last_error",
     "hg_version", "hg_prof_enable", "hg_prof_reset", "hg_prof_read", "hg_grid_create", "hg_grid_destroy", "hg_grid_clear", "hg_grid_resolution", "hg_grid_params",
     "hg_grid_set_cells", "hg_grid_read_cells", "hg_grid_count", "hg_grid_export",
     "hg_grid_num_blocks", "hg_grid_window_status", "hg_grid_to_proto", "hg_grid_from_proto", "hg_grid_xray", "hg_grid_block_arrays", "hg_grid_import_blocks", "hg_grid_insert",
@@ -149,6 +149,8 @@ def load():
     L.hg_ctx_create.argtypes = [i32, vp, P(vp)]
     L.hg_ctx_destroy.argtypes = [vp]
     L.hg_ctx_synchronize.argtypes = [vp]
+    L.hg_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    L.hg_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.hg_ctx_stream.restype = vp
     L.hg_ctx_stream.argtypes = [vp]
     L.hg_last_error.restype = C.c_char_p

@@ -10,6 +10,7 @@ Class and method names follow cartographer::mapping (ref paths relative to
 Everything computes on the GPU through the C ABI (include/hg_mi355x.h); numpy
 arrays are host buffers, torch CUDA tensors are passed as device pointers.
 """
+import contextlib
 import ctypes as C
 import weakref
 
@@ -47,6 +48,25 @@ class Context:
 
     def synchronize(self):
         check(self._L.hg_ctx_synchronize(self._h), "hg_ctx_synchronize")
+
+    def set_option(self, key, value):
+        """A tuning / diagnostic switch of the context (hg_ctx_set_option; keys: include/hg_mi355x.h)."""
+        check(self._L.hg_ctx_set_option(self._h, key.encode(), int(value)), "hg_ctx_set_option")
+
+    def get_option(self, key):
+        v = C.c_longlong()
+        check(self._L.hg_ctx_get_option(self._h, key.encode(), C.byref(v)), "hg_ctx_get_option")
+        return v.value
+
+    @contextlib.contextmanager
+    def option(self, key, value):
+        """`with ctx.option("lm_band", 1): ...` -- the switch set inside the block, restored behind it."""
+        old = self.get_option(key)
+        self.set_option(key, value)
+        try:
+            yield self
+        finally:
+            self.set_option(key, old)
 
     def prof_enable(self, on=True):
         check(self._L.hg_prof_enable(self._h, int(on)), "hg_prof_enable")
@@ -413,7 +433,10 @@ def _timed_clouds(clouds):
             raise ValueError("timed cloud on the device must be [n, 4] (x y z time), got %s" % (tuple(p.shape),))
         import torch
         if p.dtype != torch.float32 or not p.is_contiguous():
+            # the conversion runs on torch's current stream, the library's kernels on the context's own: the copy must
+            # be complete before its pointer is handed over (read-before-write race)
             p = p.to(torch.float32).contiguous()
+            torch.cuda.current_stream(p.device).synchronize()
         return arr, p, p.data_ptr(), begin, _lib.HG_DEVICE
     allp = np.ascontiguousarray(np.concatenate([_host(c[2], np.float32, 4) for c in clouds], 0))
     return arr, allp, allp.ctypes.data, begin, _lib.HG_HOST
@@ -436,7 +459,10 @@ def insert_pyramid_unwarped(inserters, clouds, width, control_times, control_pos
     st = (InsertStats * n_l)() if want_stats else None
     check(L.hg_pyramid_insert_unwarped(garr, opts, n_l, ptr, n, int(width), space, arr, len(clouds), _p(cp), _p(ct),
                                        len(ct), _p(pose), inserters[0].mode, st), "hg_pyramid_insert_unwarped")
-    del keep
+    if want_stats:
+        del keep        # (the stats read-back has synchronised the stream)
+    else:
+        grids[0]._keep_unwarp = keep   # the enqueued kernels still read it: held until the next call replaces it
     return list(st) if want_stats else None
 
 

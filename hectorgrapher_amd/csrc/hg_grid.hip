@@ -159,6 +159,10 @@ int ensure_apply_stream(hg_ctx* c) {
 using namespace hg;
 
 namespace {
+std::atomic<int> g_live_contexts{0};
+}
+int hg::live_contexts() { return g_live_contexts.load(); }
+namespace {
 // CU-mask streams of destroyed contexts, kept for the next context of the same device (see hg_ctx_destroy).
 std::mutex g_stream_pool_mutex;
 std::vector<std::pair<int, hipStream_t>> g_stream_pool;
@@ -257,6 +261,14 @@ int hg_ctx_create(int device, void* stream, hg_ctx** out) {
   HG_HIP_CHECK(hipSetDevice(device));
   hg_ctx* c = new hg_ctx();
   c->device = device;
+  for (int o = 0; o < OPT_COUNT; ++o) {  // defaults, or the environment's HG_<KEY>
+    std::string env = "HG_";
+    for (const char* k = kOptDesc[o].key; *k; ++k) env.push_back(static_cast<char>(std::toupper(static_cast<unsigned char>(*k))));
+    const char* e = std::getenv(env.c_str());
+    c->opts[o] = (e && *e) ? std::atoll(e) : kOptDesc[o].def;
+  }
+  (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device);
+  g_live_contexts.fetch_add(1);
   if (stream) {
     c->stream = static_cast<hipStream_t>(stream);
   } else {
@@ -319,8 +331,30 @@ int hg_ctx_create(int device, void* stream, hg_ctx** out) {
   return HG_OK;
 }
 
+int hg_ctx_set_option(hg_ctx* c, const char* key, long long value) {
+  if (!c || !key) return HG_ERR_INVALID;
+  for (int o = 0; o < OPT_COUNT; ++o)
+    if (std::strcmp(kOptDesc[o].key, key) == 0) {
+      c->opts[o] = value;
+      return HG_OK;
+    }
+  set_last_error(std::string("hg_ctx_set_option: unknown key ") + key);
+  return HG_ERR_INVALID;
+}
+int hg_ctx_get_option(hg_ctx* c, const char* key, long long* value) {
+  if (!c || !key || !value) return HG_ERR_INVALID;
+  for (int o = 0; o < OPT_COUNT; ++o)
+    if (std::strcmp(kOptDesc[o].key, key) == 0) {
+      *value = c->opts[o];
+      return HG_OK;
+    }
+  set_last_error(std::string("hg_ctx_get_option: unknown key ") + key);
+  return HG_ERR_INVALID;
+}
+
 int hg_ctx_destroy(hg_ctx* c) {
   if (!c) return HG_ERR_INVALID;
+  g_live_contexts.fetch_sub(1);
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   // children that outlive the context keep their device memory and lose the context (see live_grids)

@@ -2611,16 +2611,16 @@ namespace {
 
 // Launch shape of k_bin_apply (see there): one grid row per level; HG_APPLY_TURNS=1 lets the levels take turns
 // (measured: slower, kept as a switch for the diagnostics).
-dim3 apply_grid(int levels) {
-  static const int turns = [] { const char* e = getenv("HG_APPLY_TURNS"); return e ? atoi(e) : 0; }();
+dim3 apply_grid(const hg_ctx* c, int levels) {
+  const bool turns = c->opt(OPT_APPLY_TURNS) != 0;
   return turns ? dim3(1024u * static_cast<unsigned>(levels), 1u) : dim3(1024u, static_cast<unsigned>(levels));
 }
 // Slice size of the large bins of a scan stream (PyramidIns::slice_records < 0). HG_STREAM_SLICE overrides.
-int stream_slice_records() {
+int stream_slice_records(const hg_ctx* c) {
   // 1024: measured 16.4k scans/s at B = 32 against 14.9k with the single chain's 512 (768: 16.0k, 1280: 15.9k,
   // 1536: 15.7k) -- applies of consecutive scans queue behind each other, so total work counts for more than
   // the latency of the heaviest slice
-  static const int v = [] { const char* e = getenv("HG_STREAM_SLICE"); return e ? atoi(e) : 1024; }();
+  const int v = static_cast<int>(c->opt(OPT_STREAM_SLICE));
   return v > 0 ? -v : 0;
 }
 
@@ -2790,10 +2790,9 @@ int insert_chunk_fixed(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans,
 // of `grid_x` workgroups. `val_off` / `list_off`: this launch's share of the context's buffers, in values / entries
 // (several jobs in one launch); the caller has reserved ws_heavy / ws_heavy_list. HG_NO_DEFER=1 switches the
 // deferral off (every chain applied in its pass by one lane, as before round 5).
-bool heavy_enabled() {
+bool heavy_enabled(const hg_ctx* c) {
 #ifdef HG_DEFER_LONG_CHAINS
-  static const bool on = [] { const char* e = getenv("HG_NO_DEFER"); return !(e && atoi(e)); }();
-  return on;
+  return c->opt(OPT_DEFER_LONG_CHAINS) != 0;
 #else
   return false;
 #endif
@@ -2801,7 +2800,7 @@ bool heavy_enabled() {
 void attach_heavy(hg_ctx* c, PyramidIns& P, size_t records_per_level, unsigned grid_x, size_t val_off, size_t list_off) {
   for (int l = 0; l < P.levels; ++l) {
     LevelIns& L = P.lv[l];
-    if (!heavy_enabled()) {
+    if (!heavy_enabled(c)) {
       L.heavy_vals = nullptr;
       L.heavy_list = nullptr;
       L.heavy_capacity = 0;
@@ -2859,7 +2858,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
   if ((rc = buf_keys.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
   if ((rc = buf_vals.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
   // (one buffer for both parities: the apply passes of a pipelined stream run one after the other on their stream)
-  if (heavy_enabled()) {
+  if (heavy_enabled(c)) {
     if ((rc = c->ws_heavy.reserve(sizeof(uint32_t) * slots)) != HG_OK) return rc;
     if ((rc = c->ws_heavy_list.reserve(sizeof(uint4) * 1024u * kHeavyPerWg * P.levels)) != HG_OK) return rc;
   }
@@ -2902,7 +2901,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
     static long long* d_st = nullptr;
     if (!d_st) hipMalloc(reinterpret_cast<void**>(&d_st), 3 * 4096 * 8 * sizeof(long long));
     hipMemsetAsync(d_st, 0, 3 * 4096 * 8 * sizeof(long long), s);
-    hipLaunchKernelGGL(k_bin_apply, apply_grid(P.levels), dim3(kBinThreads), 0, s, P, rk, rv, d_st);
+    hipLaunchKernelGGL(k_bin_apply, apply_grid(c, P.levels), dim3(kBinThreads), 0, s, P, rk, rv, d_st);
     {
       std::vector<long long> h(3 * 4096 * 8);
       hipMemcpy(h.data(), d_st, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
@@ -2984,7 +2983,7 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
       }
     }
 #else
-    hipLaunchKernelGGL(k_bin_apply, apply_grid(P.levels), dim3(kBinThreads), 0, sa, P, rk, rv);
+    hipLaunchKernelGGL(k_bin_apply, apply_grid(c, P.levels), dim3(kBinThreads), 0, sa, P, rk, rv);
 #endif
   }
   HG_HIP_CHECK(hipGetLastError());
@@ -3228,7 +3227,7 @@ int hg::pyramid_insert_jobs(hg_ctx* c, int count, hg_grid* const* grids, const h
   if ((rc = c->ws_offsets.reserve(sizeof(uint4) * work_items)) != HG_OK) return rc;
   if ((rc = c->ws_jobs.reserve(table_bytes)) != HG_OK) return rc;
   const unsigned apply_gx = count <= 2 ? 1024u : 512u;
-  if (heavy_enabled()) {
+  if (heavy_enabled(c)) {
     if ((rc = c->ws_heavy.reserve(sizeof(uint32_t) * rec_words)) != HG_OK) return rc;
     if ((rc = c->ws_heavy_list.reserve(sizeof(uint4) * apply_gx * kHeavyPerWg * levels * count)) != HG_OK) return rc;
   }
@@ -3343,8 +3342,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
                           bool want_stats) {
   hipStream_t s = c->stream;
   const int levels = P0.levels;
-  int group = 8;
-  if (const char* e = getenv("HG_STREAM_GROUP")) group = std::max(1, std::min(32, std::atoi(e)));
+  const int group = std::max(1, std::min(32, static_cast<int>(c->opt(OPT_STREAM_GROUP))));
   std::vector<size_t> scans;  // the non-empty scans
   for (size_t i = 0; i < n_scans; ++i)
     if (scan_offsets[i + 1] > scan_offsets[i]) scans.push_back(i);
@@ -3393,7 +3391,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   if ((rc = c->ws_sjobs.reserve(table_bytes)) != HG_OK) return rc;
   if ((rc = c->ws_shadow.reserve(sizeof(uint32_t) * shadow_words)) != HG_OK) return rc;
   // (the apply passes run one after the other: they share one set of deferral buffers)
-  if (heavy_enabled()) {
+  if (heavy_enabled(c)) {
     if ((rc = c->ws_heavy.reserve(sizeof(uint32_t) * static_cast<size_t>(n_max) * kSlots * levels)) != HG_OK) return rc;
     if ((rc = c->ws_heavy_list.reserve(sizeof(uint4) * 1024u * kHeavyPerWg * levels)) != HG_OK) return rc;
   }
@@ -3441,7 +3439,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
     P.d_pose = nullptr;
     P.accumulate = 1;
     P.shared = 1;
-    P.slice_records = stream_slice_records();
+    P.slice_records = stream_slice_records(c);
     P.scan0.begin = 0;
     P.scan0.count = nj;
     std::memcpy(P.scan0.origin, origins + 3 * i, sizeof(P.scan0.origin));
@@ -3496,7 +3494,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
       ProfScope ps(c, HG_K_APPLY, units * kSlots, static_cast<unsigned>(gn));
 #ifndef HG_BIN_STAMPS
       for (int j = g0; j < g0 + gn; ++j)  // pyramid as kernel argument (scalar registers), as scan by scan
-        hipLaunchKernelGGL(k_bin_apply, apply_grid(levels), dim3(kBinThreads), 0, s, jobs[j].P, jobs[j].rec_keys,
+        hipLaunchKernelGGL(k_bin_apply, apply_grid(c, levels), dim3(kBinThreads), 0, s, jobs[j].P, jobs[j].rec_keys,
                            jobs[j].rec_vals);
 #endif
     }
@@ -3614,8 +3612,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     if (opts[l].num_free_space_voxels > 0 || !(opts[l].relative_truncation_distance <= 3.0)) fixed_ok = false;
     if (!(static_cast<float>(opts[l].weight_function_epsilon) >= 1.0f)) unit_weight = false;
   }
-  const char* fa_env = getenv("HG_FAST_ATOMICS");
-  const bool fast_atomics = fa_env && fa_env[0] == '1';
+  const bool fast_atomics = c->opt(OPT_FAST_ATOMICS) != 0;
   if (mode == HG_INSERT_FAST) {
     if (!fixed_ok || !unit_weight) {
       set_last_error("HG_INSERT_FAST needs unit update weights (weight_function_epsilon >= 1), no free-space "
@@ -3673,8 +3670,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
 
   // chunk by scans so the record workspace stays bounded; when the binned path applies every scan
   // is its own chunk (same per-voxel chain length as one sorted batch, without the global sort)
-  const char* force_sort = getenv("HG_INSERT_SORT");
-  const bool binned_ok = fixed_ok && unit_weight && !(force_sort && force_sort[0] == '1');
+  const bool binned_ok = fixed_ok && unit_weight && c->opt(OPT_INSERT_SORT) == 0;
   // a voxel receives at most one update per return: FAST chunks stay below the 20-bit update count
   const unsigned long long kMaxChunkPoints = mode == HG_INSERT_FAST ? (1ull << 20) - 1ull : 4ull << 20;
   const bool fast = mode == HG_INSERT_FAST;
@@ -3692,13 +3688,11 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     bool fits = true;  // every scan within the 23-bit seq of the binned records
     for (size_t i = 0; i < n_scans; ++i)
       if (scan_offsets[i + 1] - scan_offsets[i] >= (1ull << 20)) fits = false;
-    const char* ge = getenv("HG_STREAM_GROUP");
-    const char* pe = getenv("HG_INSERT_PIPELINE");
-    if (fits && n_total / n_scans >= (1ull << 14) && !(ge && ge[0] == '0')) {
+    if (fits && n_total / n_scans >= (1ull << 14) && c->opt(OPT_STREAM_GROUP) > 0) {
       rc = insert_stream_grouped(c, P, origins, d_xyz, scan_offsets, n_scans, poses_tq, stats != nullptr);
       s0 = n_scans;  // done (or failed)
     } else {
-      pipelined = fits && !(pe && pe[0] == '0');
+      pipelined = fits && c->opt(OPT_INSERT_PIPELINE) != 0;
     }
   }
   int pipe_chunks = 0;

@@ -1029,6 +1029,16 @@ __device__ __forceinline__ void load_granule_pairs(hg_u64x2 (&v)[kSweep], const 
         "v"(g[11]), "v"(g[12]), "v"(g[13])
       : "memory");
 }
+[[maybe_unused]] constexpr unsigned kBcastReplicas = 32;  // copies of the persistent solve's hand-back (k_tsdf_residuals_single_persist)
+__device__ inline hg_u64x2 load_granule_pair16(const unsigned long long* g) {  // one 16-byte load around the L1, waited for
+  hg_u64x2 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=&v"(v) : "v"(g) : "memory");
+  return v;
+}
+__device__ inline double uniform_f64(double x) {  // a value every lane holds, moved to scalar registers
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
 __device__ inline hg_u64x2 load_granule_pair(const unsigned long long* g) {  // (the re-reads: two 8-byte loads)
   return hg_u64x2{__hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                   __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
@@ -1110,7 +1120,9 @@ __device__ __forceinline__ void tsdf_residuals_body(
     const double* pose_tq = nullptr /* the transform when it does not come from xf (first launch) */,
     unsigned width = 0, unsigned tiles = 1 /* tiles of THREADS returns per workgroup (the batched kernel) */,
     unsigned fast_n = 0 /* the first fast_n returns are expected to stop at the finest level (level partition) */,
-    unsigned epoch = 0 /* != 0: the partial sums go out as tagged granules (store_partial_tagged), `partials` = the granule buffer */) {
+    unsigned epoch = 0 /* != 0: the partial sums go out as tagged granules (store_partial_tagged), `partials` = the granule buffer */,
+    const double* pre_v = nullptr, const DirectRaw* pre_dp = nullptr /* the lane's return and the window counters, loaded
+        by the caller (the persistent solve evaluates the same returns against the same map many times) */) {
   const ScanOrder order = make_scan_order(n, width);
   const unsigned first_i0 = wg * tiles * THREADS + threadIdx.x;
   BODY_STAMP(0);
@@ -1118,8 +1130,9 @@ __device__ __forceinline__ void tsdf_residuals_body(
   // (the point load is issued in front of the scalar loads of direct_issue, whose wait it then overlaps)
   unsigned i = scan_index(order, first_i0 < n ? first_i0 : 0u);
   double v[3];
-  load_point(xyz, i, v);
-  const DirectRaw dp = direct_issue(pv);
+  if (pre_v) { v[0] = pre_v[0]; v[1] = pre_v[1]; v[2] = pre_v[2]; }
+  else load_point(xyz, i, v);
+  const DirectRaw dp = pre_dp ? *pre_dp : direct_issue(pv);
   double tq[7];
   if (pose_tq) {
 #pragma unroll
@@ -3556,7 +3569,9 @@ __device__ inline int b6(int i, int j) { return i * 6 + 5 - (i - j); }  // band_
 template <bool FIRST = false>
 __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, BlockXform* xf, const double* partials,
                                unsigned num_wg, const PinBox* host_up = nullptr, unsigned up_words = 0,
-                               unsigned epoch = 0 /* != 0: `partials` holds tagged granules of this epoch */) {
+                               unsigned epoch = 0 /* != 0: `partials` holds tagged granules of this epoch */,
+                               double* persist_out = nullptr /* LDS, 8 doubles: the next candidate and the done flag (persistent solve) */,
+                               int* timeout_flag = nullptr /* LDS: set when a granule never arrived; the step then ends the solve as failed */) {
   // (Round 5: multiply-adds of this function are fused -- the file is compiled -ffp-contract=off for the voxel lookups,
   // whose discrete decisions need the reference's roundings; nothing in the LM step takes one, and the tail is a chain
   // of dependent fp64 operations: 14.7 -> 14.0 us per launch together with the right-looking factorisation below.)
@@ -3624,6 +3639,11 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
               }
             }
             if (pending && spins == 0u) t_first = __builtin_amdgcn_s_memrealtime();
+            // (back off between re-reads: the other workgroups of the launch, and other processes on the device,
+            // share the L2 this loop polls through -- ADVICE r5. Each 8-byte half of a 16-byte sc1 load is taken
+            // as single-copy atomic: observed untorn on gfx950 / ROCm 7.2, MI355X_MICROARCH.md "R2's granule"; a
+            // torn half would carry a stale tag and simply be read again)
+            if (pending) __builtin_amdgcn_s_sleep(1);
             if (pending && (spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t_first > 200000000ull) {
               // (two seconds of polling -- s_memrealtime counts 100 MHz -- cannot happen: every workgroup of the launch
               // runs, the others never wait for this one) the sum becomes NaN and the step is reported as failed
@@ -3631,6 +3651,7 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
               gr[0] = hg_u64x2{0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull};
 #pragma unroll
               for (int u = 1; u < kSweep; ++u) gr[u] = hg_u64x2{none, none};
+              if (timeout_flag) *timeout_flag = 1;
               break;
             }
           }
@@ -3775,7 +3796,11 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   bool h_changed = false;
   bool want_candidate = false;
   TAIL_STAMP(3);
-  if (phase == PHASE_INIT) {
+  // (persistent solve) a workgroup's sums never arrived: the solve ends here as FAILURE, x stays the last accepted point
+  const bool timed_out = timeout_flag != nullptr && *timeout_flag != 0;
+  if (timed_out) {
+    finish_(2, 7);
+  } else if (phase == PHASE_INIT) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -3974,6 +3999,11 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
       for (int k = 0; k < 6; ++k) { d.scale[k] = scale[k]; d.diagonal[k] = diagonal[k]; d.g[k] = g[k]; d.gc[k] = gc[k]; }
     };
     store_fields(gh);
+    if (persist_out) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) persist_out[k] = cand[k];
+      persist_out[7] = done ? 1.0 : 0.0;
+    }
     if (h_changed) {
 #pragma unroll
       for (int i = 0; i < 6; ++i)
@@ -4255,6 +4285,109 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_first(
     FirstUpload up, unsigned epoch) {
   single_eval<THREADS, true>(pv, xyz, n, width, scaling, xf, partials, G, ticket, blockIdx.x, gridDim.x, epoch, &up);
 }
+
+#ifndef HG_BIG
+// The whole single-pose solve in ONE launch (round 6). The launch-per-evaluation chain pays
+// 1.8 us between dependent launches, the ramp of 196 workgroups and one or two empty launches behind convergence,
+// per evaluation: ~3 of its ~14 us. Here every workgroup stays and loops over the evaluations:
+//   body at the current candidate -> partial sums as granules tagged with the evaluation's epoch (as before)
+//   workgroup 0: the LM step on the sums, then the next candidate + done flag as eight granules tagged epoch + 1
+//   the others: one wavefront polls those eight granules (sc1 loads, s_sleep between polls), a barrier, next body.
+// Same arithmetic in the same order as the launch-per-evaluation chain: bitwise the same poses and iterations.
+// Every wait is bounded (two seconds of s_memrealtime); a workgroup that gives up leaves, its granules then never
+// arrive, workgroup 0 times out in turn and ends the solve as FAILURE (termination_reason 7) -- the host then stops
+// using this form on the context. That can only happen when the 196 workgroups are not resident together, which the
+// host rules out before it takes this path (persist_ok: occupancy x CUs >= workgroups, this context the only one of
+// the process); bench.py --submaps (several PROCESSES on one GPU) is the case the bound exists for.
+#ifdef HG_PERSIST_STAMPS
+// diagnostics: s_memrealtime (10 ns) per evaluation: workgroup 0 [e][0] body start, [1] body end, [2] LM step end,
+// [3] hand-back stored; workgroup 97 [4] hand-back seen, [5] body end; [6] workgroup 195's body end
+__device__ unsigned long long g_persist_stamps[16][8];
+#define PSTAMP(w, k) do { if (threadIdx.x == 0 && wg == (w) && e < 16u) g_persist_stamps[e][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(w, k) do {} while (0)
+#endif
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
+    PyramidView pv, const float* __restrict__ xyz, unsigned n, unsigned width, double scaling,
+    const BlockXform* __restrict__ xf, double* __restrict__ granules, LmState* G, FirstUpload up, unsigned epoch0,
+    unsigned evals, unsigned long long* __restrict__ bcast) {
+  constexpr size_t kTiles = (THREADS / kWave) * (kWave * 8 + 64) * sizeof(double);
+  constexpr size_t kTail = ((THREADS / kAcc) + 1) * kAcc * sizeof(double) + sizeof(LmHead) + 36 * sizeof(double);
+  __shared__ __align__(16) unsigned char smem[kTiles > kTail ? kTiles : kTail];
+  __shared__ double s_out[8];
+  __shared__ int s_timeout;
+  const unsigned wg = blockIdx.x, num_wg = gridDim.x;
+  double pose[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) pose[k] = up.pose[k];
+  if (threadIdx.x == 0) s_timeout = 0;  // (the body's barriers come before anything reads it)
+#ifdef HG_EVAL_STAMPS
+  const int eval_it = 0;
+#endif
+  // what does not change from one evaluation to the next is loaded once: the lane's return and the levels' window
+  // counters (the map is not written while the solve runs)
+  double pre_v[3];
+  {
+    const ScanOrder order = make_scan_order(n, width);
+    const unsigned first_i0 = xcd_chunk(wg, num_wg) * THREADS + threadIdx.x;
+    load_point(xyz, scan_index(order, first_i0 < n ? first_i0 : 0u), pre_v);
+  }
+  const DirectRaw pre_dp = direct_issue(pv);
+  for (unsigned e = 0; e < evals; ++e) {
+    const unsigned epoch = epoch0 + e;
+    PSTAMP(0u, 0);
+    tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, granules, nullptr,
+                                 reinterpret_cast<double (*)[kWave][8]>(smem),
+                                 reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
+                                 xcd_chunk(wg, num_wg), pose, width, 1, 0, epoch, pre_v, &pre_dp);
+    PSTAMP(0u, 1);
+    PSTAMP(97u, 5);
+    PSTAMP(195u, 6);
+    if (wg == 0u) {
+      __syncthreads();  // (ends this workgroup's use of the tiles in smem)
+      if (e == 0u)
+        lm_step_single<true>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, up.box,
+                             up.up_words, epoch, s_out, &s_timeout);
+      else
+        lm_step_single<false>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, nullptr, 0u,
+                              epoch, s_out, &s_timeout);
+      PSTAMP(0u, 2);
+      __syncthreads();
+      // kBcastReplicas copies, a 128-byte line each: 195 workgroups polling ONE line queue at its memory channel
+      if (threadIdx.x < 8u * kBcastReplicas)
+        store_partial_tagged(bcast + 16u * (threadIdx.x >> 3) + 2u * (threadIdx.x & 7u), s_out[threadIdx.x & 7u], epoch + 1u);
+      PSTAMP(0u, 3);
+    } else {
+      if (e + 1u == evals) break;  // (uniform) nothing follows the last evaluation
+      if (threadIdx.x < 8u) {
+        const unsigned long long* g = bcast + 16u * (wg % kBcastReplicas) + 2u * threadIdx.x;
+        unsigned long long t_first = 0;
+        for (unsigned spins = 0;; ++spins) {
+          const hg_u64x2 v = load_granule_pair16(g);
+          if (static_cast<unsigned>(v.x >> 32) == epoch + 1u && static_cast<unsigned>(v.y >> 32) == epoch + 1u) {
+            s_out[threadIdx.x] = __longlong_as_double(static_cast<long long>((v.y << 32) | (v.x & 0xFFFFFFFFull)));
+            break;
+          }
+          if (spins == 0u) t_first = __builtin_amdgcn_s_memrealtime();
+          if ((spins & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t_first > 200000000ull) {
+            s_timeout = 1;  // (s_memrealtime counts 100 MHz: two seconds) workgroup 0 is not there: leave
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      __syncthreads();
+      PSTAMP(97u, 4);
+    }
+    if (s_timeout != 0) break;     // (uniform per workgroup)
+    if (s_out[7] != 0.0) break;    // the solve has terminated
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pose[k] = uniform_f64(s_out[k]);  // (into scalar registers, as a kernel argument would be)
+    __syncthreads();  // everyone has the candidate before workgroup 0's next step rewrites s_out
+  }
+}
+#endif  // !HG_BIG
 
 // Several INDEPENDENT single-pose problems per launch (blockIdx.y = problem): each keeps its own
 // state, partials, ticket and mailbox and runs exactly the arithmetic of k_tsdf_residuals_single,
@@ -4591,6 +4724,8 @@ struct hg_problem {
   // device state
   LmState* d_state = nullptr;
   unsigned* d_ticket = nullptr;
+  hg::DeviceBuffer bcast;      // persistent solve: the candidate + done flag workgroup 0 hands to the others (8 granule pairs)
+  bool persist_last = false;   // the solve in flight is a persistent one (its evaluations are one launch)
   hg::DeviceBuffer granules;   // tagged partial sums of the single-pose chain (store_partial_tagged)
   unsigned epoch = 0;          // launches of that chain so far
   BlockXform* d_xf = nullptr;
@@ -4616,6 +4751,8 @@ struct hg_problem {
   // the last launches of a general solve, held back until the solve is seen to need them (solve_settle)
   int lazy_left = 0;
   hipEvent_t ev_lazy = nullptr;
+  hipEvent_t ev_pv = nullptr;  // behind the last copy out of h_pv (the pinned staging of the blocks' pyramids)
+  bool pv_pending = false;
   int single_threads = 0;      // > 0: single-pose registration step with this workgroup size
 #ifndef HG_BIG
   // A problem beyond the plain build's limits (kMaxPoses / kMaxBlocks / kMaxSmall, band capacity) is
@@ -4663,7 +4800,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   p->single_threads = 0;
 #ifndef HG_BIG  // (a problem of that shape never reaches the big build)
   if (opts && S.num_poses == 1 && !p->constant[0] && !p->vfree[0] && S.num_blocks == 1 && p->small.empty() &&
-      !p->blocks[0].d_factor && p->blocks[0].pose_b < 0 && p->blocks[0].n > 0 && std::getenv("HG_LM_GENERAL") == nullptr) {
+      !p->blocks[0].d_factor && p->blocks[0].pose_b < 0 && p->blocks[0].n > 0 && p->ctx->opt(OPT_LM_GENERAL) == 0) {
     p->single_threads = kEvalThreads;  // 256-thread workgroups were measured 19 % slower per step
   }
 #endif
@@ -4678,7 +4815,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       HG_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_u, k_window_residuals<true>, kBatchThreads, 0));
       p->cap_plain = static_cast<unsigned>(std::max(1, cus) * std::max(1, occ_p));
       p->cap_unwarp = static_cast<unsigned>(std::max(1, cus) * std::max(1, occ_u));
-      if (const char* e = std::getenv("HG_WINDOW_CAPACITY")) p->cap_plain = p->cap_unwarp = std::max(1, std::atoi(e));
+      if (p->ctx->opt(OPT_WINDOW_CAPACITY) > 0) p->cap_plain = p->cap_unwarp = static_cast<unsigned>(p->ctx->opt(OPT_WINDOW_CAPACITY));
     }
     unsigned long long tiles_plain = 0, tiles_unwarp = 0;
     for (const hg_problem::Block& hb : p->blocks)
@@ -4692,7 +4829,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
     const unsigned long long tu = (tiles_unwarp + std::max(1u, cap_u - std::min(cap_u - 1u, slack)) - 1) /
                                   std::max(1u, cap_u - std::min(cap_u - 1u, slack));
     p->tiles = static_cast<unsigned>(std::min<unsigned long long>(kMaxTiles, std::max<unsigned long long>(1, std::max(tp, tu))));
-    if (const char* e = std::getenv("HG_WINDOW_TILES")) p->tiles = std::max(1, std::min(kMaxTiles, std::atoi(e)));
+    if (p->ctx->opt(OPT_WINDOW_TILES) > 0) p->tiles = static_cast<unsigned>(std::min<long long>(kMaxTiles, p->ctx->opt(OPT_WINDOW_TILES)));
   }
   const unsigned eval_threads = p->single_threads ? static_cast<unsigned>(p->single_threads) : kBatchThreads * p->tiles;
   unsigned wg_off = 0, row = 0;
@@ -4754,7 +4891,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       S.btd_size[groups] = (!S.constant[i] ? 6 : 0) + (S.vfree[i] ? 3 : 0);
       ++groups;
     }
-    bool ok = groups >= 2 && std::getenv("HG_LM_BAND") == nullptr;
+    bool ok = groups >= 2 && p->ctx->opt(OPT_LM_BAND) == 0;
     auto near = [&](int a, int b) {
       if (a < 0 || b < 0 || group_of[a] < 0 || group_of[b] < 0) return true;  // a constant end couples nothing
       return std::abs(group_of[a] - group_of[b]) <= 1;
@@ -4769,10 +4906,10 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       const int mb = S.btd_size[0];
       bool uni = (mb == 6 || mb == 9) && bw >= 2 * mb - 1;
       for (int g = 1; g < groups; ++g) uni = uni && S.btd_size[g] == mb;
-      if (uni && std::getenv("HG_LM_BTD_GENERIC") == nullptr) S.btd_uniform = mb;
+      if (uni && p->ctx->opt(OPT_LM_BTD_GENERIC) == 0) S.btd_uniform = mb;
       // 2: twisted factorisation from both ends of the chain (up to nine groups: the default shape), 1: cyclic reduction
       // over the workgroup (long chains, or HG_LM_BTD_CR=1), 0: the chain in one wavefront (HG_LM_BTD_CHAIN=1)
-      S.btd_cr = std::getenv("HG_LM_BTD_CHAIN") != nullptr ? 0 : (std::getenv("HG_LM_BTD_CR") != nullptr || groups > 9) ? 1 : 2;
+      S.btd_cr = p->ctx->opt(OPT_LM_BTD_CHAIN) != 0 ? 0 : (p->ctx->opt(OPT_LM_BTD_CR) != 0 || groups > 9) ? 1 : 2;
     }
     if (!ok) {
       std::memset(S.btd_start, 0, sizeof(S.btd_start));
@@ -4791,6 +4928,7 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   // block table of the window pass: per-scan blocks first, then the blocks with a ratio per return
   p->num_eval = p->num_plain = p->num_unwarp = 0;
   p->wg_plain = p->wg_unwarp = 0;
+  bool pv_copied = false;
   for (int kind = 0; kind < 2; ++kind) {
     unsigned wg_next = 0;
     for (int b = 0; b < S.num_blocks; ++b) {
@@ -4808,11 +4946,17 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
         for (int l = 0; l < pv.levels; ++l) pv.level[l] = hb.pyramid[l]->view;
         pv.self_mem = p->d_pv + b;
         if (std::memcmp(&p->h_pv[b], &pv, sizeof(pv)) != 0) {
-          // the staging slot may still feed an earlier copy: drain the stream before rewriting it (rare:
-          // only when a block's pyramid changes)
-          HG_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+          // the staging slot may still feed THIS problem's earlier copy: wait for that copy alone (an event behind it),
+          // not for the stream -- a constraint search matches every batch against other submaps, and a stream
+          // synchronisation here drained batch k before batch k + 1 could be enqueued: the previous solve of
+          // this problem has been fetched, so its copy is long done and the wait returns at once
+          if (p->pv_pending) {
+            HG_HIP_CHECK(hipEventSynchronize(p->ev_pv));
+            p->pv_pending = false;
+          }
           p->h_pv[b] = pv;
           HG_HIP_CHECK(hipMemcpyAsync(p->d_pv + b, &p->h_pv[b], sizeof(pv), hipMemcpyHostToDevice, p->ctx->stream));
+          pv_copied = true;
         }
         eb.pv = pv;
       }
@@ -4833,6 +4977,11 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
       ++(kind ? p->num_unwarp : p->num_plain);
     }
     (kind ? p->wg_unwarp : p->wg_plain) = wg_next;
+  }
+  if (pv_copied) {
+    if (!p->ev_pv) HG_HIP_CHECK(hipEventCreateWithFlags(&p->ev_pv, hipEventDisableTiming));
+    HG_HIP_CHECK(hipEventRecord(p->ev_pv, p->ctx->stream));
+    p->pv_pending = true;
   }
   if (p->num_eval >= 1 && !p->single_threads)
     HG_HIP_CHECK(hipMemcpyAsync(p->d_eval, p->h_eval, sizeof(EvalBlock) * p->num_eval,
@@ -4857,6 +5006,56 @@ int upload_state(hg_problem* p, const hg_solver_opts* opts) {
   return HG_OK;
 }
 
+#ifndef HG_BIG
+// May the single-pose solve of `p` run as ONE persistent launch (k_tsdf_residuals_single_persist)? Its workgroups wait
+// for each other inside the launch, so all of them must be resident at once: the kernel's occupancy times the CUs
+// covers the grid, and no other context of this process competes for the CUs (another process may: the kernel's
+// waits are bounded, and a solve that timed out switches the form off for the context).
+bool persist_ok(hg_problem* p, unsigned num_wg) {
+  hg_ctx* c = p->ctx;
+  if (c->opt(OPT_PERSISTENT_SOLVE) == 0 || c->opt(OPT_TICKET_HANDOVER) != 0 || c->persist_failed) return false;
+  if (live_contexts() != 1) return false;
+  if (c->persist_blocks_per_cu < 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tsdf_residuals_single_persist<kEvalThreads>, kEvalThreads, 0) != hipSuccess) nb = 0;
+    c->persist_blocks_per_cu = nb;
+  }
+  return c->persist_blocks_per_cu >= 1 && static_cast<unsigned long long>(c->persist_blocks_per_cu) * static_cast<unsigned>(std::max(0, c->num_cus)) >= num_wg;
+}
+
+// The whole solve of the single-pose registration shape as one launch of `evals` evaluations.
+int launch_persistent(hg_problem* p, unsigned evals) {
+  hipStream_t s = p->ctx->stream;
+  const LmHead& S = p->h_state.h;
+  const BlockInfo& bi = S.blocks[0];
+  const hg_problem::Block& hb = p->blocks[0];
+  const PyramidView& pv = p->h_pv[0];
+  const size_t need = static_cast<size_t>(bi.num_wg) * kAcc * 2 * sizeof(unsigned long long);
+  int rc;
+  if (p->granules.bytes < need) {
+    if ((rc = p->granules.reserve(need)) != HG_OK) return rc;
+    HG_HIP_CHECK(hipMemsetAsync(p->granules.ptr, 0, p->granules.bytes, s));  // (no tag equals an epoch: epochs start at 1)
+  }
+  if (!p->bcast.ptr) {
+    if ((rc = p->bcast.reserve(16 * kBcastReplicas * sizeof(unsigned long long))) != HG_OK) return rc;
+    HG_HIP_CHECK(hipMemsetAsync(p->bcast.ptr, 0, p->bcast.bytes, s));
+  }
+  if (p->epoch > 0xFFFFFFFFu - 2u * (evals + 2u)) p->epoch = 0;  // (tags of four billion evaluations ago match nothing that is left)
+  const unsigned epoch0 = p->epoch + 1u;
+  p->epoch += evals + 1u;  // epochs epoch0 .. epoch0 + evals - 1 tag the sums, + 1 each the hand-back
+  FirstUpload up;
+  std::memcpy(up.pose, S.cand[0], sizeof(up.pose));
+  up.box = p->d_box;
+  up.up_words = p->up_words;
+  up.pad = 0;
+  hipLaunchKernelGGL(k_tsdf_residuals_single_persist<kEvalThreads>, dim3(bi.num_wg), dim3(kEvalThreads), 0, s, pv, hb.d_xyz,
+                     bi.n, hb.width, bi.scaling, p->d_xf, p->granules.as<double>(), p->d_state, up, epoch0, evals,
+                     p->bcast.as<unsigned long long>());
+  HG_HIP_CHECK(hipGetLastError());
+  return HG_OK;
+}
+#endif
+
 // One evaluation of every residual block at the candidate. with_lm: followed by one LM step (the
 // single-pose registration shape runs it in the tail of its residual launch, every other problem as a
 // k_lm launch behind the window pass).
@@ -4870,7 +5069,7 @@ int launch_eval(hg_problem* p, double* d_residuals, bool with_lm, bool first = f
     (void)hb;
     ProfScope ps(p->ctx, HG_K_RESIDUALS, bi.n, 1, !p->prof_grouped);
     // partial sums as tagged granules (HG_TICKET_HANDOVER=1: the acknowledged stores + ticket of rounds 1-4)
-    static const bool tagged = std::getenv("HG_TICKET_HANDOVER") == nullptr;
+    const bool tagged = p->ctx->opt(OPT_TICKET_HANDOVER) == 0;
     double* sums = p->partials.as<double>();
     unsigned epoch = 0;
     if (tagged) {
@@ -5071,12 +5270,14 @@ int hg_problem_destroy(hg_problem* p) {
   if (p->d_loc) (void)hipFree(p->d_loc);
   if (p->h_box) (void)hipHostFree(p->h_box);
   if (p->ev_lazy) (void)hipEventDestroy(p->ev_lazy);
+  if (p->ev_pv) (void)hipEventDestroy(p->ev_pv);
   if (p->d_eval) (void)hipFree(p->d_eval);
   if (p->d_pv) (void)hipFree(p->d_pv);
   if (p->h_pv) (void)hipHostFree(p->h_pv);
   if (p->h_eval) (void)hipHostFree(p->h_eval);
   p->partials.release();
   p->granules.release();
+  p->bcast.release();
   p->part_xyz.release();
   p->part_flags.release();
   p->part_counts.release();
@@ -5408,7 +5609,7 @@ static int solve_async_impl(hg_problem* p, const hg_solver_opts* opts, bool lazy
   // the single-pose registration shape uploads its head inside the first residual launch (FirstUpload)
   const bool first_uploads = p->single_threads && S0.ncols == 6 && S0.bw == 5 && S0.num_blocks == 1 &&
                              S0.blocks[0].active && S0.num_small == 0 && p->num_eval < 2 &&
-                             !std::getenv("HG_PREPARE_KERNEL");
+                             p->ctx->opt(OPT_PREPARE_KERNEL) == 0;
   if (!first_uploads) {
     hipLaunchKernelGGL(k_lm, dim3(1), dim3(kLmBlock), 0, s, p->d_state, p->d_xf, static_cast<const double*>(p->d_loc), p->d_small, MODE_PREPARE, p->d_box, p->up_words, 0u);
     HG_HIP_CHECK(hipGetLastError());
@@ -5416,16 +5617,26 @@ static int solve_async_impl(hg_problem* p, const hg_solver_opts* opts, bool lazy
   // the launches of the single-pose registration step are back-to-back: one event pair brackets all
   // of them (an event pair costs ~8 us of stream serialisation); the window pass is bracketed per launch
   p->prof_grouped = first_uploads || (p->single_threads && S0.ncols == 6 && S0.bw == 5 && S0.blocks[0].active);
+  p->persist_last = false;
+#ifndef HG_BIG
+  p->persist_last = first_uploads && persist_ok(p, S0.blocks[0].num_wg);
+#endif
   ProfScope group(p->ctx, HG_K_RESIDUALS, static_cast<unsigned long long>(S0.blocks[0].n) * (max_it + 1),
-                  static_cast<unsigned>(max_it + 1), p->prof_grouped);
+                  p->persist_last ? 1u : static_cast<unsigned>(max_it + 1), p->prof_grouped);
   // General problems (two launches per iteration, 5 us each even when the solve has terminated; a window of ten
   // control points converges in nine or ten of its twelve iterations): the last three iterations are enqueued only
   // if the solve turns out to need them (solve_settle, called before anything that depends on the solve is
   // enqueued). The single-pose chain keeps its launches together: its insertion follows without the host.
 #ifndef HG_BIG
-  static const bool lazy_ok = std::getenv("HG_EAGER_SOLVE") == nullptr;
-  static const int kLazyTail = std::getenv("HG_LAZY_TAIL") ? std::max(1, std::atoi(std::getenv("HG_LAZY_TAIL"))) : 3;
+  const bool lazy_ok = p->ctx->opt(OPT_EAGER_SOLVE) == 0;
+  const int kLazyTail = static_cast<int>(std::max<long long>(1, p->ctx->opt(OPT_LAZY_TAIL)));
   if (lazy && lazy_ok && !p->prof_grouped && max_it + 1 >= 2 * kLazyTail + 2) p->lazy_left = kLazyTail;
+#endif
+#ifndef HG_BIG
+  if (p->persist_last) {
+    rc = launch_persistent(p, static_cast<unsigned>(max_it + 1));
+    if (rc != HG_OK) return rc;
+  } else
 #endif
   for (int it = 0; it <= max_it - p->lazy_left; ++it) {
     // residuals of every block at the candidate + one LM step
@@ -5575,6 +5786,23 @@ int hg_problem_fetch(hg_problem* p, hg_solver_summary* summary) {
     std::memcpy(p->poses[i].data(), S.x[i], sizeof(double) * 7);
     std::memcpy(p->velocity[i].data(), S.x[i] + 7, sizeof(double) * 3);
   }
+#if defined(HG_PERSIST_STAMPS) && !defined(HG_BIG)
+  if (p->persist_last) {
+    unsigned long long st[16][8];
+    (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_persist_stamps), sizeof(st));
+    const unsigned long long t0 = st[0][0];
+    fprintf(stderr, "persist stamps (us from the first body start): eval: wg0 body start / body end / step end / hand-back stored | wg97 hand-back seen / body end | wg195 body end\n");
+    for (int e = 0; e < 14 && e <= S.num_iterations; ++e)
+      fprintf(stderr, "  %2d: %7.2f %7.2f %7.2f %7.2f | %7.2f %7.2f | %7.2f\n", e, (st[e][0] - t0) * 0.01, (st[e][1] - t0) * 0.01,
+              (st[e][2] - t0) * 0.01, (st[e][3] - t0) * 0.01, (st[e][4] - t0) * 0.01, (st[e][5] - t0) * 0.01, (st[e][6] - t0) * 0.01);
+  }
+#endif
+  if (p->persist_last && S.termination_reason == 7) {
+    // the persistent launch gave up waiting for one of its workgroups (they were not resident together): the solve is
+    // reported as FAILURE with the last accepted pose, and this context goes back to a launch per evaluation
+    p->ctx->persist_failed = true;
+    set_last_error("persistent solve timed out waiting for a workgroup; the context now launches per evaluation");
+  }
   if (summary) {
     summary->initial_cost = S.initial_cost;
     summary->final_cost = S.x_cost;
@@ -5708,7 +5936,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   HG_HIP_CHECK(hipSetDevice(c->device));
   // the batched launch covers problems that take the register-resident single-pose step
   bool batchable = count >= 2;
-  bool windows = count >= 2 && std::getenv("HG_NO_WINDOW_BATCH") == nullptr;  // general problems sharing their launches
+  bool windows = count >= 2 && c->opt(OPT_WINDOW_BATCH) != 0;  // general problems sharing their launches
   int rc = HG_OK;
   for (int i = 0; i < count && rc == HG_OK; ++i) {
     hg_problem* p = problems[i];
@@ -5784,7 +6012,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     c->lazy_batch_left = 0;
     c->lazy_batch_dims[0] = max_plain; c->lazy_batch_dims[1] = max_unwarp; c->lazy_batch_dims[2] = static_cast<unsigned>(count);
     c->lazy_batch_units[0] = units_plain; c->lazy_batch_units[1] = units_unwarp;
-    static const bool lazy_ok = std::getenv("HG_EAGER_SOLVE") == nullptr;
+    const bool lazy_ok = c->opt(OPT_EAGER_SOLVE) == 0;
     if (lazy_ok && max_it + 1 >= 8) {
       c->lazy_batch_left = 3;
       c->lazy_batch_flags.clear();
@@ -5817,7 +6045,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   // Level partition (see k_level_classify): worth its three launches and one finest-level lookup per return once the
   // batch is large enough to be bound by throughput (HG_PARTITION_MIN problems, default 48: 64 matches 27.3k -> 29.4k
   // matches/s, 32 and 16 even; 0 switches it off)
-  static const int part_min = std::getenv("HG_PARTITION_MIN") ? std::atoi(std::getenv("HG_PARTITION_MIN")) : 48;
+  const int part_min = static_cast<int>(c->opt(OPT_PARTITION_MIN));
   bool partition = part_min > 0 && count >= part_min;
   for (int i = 0; i < count && partition; ++i) {
     const PyramidView& pv = problems[i]->h_pv[0];
@@ -5861,7 +6089,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     // the batched pass has its own workgroup size; several tiles per workgroup once the batch fills the chip more
     // than once (64 matches of 100k returns: 25.5k / 27.5k / 28.3k / 27.9k matches/s at 1 / 2 / 4 / 8 tiles; 32: 22.7k /
     // 24.6k / 24.5k at 1 / 2 / 4; 8 and 16: + 3 - 5 % at 2, back to where it was at 4). HG_BATCH_TILES overrides.
-    static const int env_tiles = std::getenv("HG_BATCH_TILES") ? std::atoi(std::getenv("HG_BATCH_TILES")) : 0;
+    const int env_tiles = static_cast<int>(c->opt(OPT_BATCH_TILES));
     J.tiles = env_tiles > 0 ? static_cast<unsigned>(env_tiles) : (count >= 48 ? 4u : count >= 8 ? 2u : 1u);
     J.num_wg = (bi.n + kBatchThreads * J.tiles - 1) / (kBatchThreads * J.tiles);
     if ((rc = p->partials.reserve(static_cast<size_t>(J.num_wg) * kAcc * sizeof(double))) != HG_OK) return rc;
@@ -5912,7 +6140,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   // finest level's known voxels changes sides with every voxel the pose moves -- classified at the guess itself,
   // 35 % of the wavefronts that were expected fast held such a lane a few iterations later and paid the second
   // round trip. HG_PARTITION_AT overrides the iteration.
-  static const int part_at = std::getenv("HG_PARTITION_AT") ? std::atoi(std::getenv("HG_PARTITION_AT")) : 2;
+  const int part_at = static_cast<int>(c->opt(OPT_PARTITION_AT));
   // (Round 4, measured and dropped: the batch cut in two halves on two streams, the second one residual pass behind
   // the first, so that one half's step kernel -- `count` workgroups on an otherwise idle chip, 10 us per iteration
   // against 22 us of residual pass for eight 100k-point scans -- would run under the other half's residual pass.
@@ -5968,7 +6196,7 @@ int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solv
   bool batched = false;
   // HG_HOST_TIMES=1: where the host spends the call (stderr; enqueue = uploads + tables + launches, first fetch =
   // the wait for the device)
-  static const bool host_times = std::getenv("HG_HOST_TIMES") != nullptr;
+  const bool host_times = problems && count > 0 && problems[0] && problems[0]->ctx && problems[0]->ctx->opt(OPT_HOST_TIMES) != 0;
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = solve_batch_enqueue(problems, count, opts, &batched);
   if (rc != HG_OK) return rc;

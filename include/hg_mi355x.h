@@ -126,6 +126,42 @@ int hg_ctx_destroy(hg_ctx* ctx);
  * was last cleared (the flags are kept per grid: hg_grid_clear / hg_grid_destroy reset only the grid's
  * own). */
 int hg_ctx_synchronize(hg_ctx* ctx);
+/* Tuning and diagnostic switches of a context (round 6: they used to be HG_* environment variables read inside the
+ * library; the environment now only supplies the DEFAULT a context starts from, variable HG_<KEY IN UPPER CASE>).
+ * None changes what a call computes beyond what its entry states (summation orders of the matcher, launch shapes,
+ * the linear solver of the LM step); results stay inside every tolerance the header gives. Keys:
+ *   persistent_solve   1: the single-pose registration solve runs as ONE launch whose workgroups loop over the
+ *                         evaluations and wait for each other inside the launch (same arithmetic in the same order:
+ *                         bitwise the same poses; no launch gaps, no empty launches behind convergence). OFF by
+ *                         default: the launch needs all of its workgroups resident at once -- one 512-thread
+ *                         workgroup per CU -- which holds while the GPU is this context's alone; the library checks
+ *                         what it can see (occupancy x CUs >= workgroups, no other context in this process) and
+ *                         every wait inside the launch is bounded (two seconds; the solve then reports FAILURE,
+ *                         termination_reason 7, and the context returns to a launch per evaluation), but another
+ *                         PROCESS holding CUs is invisible to it. Set it where the device is not shared.
+ *                         0: a launch per evaluation (default)
+ *   ticket_handover    1: partial sums by acknowledged stores + ticket (rounds 1-4) instead of tagged granules
+ *   prepare_kernel     1: a separate head-upload launch in front of a single-pose solve
+ *   eager_solve        1: every launch of a general solve enqueued up front (no held-back tail)
+ *   lazy_tail          launches of a general solve held back until needed (default 3)
+ *   lm_general         1: single-pose problems through the general k_lm path
+ *   lm_band / lm_btd_generic / lm_btd_chain / lm_btd_cr   1: the band / generic block / one-wavefront chain /
+ *                         cyclic-reduction factorisation of the LM step instead of the default (twisted block)
+ *   window_capacity, window_tiles, batch_tiles   launch shapes of the window / batched residual passes (0: automatic)
+ *   window_batch       0: windows of a batch solved one after the other
+ *   partition_min      batch size from which the level partition is used (default 48; 0: never)
+ *   partition_at       LM iteration at which the returns are classified (default 2)
+ *   host_times         1: host-side timing of hg_register_scan_sequence printed to stderr
+ *   stream_group       scans whose front ends share launches in a scan stream (default 8; 0: off)
+ *   stream_slice       records per voxel slice of large bins in a scan stream (default 1024)
+ *   apply_turns        1: the levels of k_bin_apply take turns
+ *   defer_long_chains  0: no deferral of long chains (only in builds with -DHG_DEFER_LONG_CHAINS)
+ *   insert_sort        1: exact insertion through the radix-sort path
+ *   insert_pipeline    0: small-scan streams on one stream
+ *   fast_atomics       1: tolerance insertion through per-voxel device atomics (round 2) instead of the bins
+ * Unknown key: HG_ERR_INVALID. */
+int hg_ctx_set_option(hg_ctx* ctx, const char* key, long long value);
+int hg_ctx_get_option(hg_ctx* ctx, const char* key, long long* value);
 void* hg_ctx_stream(hg_ctx* ctx);
 const char* hg_last_error(void);
 const char* hg_version(void);
@@ -370,9 +406,12 @@ int hg_problem_solve(hg_problem* p, const hg_solver_opts* opts, hg_solver_summar
  * search hands to CeresScanMatcher3D::Match one by one (mapping/internal/3d/scan_matching/
  * ceres_scan_matcher_3d.cc:72-118). Problems of the single-pose shape (one free pose, one TSDF
  * block, no odometry / IMU blocks) share their kernel launches (one grid row per problem); every
- * problem keeps its own solver state, so iteration counts and termination are those of
- * hg_problem_solve on each, poses and costs agree with it to the rounding of the normal-equation sums
- * (the batched pass sums over smaller workgroups: same terms, another association; observed 1e-12).
+ * problem keeps its own solver state; poses and costs agree with hg_problem_solve on each to the rounding of
+ * the normal-equation sums (the batched pass sums over smaller workgroups, and from batches of partition_min
+ * problems on it re-orders the returns of every problem after its second step -- same terms, another association;
+ * observed 1e-12). Iteration counts and termination are those of hg_problem_solve wherever a decision of the
+ * trust-region loop does not hinge on that rounding (an accept / reject or tolerance test within ~1e-12 of its
+ * threshold can fall the other way; not observed in the tests' batches).
  * Other shapes are solved one after the other. summaries: count entries or NULL. */
 int hg_problem_solve_batch(hg_problem* const* problems, int count, const hg_solver_opts* opts,
                            hg_solver_summary* summaries);

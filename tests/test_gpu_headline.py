@@ -220,7 +220,7 @@ def test_register_scan_batch_of_100k_point_scans_against_oracle(po, hg, ctx):
 
 def test_both_hand_overs_of_the_partial_sums_pass_the_bench_gate():
     """The single-pose chain hands its partial sums to the LM tail as tagged granules (round 5) or, with
-    HG_TICKET_HANDOVER=1, by acknowledged stores and a ticket (rounds 1 - 4). The switch is read once per process, so
+    HG_TICKET_HANDOVER=1 (the default of the context option ticket_handover), by acknowledged stores and a ticket (rounds 1 - 4). The switch is read when a context is created, so
     each form runs the headline command in a process of its own: bench.py aborts unless the first timed steps equal the
     oracle's (poses within 1e-4 m / 1e-4 rad, same iterations and termination), and the two forms must agree with
     each other far below that."""
@@ -230,12 +230,16 @@ def test_both_hand_overs_of_the_partial_sums_pass_the_bench_gate():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = []
-    for env_extra in ({}, {"HG_TICKET_HANDOVER": "1"}):
+    # (round 6) and the third form: the whole solve as ONE persistent launch, which bench.py's headline asks for
+    # (hg_ctx_set_option "persistent_solve"); --no-persistent-solve keeps a launch per evaluation
+    for env_extra, extra_args in (({}, []), ({}, ["--no-persistent-solve"]), ({"HG_TICKET_HANDOVER": "1"}, ["--no-persistent-solve"])):
         env = dict(os.environ, **env_extra)
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-scans", "2",
-                              "--no-secondary", "--host-steps", "0"], capture_output=True, text=True, timeout=600, env=env)
+                              "--no-secondary", "--host-steps", "0"] + extra_args, capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode == 0, out.stderr[-2000:]
         lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
     for d in lines:
         assert d["parity"]["same_iterations_and_termination"] and d["parity"]["max_dt_m"] < 1e-9
-    assert abs(lines[0]["config"]["mean_pose_error_m"] - lines[1]["config"]["mean_pose_error_m"]) < 1e-9
+    assert lines[0]["roofline"]["solve_form"].startswith("persistent") and lines[1]["roofline"]["solve_form"].startswith("one ")
+    assert lines[0]["config"]["mean_pose_error_m"] == lines[1]["config"]["mean_pose_error_m"]   # the same arithmetic
+    assert abs(lines[0]["config"]["mean_pose_error_m"] - lines[2]["config"]["mean_pose_error_m"]) < 1e-9

@@ -115,13 +115,12 @@ def test_evaluate_interpolated_two_poses(po, hg, ctx, maps):
 @pytest.mark.parametrize("general_lm", [False, True])
 @pytest.mark.parametrize("levels,multi", [([1], False), ([0, 1, 2], True)])
 def test_solve_single_pose(po, hg, ctx, maps_by_path, levels, multi, general_lm, monkeypatch):
-    """Both LM tails: the register-resident single-pose step and (HG_LM_GENERAL=1) the general one;
+    """Both LM tails: the register-resident single-pose step and (context option lm_general) the general one;
     both voxel-lookup paths."""
-    if general_lm:
-        monkeypatch.setenv("HG_LM_GENERAL", "1")
     truth, pts, guess = query()
-    op, gp = both_problems(po, hg, ctx, maps_by_path, levels, multi, pts, [guess], [False])
-    so, sg = op.solve(), gp.solve()
+    with ctx.option("lm_general", 1 if general_lm else 0):   # (read when the solve is prepared)
+        op, gp = both_problems(po, hg, ctx, maps_by_path, levels, multi, pts, [guess], [False])
+        so, sg = op.solve(), gp.solve()
     a, b = op.get_pose(0), gp.get_pose(0)
     assert np.linalg.norm(a[:3] - b[:3]) < POSE_TOL_M
     assert rot_angle(a[3:], b[3:]) < POSE_TOL_RAD
@@ -431,21 +430,17 @@ def test_window_of_ten_control_points(po, hg, ctx, maps):
 
 @pytest.mark.parametrize("velocities", [True, False])
 @pytest.mark.parametrize("path", ["twisted", "cyclic_reduction", "btd_chain", "btd_padded", "band"])
-def test_window_linear_solver_paths(po, hg, ctx, maps, path, velocities, monkeypatch):
+def test_window_linear_solver_paths(po, hg, ctx, maps, path, velocities, request):
     """The factorisations of the window's normal equations -- the twisted block factorisation from both ends of the
     chain with a wavefront per group (the default up to nine groups), block cyclic reduction over the workgroup
     (uniform 9- or 6-column groups), the block chain in one wavefront (registers, forward pass folded in),
     the padded block form, the band Cholesky -- give the oracle's solve: same iterations, poses within
     tolerance. With velocities: 9-column groups (pose + velocity, IMU blocks); without: 6-column groups
-    coupled by two-pose scan blocks. (The environment switches are read at every solve.)"""
-    if path == "cyclic_reduction":
-        monkeypatch.setenv("HG_LM_BTD_CR", "1")
-    elif path == "btd_chain":
-        monkeypatch.setenv("HG_LM_BTD_CHAIN", "1")
-    elif path == "btd_padded":
-        monkeypatch.setenv("HG_LM_BTD_GENERIC", "1")
-    elif path == "band":
-        monkeypatch.setenv("HG_LM_BAND", "1")
+    coupled by two-pose scan blocks. (Context options, read at every solve.)"""
+    key = {"cyclic_reduction": "lm_btd_cr", "btd_chain": "lm_btd_chain", "btd_padded": "lm_btd_generic", "band": "lm_band"}.get(path)
+    if key:
+        ctx.set_option(key, 1)
+        request.addfinalizer(lambda: ctx.set_option(key, 0))
     og, gg = maps
     n_cp = 7
     poses = [synth.pose_k(3 + i) if i == 0 else synth.pose_mul(synth.pose_k(3 + i), synth.perturbation())

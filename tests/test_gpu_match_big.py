@@ -88,10 +88,12 @@ def test_large_window_against_oracle(po, hg, ctx, maps, n_cp, velocities):
 
 
 @pytest.mark.parametrize("path", ["btd_chain", "btd_padded", "band"])
-def test_large_window_linear_solver_paths(po, hg, ctx, maps, path, monkeypatch):
+def test_large_window_linear_solver_paths(po, hg, ctx, maps, path, request):
     """The other factorisations of the big build (block chain, padded block form, band Cholesky) on a window of
     14 control points with velocities."""
-    monkeypatch.setenv({"btd_chain": "HG_LM_BTD_CHAIN", "btd_padded": "HG_LM_BTD_GENERIC", "band": "HG_LM_BAND"}[path], "1")
+    key = {"btd_chain": "lm_btd_chain", "btd_padded": "lm_btd_generic", "band": "lm_band"}[path]
+    ctx.set_option(key, 1)
+    request.addfinalizer(lambda: ctx.set_option(key, 0))
     op, gp = window(po, hg, ctx, maps, 14, True)
     compare_solutions(op, gp, 14, True)
     gp.close()
