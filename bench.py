@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--no-window-unwarp", action="store_true",
                     help="--workload window: insert the leaving scan at control point 1's pose instead of unwarping it "
                          "per point between control points 0 and 1 (hg_register_scan_unwarped)")
-    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "window_batch", "register_filtered", "match_batch", "register_batch"],
+    ap.add_argument("--workload", default="register", choices=["register", "insert_stream", "window", "window_batch", "register_filtered", "match_batch", "register_batch", "c1_10k"],
                     help="register = BASELINE configs[1] (default, the headline metric); insert_stream = "
                          "configs[2]: B scans with known poses inserted per step in one batched call")
     ap.add_argument("--stream-scans", type=int, default=64)
@@ -528,6 +528,133 @@ def run_insert_stream(args):
         "parity": parity, "cpu_baseline": base,
         "gpu_over_cpu": (args.steps * B / elapsed) / base["value"] if base else None,
     }
+
+
+def run_c1_10k(args):
+    """BASELINE configs[0]: a 10k-point scan (16 rings x 625 columns) registered into ONE 0.10 m TSDF (+ the 0.45 m
+    low-resolution grid every Submap3D carries, submap_3d.h:89-90). Two sub-rows:
+      all_points   every return matched (single-resolution LM on the 0.10 m grid) + exact insertion into both grids, one
+                   hg_register_scan call per scan from this process; oracle beside it, poses gated at 1e-4 m / 1e-4 rad
+      lua_default  the shipped C++ OptimizingLocalTrajectoryBuilder (cpp/hg_adapter.h) with the options of
+                   trajectory_builder_3d.lua -- adaptive voxel filters (>= 150 / 200 points), CONSTANT control points,
+                   odometry + IMU blocks -- over cpp/example_oltb's sensor stream at 16 x 625 returns per scan; the
+                   value is scans / time inside AddRangeData; gate and CPU figure: the same messages replayed through the
+                   Python statement of optimizing_local_trajectory_builder.cc over the oracle (tests/oltb_replay.py)."""
+    import subprocess
+    import tempfile
+    import torch
+    from hectorgrapher_amd import api, synth
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    dev = torch.device("cuda", 0)
+    rings, cols = 16, 625
+    n_pts = rings * cols
+    res = (0.10, 0.45)
+    out = {}
+    # ---- all_points ----
+    ctx = api.Context(0)
+    grids = [api.HybridGridTSDF(ctx, r, max_blocks=1 << 15) for r in res]
+    ins = [api.TSDFRangeDataInserter3D() for _ in res]
+    map_scans = make_scans(rings, cols, 0, args.map_scans, 0)
+    for pose, pts in map_scans:
+        api.insert_pyramid(ins, api.RangeData([0, 0, 0], torch.from_numpy(pts).to(dev)), grids, pose_tq=pose.astype(np.float32))
+    query = make_scans(rings, cols, args.map_scans, args.warmup + args.steps, 0)
+    d_scans = [torch.from_numpy(pts).to(dev) for _, pts in query]
+    guesses = [synth.pose_mul(pose, synth.perturbation()) for pose, _ in query]
+    scale = 1.0 / np.sqrt(float(n_pts))
+    problem = api.Problem(ctx)
+    gpu_steps = []
+
+    def step(i):
+        problem.reset()
+        pi = problem.add_pose(guesses[i])
+        problem.add_block(d_scans[i], [grids[0]], scale, pi, multi_res=False, width=rings)
+        est, summ = api.register_scan(problem, pi, ins, api.RangeData([0, 0, 0], d_scans[i], width=rings), grids)
+        gpu_steps.append((est, summ.num_iterations, summ.termination_type, summ.termination_reason))
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    og = [po.Grid(r) for r in res]
+    for pose, pts in map_scans:
+        loc = synth.transform_points(pose, pts)
+        for g in og:
+            g.insert(pose[:3], loc)
+    n_cpu = min(args.cpu_scans + args.warmup, len(query))
+    max_dt = max_dr = 0.0
+    same = True
+    t1 = time.perf_counter()
+    for i in range(n_cpu):
+        pr = po.Problem()
+        pi = pr.add_pose(guesses[i])
+        pr.add_block(query[i][1], [og[0]], scale, pi, multi_res=False)
+        so = pr.solve()
+        o = pr.get_pose(pi)
+        est, it, tt, tr = gpu_steps[i]
+        # (as cpu_baseline: the next step's map must be the GPU's -- insert where the GPU inserted if the float casts differ)
+        at = o if np.array_equal(o.astype(np.float32), est.astype(np.float32)) else est
+        loc = synth.transform_points(at, query[i][1])
+        for g in og:
+            g.insert(at[:3].astype(np.float32), loc)
+        max_dt = max(max_dt, float(np.linalg.norm(o[:3] - est[:3])))
+        max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(np.dot(o[3:], est[3:])))))))
+        same = same and (so.num_iterations, so.termination_type, so.termination_reason) == (it, tt, tr)
+    cpu_rate = n_cpu / (time.perf_counter() - t1)
+    problem.close()
+    for g in grids:
+        g.close()
+    ctx.close()
+    out["all_points"] = {"value": args.steps / elapsed, "unit": "scans/s", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps,
+                         "parity": {"max_dt_m": max_dt, "max_dr_rad": max_dr, "scans": n_cpu, "tolerance": 1e-4,
+                                    "same_iterations_and_termination": bool(same)},
+                         "cpu_baseline": {"value": cpu_rate, "unit": "scans/s", "cores": 1, "kind": "port",
+                                          "sample": "%d scans of the same workload, oracle -O3 1 thread" % n_cpu},
+                         "gpu_over_cpu": (args.steps / elapsed) / cpu_rate}
+    if not (max_dt <= 1e-4 and max_dr <= 1e-4):
+        raise SystemExit("bench.py: parity gate of c1_10k failed: %r" % (out["all_points"]["parity"],))
+    # ---- lua_default: the C++ builder ----
+    exe = os.path.join(ROOT, "hectorgrapher_amd", "cpp", "example_oltb")
+    scans = 40
+    try:
+        if not os.path.exists(exe):
+            raise RuntimeError("hectorgrapher_amd/cpp/example_oltb is not built (python -c 'import __graft_entry__ as g; g.build()')")
+        with tempfile.TemporaryDirectory() as td:
+            dump = os.path.join(td, "oltb.bin")
+            run_ = subprocess.run([exe, dump, "0", str(scans), str(rings), str(cols), "1"], capture_output=True, text=True, timeout=600)
+            if run_.returncode != 0:
+                raise RuntimeError(run_.stderr[-500:])
+            m = [l for l in run_.stdout.splitlines() if l.startswith("timing:")][-1].split()
+            gpu_s = float(m[6])
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oltb_replay as rp
+            r = rp.replay_and_compare(po, open(dump, "rb").read(), run_.stdout, 0, scans, width=rings, check_window=False)
+        ok = max(r["b"].cloud_errors) < 1e-5 if r["b"].cloud_errors else True
+        out["lua_default"] = {"value": scans / gpu_s, "unit": "scans/s", "ms_per_step": gpu_s / scans * 1e3, "steps": scans,
+                              "solves": r["solves"],
+                              "parity": {"same_solves_iterations_terminations_and_blocks": True, "inserted_range_data_max_err_m":
+                                         float(max(r["b"].cloud_errors)) if r["b"].cloud_errors else 0.0, "ok": bool(ok),
+                                         "check": "every step of the C++ builder against tests/oltb_replay.py over the oracle: solve / no solve, "
+                                                  "iterations, termination, block wiring, result and insertion decisions, inserted range data"},
+                              "cpu_baseline": {"value": scans / r["cpu_seconds"], "unit": "scans/s", "cores": 1, "kind": "port",
+                                               "sample": "the same %d scans: Python statement of optimizing_local_trajectory_builder.cc "
+                                                         "driving the -O3 oracle (inserts, filters and solves in C; orchestration in Python)" % scans},
+                              "gpu_over_cpu": (scans / gpu_s) / (scans / r["cpu_seconds"])}
+        if not ok:
+            raise SystemExit("bench.py: parity gate of c1_10k lua_default failed")
+    except AssertionError as e:
+        raise SystemExit("bench.py: c1_10k lua_default differs from the replay: %r" % (e,))
+    v = out["all_points"]
+    return {"metric": "scans/s (10k-pt scan into one 0.10 m TSDF, BASELINE configs[0])", "value": v["value"], "unit": "scans/s",
+            "ms_per_step": v["ms_per_step"], "steps": args.steps, "n_gpus": 1, "warmup": args.warmup, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "c1_10k: 16 x 625 returns, one 0.10 m TSDF (+ 0.45 m low-resolution grid): all points matched "
+                                   "(value) and the Lua-default builder (rows.lua_default)"},
+            "roofline": None, "parity": v["parity"], "cpu_baseline": v["cpu_baseline"], "rows": out}
 
 
 def window_spec(synth, first, n_cp):
@@ -1657,6 +1784,8 @@ def secondary_workloads(args):
         # the tolerance mode of the same stream (order-free sums on the bins, one closed-form update per voxel and chunk)
         ("insert_stream_fast", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "insert_mode": "fast", "steps": 6,
                                                    "warmup": 1, "prof_every": 2, "cpu_scans": 2}),
+        # BASELINE configs[0]: the 10k-point scan into one 0.10 m grid, all points matched and through the C++ builder
+        ("c1_10k", run_c1_10k, {"workload": "c1_10k", "steps": 30, "warmup": 3, "cpu_scans": 3}),
         ("window_10", run_window, {"workload": "window", "window": 10, "steps": 12, "warmup": 3, "prof_every": 3}),
         # BASELINE configs[2] with the voxels in HBM: 64 scans over 64 copies of the room (~0.4 GB of voxel
         # blocks touched per call, beyond the 256 MB Infinity Cache); insert_stream_32 above stays in cache
@@ -1695,6 +1824,8 @@ def secondary_workloads(args):
             if r.get("cpu_baseline"):
                 out[name]["cpu_baseline"] = r["cpu_baseline"]
                 out[name]["gpu_over_cpu"] = r["value"] / r["cpu_baseline"]["value"]
+            if r.get("rows"):
+                out[name]["rows"] = r["rows"]
             cfg = r.get("config") or {}
             for k in ("gather_ms", "gather_check", "process_group", "voxel_working_set_mib", "room_copies"):
                 if cfg.get(k) is not None:
@@ -1720,6 +1851,8 @@ def run(args, out_fd=None):
         return run_insert_stream(args)
     if args.workload == "register_filtered":
         return run_register_filtered(args)
+    if args.workload == "c1_10k":
+        return run_c1_10k(args)
     if args.workload == "window":
         return run_window(args)
     if args.workload == "window_batch":

@@ -10,6 +10,8 @@
 //   mode 1: SYNCED_WITH_RANGE_DATA sampling (clouds sit ON control points: single-pose blocks)
 //   mode 2: ADAPTIVE sampling + use_multi_resolution_matching
 //   mode 3: CONSTANT sampling + use_per_point_unwarping
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -30,16 +32,18 @@ void TruePose(double t, double* x, double* y, double* z, double* yaw) {
 
 // box room [-5, 6] x [-4, 3] x [-1.2, 2.6] with a pillar, 12 rings x 240 columns, swept over the 40 ms before the
 // scan's time stamp (point times <= 0, the sensor moves while it sweeps)
+int g_rings = 12, g_cols = 240;  // (argv[4], argv[5]: BASELINE configs[0] is 16 x 625)
 sensor::TimedPointCloudData MakeScan(common::Time time) {
   sensor::TimedPointCloudData scan;
   scan.time = time;
-  scan.width = 12;
-  for (int c = 0; c < 240; ++c) {
-    const float point_time = -0.04f * (1.0f - static_cast<float>(c) / 239.0f);
+  scan.width = static_cast<size_t>(g_rings);
+  for (int c = 0; c < g_cols; ++c) {
+    const float point_time = -0.04f * (1.0f - static_cast<float>(c) / static_cast<float>(g_cols - 1));
     double sx, sy, sz, yaw;
     TruePose(common::ToSeconds(time) + static_cast<double>(point_time), &sx, &sy, &sz, &yaw);
-    for (int r = 0; r < 12; ++r) {
-      const double az = 6.283185307179586 * c / 240.0 + yaw, el = (-14.0 + 2.5 * r) * 0.017453292519943295;
+    for (int r = 0; r < g_rings; ++r) {
+      const double el_deg = g_rings == 12 ? -14.0 + 2.5 * r : -15.0 + 30.0 * r / (g_rings - 1);
+      const double az = 6.283185307179586 * c / static_cast<double>(g_cols) + yaw, el = el_deg * 0.017453292519943295;
       const double d[3] = {std::cos(el) * std::cos(az), std::cos(el) * std::sin(az), std::sin(el)};
       double t = 1e9;
       const double o[3] = {sx, sy, sz};
@@ -61,7 +65,7 @@ sensor::TimedPointCloudData MakeScan(common::Time time) {
       const double wx = d[0] * t, wy = d[1] * t, wz = d[2] * t;
       std::array<float, 4> p{{static_cast<float>(cs * wx - sn * wy), static_cast<float>(sn * wx + cs * wy),
                               static_cast<float>(wz), point_time}};
-      if ((c * 12 + r) % 97 == 13) p[1] = std::nanf("");  // a few invalid returns, as a real driver delivers them
+      if ((c * g_rings + r) % 97 == 13) p[1] = std::nanf("");  // a few invalid returns, as a real driver delivers them
       scan.ranges.push_back(p);
     }
   }
@@ -83,6 +87,9 @@ int main(int argc, char** argv) {
   if (argc < 3) return 2;
   const int mode = std::atoi(argv[2]);
   const int scans = argc > 3 ? std::atoi(argv[3]) : 36;
+  if (argc > 5) { g_rings = std::max(2, std::atoi(argv[4])); g_cols = std::max(2, std::atoi(argv[5])); }
+  const bool quiet = argc > 6 && std::atoi(argv[6]) != 0;  // no window dump per step (timed runs)
+  double add_range_seconds = 0.0;
   std::FILE* f = std::fopen(argv[1], "wb");
   if (!f) return 2;
   try {
@@ -150,7 +157,9 @@ int main(int argc, char** argv) {
         std::fwrite(scan.ranges.data(), sizeof(float) * 4, n, f);
       }
       const int solves_before = builder.num_optimizations(), inserts_before = builder.num_insertions();
+      const auto t_add = std::chrono::steady_clock::now();
       auto result = builder.AddRangeData("lidar", scan);
+      add_range_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_add).count();
       const hg_solver_summary& s = builder.last_summary();
       const int solved = builder.num_optimizations() - solves_before;
       std::printf("scan %d time %lld result %d solved %d iterations %d termination %d %d queued %zu imu_blocks %d odometry_blocks %d residuals %d\n", scan_index,
@@ -159,7 +168,7 @@ int main(int argc, char** argv) {
       if (solved)
         for (const auto& b : builder.last_blocks())
           std::printf("  block %zu %d %d %.17g %d\n", b.points, b.pose_a, b.pose_b, b.factor, b.grid);
-      PrintWindow(builder);
+      if (!quiet) PrintWindow(builder);
       // the range data of this step's insertion (kind 3), as it went into the submaps
       int inserted = 0;
       if (result) {
@@ -200,6 +209,7 @@ int main(int argc, char** argv) {
       }
     }
     std::printf("done: %d optimizations, %d insertions, %zu submaps\n", builder.num_optimizations(), builder.num_insertions(), submaps.size());
+    std::printf("timing: %d scans of %d returns, %.6f s inside AddRangeData\n", scan_index, g_rings * g_cols, add_range_seconds);
   } catch (const Error& e) {
     std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
     std::fclose(f);

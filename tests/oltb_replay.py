@@ -7,6 +7,9 @@ of every solve with what the C++ adapter (cpp/hg_adapter.h, device solves) repor
 Times are integers (common::Time ticks of 100 ns), poses (t xyz, q wxyz) float64 arrays."""
 import bisect
 import math
+import re
+import struct
+import sys
 
 import numpy as np
 
@@ -542,3 +545,165 @@ class OracleOLTB:
             sm.num_range_data += 1
         if self.submaps[0].num_range_data == 2 * o.num_range_data:
             self.submaps[0].finished = True
+
+
+# ---- the C++ builder's dump (cpp/example_oltb.cc) and its comparison with the replay ----
+def parse_stdout(text):
+    steps, cur = [], None
+    for line in text.splitlines():
+        m = re.match(r"scan (\d+) time (-?\d+) result (\d) solved (\d) iterations (\d+) termination (\d+) (\d+) queued (\d+) "
+                     r"imu_blocks (\d+) odometry_blocks (\d+) residuals (\d+)", line)
+        if m:
+            v = [int(x) for x in m.groups()]
+            cur = {"scan": v[0], "time": v[1], "result": v[2], "solved": v[3], "it": v[4], "term": (v[5], v[6]), "queued": v[7],
+                   "imu_blocks": v[8], "odometry_blocks": v[9], "residuals": v[10], "blocks": [], "cps": [], "local_pose": None,
+                   "inserted": 0}
+            steps.append(cur)
+            continue
+        m = re.match(r"\s+block (\d+) (-?\d+) (-?\d+) (\S+) (\d)", line)
+        if m:
+            cur["blocks"].append((int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4)), int(m.group(5))))
+            continue
+        m = re.match(r"\s+cp (-?\d+) pose (.*) vel (.*)", line)
+        if m:
+            cur["cps"].append((int(m.group(1)), np.array([float(x) for x in m.group(2).split()]),
+                               np.array([float(x) for x in m.group(3).split()])))
+            continue
+        m = re.match(r"\s+local_pose (-?\d+) (.*) inserted (\d+) submaps (\d+)", line)
+        if m:
+            cur["local_pose"] = (int(m.group(1)), np.array([float(x) for x in m.group(2).split()]))
+            cur["inserted"] = int(m.group(3))
+            cur["submaps"] = int(m.group(4))
+    return steps
+
+
+def messages(raw):
+    off = 4
+    while off < len(raw):
+        (kind,) = struct.unpack_from("i", raw, off); off += 4
+        if kind == 0:
+            (t,) = struct.unpack_from("q", raw, off); off += 8
+            w = np.frombuffer(raw, np.float64, 3, off).copy(); off += 24
+            yield ("imu", t, w)
+        elif kind == 1:
+            (t,) = struct.unpack_from("q", raw, off); off += 8
+            pose = np.frombuffer(raw, np.float64, 7, off).copy(); off += 56
+            yield ("odom", t, pose)
+        elif kind == 2:
+            (t,) = struct.unpack_from("q", raw, off); off += 8
+            origin = np.frombuffer(raw, np.float32, 3, off).copy(); off += 12
+            (n,) = struct.unpack_from("i", raw, off); off += 4
+            pts = np.frombuffer(raw, np.float32, n * 4, off).reshape(n, 4).copy(); off += 16 * n
+            yield ("scan", t, origin, pts)
+        elif kind == 3:
+            (n,) = struct.unpack_from("i", raw, off); off += 4
+            if n:
+                origin = np.frombuffer(raw, np.float32, 3, off).copy(); off += 12
+                ret = np.frombuffer(raw, np.float32, n * 3, off).reshape(n, 3).copy(); off += 12 * n
+                yield ("inserted", origin, ret)
+            else:
+                yield ("inserted", None, None)
+        elif kind == 4:
+            pose = np.frombuffer(raw, np.float64, 7, off).copy(); off += 56
+            (num,) = struct.unpack_from("i", raw, off); off += 4
+            grids = []
+            for _ in range(2):
+                (n,) = struct.unpack_from("i", raw, off); off += 4
+                cells = np.frombuffer(raw, np.int32, n * 3, off).reshape(n, 3).copy(); off += 12 * n
+                tsd = np.frombuffer(raw, np.uint16, n, off).copy(); off += 2 * n
+                weight = np.frombuffer(raw, np.uint16, n, off).copy(); off += 2 * n
+                grids.append((cells, tsd, weight))
+            yield ("submap", pose, num, grids)
+        else:
+            raise AssertionError("bad record kind %d" % kind)
+
+
+MODES = {
+    0: dict(),                                                      # the Lua defaults
+    1: dict(control_point_sampling="SYNCED_WITH_RANGE_DATA"),
+    2: dict(control_point_sampling="ADAPTIVE", use_multi_resolution_matching=True, sampling_max_delta_translation=0.03),
+    3: dict(use_per_point_unwarping=True),
+}
+
+
+
+
+def replay_and_compare(po, raw, stdout_text, mode, scans, width=12, check_window=True):
+    """Replays the messages example_oltb dumped (`raw`) through OracleOLTB and compares every step with what the C++
+    builder printed (`stdout_text`). Returns a dict of what was seen; raises AssertionError where the two differ."""
+    import struct
+    import time as _time
+    rp = sys.modules[__name__]
+    gpu = parse_stdout(stdout_text)
+    assert len(gpu) == scans
+    assert struct.unpack_from("i", raw, 0)[0] == mode
+    cpu_seconds = 0.0
+    opt = Options()
+    opt.initialization_duration = 0.2
+    opt.num_range_data = 4
+    for k, v in MODES[mode].items():
+        setattr(opt, k, v)
+    b = OracleOLTB(po, opt)
+
+    msgs = list(messages(raw))
+    max_dt = max_dr = max_dv = 0.0
+    solves = interpolated = single = 0
+    k = 0
+    i = 0
+    final_submaps = []
+    while i < len(msgs):
+        m = msgs[i]
+        if m[0] == "imu":
+            b.add_imu(m[1], m[2])
+        elif m[0] == "odom":
+            b.add_odometry(m[1], m[2])
+        elif m[0] == "submap":
+            final_submaps.append(m[1:])
+        elif m[0] == "scan":
+            ins = msgs[i + 1]
+            assert ins[0] == "inserted"
+            i += 1
+            b.forced_range_data = None if ins[1] is None else (ins[1], ins[2])
+            before = b.num_optimizations
+            _t0 = _time.perf_counter()
+            res = b.add_range_data(m[1], m[2], m[3], width)
+            cpu_seconds += _time.perf_counter() - _t0
+            g = gpu[k]
+            assert g["time"] == m[1]
+            solved = b.num_optimizations - before
+            assert g["solved"] == solved, (k, g["solved"], solved)
+            assert g["result"] == (1 if res is not None else 0), k
+            assert g["queued"] == len(b.clouds), (k, g["queued"], len(b.clouds))
+            if solved:
+                solves += 1
+                so = b.last_summary
+                assert (so.num_iterations, so.termination_type, so.termination_reason) == (g["it"], g["term"][0], g["term"][1]), k
+                assert g["imu_blocks"] == b.last_imu_blocks and g["odometry_blocks"] == b.last_odometry_blocks, k
+                assert g["residuals"] == sum(x[0] for x in b.last_blocks) + 9 * b.last_imu_blocks + 6 * b.last_odometry_blocks, k
+                if mode == 3:   # (the device merges the subdivisions between two control points into one block)
+                    interpolated += len(b.last_blocks)
+                else:
+                    assert len(g["blocks"]) == len(b.last_blocks), k
+                for gb, ob in zip(g["blocks"] if mode != 3 else [], b.last_blocks):
+                    assert gb[:3] == tuple(ob[:3]) and gb[4] == ob[4], (k, gb, ob)
+                    assert gb[3] == ob[3], (k, gb, ob)       # the interpolation factor: same ticks, same division
+                    if gb[2] >= 0:
+                        interpolated += 1
+                        assert 0.0 < gb[3] < 1.0
+                    else:
+                        single += 1
+            if res is not None:
+                assert g["local_pose"][0] == res["time"]
+                assert g["inserted"] == (1 if res["inserted"] else 0), k
+                assert (ins[1] is not None) == res["inserted"]
+            # the window as it stands after the step
+            assert (not check_window) or [c[0] for c in g["cps"]] == [c["time"] for c in b.cps], k
+            for (t, gp, gv), c in (zip(g["cps"], b.cps) if check_window else []):
+                max_dt = max(max_dt, float(np.linalg.norm(gp[:3] - c["t"])))
+                max_dr = max(max_dr, float(2.0 * np.arccos(min(1.0, abs(float(gp[3:] @ c["q"]))))))
+                max_dv = max(max_dv, float(np.linalg.norm(gv - c["v"])))
+            k += 1
+        i += 1
+    assert k == scans
+    return {"b": b, "solves": solves, "interpolated": interpolated, "single": single, "max_dt": max_dt, "max_dr": max_dr,
+            "max_dv": max_dv, "final_submaps": final_submaps, "cpu_seconds": cpu_seconds}
