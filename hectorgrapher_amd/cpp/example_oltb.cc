@@ -10,6 +10,7 @@
 //   mode 1: SYNCED_WITH_RANGE_DATA sampling (clouds sit ON control points: single-pose blocks)
 //   mode 2: ADAPTIVE sampling + use_multi_resolution_matching
 //   mode 3: CONSTANT sampling + use_per_point_unwarping
+//   mode 4: mode 3 with SetMapUpdateEnabled(false) from scan 30 on (the window keeps running on a frozen map)
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -104,7 +105,7 @@ int main(int argc, char** argv) {
       opt.use_multi_resolution_matching = true;
       opt.sampling_max_delta_translation = 0.03;  // (the stream moves 0.35 m/s: translation, not time, places the points)
     }
-    if (mode == 3) opt.use_per_point_unwarping = true;
+    if (mode == 3 || mode == 4) opt.use_per_point_unwarping = true;
     mapping::OptimizingLocalTrajectoryBuilder builder(&ctx, opt);
     std::fwrite(&mode, sizeof(int), 1, f);
     // the message stream, time-ordered: kind 0 = IMU, 1 = odometry, 2 = scan
@@ -157,6 +158,7 @@ int main(int argc, char** argv) {
         std::fwrite(scan.ranges.data(), sizeof(float) * 4, n, f);
       }
       const int solves_before = builder.num_optimizations(), inserts_before = builder.num_insertions();
+      if (mode == 4 && scan_index == 30) builder.SetMapUpdateEnabled(false);
       const auto t_add = std::chrono::steady_clock::now();
       auto result = builder.AddRangeData("lidar", scan);
       add_range_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_add).count();

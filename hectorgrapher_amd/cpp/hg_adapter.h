@@ -1420,7 +1420,7 @@ class OptimizingLocalTrajectoryBuilder {
         accumulated.origin = transform::TransformPoint(tf, set.origin);
       }
     } else if (options_.use_per_point_unwarping) {
-      return UnwarpAndInsert(time_optimized_pose, optimized_pose);
+      UnwarpLeavingClouds(&accumulated);  // (:1331-1379) accumulated_range_data_in_tracking, then the common path below
     } else {
       if (!(control_points_.front().time <= point_cloud_data_.front().time))
         throw Error("the oldest cloud is older than the window", HG_ERR_TIME);  // CHECK :1381
@@ -1476,14 +1476,17 @@ class OptimizingLocalTrajectoryBuilder {
     return result;
   }
 
-  // use_per_point_unwarping (:1331-1379): the clouds that leave are unwarped return by return on the device with the
-  // window's control poses and go into every live submap from there (no host copy of the unwarped cloud)
-  std::unique_ptr<MatchingResult> UnwarpAndInsert(common::Time time, const Pose& optimized_pose) {
+  // use_per_point_unwarping (:1331-1379): the clouds that leave the window are unwarped return by return on the device
+  // (hg_unwarp_range_data, frame 0: every return into the tracking frame of the first control point with the pose
+  // interpolated at its own time; NaN returns kept; the origin from the first unwarped return's transform) into
+  // accumulated_range_data_in_tracking. What follows is AddAccumulatedRangeData for every mode alike (this
+  // path used to insert on its own and skipped the filters, the node's clouds and the map-update / motion-filter
+  // rules of :1415-1514).
+  void UnwarpLeavingClouds(sensor::RangeData* accumulated) {
     if (!(control_points_.front().time <= point_cloud_data_.front().StartTime()))
       throw Error("the oldest cloud starts before the window", HG_ERR_TIME);  // CHECK :1333-1334
     std::vector<hg_timed_cloud> table;
     std::vector<float> points;
-    size_t width = point_cloud_data_.front().width;
     while (!point_cloud_data_.empty() && ct_window_horizon_ < control_points_.back().time - point_cloud_data_.front().StartTime() &&
            control_points_.back().time > point_cloud_data_.front().EndTime()) {
       const PointCloudSet& set = point_cloud_data_.front();
@@ -1496,6 +1499,7 @@ class OptimizingLocalTrajectoryBuilder {
       for (const auto& p : set.points) points.insert(points.end(), p.begin(), p.end());
       point_cloud_data_.pop_front();
     }
+    if (points.empty()) return;
     std::vector<double> poses;
     std::vector<int64_t> times;
     for (const ControlPoint& cp : control_points_) {
@@ -1503,27 +1507,11 @@ class OptimizingLocalTrajectoryBuilder {
       poses.insert(poses.end(), p.begin(), p.end());
       times.push_back(cp.time);
     }
-    RemoveObsoleteSensorData();
-    if (points.empty()) return nullptr;
-    std::unique_ptr<MatchingResult> result(new MatchingResult);
-    result->time = time;
-    result->local_pose = optimized_pose;
-    if (MotionFilterIsSimilar(time, optimized_pose) || !map_update_enabled_) return result;
-    // frame 1 = range_data_in_local on the device; every live submap then takes it with its own frame change
-    result->range_data_in_local.returns.resize(points.size() / 4);
+    accumulated->returns.resize(points.size() / 4);
     Check(hg_unwarp_range_data(ctx_->get(), points.data(), points.size() / 4, HG_HOST, table.data(), static_cast<int>(table.size()),
-                               poses.data(), times.data(), static_cast<int>(times.size()), 1, nullptr,
-                               result->range_data_in_local.returns[0].data(), result->range_data_in_local.origin.data()),
+                               poses.data(), times.data(), static_cast<int>(times.size()), 0, nullptr,
+                               accumulated->returns[0].data(), accumulated->origin.data()),
           "hg_unwarp_range_data");
-    result->range_data_in_local.width = width;
-    const Pose rot{{0, 0, 0, optimized_pose[3], optimized_pose[4], optimized_pose[5], optimized_pose[6]}};
-    const Pose lfg = transform::Multiply(rot, transform::Inverse(rot));
-    active_submaps_.InsertData(result->range_data_in_local, {{lfg[3], lfg[4], lfg[5], lfg[6]}});
-    ++num_insertions_;
-    std::unique_ptr<InsertionResult> insertion(new InsertionResult);
-    insertion->insertion_submaps = active_submaps_.submaps();
-    result->insertion_result = std::move(insertion);
-    return result;
   }
 
   bool MotionFilterIsSimilar(common::Time time, const Pose& pose) {  // (mapping/internal/motion_filter.cc:40-58)

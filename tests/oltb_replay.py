@@ -184,6 +184,7 @@ class OracleOLTB:
                                       normal_computation_horizontal_stride=20, normal_computation_vertical_stride=4)
         # what the adapter inserted (the test hands the dumped range data over so that both maps stay the same map)
         self.forced_range_data = None
+        self.map_update_enabled = True   # SetMapUpdateEnabled (:1493-1503: the insertion is still counted and reported)
         self.cloud_errors = []
 
     # ---- sensor queues (:153-186) ----
@@ -527,7 +528,8 @@ class OracleOLTB:
             self.cloud_errors.append(float(np.nanmax(np.abs(f_returns - local_returns))) if len(local_returns) else 0.0)
             self.cloud_errors.append(float(np.abs(f_origin - local_origin).max()))
             local_origin, local_returns = f_origin, f_returns
-        self.insert_into_submaps(local_origin, local_returns, width, lfg)
+        if self.map_update_enabled:
+            self.insert_into_submaps(local_origin, local_returns, width, lfg)
         self.num_insertions += 1
         result["inserted"] = True
         return result
@@ -623,6 +625,7 @@ MODES = {
     1: dict(control_point_sampling="SYNCED_WITH_RANGE_DATA"),
     2: dict(control_point_sampling="ADAPTIVE", use_multi_resolution_matching=True, sampling_max_delta_translation=0.03),
     3: dict(use_per_point_unwarping=True),
+    4: dict(use_per_point_unwarping=True),   # + SetMapUpdateEnabled(false) from scan 30 on (example_oltb.cc)
 }
 
 
@@ -664,6 +667,8 @@ def replay_and_compare(po, raw, stdout_text, mode, scans, width=12, check_window
             assert ins[0] == "inserted"
             i += 1
             b.forced_range_data = None if ins[1] is None else (ins[1], ins[2])
+            if mode == 4 and k == 30:
+                b.map_update_enabled = False
             before = b.num_optimizations
             _t0 = _time.perf_counter()
             res = b.add_range_data(m[1], m[2], m[3], width)
@@ -680,11 +685,11 @@ def replay_and_compare(po, raw, stdout_text, mode, scans, width=12, check_window
                 assert (so.num_iterations, so.termination_type, so.termination_reason) == (g["it"], g["term"][0], g["term"][1]), k
                 assert g["imu_blocks"] == b.last_imu_blocks and g["odometry_blocks"] == b.last_odometry_blocks, k
                 assert g["residuals"] == sum(x[0] for x in b.last_blocks) + 9 * b.last_imu_blocks + 6 * b.last_odometry_blocks, k
-                if mode == 3:   # (the device merges the subdivisions between two control points into one block)
+                if mode in (3, 4):   # (the device merges the subdivisions between two control points into one block)
                     interpolated += len(b.last_blocks)
                 else:
                     assert len(g["blocks"]) == len(b.last_blocks), k
-                for gb, ob in zip(g["blocks"] if mode != 3 else [], b.last_blocks):
+                for gb, ob in zip(g["blocks"] if mode not in (3, 4) else [], b.last_blocks):
                     assert gb[:3] == tuple(ob[:3]) and gb[4] == ob[4], (k, gb, ob)
                     assert gb[3] == ob[3], (k, gb, ob)       # the interpolation factor: same ticks, same division
                     if gb[2] >= 0:

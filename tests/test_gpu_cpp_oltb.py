@@ -35,7 +35,7 @@ def _build():
     return exe
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_cpp_oltb_reference_shape_against_oracle(tmp_path, mode):
     import oltb_replay as rp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -60,7 +60,8 @@ def test_cpp_oltb_reference_shape_against_oracle(tmp_path, mode):
     # the range data the adapter inserted is the replay's own, to float rounding of a last-bit pose difference
     assert b.cloud_errors and max(b.cloud_errors) < 1e-5, max(b.cloud_errors)
     # the live submaps at the end: same local poses, same voxels in the same order
-    assert len(final_submaps) == len(b.submaps) >= 2
+    # (mode 4 freezes the map at scan 30, when the motion filter has let four insertions through: one submap)
+    assert len(final_submaps) == len(b.submaps) >= (1 if mode == 4 else 2), (len(final_submaps), len(b.submaps), b.num_insertions)
     for (pose, num, grids), sm in zip(final_submaps, b.submaps):
         assert num == sm.num_range_data
         np.testing.assert_allclose(pose, sm.local_pose, atol=1e-5)
