@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="host threads of the all-cores CPU baseline of the batch workloads (default: every core, at most 64)")
+                    help="host threads of the all-cores CPU baseline of the batch workloads (default: every core the box reports)")
     ap.add_argument("--max-blocks", type=int, default=1 << 18)
     ap.add_argument("--window", type=int, default=10, help="control points of --workload window")
     ap.add_argument("--no-window-unwarp", action="store_true",
@@ -112,11 +112,11 @@ def make_scans(rings, cols, first, count, stream_base):
 
 
 def cpu_threads(args):
-    """Host threads of the all-cores CPU legs: every core, bounded (a GPU box has hundreds; each thread builds a
-    map of its own)."""
+    """Host threads of the all-cores CPU legs: EVERY core the box reports (round 5 stopped at 64 of the
+    driver box's 256), --cpu-threads to bound it; each thread builds a map of its own."""
     cores = os.cpu_count() or 1
     want = getattr(args, "cpu_threads", 0)
-    return max(1, min(cores, want if want > 0 else 64))
+    return max(1, min(cores, want if want > 0 else cores))
 
 
 def all_cores_baseline(args, prepare, work, units_per_thread, what):
