@@ -2001,13 +2001,24 @@ __global__ __launch_bounds__(kSmallThreads) void k_bin_apply_small_jobs(const In
 
 // `order` = position of the level in dispatch order (0 = coarsest), `bx` of `gstride` = workgroup of
 // the level's grid-stride loop over its work items.
+// Units of a MERGED stream apply (round 6, k_stream_units): a unit is a run of consecutive work items that ONE
+// workgroup (wg_units) or ONE wavefront (wave_units) applies in list order -- the items of one (block, voxel slice)
+// for the scans of a group, in scan order. Different units never share a voxel, so the launch needs no order between
+// workgroups, and a voxel still receives its updates scan by scan, return by return. Null: every item on its own.
+struct ApplyUnits {
+  const uint2* wg_units;    // {first item, items}; kUnitTiers tables of `tier_stride` entries, heaviest blocks first
+  const uint2* wave_units;
+  const uint32_t* counts;   // [0 .. kUnitTiers) workgroup units per tier, [kUnitTiers] wavefront units
+  unsigned tier_stride;
+};
+constexpr unsigned kUnitTiers = 4;  // by the largest bin of the block: >= 16384, >= 4096, >= 1024 records, the rest
 __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order, unsigned bx, unsigned gstride,
                                                const uint32_t* __restrict__ rec_keys,
                                                const uint32_t* __restrict__ rec_vals, bool small_in_kernel
 #ifdef HG_BIN_STAMPS
                                                , long long* stamps
 #endif
-                                               ) {
+                                               , const ApplyUnits* units = nullptr) {
   const GridView& g = L.g;
   // one LDS pool, laid out for a workgroup item (3 x 512 + 4 x kBinCap words) or for eight small bins
   // (one per wavefront, 512 + 3 x 256 words each)
@@ -2051,9 +2062,26 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
   constexpr bool defer_ok = false;  // (everything that hangs off it, the tail included, is compiled away)
 #endif
   uint4* const my_heavy = defer_ok ? L.heavy_list + static_cast<size_t>(bx) * kHeavyPerWg : nullptr;
-  const unsigned nwork = min(g.call[2], g.call[1]);  // the slices of large bins; whole bins: k_bin_apply_small
+  unsigned tier_end[kUnitTiers] = {0u, 0u, 0u, 0u};  // (units) running totals of the tiers: the list is their concatenation
+  if (units) {
+    unsigned acc = 0;
+#pragma unroll
+    for (unsigned t = 0; t < kUnitTiers; ++t) { acc += units->counts[t]; tier_end[t] = acc; }
+  }
+  const unsigned nwork = units ? tier_end[kUnitTiers - 1u] : min(g.call[2], g.call[1]);  // the slices of large bins; whole bins: k_bin_apply_small
   const unsigned tid = threadIdx.x;
-  for (unsigned wi = bx; wi < nwork; wi += gstride) {
+  for (unsigned oi = bx; oi < nwork; oi += gstride) {
+   unsigned wi_first = oi, wi_end = oi + 1u;
+   if (units) {
+     unsigned t = 0, before = 0;
+#pragma unroll
+     for (unsigned q = 0; q + 1u < kUnitTiers; ++q)
+       if (oi >= tier_end[q]) { t = q + 1u; before = tier_end[q]; }
+     const uint2 u = units->wg_units[static_cast<size_t>(t) * units->tier_stride + (oi - before)];
+     wi_first = u.x;
+     wi_end = u.x + u.y;
+   }
+   for (unsigned wi = wi_first; wi < wi_end; ++wi) {
     const uint4 item = g.work[wi];
     const uint32_t slot = item.x;
     const unsigned n = item.z;  // all 32 bits: a bin may hold every record of the scan
@@ -2464,6 +2492,7 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
       lo = hi;
     }
     BIN_STAMP(5);  // (every pass ends behind a barrier)
+   }
   }
   if (small_in_kernel) {
     // the wavefronts' small-bin scratch aliases hist / base of the work items above, and an item whose
@@ -2473,13 +2502,27 @@ __device__ __forceinline__ void bin_apply_body(const LevelIns& L, unsigned order
     // the whole small bins of the level, one wavefront each: most touched blocks of a scan are of
     // this kind (65 % / 45 % of the bins at 0.05 / 0.10 m hold <= 256 records), and as 512-thread
     // items they queued for workgroup slots with a dozen barriers around a few hundred records
-    const unsigned n_all = g.call[1];
     const unsigned wave = tid / kWave;
     constexpr unsigned kWaves = kBinThreads / kWave;
+    if (units) {
+      const unsigned n_wave = units->counts[kUnitTiers];
+      for (unsigned ui = bx * kWaves + wave; ui < n_wave; ui += gstride * kWaves) {
+        const uint2 u = units->wave_units[ui];
+        for (unsigned idx = u.x; idx < u.x + u.y; ++idx) {
+          const uint4 it = g.work[idx];
+          apply_small_bin<kSmallBinInKernel>(g, L.p.maximum_weight, it.x, it.z, rec_keys + it.w, rec_vals + it.w,
+                                             pool + wave * kSmallWords);
+          // the next item of the unit reads voxels this one wrote (other lanes of this wavefront)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+    } else {
+    const unsigned n_all = g.call[1];
     for (unsigned idx = nwork + bx * kWaves + wave; idx < n_all; idx += gstride * kWaves) {
       const uint4 it = g.work[idx];
       apply_small_bin<kSmallBinInKernel>(g, L.p.maximum_weight, it.x, it.z, rec_keys + it.w, rec_vals + it.w,
                                          pool + wave * kSmallWords);
+    }
     }
   }
 #ifdef HG_DEFER_LONG_CHAINS
@@ -2602,6 +2645,137 @@ __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply_jobs(const InsertJ
   bin_apply_body(L, order, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals, J.P.slice_records <= 0);
 }
 #endif
+
+#ifndef HG_BIN_STAMPS
+// ==========================================================================================
+// Merged apply of a scan stream's group (round 6). Scan after scan, the apply launches of a stream were 67 % of its
+// time: every launch drains three levels of ~2400 work items over 1024 workgroup slots and ends on its slowest
+// item, 32 times per call. The scans of a group cannot share a launch item by item -- a voxel's updates of scan
+// k + 1 must follow those of scan k -- but blocks (and voxel slices of a block) are independent of each other:
+//   k_stream_offsets_jobs   per (scan, level): bin offsets as k_bin_offsets_jobs, bin counts left in place
+//   k_stream_units          per level: the union of the group's touched blocks (a claim word per block, tagged with
+//                           the group's epoch); the owner of a block reads every scan's count and offset for it, cuts
+//                           the block into S voxel slices from the LARGEST of those bins, and emits per slice one
+//                           UNIT = the slice's work items of the scans that touch the block, in scan order
+//   k_bin_apply_stream      one launch for the group: a workgroup (or, for blocks whose bins all hold <= 256 records, a
+//                           wavefront) takes a unit and applies its items one after the other (bin_apply_body)
+// Every voxel belongs to exactly one unit, so it receives the updates of the group's scans in scan order and, inside
+// a scan, in seq order: bit for bit the result of scan-by-scan insertion.
+// ==========================================================================================
+struct StreamGroup {
+  uint32_t* claim[kMaxInsLevels];      // per level: epoch of the group that last claimed the block slot
+  uint2* wg_units[kMaxInsLevels];      // per level: unit tables and their counters {workgroup units, wavefront units,
+  uint2* wave_units[kMaxInsLevels];    //   items} (counts[level][0..2]); the items go to lv[].g.work of job 0
+  uint32_t* counts;                    // kMaxInsLevels x 8 words (ApplyUnits::counts + the item cursor), zero between groups
+  uint32_t unit_capacity, item_capacity;
+  uint32_t epoch;
+  int slice_records;                   // as PyramidIns::slice_records of the stream (< 0: -records per slice of large bins)
+};
+
+__global__ __launch_bounds__(1024) void k_stream_offsets_jobs(const InsertJob* __restrict__ jobs, int levels) {
+  const InsertJob& J = jobs[blockIdx.x / levels];
+  const int level = blockIdx.x % levels;
+  const LevelIns L = J.P.lv[level];
+  __shared__ unsigned s_scan[16];
+  __shared__ unsigned s_base;
+  const unsigned nt = L.g.call[0];
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (unsigned c0 = 0; c0 < nt; c0 += 1024u) {
+    const unsigned i = c0 + threadIdx.x;
+    const unsigned slot = i < nt ? L.g.touched[i] : 0u;
+    const unsigned cnt = i < nt ? L.g.bin_count[slot] : 0u;
+    unsigned chunk_total = 0;
+    const unsigned excl = block_exclusive_scan(cnt, s_scan, &chunk_total);
+    if (i < nt) L.g.bin_offset[slot] = static_cast<unsigned>(level) * J.records_per_level + s_base + excl;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += chunk_total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    unsigned long long* upd = reinterpret_cast<unsigned long long*>(&L.g.counters[4]);
+    if (J.P.shared) atomicAdd(upd, static_cast<unsigned long long>(s_base));
+    else *upd = s_base + (J.P.accumulate ? *upd : 0ull);  // U of this call
+    publish_flags(J.P, level);
+  }
+}
+
+// grid (levels), 1024 threads; jobs = the group's scans in order.
+__global__ __launch_bounds__(1024) void k_stream_units(const InsertJob* __restrict__ jobs, int njobs, int levels, StreamGroup G,
+                                                       const uint32_t* rec_base /* the group's record buffer: jobs[j].rec_keys - rec_base = job j's offset in it */) {
+  const int level = blockIdx.x;
+  uint32_t* const claim = G.claim[level];
+  uint32_t* const counts = G.counts + 8 * level;
+  uint4* const work = jobs[0].P.lv[level].g.work;
+  const unsigned slice_above = G.slice_records < 0 ? static_cast<unsigned>(-G.slice_records) : HG_SLICE_ABOVE;
+  for (int j = 0; j < njobs; ++j) {
+    const LevelIns& Lj = jobs[j].P.lv[level];
+    const unsigned nt = Lj.g.call[0];
+    for (unsigned i = threadIdx.x; i < nt; i += 1024u) {
+      const uint32_t slot = Lj.g.touched[i];
+      if (atomicExch(&claim[slot], G.epoch) == G.epoch) continue;  // another scan's thread owns the block
+      // (whichever scan's thread gets there first owns the block and reads EVERY scan's bin for it; nothing orders
+      // the threads of different scans inside this loop)
+      unsigned cnt[32], off[32];
+      unsigned maxc = 0, touching = 0;
+      for (int q = 0; q < njobs; ++q) {
+        const LevelIns& Lq = jobs[q].P.lv[level];
+        const unsigned c = Lq.g.bin_count[slot];
+        cnt[q] = c;
+        off[q] = c ? Lq.g.bin_offset[slot] + static_cast<unsigned>(jobs[q].rec_keys - rec_base) : 0u;
+        if (c) {
+          Lq.g.bin_count[slot] = 0u;  // ready for the next call
+          maxc = max(maxc, c);
+          ++touching;
+        }
+      }
+      const bool small = maxc <= kSmallBinInKernel;
+      unsigned slices = 1u;
+      if (!small) {
+        const unsigned per_slice = maxc < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above;
+        while (slices < 128u && maxc > slices * per_slice) slices <<= 1;
+      }
+      const unsigned tier = maxc >= 16384u ? 0u : maxc >= 4096u ? 1u : maxc >= 1024u ? 2u : 3u;
+      const unsigned u0 = atomicAdd(&counts[small ? kUnitTiers : tier], slices);
+      const unsigned w0 = atomicAdd(&counts[kUnitTiers + 1u], slices * touching);
+      if (u0 + slices > G.unit_capacity || w0 + slices * touching > G.item_capacity) {
+        atomicOr(&Lj.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes both from the group's records
+        continue;
+      }
+      uint2* const table = small ? G.wave_units[level] : G.wg_units[level] + static_cast<size_t>(tier) * G.unit_capacity;
+      const unsigned step = 512u / slices;
+      for (unsigned k = 0; k < slices; ++k) {
+        table[u0 + k] = make_uint2(w0 + k * touching, touching);
+        unsigned w = w0 + k * touching;
+        for (int q = 0; q < njobs; ++q) {  // scan order
+          if (!cnt[q]) continue;
+          const unsigned rpl = jobs[q].records_per_level;
+          const unsigned seq_bits = 32u - static_cast<unsigned>(__builtin_clz((rpl > 2u ? rpl : 2u) - 1u));
+          work[w++] = make_uint4(slot, (k * step) | (((k + 1u) * step) << 10) | (seq_bits << 20), cnt[q], off[q]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < njobs; j += 1024) jobs[j].P.lv[level].g.call[0] = 0u;  // next call collects from scratch
+}
+
+// grid (G, levels): one launch for the group; the pyramid of the group's first scan stands for all (same grids).
+__global__ __launch_bounds__(kBinThreads, HG_APPLY_WAVES) void k_bin_apply_stream(PyramidIns P, const uint32_t* __restrict__ rec_keys,
+                                                                 const uint32_t* __restrict__ rec_vals, StreamGroup G) {
+  const unsigned order = blockIdx.y;
+  const int level = P.levels - 1 - static_cast<int>(order);
+  ApplyUnits units;
+  units.wg_units = G.wg_units[level];
+  units.wave_units = G.wave_units[level];
+  units.counts = G.counts + 8 * level;
+  units.tier_stride = G.unit_capacity;
+  bin_apply_body(P.lv[level], order, blockIdx.x, gridDim.x, rec_keys, rec_vals, true, &units);
+}
+__global__ void k_stream_reset(StreamGroup G, int levels) {  // <<<1, 64>>> behind the apply launch
+  if (threadIdx.x < static_cast<unsigned>(levels) * 8u) G.counts[threadIdx.x] = 0u;
+}
+#endif  // !HG_BIN_STAMPS
 
 }  // namespace hg
 
@@ -3379,10 +3553,59 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   }
   const size_t touched_cap = std::min<size_t>(static_cast<size_t>(n_max) * kMaxRuns, max_blocks) + 64u;
   // shadow layout: [group][levels] call counters (4 words), then per (job slot, level)
-  // bin_count[pool], bin_offset[pool], touched[touched_cap]
+  // bin_count[pool], bin_offset[pool], touched[touched_cap]; merged apply: + per level claim[pool], + 16 counter words
+  // stream_merge: 0 never, 2 always, 1 (default) per group, when its scans were taken at places farther apart than the
+  // sensor reaches (max_range + tau between consecutive origins: submaps of different rooms folded into one pool, the
+  // multi-robot / multi-room streams). There every unit holds ONE scan's item, the merged launch is the eight per-scan
+  // launches side by side (64 room copies: 9.1k -> 11.5k scans/s). Scans of one place share their heavy voxels: the
+  // group is then bound by those voxels' serial chains either way, and the merged form -- one slice count per block for
+  // all scans, small bins of a block on the workgroup path as soon as one scan's bin is large -- measured 14 % SLOWER
+  // (B = 32 in one room: 15.8k against 18.4k scans/s); such groups keep a launch per scan.
+  const int merge_mode = (group >= 2 && group <= 32 && !heavy_enabled(c)) ? static_cast<int>(c->opt(OPT_STREAM_MERGE)) : 0;
+  const bool merged = merge_mode != 0;  // (the layout has room for it)
+  std::vector<char> group_merged((count + group - 1) / group, 0);
+  if (merged) {
+    double reach = 0.0;
+    for (int l = 0; l < levels; ++l) reach = std::max(reach, P0.lv[l].p.max_range + static_cast<double>(P0.lv[l].p.truncation_distance));
+    for (int g0 = 0; g0 < count; g0 += group) {
+      bool spread = std::min(group, count - g0) >= 2;
+      float prev[3] = {0.f, 0.f, 0.f};
+      for (int j = g0; j < std::min(count, g0 + group) && spread; ++j) {
+        float o[3];
+        if (poses_tq) host_transform(poses_tq + 7 * scans[j], origins + 3 * scans[j], o);
+        else std::memcpy(o, origins + 3 * scans[j], sizeof(o));
+        if (j > g0) {
+          const double dx = o[0] - prev[0], dy = o[1] - prev[1], dz = o[2] - prev[2];
+          spread = std::sqrt(dx * dx + dy * dy + dz * dz) > reach;
+        }
+        std::memcpy(prev, o, sizeof(prev));
+      }
+      group_merged[g0 / group] = (merge_mode == 2 || spread) ? 1 : 0;
+    }
+  }
   const size_t call_words = static_cast<size_t>(group) * levels * 4u;
   const size_t per_slot_level = 2u * max_pool + touched_cap;
-  const size_t shadow_words = call_words + per_slot_level * levels * group;
+  const size_t claim_words = merged ? max_pool * levels + 8u * kMaxInsLevels : 0u;
+  const size_t shadow_words = call_words + per_slot_level * levels * group + claim_words;
+  // merged apply: unit tables and items of a group, per level (k_stream_units)
+  size_t unit_cap = 0, item_cap = 0;
+  if (merged) {
+    size_t group_records = 0, group_runs = 0;
+    for (int g0 = 0; g0 < count; g0 += group) {
+      size_t r = 0, u = 0;
+      for (int j = g0; j < std::min(count, g0 + group); ++j) {
+        const unsigned long long nj = scan_offsets[scans[j] + 1] - scan_offsets[scans[j]];
+        r += nj * kSlots;
+        u += nj * kMaxRuns;
+      }
+      group_records = std::max(group_records, r);
+      group_runs = std::max(group_runs, u);
+    }
+    unit_cap = std::min<size_t>(group_runs, max_blocks) + 2u * (group_records / 1024u) + 64u;
+    item_cap = unit_cap * static_cast<size_t>(group);
+    // [levels][2 unit tables of unit_cap uint2] behind [levels][item_cap uint4]
+    work_items = std::max(work_items, (item_cap + ((kUnitTiers + 1u) * unit_cap * sizeof(uint2) + sizeof(uint4) - 1u) / sizeof(uint4)) * levels);
+  }
   if ((rc = c->ws_keys_a.reserve(sizeof(uint32_t) * rec_words)) != HG_OK) return rc;
   if ((rc = c->ws_vals_a.reserve(sizeof(uint32_t) * rec_words)) != HG_OK) return rc;
   if ((rc = c->ws_offsets.reserve(sizeof(uint4) * work_items)) != HG_OK) return rc;
@@ -3400,8 +3623,8 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
     // that); bin offsets and touched lists keep their last values, so a call that lays the buffer out
     // differently (other scan sizes, pyramid, pool, group) must start from zeroes again
     const unsigned long long layout[7] = {reinterpret_cast<unsigned long long>(c->ws_shadow.ptr), c->ws_shadow.bytes,
-                                          call_words, per_slot_level, max_pool, static_cast<unsigned long long>(levels),
-                                          static_cast<unsigned long long>(group)};
+                                          call_words, per_slot_level + (merged ? (1ull << 40) : 0ull), max_pool,
+                                          static_cast<unsigned long long>(levels), static_cast<unsigned long long>(group)};
     if (std::memcmp(layout, c->shadow_layout, sizeof(layout)) != 0) {
       HG_HIP_CHECK(hipMemsetAsync(c->ws_shadow.ptr, 0, c->ws_shadow.bytes, s));
       std::memcpy(c->shadow_layout, layout, sizeof(layout));
@@ -3450,8 +3673,13 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
     for (int l = 0; l < levels; ++l) {
       LevelIns& L = P.lv[l];
       if (L.gate) L.gate += first;
-      L.g.work = c->ws_offsets.as<uint4>() + work_off + per_level * l;
-      L.g.work_capacity = static_cast<uint32_t>(per_level);
+      if (group_merged[g]) {  // the level's items of the whole group
+        L.g.work = c->ws_offsets.as<uint4>() + item_cap * l;
+        L.g.work_capacity = static_cast<uint32_t>(item_cap);
+      } else {
+        L.g.work = c->ws_offsets.as<uint4>() + work_off + per_level * l;
+        L.g.work_capacity = static_cast<uint32_t>(per_level);
+      }
       L.g.call = shadow + (static_cast<size_t>(q) * levels + l) * 4u;
       uint32_t* base = shadow + call_words + (static_cast<size_t>(q) * levels + l) * per_slot_level;
       L.g.bin_count = base;
@@ -3478,9 +3706,30 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
       ProfScope ps(c, HG_K_RAY_COUNT, units);
       hipLaunchKernelGGL(k_bin_count_jobs, dim3(max_nwg, gn * levels), dim3(256), 0, s, d_jobs + g0, levels);
     }
+#ifndef HG_BIN_STAMPS
+    StreamGroup SG;
+    std::memset(&SG, 0, sizeof(SG));
+    const bool merged_g = merged && group_merged[g0 / group] != 0;
+    if (merged_g) {
+      uint32_t* claim0 = shadow + call_words + per_slot_level * levels * group;
+      for (int l = 0; l < levels; ++l) {
+        SG.claim[l] = claim0 + max_pool * l;
+        uint2* tables = reinterpret_cast<uint2*>(c->ws_offsets.as<uint4>() + item_cap * levels) + (kUnitTiers + 1u) * unit_cap * l;
+        SG.wg_units[l] = tables;
+        SG.wave_units[l] = tables + kUnitTiers * unit_cap;
+      }
+      SG.counts = claim0 + max_pool * levels;
+      SG.unit_capacity = static_cast<uint32_t>(unit_cap);
+      SG.item_capacity = static_cast<uint32_t>(item_cap);
+      if (++c->stream_epoch == 0u) ++c->stream_epoch;  // (0 = never claimed; a tag of 2^32 groups ago cannot be met again: the layout is re-zeroed long before)
+      SG.epoch = c->stream_epoch;
+      SG.slice_records = stream_slice_records(c);
+    }
+#endif
     {
       ProfScope ps(c, HG_K_SCAN, gn * levels);
-      hipLaunchKernelGGL(k_bin_offsets_jobs, dim3(gn * levels), dim3(1024), 0, s, d_jobs + g0, levels);
+      if (merged_g) hipLaunchKernelGGL(k_stream_offsets_jobs, dim3(gn * levels), dim3(1024), 0, s, d_jobs + g0, levels);
+      else hipLaunchKernelGGL(k_bin_offsets_jobs, dim3(gn * levels), dim3(1024), 0, s, d_jobs + g0, levels);
     }
     {
       ProfScope ps(c, HG_K_RAY_EXPAND, units);
@@ -3493,9 +3742,18 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
     {
       ProfScope ps(c, HG_K_APPLY, units * kSlots, static_cast<unsigned>(gn));
 #ifndef HG_BIN_STAMPS
-      for (int j = g0; j < g0 + gn; ++j)  // pyramid as kernel argument (scalar registers), as scan by scan
-        hipLaunchKernelGGL(k_bin_apply, apply_grid(c, levels), dim3(kBinThreads), 0, s, jobs[j].P, jobs[j].rec_keys,
-                           jobs[j].rec_vals);
+      if (merged_g) {
+        // one apply launch for the group: units of (block, voxel slice) x scans (k_stream_units)
+        hipLaunchKernelGGL(k_stream_units, dim3(levels), dim3(1024), 0, s, d_jobs + g0, gn, levels, SG,
+                           static_cast<const uint32_t*>(jobs[g0].rec_keys));
+        hipLaunchKernelGGL(k_bin_apply_stream, dim3(1024u, static_cast<unsigned>(levels)), dim3(kBinThreads), 0, s, jobs[g0].P,
+                           jobs[g0].rec_keys, jobs[g0].rec_vals, SG);
+        hipLaunchKernelGGL(k_stream_reset, dim3(1), dim3(64), 0, s, SG, levels);
+      } else {
+        for (int j = g0; j < g0 + gn; ++j)  // pyramid as kernel argument (scalar registers), as scan by scan
+          hipLaunchKernelGGL(k_bin_apply, apply_grid(c, levels), dim3(kBinThreads), 0, s, jobs[j].P, jobs[j].rec_keys,
+                             jobs[j].rec_vals);
+      }
 #endif
     }
     HG_HIP_CHECK(hipGetLastError());

@@ -75,14 +75,14 @@ enum Opt {
   OPT_PERSISTENT_SOLVE, OPT_TICKET_HANDOVER, OPT_PREPARE_KERNEL, OPT_EAGER_SOLVE, OPT_LAZY_TAIL, OPT_LM_GENERAL, OPT_LM_BAND,
   OPT_LM_BTD_GENERIC, OPT_LM_BTD_CHAIN, OPT_LM_BTD_CR, OPT_WINDOW_CAPACITY, OPT_WINDOW_TILES, OPT_BATCH_TILES,
   OPT_WINDOW_BATCH, OPT_PARTITION_MIN, OPT_PARTITION_AT, OPT_HOST_TIMES, OPT_STREAM_GROUP, OPT_STREAM_SLICE,
-  OPT_APPLY_TURNS, OPT_DEFER_LONG_CHAINS, OPT_INSERT_SORT, OPT_INSERT_PIPELINE, OPT_FAST_ATOMICS, OPT_COUNT
+  OPT_STREAM_MERGE, OPT_APPLY_TURNS, OPT_DEFER_LONG_CHAINS, OPT_INSERT_SORT, OPT_INSERT_PIPELINE, OPT_FAST_ATOMICS, OPT_COUNT
 };
 struct OptDesc { const char* key; long long def; };
 constexpr OptDesc kOptDesc[OPT_COUNT] = {
   {"persistent_solve", 0}, {"ticket_handover", 0}, {"prepare_kernel", 0}, {"eager_solve", 0}, {"lazy_tail", 3},
   {"lm_general", 0}, {"lm_band", 0}, {"lm_btd_generic", 0}, {"lm_btd_chain", 0}, {"lm_btd_cr", 0},
   {"window_capacity", 0}, {"window_tiles", 0}, {"batch_tiles", 0}, {"window_batch", 1}, {"partition_min", 48},
-  {"partition_at", 2}, {"host_times", 0}, {"stream_group", 8}, {"stream_slice", 1024}, {"apply_turns", 0},
+  {"partition_at", 2}, {"host_times", 0}, {"stream_group", 8}, {"stream_slice", 1024}, {"stream_merge", 1}, {"apply_turns", 0},
   {"defer_long_chains", 1}, {"insert_sort", 0}, {"insert_pipeline", 1}, {"fast_atomics", 0},
 };
 int live_contexts();  // contexts of this process (hg_grid.hip)
@@ -92,6 +92,7 @@ struct hg_problem;
 struct hg_ctx {
   long long opts[hg::OPT_COUNT] = {0};
   long long opt(hg::Opt o) const { return opts[o]; }
+  uint32_t stream_epoch = 0;    // groups of merged stream applies so far (claim tags, hg_insert.hip)
   bool persist_failed = false;  // a persistent solve timed out on this context: later solves take a launch per evaluation
   int persist_blocks_per_cu = -1;  // hipOccupancyMaxActiveBlocksPerMultiprocessor of the persistent kernel (-1: not asked yet)
   int num_cus = 0;

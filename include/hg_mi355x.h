@@ -154,6 +154,9 @@ int hg_ctx_synchronize(hg_ctx* ctx);
  *   host_times         1: host-side timing of hg_register_scan_sequence printed to stderr
  *   stream_group       scans whose front ends share launches in a scan stream (default 8; 0: off)
  *   stream_slice       records per voxel slice of large bins in a scan stream (default 1024)
+ *   stream_merge       apply launches of a scan stream: 0 one per scan; 2 one per group of scans (units of (block, voxel
+ *                         slice) x scans, applied in scan order); 1 (default) per group, when its scans were taken
+ *                         farther apart than the sensor reaches. Bit-identical results in every setting
  *   apply_turns        1: the levels of k_bin_apply take turns
  *   defer_long_chains  0: no deferral of long chains (only in builds with -DHG_DEFER_LONG_CHAINS)
  *   insert_sort        1: exact insertion through the radix-sort path
