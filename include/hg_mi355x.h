@@ -118,7 +118,16 @@ typedef struct hg_solver_summary {
 } hg_solver_summary;
 
 /* ---- context ---------------------------------------------------------------------------- */
-/* `stream` is a hipStream_t to run on, or NULL to create a private stream. */
+/* `stream` is a hipStream_t to run on, or NULL to create a private stream.
+ * Several contexts of one process (the reference's deployment: a thread and a trajectory builder per trajectory,
+ * mapping/map_builder.cc:120-175) run side by side: every private stream is created with a CU mask of all CUs, which
+ * gives it a hardware queue of its own. Measured on MI355X (cpp/example_threads, 100k-point registration steps): 1.95x
+ * of one context at two, 2.16x at three; at FOUR the first and the fourth context run at half pace (5.4k scans/s in
+ * all against 8.8k at three) whatever GPU_MAX_HW_QUEUES says and with ordinary streams of distinct priorities too
+ * (7.3k): the device gives a process' compute queues three pipes, the fourth busy queue shares one with the first,
+ * and a pipe serves one queue's dependent launch chain at a time. Rule: up to THREE concurrently busy contexts per
+ * process and device; beyond that hg_register_scan_batch / hg_problem_solve_batch (one context, shared launches:
+ * 9.8k scans/s at eight submaps), or further processes. */
 int hg_ctx_create(int device, void* stream, hg_ctx** out);
 int hg_ctx_destroy(hg_ctx* ctx);
 /* Waits for the context's stream. Also returns the error (HG_ERR_CAPACITY, HG_ERR_RANGE, ...) an
