@@ -2079,18 +2079,18 @@ def run(args, out_fd=None):
     avg_ms, bytes_per, _ = fam[dom]
     # HBM traffic of the dominant kernel: PMC counters cannot be collected by the timed run itself (separate
     # rocprofv3 --pmc passes, MI355X guide), so the figure comes from the committed passes of this same
-    # command (scripts/r05_profile.sh -> profiles/r05_bench_pmc_traffic.json) and is labelled as such
+    # command (scripts/r06_profile.sh -> profiles/r06_bench_pmc_traffic.json) and is labelled as such
     traffic = None
     traffic_source = None
     build_digest = api._lib.source_digest()
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_bench_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_bench_pmc_traffic.json")) as f:
             doc = json.load(f)
         pmc = doc["kernels"]
         if doc.get("csrc_sha16") != build_digest:
             # the committed passes were taken on other sources: their bytes are not this build's
-            traffic_source = ("none: profiles/r05_bench_pmc_traffic.json was collected on sources %s, this build is %s "
-                              "(re-run scripts/r05_profile.sh)" % (doc.get("csrc_sha16"), build_digest))
+            traffic_source = ("none: profiles/r06_bench_pmc_traffic.json was collected on sources %s, this build is %s "
+                              "(re-run scripts/r06_profile.sh)" % (doc.get("csrc_sha16"), build_digest))
         else:
             if dom == "k_tsdf_residuals":
                 # the single-pose registration step runs the k_tsdf_residuals_single<512> instantiation
@@ -2098,8 +2098,8 @@ def run(args, out_fd=None):
                 traffic = max(pmc[k]["traffic_bytes"] for k in key)
             else:
                 traffic = sum(pmc[k]["traffic_bytes"] for k in pmc if k.startswith("hg::k_bin_"))
-            traffic_source = ("from_profile: profiles/r05_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                              "this command on the same sources, scripts/r05_profile.sh), not collected by this run")
+            traffic_source = ("from_profile: profiles/r06_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                              "this command on the same sources, scripts/r06_profile.sh), not collected by this run")
     except Exception as e:
         traffic = None
         traffic_source = "none: %r" % (e,)
@@ -2117,7 +2117,7 @@ def run(args, out_fd=None):
                 "families": families,
                 "hip_event_sampling": "residual family on every %d-th of the %d timed steps, insert kernels on every %d-th; "
                                       "an event pair serialises the stream (~8 us), so sampled steps run longer than the others "
-                                      "and per_kernel_ms_total does not add up to ms_per_step (rocprofv3 trace: profiles/r05_trace_gaps.txt)"
+                                      "and per_kernel_ms_total does not add up to ms_per_step (rocprofv3 trace: profiles/r06_trace_gaps.txt)"
                                       % (max(1, args.prof_every), args.steps, 5 * max(1, args.prof_every)),
                 "build": {"version": api._lib.load().hg_version().decode(), "csrc_sha16": build_digest},
                 "residual_launches_evaluating": active_share,

@@ -223,6 +223,13 @@ class Context {
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   hg_ctx* get() const { return ctx_; }
+  // tuning / diagnostic switches of the context (keys: include/hg_mi355x.h, hg_ctx_set_option)
+  void SetOption(const char* key, long long value) { Check(hg_ctx_set_option(ctx_, key, value), "hg_ctx_set_option"); }
+  long long GetOption(const char* key) const {
+    long long v = 0;
+    Check(hg_ctx_get_option(ctx_, key, &v), "hg_ctx_get_option");
+    return v;
+  }
  private:
   hg_ctx* ctx_ = nullptr;
 };

@@ -2700,64 +2700,101 @@ __global__ __launch_bounds__(1024) void k_stream_offsets_jobs(const InsertJob* _
   }
 }
 
-// grid (levels), 1024 threads; jobs = the group's scans in order.
-__global__ __launch_bounds__(1024) void k_stream_units(const InsertJob* __restrict__ jobs, int njobs, int levels, StreamGroup G,
-                                                       const uint32_t* rec_base /* the group's record buffer: jobs[j].rec_keys - rec_base = job j's offset in it */) {
-  const int level = blockIdx.x;
+// grid (kStreamUnitWgs, levels), 256 threads; jobs = the group's scans in order (at most kStreamGroupMax).
+// (First form: one workgroup per level walking the scans' lists one after the other, every owner reserving its units
+// and items with returning atomics on the level's counters -- six dependent round trips per list pass and ~6000
+// atomics on five words per level: 160 us per group of eight, a third of the apply it feeds. Now the entries of all
+// scans are one flat list cut into chunks of 256 over 32 workgroups, an owner's eight counts / offsets are loaded
+// together, and a chunk reserves through LDS with ONE device atomic per counter.)
+constexpr int kStreamGroupMax = 32;
+constexpr unsigned kStreamUnitWgs = 32;
+__global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restrict__ jobs, int njobs, int levels, StreamGroup G,
+                                                      const uint32_t* rec_base /* the group's record buffer: jobs[j].rec_keys - rec_base = job j's offset in it */) {
+  const int level = blockIdx.y;
   uint32_t* const claim = G.claim[level];
   uint32_t* const counts = G.counts + 8 * level;
   uint4* const work = jobs[0].P.lv[level].g.work;
   const unsigned slice_above = G.slice_records < 0 ? static_cast<unsigned>(-G.slice_records) : HG_SLICE_ABOVE;
-  for (int j = 0; j < njobs; ++j) {
-    const LevelIns& Lj = jobs[j].P.lv[level];
-    const unsigned nt = Lj.g.call[0];
-    for (unsigned i = threadIdx.x; i < nt; i += 1024u) {
-      const uint32_t slot = Lj.g.touched[i];
-      if (atomicExch(&claim[slot], G.epoch) == G.epoch) continue;  // another scan's thread owns the block
-      // (whichever scan's thread gets there first owns the block and reads EVERY scan's bin for it; nothing orders
-      // the threads of different scans inside this loop)
-      unsigned cnt[32], off[32];
-      unsigned maxc = 0, touching = 0;
-      for (int q = 0; q < njobs; ++q) {
-        const LevelIns& Lq = jobs[q].P.lv[level];
-        const unsigned c = Lq.g.bin_count[slot];
-        cnt[q] = c;
-        off[q] = c ? Lq.g.bin_offset[slot] + static_cast<unsigned>(jobs[q].rec_keys - rec_base) : 0u;
-        if (c) {
-          Lq.g.bin_count[slot] = 0u;  // ready for the next call
-          maxc = max(maxc, c);
-          ++touching;
-        }
-      }
-      const bool small = maxc <= kSmallBinInKernel;
-      unsigned slices = 1u;
-      if (!small) {
-        const unsigned per_slice = maxc < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above;
-        while (slices < 128u && maxc > slices * per_slice) slices <<= 1;
-      }
-      const unsigned tier = maxc >= 16384u ? 0u : maxc >= 4096u ? 1u : maxc >= 1024u ? 2u : 3u;
-      const unsigned u0 = atomicAdd(&counts[small ? kUnitTiers : tier], slices);
-      const unsigned w0 = atomicAdd(&counts[kUnitTiers + 1u], slices * touching);
-      if (u0 + slices > G.unit_capacity || w0 + slices * touching > G.item_capacity) {
-        atomicOr(&Lj.g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes both from the group's records
-        continue;
-      }
-      uint2* const table = small ? G.wave_units[level] : G.wg_units[level] + static_cast<size_t>(tier) * G.unit_capacity;
-      const unsigned step = 512u / slices;
-      for (unsigned k = 0; k < slices; ++k) {
-        table[u0 + k] = make_uint2(w0 + k * touching, touching);
-        unsigned w = w0 + k * touching;
-        for (int q = 0; q < njobs; ++q) {  // scan order
-          if (!cnt[q]) continue;
-          const unsigned rpl = jobs[q].records_per_level;
-          const unsigned seq_bits = 32u - static_cast<unsigned>(__builtin_clz((rpl > 2u ? rpl : 2u) - 1u));
-          work[w++] = make_uint4(slot, (k * step) | (((k + 1u) * step) << 10) | (seq_bits << 20), cnt[q], off[q]);
-        }
-      }
+  __shared__ unsigned s_nt[kStreamGroupMax + 1];  // prefix of the scans' touched counts
+  __shared__ unsigned s_need[kUnitTiers + 2], s_base[kUnitTiers + 2];
+  if (threadIdx.x == 0) {
+    unsigned acc = 0;
+    for (int j = 0; j < kStreamGroupMax; ++j) {
+      s_nt[j] = acc;
+      if (j < njobs) acc += jobs[j].P.lv[level].g.call[0];
     }
+    s_nt[kStreamGroupMax] = acc;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < njobs; j += 1024) jobs[j].P.lv[level].g.call[0] = 0u;  // next call collects from scratch
+  const unsigned total = s_nt[kStreamGroupMax];
+  for (unsigned c0 = blockIdx.x * 256u; c0 < total; c0 += gridDim.x * 256u) {
+    if (threadIdx.x < kUnitTiers + 2u) s_need[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned e = c0 + threadIdx.x;
+    bool owner = false;
+    uint32_t slot = 0;
+    if (e < total) {
+      int j = 0;
+#pragma unroll
+      for (int q = 1; q < kStreamGroupMax; ++q) j = (e >= s_nt[q]) ? q : j;
+      slot = jobs[j].P.lv[level].g.touched[e - s_nt[j]];
+      // whichever scan's thread gets there first owns the block and reads EVERY scan's bin for it
+      owner = atomicExch(&claim[slot], G.epoch) != G.epoch;
+    }
+    unsigned cnt[kStreamGroupMax], off[kStreamGroupMax];
+    unsigned maxc = 0, touching = 0;
+    if (owner) {
+#pragma unroll
+      for (int q = 0; q < kStreamGroupMax; ++q) cnt[q] = q < njobs ? jobs[q].P.lv[level].g.bin_count[slot] : 0u;
+#pragma unroll
+      for (int q = 0; q < kStreamGroupMax; ++q)
+        off[q] = cnt[q] ? jobs[q].P.lv[level].g.bin_offset[slot] + static_cast<unsigned>(jobs[q].rec_keys - rec_base) : 0u;
+#pragma unroll
+      for (int q = 0; q < kStreamGroupMax; ++q) {
+        maxc = max(maxc, cnt[q]);
+        touching += cnt[q] ? 1u : 0u;
+      }
+    }
+    const bool small = maxc <= kSmallBinInKernel;
+    unsigned slices = owner ? 1u : 0u;
+    if (owner && !small) {
+      const unsigned per_slice = maxc < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above;
+      while (slices < 128u && maxc > slices * per_slice) slices <<= 1;
+    }
+    const unsigned cls = small ? kUnitTiers : (maxc >= 16384u ? 0u : maxc >= 4096u ? 1u : maxc >= 1024u ? 2u : 3u);
+    unsigned lu = 0, lw = 0;
+    if (owner) {
+      lu = atomicAdd(&s_need[cls], slices);
+      lw = atomicAdd(&s_need[kUnitTiers + 1u], slices * touching);
+    }
+    __syncthreads();
+    if (threadIdx.x < kUnitTiers + 2u && s_need[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_need[threadIdx.x]);
+    __syncthreads();
+    if (owner) {
+      const unsigned u0 = s_base[cls] + lu, w0 = s_base[kUnitTiers + 1u] + lw;
+      if (u0 + slices > G.unit_capacity || w0 + slices * touching > G.item_capacity) {
+        atomicOr(&jobs[0].P.lv[level].g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes both from the group's records
+      } else {
+        uint2* const table = small ? G.wave_units[level] : G.wg_units[level] + static_cast<size_t>(cls) * G.unit_capacity;
+        const unsigned step = 512u / slices;
+        for (unsigned k = 0; k < slices; ++k) {
+          table[u0 + k] = make_uint2(w0 + k * touching, touching);
+          unsigned w = w0 + k * touching;
+#pragma unroll
+          for (int q = 0; q < kStreamGroupMax; ++q) {  // scan order
+            if (!cnt[q]) continue;
+            const unsigned rpl = jobs[q].records_per_level;
+            const unsigned seq_bits = 32u - static_cast<unsigned>(__builtin_clz((rpl > 2u ? rpl : 2u) - 1u));
+            work[w++] = make_uint4(slot, (k * step) | (((k + 1u) * step) << 10) | (seq_bits << 20), cnt[q], off[q]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kStreamGroupMax; ++q)
+        if (cnt[q]) jobs[q].P.lv[level].g.bin_count[slot] = 0u;  // ready for the next call
+    }
+    __syncthreads();  // s_need / s_base are reused by the next chunk
+  }
 }
 
 // grid (G, levels): one launch for the group; the pyramid of the group's first scan stands for all (same grids).
@@ -2772,8 +2809,11 @@ __global__ __launch_bounds__(kBinThreads, HG_APPLY_WAVES) void k_bin_apply_strea
   units.tier_stride = G.unit_capacity;
   bin_apply_body(P.lv[level], order, blockIdx.x, gridDim.x, rec_keys, rec_vals, true, &units);
 }
-__global__ void k_stream_reset(StreamGroup G, int levels) {  // <<<1, 64>>> behind the apply launch
+// <<<1, 64>>> behind the apply launch: the level counters and the scans' touched counts start from zero again
+__global__ void k_stream_reset(StreamGroup G, int levels, const InsertJob* __restrict__ jobs, int njobs) {
   if (threadIdx.x < static_cast<unsigned>(levels) * 8u) G.counts[threadIdx.x] = 0u;
+  for (unsigned t = threadIdx.x; t < static_cast<unsigned>(levels * njobs); t += blockDim.x)
+    jobs[t / levels].P.lv[t % levels].g.call[0] = 0u;
 }
 #endif  // !HG_BIN_STAMPS
 
@@ -3554,35 +3594,14 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   const size_t touched_cap = std::min<size_t>(static_cast<size_t>(n_max) * kMaxRuns, max_blocks) + 64u;
   // shadow layout: [group][levels] call counters (4 words), then per (job slot, level)
   // bin_count[pool], bin_offset[pool], touched[touched_cap]; merged apply: + per level claim[pool], + 16 counter words
-  // stream_merge: 0 never, 2 always, 1 (default) per group, when its scans were taken at places farther apart than the
-  // sensor reaches (max_range + tau between consecutive origins: submaps of different rooms folded into one pool, the
-  // multi-robot / multi-room streams). There every unit holds ONE scan's item, the merged launch is the eight per-scan
-  // launches side by side (64 room copies: 9.1k -> 11.5k scans/s). Scans of one place share their heavy voxels: the
-  // group is then bound by those voxels' serial chains either way, and the merged form -- one slice count per block for
-  // all scans, small bins of a block on the workgroup path as soon as one scan's bin is large -- measured 14 % SLOWER
-  // (B = 32 in one room: 15.8k against 18.4k scans/s); such groups keep a launch per scan.
-  const int merge_mode = (group >= 2 && group <= 32 && !heavy_enabled(c)) ? static_cast<int>(c->opt(OPT_STREAM_MERGE)) : 0;
-  const bool merged = merge_mode != 0;  // (the layout has room for it)
-  std::vector<char> group_merged((count + group - 1) / group, 0);
-  if (merged) {
-    double reach = 0.0;
-    for (int l = 0; l < levels; ++l) reach = std::max(reach, P0.lv[l].p.max_range + static_cast<double>(P0.lv[l].p.truncation_distance));
-    for (int g0 = 0; g0 < count; g0 += group) {
-      bool spread = std::min(group, count - g0) >= 2;
-      float prev[3] = {0.f, 0.f, 0.f};
-      for (int j = g0; j < std::min(count, g0 + group) && spread; ++j) {
-        float o[3];
-        if (poses_tq) host_transform(poses_tq + 7 * scans[j], origins + 3 * scans[j], o);
-        else std::memcpy(o, origins + 3 * scans[j], sizeof(o));
-        if (j > g0) {
-          const double dx = o[0] - prev[0], dy = o[1] - prev[1], dz = o[2] - prev[2];
-          spread = std::sqrt(dx * dx + dy * dy + dz * dz) > reach;
-        }
-        std::memcpy(prev, o, sizeof(prev));
-      }
-      group_merged[g0 / group] = (merge_mode == 2 || spread) ? 1 : 0;
-    }
-  }
+  // stream_merge (default 1): ONE apply launch per group of scans (k_stream_units / k_bin_apply_stream) instead of one per
+  // scan. Measured on one box, interleaved (scripts/r06_stream_ab.sh, groups of 8): 32 scans of one room 18.3k -> 18.8k
+  // scans/s, 32 scans over 32 rooms 16.4k -> 22.1k, 64 over 64 rooms 9.2k -> 17.7k, 500 over 400 rooms (2 GB of voxels)
+  // 10.2k -> 18.8k: where the scans of a group touch different blocks their launches now run side by side. Groups of
+  // 16 / 32 (the default since): one room 19.2k / 20.7k, 64 rooms 19.3k / 19.9k. What is left in one room is the unit of
+  // the busiest (block, slice): its voxels' updates of all scans of the group in one serial chain.
+  const bool merged = group >= 2 && group <= kStreamGroupMax && !heavy_enabled(c) && c->opt(OPT_STREAM_MERGE) != 0;
+  std::vector<char> group_merged((count + group - 1) / group, merged ? 1 : 0);
   const size_t call_words = static_cast<size_t>(group) * levels * 4u;
   const size_t per_slot_level = 2u * max_pool + touched_cap;
   const size_t claim_words = merged ? max_pool * levels + 8u * kMaxInsLevels : 0u;
@@ -3744,11 +3763,11 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
 #ifndef HG_BIN_STAMPS
       if (merged_g) {
         // one apply launch for the group: units of (block, voxel slice) x scans (k_stream_units)
-        hipLaunchKernelGGL(k_stream_units, dim3(levels), dim3(1024), 0, s, d_jobs + g0, gn, levels, SG,
-                           static_cast<const uint32_t*>(jobs[g0].rec_keys));
+        hipLaunchKernelGGL(k_stream_units, dim3(kStreamUnitWgs, static_cast<unsigned>(levels)), dim3(256), 0, s, d_jobs + g0, gn,
+                           levels, SG, static_cast<const uint32_t*>(jobs[g0].rec_keys));
         hipLaunchKernelGGL(k_bin_apply_stream, dim3(1024u, static_cast<unsigned>(levels)), dim3(kBinThreads), 0, s, jobs[g0].P,
                            jobs[g0].rec_keys, jobs[g0].rec_vals, SG);
-        hipLaunchKernelGGL(k_stream_reset, dim3(1), dim3(64), 0, s, SG, levels);
+        hipLaunchKernelGGL(k_stream_reset, dim3(1), dim3(64), 0, s, SG, levels, d_jobs + g0, gn);
       } else {
         for (int j = g0; j < g0 + gn; ++j)  // pyramid as kernel argument (scalar registers), as scan by scan
           hipLaunchKernelGGL(k_bin_apply, apply_grid(c, levels), dim3(kBinThreads), 0, s, jobs[j].P, jobs[j].rec_keys,

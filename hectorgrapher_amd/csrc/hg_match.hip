@@ -1293,9 +1293,37 @@ __device__ inline void quaternion_plus(const double* x, const double* delta, dou
 #pragma clang fp contract(fast)  // (LM side only: no discrete decision downstream; see lm_step_single)
   const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
   if (nd > 0.0) {
-    double sn, q0;
-    sincos(nd, &sn, &q0);  // (one argument reduction for both)
-    const double sbd = sn / nd;
+    double q0, sbd;
+    if (nd < 0.5) {
+      // (round 6) the increments of an LM step are small angles: sin(nd) / nd and cos(nd) as their Taylor series in
+      // nd^2 (terms to nd^16 / nd^18: truncation < 1e-22 for nd < 0.5, evaluation error a few 1e-17 -- what the
+      // library sincos and the division gave) -- 18 multiply-adds instead of the library's argument reduction, two
+      // polynomials and an fp64 division: this function sits twice on the serial path of every LM step
+      const double z = nd * nd;
+      double s = -1.0 / 355687428096000.0;             // 1 / 17!
+      s = fma(s, z, 1.0 / 1307674368000.0);            // 15!
+      s = fma(s, z, -1.0 / 6227020800.0);              // 13!
+      s = fma(s, z, 1.0 / 39916800.0);                 // 11!
+      s = fma(s, z, -1.0 / 362880.0);                  // 9!
+      s = fma(s, z, 1.0 / 5040.0);                     // 7!
+      s = fma(s, z, -1.0 / 120.0);                     // 5!
+      s = fma(s, z, 1.0 / 6.0);                        // 3!
+      sbd = fma(-s, z, 1.0);
+      double c = 1.0 / 6402373705728000.0;             // 1 / 18!
+      c = fma(c, z, -1.0 / 20922789888000.0);          // 16!
+      c = fma(c, z, 1.0 / 87178291200.0);              // 14!
+      c = fma(c, z, -1.0 / 479001600.0);               // 12!
+      c = fma(c, z, 1.0 / 3628800.0);                  // 10!
+      c = fma(c, z, -1.0 / 40320.0);                   // 8!
+      c = fma(c, z, 1.0 / 720.0);                      // 6!
+      c = fma(c, z, -1.0 / 24.0);                      // 4!
+      c = fma(c, z, 0.5);                              // 2!
+      q0 = fma(-c, z, 1.0);
+    } else {
+      double sn;
+      sincos(nd, &sn, &q0);  // (one argument reduction for both)
+      sbd = sn / nd;
+    }
     const double q1 = sbd * delta[0], q2 = sbd * delta[1], q3 = sbd * delta[2];
     out[0] = q0 * x[0] - q1 * x[1] - q2 * x[2] - q3 * x[3];
     out[1] = q0 * x[1] + q1 * x[0] + q2 * x[3] - q3 * x[2];
@@ -3571,7 +3599,8 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
                                unsigned num_wg, const PinBox* host_up = nullptr, unsigned up_words = 0,
                                unsigned epoch = 0 /* != 0: `partials` holds tagged granules of this epoch */,
                                double* persist_out = nullptr /* LDS, 8 doubles: the next candidate and the done flag (persistent solve) */,
-                               int* timeout_flag = nullptr /* LDS: set when a granule never arrived; the step then ends the solve as failed */) {
+                               int* timeout_flag = nullptr /* LDS: set when a granule never arrived; the step then ends the solve as failed */,
+                               unsigned long long* persist_bcast = nullptr /* persistent solve: kBcastReplicas x 8 granule pairs, the hand-back to the other workgroups */) {
   // (Round 5: multiply-adds of this function are fused -- the file is compiled -ffp-contract=off for the voxel lookups,
   // whose discrete decisions need the reference's roundings; nothing in the LM step takes one, and the tail is a chain
   // of dependent fp64 operations: 14.7 -> 14.0 us per launch together with the right-looking factorisation below.)
@@ -3981,6 +4010,19 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
     // the general path leaves cand = x's last candidate; nothing reads it after termination
   }
   TAIL_STAMP(5);
+  if (persist_bcast) {
+    // persistent solve: the hand-back leaves FIRST, straight from the registers of this wavefront (every lane holds the
+    // state): lane l writes granule pair l % 8 of replicas l / 8, + 8, + 16, + 24. Behind the write-back of the head
+    // it waited for ~80 scalar-width stores to drain and a workgroup barrier -- on the critical path of all 196
+    // workgroups, which do nothing until they see it.
+    const int k = t & 7;
+    double v = done ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) v = (k == q) ? cand[q] : v;
+#pragma unroll
+    for (unsigned r = 0; r < kBcastReplicas; r += 8u)
+      store_partial_tagged(persist_bcast + 16u * (r + (static_cast<unsigned>(t) >> 3)) + 2u * static_cast<unsigned>(k), v, epoch + 1u);
+  }
   // --- write back (lane 0; every lane holds the same values) ---
   if (t == 0) {
     auto store_fields = [&](LmHead& d) {
@@ -4348,15 +4390,14 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
       __syncthreads();  // (ends this workgroup's use of the tiles in smem)
       if (e == 0u)
         lm_step_single<true>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, up.box,
-                             up.up_words, epoch, s_out, &s_timeout);
+                             up.up_words, epoch, s_out, &s_timeout, bcast);
       else
         lm_step_single<false>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, nullptr, 0u,
-                              epoch, s_out, &s_timeout);
+                              epoch, s_out, &s_timeout, bcast);
+      // (the hand-back -- kBcastReplicas copies, a 128-byte line each: 195 workgroups polling ONE line queue at its
+      // memory channel -- has left from inside the step, ahead of the head's write-back)
       PSTAMP(0u, 2);
       __syncthreads();
-      // kBcastReplicas copies, a 128-byte line each: 195 workgroups polling ONE line queue at its memory channel
-      if (threadIdx.x < 8u * kBcastReplicas)
-        store_partial_tagged(bcast + 16u * (threadIdx.x >> 3) + 2u * (threadIdx.x & 7u), s_out[threadIdx.x & 7u], epoch + 1u);
       PSTAMP(0u, 3);
     } else {
       if (e + 1u == evals) break;  // (uniform) nothing follows the last evaluation

@@ -161,11 +161,11 @@ int hg_ctx_synchronize(hg_ctx* ctx);
  *   partition_min      batch size from which the level partition is used (default 48; 0: never)
  *   partition_at       LM iteration at which the returns are classified (default 2)
  *   host_times         1: host-side timing of hg_register_scan_sequence printed to stderr
- *   stream_group       scans whose front ends share launches in a scan stream (default 8; 0: off)
+ *   stream_group       scans of a stream whose front ends and apply pass share launches (default 32, at most 32; 0: off)
  *   stream_slice       records per voxel slice of large bins in a scan stream (default 1024)
- *   stream_merge       apply launches of a scan stream: 0 one per scan; 2 one per group of scans (units of (block, voxel
- *                         slice) x scans, applied in scan order); 1 (default) per group, when its scans were taken
- *                         farther apart than the sensor reaches. Bit-identical results in every setting
+ *   stream_merge       0: one apply launch per scan of a stream (rounds 3-5) instead of one per group of
+ *                         stream_group scans (units of (block, voxel slice) x scans, applied in scan order; default 1).
+ *                         Bit-identical results either way
  *   apply_turns        1: the levels of k_bin_apply take turns
  *   defer_long_chains  0: no deferral of long chains (only in builds with -DHG_DEFER_LONG_CHAINS)
  *   insert_sort        1: exact insertion through the radix-sort path

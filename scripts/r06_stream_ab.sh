@@ -9,11 +9,14 @@ run() { # tag, env, args
 run auto32 "HG_STREAM_MERGE=1" "--stream-scans 32 --cpu-scans 2"
 run perscan32 "HG_STREAM_MERGE=0" "--stream-scans 32 --no-cpu-baseline"
 run forced32 "HG_STREAM_MERGE=2" "--stream-scans 32 --cpu-scans 2"
-run auto64hbm_g16 "HG_STREAM_MERGE=1 HG_STREAM_GROUP=16" "--stream-scans 64 --stream-tiles 64 --steps 3 --warmup 1 --prof-every 1 --cpu-scans 2" # "--stream-scans 32 --cpu-scans 2"
+run merged32hbm "HG_STREAM_MERGE=1" "--stream-scans 32 --stream-tiles 32 --cpu-scans 2"
+run perscan32hbm "HG_STREAM_MERGE=0" "--stream-scans 32 --stream-tiles 32 --no-cpu-baseline"
 run merged64hbm "HG_STREAM_MERGE=1" "--stream-scans 64 --stream-tiles 64 --steps 3 --warmup 1 --prof-every 1 --cpu-scans 2"
 run perscan64hbm "HG_STREAM_MERGE=0" "--stream-scans 64 --stream-tiles 64 --steps 3 --warmup 1 --prof-every 1 --no-cpu-baseline"
-run merged64warm "HG_STREAM_MERGE=1" "--stream-scans 64 --steps 3 --warmup 1 --prof-every 1 --cpu-scans 2"
+run merged64warm "HG_STREAM_MERGE=2" "--stream-scans 64 --steps 3 --warmup 1 --prof-every 1 --cpu-scans 2"
 run perscan64warm "HG_STREAM_MERGE=0" "--stream-scans 64 --steps 3 --warmup 1 --prof-every 1 --no-cpu-baseline"
+run merged500 "HG_STREAM_MERGE=1" "--stream-scans 500 --stream-tiles 400 --max-blocks 1048576 --steps 2 --warmup 1 --prof-every 1 --cpu-scans 2"
+run perscan500 "HG_STREAM_MERGE=0" "--stream-scans 500 --stream-tiles 400 --max-blocks 1048576 --steps 2 --warmup 1 --prof-every 1 --no-cpu-baseline"
 for f in $O/*.json; do python3 -c "
 import json
 try:

@@ -143,3 +143,37 @@ def test_handles_of_a_destroyed_context_are_refused():
     assert b"context" in L.hg_last_error()
     assert L.hg_problem_destroy(prob) == 0
     assert L.hg_grid_destroy(grid) == 0
+
+
+def test_context_option_keys_are_documented_and_the_library_reads_no_environment_behind_them():
+    """Round 6: the library's switches are per-context options (hg_ctx_set_option); the keys the
+    library accepts (csrc/hg_internal.h kOptDesc) are exactly the keys include/hg_mi355x.h documents, and the only
+    getenv left in the sources is the one that builds a context's defaults plus HG_STREAM_PRIORITY (read before a
+    context exists)."""
+    csrc = os.path.join(ROOT, "hectorgrapher_amd", "csrc")
+    internal = open(os.path.join(csrc, "hg_internal.h")).read()
+    table = internal[internal.index("constexpr OptDesc kOptDesc"):]
+    table = table[:table.index("};")]
+    accepted = re.findall(r'\{"([a-z_]+)",\s*-?\d+\}', table)
+    enum = internal[internal.index("enum Opt {"):]
+    enum = enum[:enum.index("OPT_COUNT")]
+    assert len(accepted) == len(re.findall(r"OPT_[A-Z_]+", enum)) and len(set(accepted)) == len(accepted)
+    header = open(os.path.join(ROOT, "include", "hg_mi355x.h")).read()
+    doc = header[header.index("Tuning and diagnostic switches of a context"):header.index("int hg_ctx_set_option")]
+    documented = set()
+    for line in doc.splitlines():
+        m = re.match(r"\s*\*\s{3}([a-z_]+(?:\s*/\s*[a-z_]+)*(?:,\s*[a-z_]+)*)\s{2,}", line)
+        if m:
+            documented.update(k.strip() for k in re.split(r"[/,]", m.group(1)))
+    assert documented == set(accepted), (sorted(documented ^ set(accepted)))
+    # the order of the enum is the order of the table
+    assert [("OPT_" + k.upper()) for k in accepted] == re.findall(r"OPT_[A-Z_]+", enum)
+    getenvs = []
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(csrc, name)).read().splitlines(), 1):
+                code = line.split("//")[0]
+                if "getenv(" in code:
+                    getenvs.append((name, i, line.strip()))
+    assert len(getenvs) <= 3, getenvs
+    assert all(n == "hg_grid.hip" for n, _, _ in getenvs), getenvs

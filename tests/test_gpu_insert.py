@@ -490,12 +490,12 @@ def test_children_may_outlive_their_context(hg):
 
 
 @pytest.mark.parametrize("env", [{"HG_STREAM_SLICE": "512"}, {"HG_STREAM_SLICE": "2048"}, {"HG_APPLY_TURNS": "1"},
-                                 {"HG_STREAM_MERGE": "2"}, {"HG_STREAM_MERGE": "2", "HG_STREAM_GROUP": "3"}, {"HG_STREAM_MERGE": "0"}])
+                                 {"HG_STREAM_GROUP": "3"}, {"HG_STREAM_MERGE": "0"}])
 def test_apply_schedules_are_all_bit_exact(env):
     """The slice size of a scan stream's large bins and the dispatch order of k_bin_apply are schedules, not
     semantics: the tests that compare grouped streams, giant voxels and dense pools with the oracle pass under the
-    alternative settings too -- among them (round 6) the MERGED apply of a stream's groups forced on for scans of one
-    place (stream_merge = 2: units of (block, voxel slice) x scans) and off (the switches are the defaults of a context's
+    alternative settings too -- among them (round 6) the MERGED apply of a stream's groups (the default: units of
+    (block, voxel slice) x scans) with groups of three and switched off (the switches are the defaults of a context's
     options, read from the environment when it is created: hence a child process)."""
     import subprocess
     import sys

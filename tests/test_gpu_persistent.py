@@ -101,6 +101,6 @@ def test_options_are_per_context_and_unknown_keys_are_refused(hg, ctx):
     assert ctx.get_option("persistent_solve") in (0, 1)
     with ctx.option("stream_group", 4):
         assert ctx.get_option("stream_group") == 4
-    assert ctx.get_option("stream_group") == 8
+    assert ctx.get_option("stream_group") == 32
     with pytest.raises(hg.HgError):
         ctx.set_option("no_such_switch", 1)
