@@ -1293,37 +1293,14 @@ __device__ inline void quaternion_plus(const double* x, const double* delta, dou
 #pragma clang fp contract(fast)  // (LM side only: no discrete decision downstream; see lm_step_single)
   const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
   if (nd > 0.0) {
-    double q0, sbd;
-    if (nd < 0.5) {
-      // (round 6) the increments of an LM step are small angles: sin(nd) / nd and cos(nd) as their Taylor series in
-      // nd^2 (terms to nd^16 / nd^18: truncation < 1e-22 for nd < 0.5, evaluation error a few 1e-17 -- what the
-      // library sincos and the division gave) -- 18 multiply-adds instead of the library's argument reduction, two
-      // polynomials and an fp64 division: this function sits twice on the serial path of every LM step
-      const double z = nd * nd;
-      double s = -1.0 / 355687428096000.0;             // 1 / 17!
-      s = fma(s, z, 1.0 / 1307674368000.0);            // 15!
-      s = fma(s, z, -1.0 / 6227020800.0);              // 13!
-      s = fma(s, z, 1.0 / 39916800.0);                 // 11!
-      s = fma(s, z, -1.0 / 362880.0);                  // 9!
-      s = fma(s, z, 1.0 / 5040.0);                     // 7!
-      s = fma(s, z, -1.0 / 120.0);                     // 5!
-      s = fma(s, z, 1.0 / 6.0);                        // 3!
-      sbd = fma(-s, z, 1.0);
-      double c = 1.0 / 6402373705728000.0;             // 1 / 18!
-      c = fma(c, z, -1.0 / 20922789888000.0);          // 16!
-      c = fma(c, z, 1.0 / 87178291200.0);              // 14!
-      c = fma(c, z, -1.0 / 479001600.0);               // 12!
-      c = fma(c, z, 1.0 / 3628800.0);                  // 10!
-      c = fma(c, z, -1.0 / 40320.0);                   // 8!
-      c = fma(c, z, 1.0 / 720.0);                      // 6!
-      c = fma(c, z, -1.0 / 24.0);                      // 4!
-      c = fma(c, z, 0.5);                              // 2!
-      q0 = fma(-c, z, 1.0);
-    } else {
-      double sn;
-      sincos(nd, &sn, &q0);  // (one argument reduction for both)
-      sbd = sn / nd;
-    }
+    // (Round 6, measured and dropped: sin(nd) / nd and cos(nd) as Taylor series below 0.5 rad -- 18 multiply-adds
+    // instead of the library's argument reduction and an fp64 division, twice on the serial path of every LM step. A
+    // launch per evaluation gained 1 % (3809 -> 3848 scans/s), the persistent solve LOST 2.5 % (3951 -> 3854): that
+    // kernel is out of registers and the polynomials' constants became spills on the serial path
+    // (scripts/r06_headline_variants.sh). Series in one form only would end the bit-for-bit equality of the two.)
+    double sn, q0;
+    sincos(nd, &sn, &q0);  // (one argument reduction for both)
+    const double sbd = sn / nd;
     const double q1 = sbd * delta[0], q2 = sbd * delta[1], q3 = sbd * delta[2];
     out[0] = q0 * x[0] - q1 * x[1] - q2 * x[2] - q3 * x[3];
     out[1] = q0 * x[1] + q1 * x[0] + q2 * x[3] - q3 * x[2];
@@ -3594,7 +3571,7 @@ __device__ unsigned long long g_tail_stamps[8];
 #endif
 __device__ inline int b6(int i, int j) { return i * 6 + 5 - (i - j); }  // band_index(i, j, W = 6), j <= i
 
-template <bool FIRST = false>
+template <bool FIRST = false, bool PERSIST = false /* called from the persistent solve */>
 __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, BlockXform* xf, const double* partials,
                                unsigned num_wg, const PinBox* host_up = nullptr, unsigned up_words = 0,
                                unsigned epoch = 0 /* != 0: `partials` holds tagged granules of this epoch */,
@@ -4010,7 +3987,11 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
     // the general path leaves cand = x's last candidate; nothing reads it after termination
   }
   TAIL_STAMP(5);
+#ifdef HG_PERSIST_LATE_HANDBACK
+  if (false) {
+#else
   if (persist_bcast) {
+#endif
     // persistent solve: the hand-back leaves FIRST, straight from the registers of this wavefront (every lane holds the
     // state): lane l writes granule pair l % 8 of replicas l / 8, + 8, + 16, + 24. Behind the write-back of the head
     // it waited for ~80 scalar-width stores to drain and a workgroup barrier -- on the critical path of all 196
@@ -4369,6 +4350,7 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
 #endif
   // what does not change from one evaluation to the next is loaded once: the lane's return and the levels' window
   // counters (the map is not written while the solve runs)
+#ifndef HG_PERSIST_NO_HOIST
   double pre_v[3];
   {
     const ScanOrder order = make_scan_order(n, width);
@@ -4376,28 +4358,37 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
     load_point(xyz, scan_index(order, first_i0 < n ? first_i0 : 0u), pre_v);
   }
   const DirectRaw pre_dp = direct_issue(pv);
+#endif
   for (unsigned e = 0; e < evals; ++e) {
     const unsigned epoch = epoch0 + e;
     PSTAMP(0u, 0);
     tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, granules, nullptr,
                                  reinterpret_cast<double (*)[kWave][8]>(smem),
                                  reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
+#ifdef HG_PERSIST_NO_HOIST
+                                 xcd_chunk(wg, num_wg), pose, width, 1, 0, epoch);
+#else
                                  xcd_chunk(wg, num_wg), pose, width, 1, 0, epoch, pre_v, &pre_dp);
+#endif
     PSTAMP(0u, 1);
     PSTAMP(97u, 5);
     PSTAMP(195u, 6);
     if (wg == 0u) {
       __syncthreads();  // (ends this workgroup's use of the tiles in smem)
       if (e == 0u)
-        lm_step_single<true>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, up.box,
-                             up.up_words, epoch, s_out, &s_timeout, bcast);
+        lm_step_single<true, true>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, up.box,
+                                   up.up_words, epoch, s_out, &s_timeout, bcast);
       else
-        lm_step_single<false>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, nullptr, 0u,
-                              epoch, s_out, &s_timeout, bcast);
+        lm_step_single<false, true>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, nullptr, 0u,
+                                    epoch, s_out, &s_timeout, bcast);
       // (the hand-back -- kBcastReplicas copies, a 128-byte line each: 195 workgroups polling ONE line queue at its
       // memory channel -- has left from inside the step, ahead of the head's write-back)
       PSTAMP(0u, 2);
       __syncthreads();
+#ifdef HG_PERSIST_LATE_HANDBACK
+      if (threadIdx.x < 8u * kBcastReplicas)
+        store_partial_tagged(bcast + 16u * (threadIdx.x >> 3) + 2u * (threadIdx.x & 7u), s_out[threadIdx.x & 7u], epoch + 1u);
+#endif
       PSTAMP(0u, 3);
     } else {
       if (e + 1u == evals) break;  // (uniform) nothing follows the last evaluation
