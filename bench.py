@@ -29,7 +29,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 120 for the headline -- the whole bench trajectory, 28 ms of timed region: the "
+                         "20 steps of rounds 1-5 were a 5 ms region, shorter than the device takes to settle its clocks, and "
+                         "read 4 %% low -- and 20 for the other workloads)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rings", type=int, default=50)
     ap.add_argument("--cols", type=int, default=2000)
@@ -237,6 +240,8 @@ def cpu_baseline(args, map_scans, query_scans, gpu_steps):
 
 def main():
     args = parse_args()
+    if args.steps is None:
+        args.steps = 120 if (args.workload == "register" and args.total_submaps == 0) else 20
     # the timed loops are a few hundred microseconds per step: a generational collection of the
     # interpreter (tens of milliseconds with torch loaded) in the middle of one would be measured as
     # the library's time
@@ -1792,8 +1797,10 @@ def secondary_workloads(args):
         ("insert_stream_64_hbm", run_insert_stream, {"workload": "insert_stream", "stream_scans": 64, "stream_tiles": 64,
                                                      "steps": 3, "warmup": 1, "prof_every": 1, "cpu_scans": 2}),
         # configs[3] with the reference's real builder: 8 submaps, each a 10-control-point window per step, shared launches
+        # (its all-cores CPU leg inside this bounded run: 64 threads -- a window of nine 100k-point blocks per thread on all 256
+        # cores of the driver box took 215 s of wall time; `--workload window_batch` on its own uses every core)
         ("window_batch_8", run_window_batch, {"workload": "window_batch", "window": 10, "batch_submaps": 8, "steps": 4, "warmup": 2,
-                                              "prof_every": 2}),
+                                              "prof_every": 2, "cpu_threads": 64}),
         # BASELINE configs[3] bounded: 8 submaps x 30 scans on this GPU, then the gather of all finished blocks
         # through a one-rank process group and its import / export-digest check (the full 8 x 500 run is
         # `bench.py --total-submaps 8 --scans-per-submap 500`, profiles/r05_bench_offline8x500.json)

@@ -2707,7 +2707,7 @@ __global__ __launch_bounds__(1024) void k_stream_offsets_jobs(const InsertJob* _
 // scans are one flat list cut into chunks of 256 over 32 workgroups, an owner's eight counts / offsets are loaded
 // together, and a chunk reserves through LDS with ONE device atomic per counter.)
 constexpr int kStreamGroupMax = 32;
-constexpr unsigned kStreamUnitWgs = 32;
+constexpr unsigned kStreamUnitWgs = 256;  // (a chunk of 256 entries each for a group of 32 scans: one pass per workgroup)
 __global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restrict__ jobs, int njobs, int levels, StreamGroup G,
                                                       const uint32_t* rec_base /* the group's record buffer: jobs[j].rec_keys - rec_base = job j's offset in it */) {
   const int level = blockIdx.y;
@@ -2717,11 +2717,17 @@ __global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restric
   const unsigned slice_above = G.slice_records < 0 ? static_cast<unsigned>(-G.slice_records) : HG_SLICE_ABOVE;
   __shared__ unsigned s_nt[kStreamGroupMax + 1];  // prefix of the scans' touched counts
   __shared__ unsigned s_need[kUnitTiers + 2], s_base[kUnitTiers + 2];
+  // (every scan's touched count by a thread of its own: one lane reading them in turn was 64 dependent loads, most of
+  // this kernel's time once the chunks were spread over the chip)
+  __shared__ unsigned s_cnt[kStreamGroupMax];
+  if (threadIdx.x < static_cast<unsigned>(kStreamGroupMax))
+    s_cnt[threadIdx.x] = static_cast<int>(threadIdx.x) < njobs ? jobs[threadIdx.x].P.lv[level].g.call[0] : 0u;
+  __syncthreads();
   if (threadIdx.x == 0) {
     unsigned acc = 0;
     for (int j = 0; j < kStreamGroupMax; ++j) {
       s_nt[j] = acc;
-      if (j < njobs) acc += jobs[j].P.lv[level].g.call[0];
+      acc += s_cnt[j];
     }
     s_nt[kStreamGroupMax] = acc;
   }
