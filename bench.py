@@ -1995,6 +1995,10 @@ def run(args, out_fd=None):
         h_err = [float(np.linalg.norm(h_res[0][k][:3] - query[lo + k][0][:3])) for k in range(host_steps)]
         host_inclusive = {"value": host_steps / th, "unit": "scans/s", "steps": host_steps, "ms_per_step": th / host_steps * 1e3,
                           "mean_pose_error_m": float(np.mean(h_err)),
+                          "mean_lm_iterations": float(np.mean([s_.num_iterations for s_ in h_res[1][:host_steps]])),
+                          "positions": "steps %d..%d of the trajectory, BEHIND the timed ones: other positions, other iteration counts "
+                                       "(compare mean_lm_iterations with config.mean_lm_iterations) -- not a like-for-like ratio to `value`"
+                                       % (lo, lo + host_steps - 1),
                           "handover": "scans in pageable host memory (HG_HOST), 1.2 MB each; copy of scan k + 1 overlapped with step k"}
     # accounting pass (untimed): N_in and U of one more scan of the same workload
     last = args.warmup + args.steps - 1
@@ -2144,6 +2148,7 @@ def run(args, out_fd=None):
                    "points_per_scan": n_pts, "map_scans": args.map_scans,
                    "parallelism": "independent submap per GPU x%d" % world,
                    "insert_mode": args.insert_mode, "mean_pose_error_m": float(np.mean(errs)),
+                   "mean_lm_iterations": float(np.mean([g_[1] for g_ in gpu_steps[args.warmup:args.warmup + args.steps]])),
                    "resident_voxel_gib": len(RESOLUTIONS) * (2 * args.max_blocks) * 2048 / 2.0 ** 30,
                    "gather_ms": gather_ms, "gather_check": gather_check},
         "roofline": roofline,
