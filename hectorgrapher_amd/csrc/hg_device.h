@@ -47,7 +47,6 @@ struct GridView {
   uint32_t* touched;          // slots touched by the current insert call
   uint4* work;                // apply work items {slot, v_lo | v_hi << 16, records of the bin, 0}: per-call
   uint32_t work_capacity;     // context workspace sized from the call's record count (set by the host per call)
-  unsigned long long* accum;  // HG_INSERT_FAST: per voxel count << 44 | fixed-point tsd sum (or null)
   float resolution;
   float max_tsd, min_tsd, max_weight;
   float tsd_resolution, weight_resolution;  // encode scales (tsd_value_converter.cc:27-28)

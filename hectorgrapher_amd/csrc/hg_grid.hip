@@ -544,7 +544,6 @@ int hg_grid_destroy(hg_grid* g) {
   if (g->view.block_keys) (void)hipFree(g->view.block_keys);
   if (g->view.counters) (void)hipFree(g->view.counters);
   if (g->view.bin_count) (void)hipFree(g->view.bin_count);
-  if (g->view.accum) (void)hipFree(g->view.accum);
   g->pack.release();
   if (g->ctx) {
     if (g->flag_slot < hg_ctx::kFlagSlots) {  // the stream has drained: nothing writes the word any more
@@ -578,8 +577,6 @@ int hg_grid_clear(hg_grid* g) {
   static const uint32_t kInit[64] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   HG_HIP_CHECK(hipMemcpyAsync(v.counters, kInit, 256, hipMemcpyHostToDevice, s));
   HG_HIP_CHECK(hipMemsetAsync(v.bin_count, 0, sizeof(uint32_t) * 2 * static_cast<size_t>(v.pool_blocks), s));
-  if (v.accum)
-    HG_HIP_CHECK(hipMemsetAsync(v.accum, 0, sizeof(unsigned long long) * kVoxelsPerBlock * static_cast<size_t>(v.pool_blocks), s));
   return HG_OK;
 }
 

@@ -1049,206 +1049,23 @@ __global__ __launch_bounds__(256) void k_bin_count_jobs(const InsertJob* __restr
 }
 
 // ==========================================================================================
-// Tolerance path (HG_INSERT_FAST, unit update weight): the updates a voxel receives in one call
-// are SUMMED (order-free integer sums) and applied once, instead of the reference's chain of
-// re-quantised updates. No per-voxel chain, no records, no sort:
-//   k_fast_accumulate  per (return, level): walks the ray, finds / inserts its blocks, and adds
-//                      every sample to the voxel's accumulator with ONE 64-bit atomic:
-//                      count << 44 | sum of (tsd + tau) in units of 2 tau / (2^23 - 1);
-//                      samples are first combined in registers (runs of neighbouring lanes) and in
-//                      an LDS table per workgroup, so one atomic leaves per distinct voxel
-//   k_fast_apply       one workgroup per touched block, one thread per voxel: closed form of the
-//                      m updates (running mean while the weight grows, the clamp's moving average
-//                      after it saturates), ONE quantisation, accumulator cleared.
-// Results differ from the exact mode by the re-quantisation noise the reference accumulates per
-// update (tests/test_gpu_insert.py states the tolerance); they do not depend on arrival order, so
-// the mode is deterministic.
+// Tolerance path (HG_INSERT_FAST, unit update weight): the updates a voxel receives in one chunk of a call are SUMMED
+// (order-free integer sums: count << 44 | sum of (tsd + tau) in units of 2 tau / (2^23 - 1)) and applied once in
+// closed form, instead of the reference's chain of re-quantised updates. Results differ from the exact mode by the
+// re-quantisation noise the reference accumulates per update (tests/test_gpu_insert_fast.py states the tolerance);
+// they do not depend on arrival order, so the mode is deterministic. Kernels: "Tolerance path on the bins" below
+// (round 6; rounds 2-5 formed the sums with device-scope atomics into an 8-byte accumulator per voxel of the pool:
+// k_fast_accumulate / k_fast_apply, git history).
 // ==========================================================================================
 constexpr unsigned kFastCountShift = 44;
 constexpr unsigned kFastUnits = (1u << 23) - 1u;
-constexpr unsigned kFastThreads = 512;   // returns per workgroup: the wider the window, the more voxels are shared
-constexpr unsigned kFastTableBits = 12;
-constexpr unsigned kFastTable = 1u << kFastTableBits;  // LDS slots per workgroup (about 5 samples per return)
 
-__global__ __launch_bounds__(kFastThreads) void k_fast_accumulate(PyramidIns P, const ScanTable* scans, uint32_t n_scans,
-                                                         const float* xyz, unsigned n, unsigned* wg_hits) {
-  const int level = blockIdx.y;
-  const LevelIns& L = P.lv[level];
-  const unsigned i = xcd_chunk(blockIdx.x, gridDim.x) * kFastThreads + threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
-  __shared__ unsigned s_hits;
-  __shared__ uint32_t s_key[kFastTable];
-  __shared__ unsigned long long s_val[kFastTable];
-  if (threadIdx.x == 0) s_hits = 0;
-  __syncthreads();
-  bool hit = false;
-  unsigned long long run_key[kMaxRuns];
-  int run_begin[kMaxRuns], run_len[kMaxRuns];
-  int nr = 0;
-  Ray r;
-  r.valid = false;
-  if (i < n) {
-    const ScanTable sc = scans ? scans[find_scan(scans, n_scans, i)] : scan_of(P);
-    r = ray_setup(L.g, L.p, sc, xyz, i, L.gate);
-    hit = r.valid && r.n + 1 <= kSlots;
-    if (r.valid && !hit) atomicOr(&L.g.counters[1], kFlagStride);
-    if (hit) {
-      bool range_err = false;
-      nr = ray_block_runs(r, run_key, run_begin, run_len, &range_err);
-      if (range_err) atomicOr(&L.g.counters[1], kFlagRange);
-    }
-  }
-  unsigned long long entry[kMaxRuns];
-  uint32_t slot[kMaxRuns];
-#pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k)
-    entry[k] = (k < nr) ? L.g.table[hash_key(run_key[k]) & L.g.table_mask] : 0ull;
-#pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k) {
-    slot[k] = 0xFFFFFFFFu;
-    if (k < nr) {
-      if ((entry[k] >> 24) == run_key[k] + 1ull && (entry[k] & 0xFFFFFFu) != kSlotPending)
-        slot[k] = static_cast<uint32_t>(entry[k] & 0xFFFFFFu);
-      else
-        slot[k] = insert_block_shared(L.g, run_key[k]);
-    }
-  }
-  // touched list: bin_count is only a flag on this path; whoever flips it 0 -> 1 enlists the block.
-  // One exchange per (wavefront, block): the returns of a wavefront share their blocks, and a hot
-  // block would otherwise take thousands of same-address atomics.
-#pragma unroll
-  for (int k = 0; k < kMaxRuns; ++k) {
-    const bool want = k < nr && slot[k] < L.g.pool_blocks;
-    unsigned long long todo = __ballot(want);
-    bool leader = false;
-    while (todo) {
-      const int l = __builtin_ctzll(todo);
-      const uint32_t ls = __builtin_amdgcn_readlane(slot[k], l);
-      leader = leader || lane == l;
-      todo &= ~__ballot(want && slot[k] == ls);
-    }
-    if (leader && atomicExch(&L.g.bin_count[slot[k]], 1u) == 0u)
-      L.g.touched[atomicAdd(&L.g.counters[6], 1u)] = slot[k];
-  }
-  const float tau = L.p.truncation_distance;
-  const float to_units = static_cast<float>(kFastUnits) / (tau + tau);
-  for (unsigned e = threadIdx.x; e < kFastTable; e += kFastThreads) {
-    s_key[e] = 0xFFFFFFFFu;
-    s_val[e] = 0ull;
-  }
-  __syncthreads();
-  // Sample `pos` of all lanes together: consecutive returns of a scan hit the same voxels, so runs
-  // of neighbouring lanes with the same (block, voxel) are summed in registers (segmented prefix
-  // sum) and only the last lane of a run issues the atomic — the hot voxels next to the sensor
-  // would otherwise serialise thousands of same-address atomics.
-  RayWalk walk;  // (hit: n <= 7, the integer walk is exact)
-  if (hit) walk.begin(r);
-  for (int pos = 0; pos < kSlots; ++pos) {
-    bool valid = hit && pos <= r.n;
-    uint32_t key = 0xFFFFFFFFu;
-    unsigned units = 0;
-    if (valid) {
-      const int cx = walk.c[0], cy = walk.c[1], cz = walk.c[2];
-      walk.step();
-      float tsd, w;
-      valid = cell_in_range(cx, cy, cz);
-      if (valid) {
-        ray_sample_cell(L.g, L.p, r, cx, cy, cz, tsd, w);
-        const unsigned long long bk = block_key(cx, cy, cz);
-        uint32_t sl = 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < kMaxRuns; ++k)
-          if (k < nr && run_key[k] == bk) sl = slot[k];
-        valid = sl < L.g.pool_blocks;
-        key = (sl << 9) | voxel_in_block(cx, cy, cz);
-        units = static_cast<unsigned>(__float2int_rn((tsd + tau) * to_units));
-      }
-    }
-    if (__ballot(valid) == 0ull) continue;
-    const uint32_t prev = __shfl_up(key, 1);
-    const uint32_t next = __shfl_down(key, 1);
-    const bool head = lane == 0 || !valid || key != prev;
-    const bool tail = lane == kWave - 1 || !valid || key != next;
-    unsigned incl = valid ? units : 0u;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const unsigned t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
-    }
-    const unsigned long long heads = __ballot(head);
-    const int start = 63 - __clzll(static_cast<long long>(heads & ((2ull << lane) - 1ull)));
-    const unsigned before = __shfl(incl, max(start - 1, 0));
-    if (valid && tail) {
-      const unsigned sum = incl - (start > 0 ? before : 0u);
-      const unsigned long long cnt = static_cast<unsigned long long>(lane - start + 1);
-      // second stage: the workgroup's LDS table (returns a few columns apart share voxels too)
-      const unsigned long long add = (cnt << kFastCountShift) | sum;
-      uint32_t h = (key * 2654435761u) >> (32 - kFastTableBits);
-      bool placed = false;
-#pragma unroll 1
-      for (int probe = 0; probe < 8 && !placed; ++probe) {
-        const uint32_t seen = atomicCAS(&s_key[h], 0xFFFFFFFFu, key);
-        if (seen == 0xFFFFFFFFu || seen == key) {
-          atomicAdd(&s_val[h], add);
-          placed = true;
-        }
-        h = (h + 1u) & (kFastTable - 1u);
-      }
-      if (!placed)
-        atomicAdd(&L.g.accum[static_cast<size_t>(key >> 9) * kVoxelsPerBlock + (key & 511u)], add);
-    }
-  }
-  const unsigned long long m = __ballot(hit);
-  if (lane == 0 && m) atomicAdd(&s_hits, static_cast<unsigned>(__popcll(m)));
-  __syncthreads();
-  // one device-scope atomic per distinct voxel of the workgroup (they execute at the memory side on
-  // a multi-XCD part and are what this kernel is bound by)
-  for (unsigned e = threadIdx.x; e < kFastTable; e += kFastThreads) {
-    const uint32_t key = s_key[e];
-    if (key != 0xFFFFFFFFu)
-      atomicAdd(&L.g.accum[static_cast<size_t>(key >> 9) * kVoxelsPerBlock + (key & 511u)], s_val[e]);
-  }
-  if (threadIdx.x == 0) wg_hits[level * gridDim.x + blockIdx.x] = s_hits;
-}
-
-// Product over the m updates of w_{k-1} / (w_{k-1} + 1): the share of the voxel's previous tsd
-// that survives (UpdateCell :725-737). The reference re-quantises the weight after every update,
-// so its weight CODE grows by round(weight_resolution) per update (33 for max weight 1000, i.e.
-// 1.0071 instead of 1) until the clamp pins it at 32767; with that sequence the product is a
-// ratio of Gamma functions. `code` is the weight code before the call (0 = unknown = weight 0).
-__device__ inline double fast_survival(const GridView& g, uint32_t code, double m, uint32_t* code_out) {
-  const int step = static_cast<int>(roundf(g.weight_resolution));
-  const double kw = static_cast<double>(g.weight_scale);
-  const int c0 = static_cast<int>(code & 0x7FFFu) == 0 ? 1 : static_cast<int>(code & 0x7FFFu);
-  // updates applied while the code still grows, then updates at the pinned maximum
-  const double grow_all = ceil(static_cast<double>(32767 - c0) / static_cast<double>(step));
-  const double n = fmin(m, fmax(0.0, grow_all));
-  const double c_end = fmin(static_cast<double>(c0) + static_cast<double>(step) * m, 32767.0);
-  *code_out = static_cast<uint32_t>(c_end);
-  double A = 1.0;
-  if (n > 0.0) {
-    if (c0 == 1) {
-      A = 0.0;  // weight 0: the first update replaces the value
-    } else if (n <= 32.0) {
-      for (int j = 0; j < static_cast<int>(n); ++j) {
-        const double w = static_cast<double>(static_cast<float>(c0 - 1 + step * j) * g.weight_scale);
-        A *= w / (w + 1.0);
-      }
-    } else {
-      const double alpha = static_cast<double>(c0 - 1) / static_cast<double>(step);
-      const double beta = alpha + 1.0 / (kw * static_cast<double>(step));
-      A = exp(lgamma(n + alpha) - lgamma(alpha) - lgamma(n + beta) + lgamma(beta));
-    }
-  }
-  if (m > n) {
-    const double wmax = static_cast<double>(32766.f * g.weight_scale);
-    A *= pow(wmax / (wmax + 1.0), m - n);
-  }
-  return A;
-}
-
-// The same product for the bins' apply pass (round 6), where the Gamma-function form above was most of the kernel
-// (240 VGPRs, two lgamma pairs + exp + pow in fp64 per touched voxel). With alpha = (c0 - 1) / step and
+// Product over the m updates of w_{k-1} / (w_{k-1} + 1): the share of the voxel's previous tsd that survives
+// (UpdateCell :725-737). The reference re-quantises the weight after every update, so its weight CODE grows by
+// round(weight_resolution) per update (33 for max weight 1000, i.e. 1.0071 instead of 1) until the clamp pins it at
+// 32767; with that sequence the product is a ratio of Gamma functions. `code` is the weight code before the call
+// (0 = unknown = weight 0). Rounds 2-5 evaluated it with lgamma / exp / pow in fp64 (240 VGPRs: most of the apply kernel).
+// Round 6: with alpha = (c0 - 1) / step and
 // beta = alpha + 1 + delta, delta = 1 / (kw step) - 1 (-0.0071 for maximum weight 1000: the stored weight of an
 // update is 1.0071, not 1), the growth phase is
 //   prod_{j<n} (alpha + j) / (beta + j) = alpha / (alpha + n) * [G(a + delta) / G(a)] / [G(b + delta) / G(b)],
@@ -1302,64 +1119,6 @@ __device__ inline double fast_survival_walk(const GridView& g, float maxw, uint3
   }
   *code_out = c;
   return A;
-}
-
-// grid (G, levels), 512 threads = the voxels of a block.
-__global__ __launch_bounds__(kBinThreads) void k_fast_apply(PyramidIns P) {
-  const LevelIns& L = P.lv[blockIdx.y];
-  const GridView& g = L.g;
-  const unsigned nt = min(g.counters[6], g.max_blocks);
-  const unsigned v = threadIdx.x;
-  const double tau = static_cast<double>(L.p.truncation_distance);
-  const double unit = (tau + tau) / static_cast<double>(kFastUnits);
-  const float maxw = L.p.maximum_weight;
-  const float frac = g.weight_resolution - floorf(g.weight_resolution);
-  const bool closed_form = fabsf(frac - 0.5f) > 0.05f && g.weight_resolution >= 1.0f && maxw == g.max_weight;
-  unsigned long long updates = 0;
-  for (unsigned t = blockIdx.x; t < nt; t += gridDim.x) {
-    const uint32_t slot = g.touched[t];
-    unsigned long long* acc = g.accum + static_cast<size_t>(slot) * kVoxelsPerBlock + v;
-    const unsigned long long a = *acc;
-    if (a) {
-      *acc = 0ull;
-      const double m = static_cast<double>(a >> kFastCountShift);
-      const double sum = static_cast<double>(a & ((1ull << kFastCountShift) - 1ull)) * unit - m * tau;
-      const double mean = sum / m;
-      uint32_t* cell = g.voxels + static_cast<size_t>(slot) * kVoxelsPerBlock + v;
-      const uint32_t code = *cell;
-      const double d0 = static_cast<double>(value_to_tsd(g, code & 0xFFFFu));
-      uint32_t wcode;
-      const double A = closed_form ? fast_survival(g, code >> 16, m, &wcode)
-                                   : fast_survival_walk(g, maxw, code >> 16, m, &wcode);
-      // every update is a convex combination, so the m updates carry the weight 1 - A together;
-      // they enter at their mean (their individual shares depend on the arrival order)
-      const double d = d0 * A + mean * (1.0 - A);
-      *cell = (tsd_to_value(g, static_cast<float>(d)) | kUpdateMarker) | (wcode << 16);
-      updates += static_cast<unsigned long long>(a >> kFastCountShift);
-    }
-    if (v == 0) g.bin_count[slot] = 0;  // ready for the next call
-  }
-  for (int off = 32; off > 0; off >>= 1) updates += __shfl_xor(updates, off);
-  __shared__ unsigned long long s_upd[kBinThreads / kWave];
-  if ((threadIdx.x & (kWave - 1)) == 0) s_upd[threadIdx.x / kWave] = updates;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long u = 0;
-    for (int w = 0; w < kBinThreads / kWave; ++w) u += s_upd[w];
-    if (u) atomicAdd(reinterpret_cast<unsigned long long*>(&g.counters[4]), u);
-  }
-}
-
-// <<<1, levels>>> before / after the two kernels above: per-call counters.
-__global__ void k_fast_begin(PyramidIns P) {
-  const GridView& g = P.lv[threadIdx.x].g;
-  if (!P.accumulate) { g.counters[4] = 0; g.counters[5] = 0; }
-}
-__global__ void k_fast_end(PyramidIns P) {
-  const GridView& g = P.lv[threadIdx.x].g;
-  if (g.counters[6] > g.max_blocks) atomicOr(&g.counters[1], kFlagCapacity);
-  g.counters[6] = 0;
-  publish_flags(P, threadIdx.x);
 }
 
 // Lanes of the wavefront (among `valid` ones) that hold the same 9-bit value as this lane.
@@ -3219,21 +2978,6 @@ int insert_chunk_binned(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_sc
   return HG_OK;
 }
 
-// The accumulators of the tolerance path (8 B per voxel) are allocated on a grid's first
-// HG_INSERT_FAST call and are all-zero between calls.
-int ensure_accumulators(hg_grid* grid) {
-  if (grid->view.accum) return HG_OK;
-  const size_t bytes = sizeof(unsigned long long) * kVoxelsPerBlock * static_cast<size_t>(grid->view.pool_blocks);
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&grid->view.accum), bytes);
-  if (e != hipSuccess) {
-    grid->view.accum = nullptr;
-    set_last_error(std::string("hipMalloc accumulators: ") + hipGetErrorString(e));
-    return HG_ERR_HIP;
-  }
-  HG_HIP_CHECK(hipMemsetAsync(grid->view.accum, 0, bytes, grid->ctx->stream));
-  return HG_OK;
-}
-
 // ---- tolerance path (HG_INSERT_FAST, unit weight) -------------------------------------------
 // Tolerance path on the bins (k_fast_offsets ... k_fast_bin_apply). One chunk = up to 2^20 - 1 returns of one or
 // several scans: the scans of a chunk share their bins, so a voxel's updates of the whole chunk are applied once.
@@ -3290,35 +3034,6 @@ int insert_chunk_fast(hg_ctx* c, const PyramidIns& P_in, const ScanTable* d_scan
   HG_HIP_CHECK(hipGetLastError());
   if (want_stats) {
     // hits from the per-workgroup counts; updates were written by k_fast_offsets
-    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, nullptr, 0u);
-    HG_HIP_CHECK(hipGetLastError());
-  }
-  return HG_OK;
-}
-
-// The round-2 form (one device-scope atomic per distinct voxel of a workgroup into an 8-byte accumulator per voxel of
-// the pool), kept for comparison: HG_FAST_ATOMICS=1.
-int insert_chunk_fast_atomics(hg_ctx* c, const PyramidIns& P, const ScanTable* d_scans, uint32_t n_scans,
-                      const float* d_xyz, unsigned long long n, bool want_stats) {
-  hipStream_t s = c->stream;
-  int rc;
-  const unsigned nwg_e = static_cast<unsigned>((n + kFastThreads - 1) / kFastThreads);
-  if ((rc = c->ws_counts.reserve(sizeof(unsigned) * static_cast<size_t>(nwg_e) * kMaxInsLevels)) != HG_OK) return rc;
-  unsigned* wg_hits = c->ws_counts.as<unsigned>();
-  hipLaunchKernelGGL(k_fast_begin, dim3(1), dim3(P.levels), 0, s, P);
-  {
-    ProfScope ps(c, HG_K_RAY_EXPAND, n * P.levels);
-    hipLaunchKernelGGL(k_fast_accumulate, dim3(nwg_e, P.levels), dim3(kFastThreads), 0, s, P, d_scans, n_scans, d_xyz,
-                       static_cast<unsigned>(n), wg_hits);
-  }
-  HG_HIP_CHECK(hipGetLastError());
-  {
-    ProfScope ps(c, HG_K_APPLY, n * P.levels);
-    hipLaunchKernelGGL(k_fast_apply, dim3(2048, P.levels), dim3(kBinThreads), 0, s, P);
-  }
-  hipLaunchKernelGGL(k_fast_end, dim3(1), dim3(P.levels), 0, s, P);
-  HG_HIP_CHECK(hipGetLastError());
-  if (want_stats) {
     hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(256), 0, s, P, wg_hits, nwg_e, nullptr, 0u);
     HG_HIP_CHECK(hipGetLastError());
   }
@@ -3895,16 +3610,11 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
     if (opts[l].num_free_space_voxels > 0 || !(opts[l].relative_truncation_distance <= 3.0)) fixed_ok = false;
     if (!(static_cast<float>(opts[l].weight_function_epsilon) >= 1.0f)) unit_weight = false;
   }
-  const bool fast_atomics = c->opt(OPT_FAST_ATOMICS) != 0;
   if (mode == HG_INSERT_FAST) {
     if (!fixed_ok || !unit_weight) {
       set_last_error("HG_INSERT_FAST needs unit update weights (weight_function_epsilon >= 1), no free-space "
                      "voxels and relative_truncation_distance <= 3");
       return HG_ERR_UNSUPPORTED;
-    }
-    for (int l = 0; l < levels && fast_atomics; ++l) {
-      const int rc = ensure_accumulators(grids[l]);
-      if (rc != HG_OK) return rc;
     }
   }
   if (!fixed_ok && levels > 1) {
@@ -4051,8 +3761,7 @@ int hg::pyramid_insert_impl(hg_grid* const* grids, const hg_insert_opts* opts, i
           set_last_error("HG_INSERT_FAST: a single scan is limited to 2^20 - 1 returns");
           return HG_ERR_UNSUPPORTED;
         }
-        rc = (fast_atomics ? insert_chunk_fast_atomics : insert_chunk_fast)(c, Pc, d_scans, static_cast<uint32_t>(tsize),
-                                                                           d_xyz + 3 * first, pts, stats != nullptr);
+        rc = insert_chunk_fast(c, Pc, d_scans, static_cast<uint32_t>(tsize), d_xyz + 3 * first, pts, stats != nullptr);
       } else if (binned_ok && pts < (1ull << 20)) {
         rc = insert_chunk_binned(c, Pc, tsize > 1 ? d_scans : nullptr, static_cast<uint32_t>(tsize),
                                  d_xyz + 3 * first, pts, stats != nullptr, pipelined ? pipe_chunks : -1);

@@ -170,7 +170,6 @@ int hg_ctx_synchronize(hg_ctx* ctx);
  *   defer_long_chains  0: no deferral of long chains (only in builds with -DHG_DEFER_LONG_CHAINS)
  *   insert_sort        1: exact insertion through the radix-sort path
  *   insert_pipeline    0: small-scan streams on one stream
- *   fast_atomics       1: tolerance insertion through per-voxel device atomics (round 2) instead of the bins
  * Unknown key: HG_ERR_INVALID. */
 int hg_ctx_set_option(hg_ctx* ctx, const char* key, long long value);
 int hg_ctx_get_option(hg_ctx* ctx, const char* key, long long* value);

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 6: tolerance insert mode on the bins (HG_FAST_ATOMICS=1: the round-2 atomics form), same box.
+# Round 6: tolerance insert mode on the bins. (The round-2 atomics form it was measured against -- HG_FAST_ATOMICS=1 --
+# lived until commit 56d0d05 and was then removed: `old` below needs that commit's library.)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r06fast
