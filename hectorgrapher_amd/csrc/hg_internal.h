@@ -74,7 +74,7 @@ namespace hg {
 enum Opt {
   OPT_PERSISTENT_SOLVE, OPT_TICKET_HANDOVER, OPT_PREPARE_KERNEL, OPT_EAGER_SOLVE, OPT_LAZY_TAIL, OPT_LM_GENERAL, OPT_LM_BAND,
   OPT_LM_BTD_GENERIC, OPT_LM_BTD_CHAIN, OPT_LM_BTD_CR, OPT_WINDOW_CAPACITY, OPT_WINDOW_TILES, OPT_BATCH_TILES,
-  OPT_WINDOW_BATCH, OPT_PARTITION_MIN, OPT_PARTITION_AT, OPT_HOST_TIMES, OPT_STREAM_GROUP, OPT_STREAM_SLICE,
+  OPT_WINDOW_BATCH, OPT_PARTITION_MIN, OPT_PARTITION_AT, OPT_PARTITION_FOLD, OPT_HOST_TIMES, OPT_STREAM_GROUP, OPT_STREAM_SLICE,
   OPT_STREAM_MERGE, OPT_APPLY_TURNS, OPT_DEFER_LONG_CHAINS, OPT_INSERT_SORT, OPT_INSERT_PIPELINE, OPT_COUNT
 };
 struct OptDesc { const char* key; long long def; };
@@ -82,7 +82,7 @@ constexpr OptDesc kOptDesc[OPT_COUNT] = {
   {"persistent_solve", 0}, {"ticket_handover", 0}, {"prepare_kernel", 0}, {"eager_solve", 0}, {"lazy_tail", 3},
   {"lm_general", 0}, {"lm_band", 0}, {"lm_btd_generic", 0}, {"lm_btd_chain", 0}, {"lm_btd_cr", 0},
   {"window_capacity", 0}, {"window_tiles", 0}, {"batch_tiles", 0}, {"window_batch", 1}, {"partition_min", 48},
-  {"partition_at", 2}, {"host_times", 0}, {"stream_group", 32}, {"stream_slice", 1024}, {"stream_merge", 1}, {"apply_turns", 0},
+  {"partition_at", 2}, {"partition_fold", 1}, {"host_times", 0}, {"stream_group", 32}, {"stream_slice", 1024}, {"stream_merge", 1}, {"apply_turns", 0},
   {"defer_long_chains", 1}, {"insert_sort", 0}, {"insert_pipeline", 1},
 };
 int live_contexts();  // contexts of this process (hg_grid.hip)

@@ -608,10 +608,11 @@ __device__ unsigned long long g_diag_levels[8];  // wavefronts, all-finest wavef
 #endif
 // SHARE: 0 = the latency-bound kernels, 1 = the batched kernel (shared division), 2 = the batched kernel over a
 // level-partitioned cloud (staged lookup; its own instantiation, so that batches without a partition keep the code
-// they had: the staged form costs them 1.5 % per launch)
+// they had: the staged form costs them 1.5 % per launch), 3 = the batched kernel of the launch that CLASSIFIES the
+// returns for the partition (as 1, and reports whether the lane's finest level was valid)
 template <int LEVELS, int SHARE>
 __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& raw, double x, double y,
-                                        double z, bool* ok, bool pred_fast = false) {
+                                        double z, bool* ok, bool pred_fast = false, bool* fine_valid = nullptr) {
   // a coordinate this large has no cell; NaN passes and indexes cell 0 like the general path
   const bool usable = !(fabs(x) >= 1e30 || fabs(y) >= 1e30 || fabs(z) >= 1e30);
   LevelPin lp[LEVELS];
@@ -760,6 +761,7 @@ __device__ inline D3 pyramid_tsd_direct(const PyramidView& pv, const DirectRaw& 
   for (int c = 0; c < 8; ++c) code[c] = f[0].code[c];
   float res = lp[0].res, tsd_scale = lp[0].tsd_scale, tsd_offset = lp[0].tsd_offset;
   bool found = staged_fast;  // (every lane's finest level is valid: nothing to select)
+  if constexpr (SHARE == 3) { if (fine_valid) *fine_valid = f[0].in & all_weights_valid(f[0].code); }
   if (!staged_fast) {
 #pragma unroll
     for (int l = 0; l < LEVELS; ++l) {
@@ -888,7 +890,7 @@ __device__ __attribute__((noinline)) D3 pyramid_tsd_general(const PyramidView* p
 
 template <int SHARE = 0>
 __device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, double x, double y, double z,
-                                 bool pred_fast = false) {
+                                 bool pred_fast = false, bool* fine_valid = nullptr) {
   const int levels = pv.multi_res ? pv.levels : 1;
   bool ok;
   D3 r;
@@ -903,12 +905,13 @@ __device__ inline D3 pyramid_tsd(const PyramidView& pv, const DirectRaw& raw, do
   if (ok) return r;
 #endif
   switch (levels) {  // wave-uniform
-    case 1: r = pyramid_tsd_direct<1, SHARE>(pv, raw, x, y, z, &ok, pred_fast); break;
-    case 2: r = pyramid_tsd_direct<2, SHARE>(pv, raw, x, y, z, &ok, pred_fast); break;
-    case 3: r = pyramid_tsd_direct<3, SHARE>(pv, raw, x, y, z, &ok, pred_fast); break;
-    default: r = pyramid_tsd_direct<4, SHARE>(pv, raw, x, y, z, &ok, pred_fast); break;
+    case 1: r = pyramid_tsd_direct<1, SHARE>(pv, raw, x, y, z, &ok, pred_fast, fine_valid); break;
+    case 2: r = pyramid_tsd_direct<2, SHARE>(pv, raw, x, y, z, &ok, pred_fast, fine_valid); break;
+    case 3: r = pyramid_tsd_direct<3, SHARE>(pv, raw, x, y, z, &ok, pred_fast, fine_valid); break;
+    default: r = pyramid_tsd_direct<4, SHARE>(pv, raw, x, y, z, &ok, pred_fast, fine_valid); break;
   }
   if (ok) return r;
+  if constexpr (SHARE == 3) *fine_valid = false;  // (a pool that is not directly addressable has no staged form)
   return pyramid_tsd_general(pv.self_mem, x, y, z);
 }
 
@@ -923,7 +926,7 @@ __device__ inline void cross3(const double* a, const double* b, double* c) {
 template <int SHARE = 0>
 __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRaw& dp, const double* t,
                                            const double* q, const double* v, double scaling, double* row8,
-                                           bool pred_fast = false) {
+                                           bool pred_fast = false, bool* fine_valid = nullptr) {
   const double qw = q[0];
   const double u[3] = {q[1], q[2], q[3]};
   double uv[3], c2[3];
@@ -934,7 +937,7 @@ __device__ __forceinline__ void return_row(const PyramidView& pv, const DirectRa
   const double wy = (v[1] + qw * uv[1] + c2[1]) + t[1];
   const double wz = (v[2] + qw * uv[2] + c2[2]) + t[2];
   ISA_MARK("transform|cells+addresses");
-  const D3 tsd = pyramid_tsd<SHARE>(pv, dp, wx, wy, wz, pred_fast);
+  const D3 tsd = pyramid_tsd<SHARE>(pv, dp, wx, wy, wz, pred_fast, fine_valid);
   const double r = scaling * tsd.a;
   const double g[3] = {scaling * tsd.d0, scaling * tsd.d1, scaling * tsd.d2};
   // d world / d q = [uv | qw duv_k + e_k x uv + u x duv_k], duv_k = 2 (e_k x v). Written out per k with
@@ -1122,7 +1125,9 @@ __device__ __forceinline__ void tsdf_residuals_body(
     unsigned fast_n = 0 /* the first fast_n returns are expected to stop at the finest level (level partition) */,
     unsigned epoch = 0 /* != 0: the partial sums go out as tagged granules (store_partial_tagged), `partials` = the granule buffer */,
     const double* pre_v = nullptr, const DirectRaw* pre_dp = nullptr /* the lane's return and the window counters, loaded
-        by the caller (the persistent solve evaluates the same returns against the same map many times) */) {
+        by the caller (the persistent solve evaluates the same returns against the same map many times) */,
+    unsigned char* flags_out = nullptr, unsigned* wave_counts = nullptr /* SHARE == 3: per return (lane order) whether it
+        stopped at the finest level, and how many of every wavefront's 64 did (the level partition's classification) */) {
   const ScanOrder order = make_scan_order(n, width);
   const unsigned first_i0 = wg * tiles * THREADS + threadIdx.x;
   BODY_STAMP(0);
@@ -1160,10 +1165,17 @@ __device__ __forceinline__ void tsdf_residuals_body(
       i = scan_index(order, i1 < n ? i1 : 0u);
       load_point(xyz, i, v);
     }
+    bool fine = false;
     if (i0 < n) {
       // (THREADS == 256: the batched kernel)
-      return_row<SHARE>(pv, dp, tq, tq + 3, vc, scaling, row8, i0 - threadIdx.x + THREADS <= fast_n);
+      return_row<SHARE>(pv, dp, tq, tq + 3, vc, scaling, row8, i0 - threadIdx.x + THREADS <= fast_n, &fine);
       if (residuals) residuals[i_cur] = row8[7];
+    }
+    if constexpr (SHARE == 3) {
+      if (i0 < n) flags_out[i0] = fine ? 1 : 0;
+      const unsigned long long m = __ballot(fine);
+      // (every wavefront of a 256-return group that holds a return reports, the empty ones of the last group 0)
+      if (lane == 0 && i0 - threadIdx.x < n) wave_counts[i0 >> 6] = static_cast<unsigned>(__popcll(m));
     }
     if (tile > 0) wave_sync();  // the operand reads of the tile before are done
     {
@@ -4442,6 +4454,8 @@ struct SingleJob {
   unsigned tiles;     // tiles of kBatchThreads returns per workgroup
   unsigned pad;
   const unsigned* fast_n;  // level partition: returns at the front of xyz that stopped at the finest level, or null
+  unsigned char* flags;    // level partition, classifying launch: per return (lane order) whether it stopped at the finest level
+  unsigned* wave_counts;   //   and per wavefront of 64 returns how many did
 };
 
 // Throughput form: the residual pass of all problems in one launch WITHOUT the LM step in its tail
@@ -4454,18 +4468,18 @@ struct SingleJob {
 #ifndef HG_BATCH_WAVES
 #define HG_BATCH_WAVES 4
 #endif
-template <int THREADS, bool STAGED>
+template <int THREADS, int MODE /* 0 plain, 1 over a level-partitioned cloud (staged lookup), 2 plain + classifies */>
 __global__ __launch_bounds__(THREADS, HG_BATCH_WAVES) void k_tsdf_residuals_single_batch(const SingleJob* __restrict__ jobs) {
   const SingleJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.num_wg) return;
   if (J.G->h.done) return;
   const PyramidView& pv = J.pv;
   __shared__ __align__(16) unsigned char smem[(THREADS / kWave) * (kWave * 8 + 64) * sizeof(double)];
-  tsdf_residuals_body<THREADS, STAGED ? 2 : 1>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
+  tsdf_residuals_body<THREADS, MODE == 1 ? 2 : MODE == 2 ? 3 : 1>(pv, J.xyz, J.n, J.scaling, J.xf, J.partials, nullptr,
                                      reinterpret_cast<double (*)[kWave][8]>(smem),
                                      reinterpret_cast<double (*)[64]>(smem + (THREADS / kWave) * kWave * 8 * sizeof(double)),
                                      xcd_chunk(blockIdx.x, J.num_wg), nullptr, J.width, J.tiles,
-                                     J.fast_n ? *J.fast_n : 0u);
+                                     J.fast_n ? *J.fast_n : 0u, 0u, nullptr, nullptr, J.flags, J.wave_counts);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4487,6 +4501,8 @@ struct PartJob {
   unsigned char* flags;  // per return (in lane order): stops at the finest level
   unsigned* counts;      // per workgroup of 256 returns: how many do (k_level_scan: their exclusive prefix); [nwg] total
   const BlockXform* xf;  // the transform the returns are classified at: the candidate the solve evaluates next
+  const unsigned* wave_counts;  // classified by the residual launch in front (round 6): per wavefront of 64 returns how many do, or null
+  const LmState* G;      // the problem's solver state: a problem that has terminated is not partitioned
   unsigned n, nwg, width, pad;
 };
 __global__ __launch_bounds__(256) void k_level_classify(const PartJob* __restrict__ jobs) {
@@ -4543,13 +4559,23 @@ __global__ __launch_bounds__(256) void k_level_classify(const PartJob* __restric
 }
 __global__ __launch_bounds__(1024) void k_level_scan(const PartJob* __restrict__ jobs) {
   const PartJob& J = jobs[blockIdx.x];
+  if (J.wave_counts && J.G->h.done) return;  // (uniform; its residual launches return at once, and nothing classified it)
   __shared__ unsigned s_wave[16], s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   for (unsigned base = 0; base < J.nwg; base += 1024u) {
     const unsigned i = base + threadIdx.x;
-    const unsigned v = i < J.nwg ? J.counts[i] : 0u;
+    unsigned v = 0u;
+    if (i < J.nwg) {
+      if (J.wave_counts) {  // (uniform) the four wavefronts of the group
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 w = *reinterpret_cast<const u4*>(J.wave_counts + 4u * i);
+        v = w[0] + w[1] + w[2] + w[3];
+      } else {
+        v = J.counts[i];
+      }
+    }
     unsigned incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -4570,6 +4596,7 @@ __global__ __launch_bounds__(1024) void k_level_scan(const PartJob* __restrict__
 __global__ __launch_bounds__(256) void k_level_scatter(const PartJob* __restrict__ jobs) {
   const PartJob& J = jobs[blockIdx.y];
   if (blockIdx.x >= J.nwg) return;
+  if (J.wave_counts && J.G->h.done) return;  // (as k_level_scan)
   const ScanOrder order = make_scan_order(J.n, J.width);
   const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
   const bool in = i0 < J.n;
@@ -6085,6 +6112,13 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   }
   PartJob* pjobs = nullptr;
   unsigned max_pwg = 0;
+  // The classification rides on the residual launch in front of the partition (round 6, `partition_fold`, default 1):
+  // that launch holds every return's finest-level validity anyway, so the partition costs a scan and a scatter
+  // instead of a lookup pass of its own (k_level_classify: 46 us and 80 MB per 64 matches); the returns are then
+  // classified at the candidate BEFORE the one the partitioned launches start with. partition_at = 0 has no launch
+  // in front and keeps the classify kernel.
+  const int part_at = static_cast<int>(c->opt(OPT_PARTITION_AT));
+  const bool fold = partition && c->opt(OPT_PARTITION_FOLD) != 0 && std::min(part_at, problems[0]->h_state.h.opt.max_num_iterations) >= 1;
   if (partition) {
     // (the job tables of the partition live behind the SingleJob table in the same staging slot / device buffer)
     pjobs = reinterpret_cast<PartJob*>(reinterpret_cast<char*>(jobs) + ((sizeof(SingleJob) * static_cast<size_t>(count) + 63) & ~size_t(63)));
@@ -6100,10 +6134,14 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
       Q.width = p->blocks[0].width;
       if ((rc = p->part_xyz.reserve(static_cast<size_t>(bi.n) * 12u)) != HG_OK) return rc;
       if ((rc = p->part_flags.reserve(bi.n)) != HG_OK) return rc;
-      if ((rc = p->part_counts.reserve((static_cast<size_t>(Q.nwg) + 1u) * sizeof(unsigned))) != HG_OK) return rc;
+      // [nwg + 1 counts | per wavefront of 64 returns: 4 nwg counts, 16-byte aligned]
+      const size_t wave_at = (static_cast<size_t>(Q.nwg) + 1u + 3u) & ~size_t(3);
+      if ((rc = p->part_counts.reserve((wave_at + 4u * static_cast<size_t>(Q.nwg)) * sizeof(unsigned))) != HG_OK) return rc;
       Q.out = p->part_xyz.as<float>();
       Q.flags = p->part_flags.as<unsigned char>();
       Q.counts = p->part_counts.as<unsigned>();
+      Q.wave_counts = fold ? Q.counts + wave_at : nullptr;
+      Q.G = p->d_state;
       Q.xf = p->d_xf;
       max_pwg = std::max(max_pwg, Q.nwg);
     }
@@ -6133,6 +6171,10 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     J.box = p->d_box;
     J.up_words = p->up_words;
     J.width = p->blocks[0].width;
+    if (fold) {
+      J.flags = pjobs[i].flags;
+      J.wave_counts = const_cast<unsigned*>(pjobs[i].wave_counts);
+    }
     max_wg = std::max(max_wg, J.num_wg);
     units += bi.n;
   }
@@ -6172,7 +6214,6 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
   // finest level's known voxels changes sides with every voxel the pose moves -- classified at the guess itself,
   // 35 % of the wavefronts that were expected fast held such a lane a few iterations later and paid the second
   // round trip. HG_PARTITION_AT overrides the iteration.
-  const int part_at = static_cast<int>(c->opt(OPT_PARTITION_AT));
   // (Round 4, measured and dropped: the batch cut in two halves on two streams, the second one residual pass behind
   // the first, so that one half's step kernel -- `count` workgroups on an otherwise idle chip, 10 us per iteration
   // against 22 us of residual pass for eight 100k-point scans -- would run under the other half's residual pass.
@@ -6184,7 +6225,7 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
     const SingleJob* table = d_jobs;
     for (int it = 0; it <= max_it; ++it) {
       if (partition && it == std::min(part_at, max_it)) {
-        hipLaunchKernelGGL(k_level_classify, dim3(max_pwg, count), dim3(256), 0, s, d_pjobs);
+        if (!fold) hipLaunchKernelGGL(k_level_classify, dim3(max_pwg, count), dim3(256), 0, s, d_pjobs);
         hipLaunchKernelGGL(k_level_scan, dim3(count), dim3(1024), 0, s, d_pjobs);
         hipLaunchKernelGGL(k_level_scatter, dim3(max_pwg, count), dim3(256), 0, s, d_pjobs);
         table = d_jobs_part;
@@ -6193,9 +6234,11 @@ int solve_batch_enqueue(hg_problem* const* problems, int count, const hg_solver_
       // slower than this one at 144 VGPRs with the general path as a cold call: the window test up
       // front and the second launch cost more than the fourth wavefront per SIMD brings)
       if (table == d_jobs_part)
-        hipLaunchKernelGGL((k_tsdf_residuals_single_batch<kBatchThreads, true>), dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
+        hipLaunchKernelGGL((k_tsdf_residuals_single_batch<kBatchThreads, 1>), dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
+      else if (fold && it + 1 == std::min(part_at, max_it))
+        hipLaunchKernelGGL((k_tsdf_residuals_single_batch<kBatchThreads, 2>), dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
       else
-        hipLaunchKernelGGL((k_tsdf_residuals_single_batch<kBatchThreads, false>), dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
+        hipLaunchKernelGGL((k_tsdf_residuals_single_batch<kBatchThreads, 0>), dim3(max_wg, count), dim3(kBatchThreads), 0, s, table);
       hipLaunchKernelGGL(k_lm_single_batch, dim3(count), dim3(kEvalThreads), 0, s, table);
     }
   }

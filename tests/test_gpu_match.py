@@ -578,12 +578,20 @@ def test_solve_batch_equals_individual_solves(po, hg, ctx):
     assert s_mixed[2].num_iterations >= 1
 
 
-@pytest.mark.parametrize("count", [9, 50])
-def test_solve_batch_with_several_tiles_per_workgroup(po, hg, ctx, count):
+@pytest.mark.parametrize("count,fold,part_at", [(9, 1, 2), (50, 1, 2), (50, 0, 2), (50, 1, 1), (50, 1, 0)])
+def test_solve_batch_with_several_tiles_per_workgroup(po, hg, ctx, count, fold, part_at):
     """From 8 problems on the batched residual pass gives a workgroup two tiles of 256 returns, from 48 on four
     (accumulators run through, next return prefetched): ragged sizes -- fewer returns than one tile, one return more
     than a workgroup's share, sizes that leave the last workgroup's later tiles empty -- against solving one by one,
-    and the first two problems against the oracle."""
+    and the first two problems against the oracle. From 48 problems on the returns are level-partitioned: classified
+    by the residual launch in front (`partition_fold`, the default) or by a lookup pass of its own, at LM iteration
+    `partition_at` (0: no launch in front, the classify kernel)."""
+    import torch
+    with ctx.option("partition_fold", fold), ctx.option("partition_at", part_at):
+        _several_tiles_case(po, hg, ctx, count)
+
+
+def _several_tiles_case(po, hg, ctx, count):
     import torch
     dev = torch.device("cuda", 0)
     res = (0.05, 0.10, 0.20)
