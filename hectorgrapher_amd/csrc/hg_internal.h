@@ -81,7 +81,7 @@ struct OptDesc { const char* key; long long def; };
 constexpr OptDesc kOptDesc[OPT_COUNT] = {
   {"persistent_solve", 0}, {"ticket_handover", 0}, {"prepare_kernel", 0}, {"eager_solve", 0}, {"lazy_tail", 3},
   {"lm_general", 0}, {"lm_band", 0}, {"lm_btd_generic", 0}, {"lm_btd_chain", 0}, {"lm_btd_cr", 0},
-  {"window_capacity", 0}, {"window_tiles", 0}, {"batch_tiles", 0}, {"window_batch", 1}, {"partition_min", 48},
+  {"window_capacity", 0}, {"window_tiles", 0}, {"batch_tiles", 0}, {"window_batch", 1}, {"partition_min", 32},
   {"partition_at", 2}, {"partition_fold", 1}, {"host_times", 0}, {"stream_group", 32}, {"stream_slice", 1024}, {"stream_merge", 1}, {"apply_turns", 0},
   {"defer_long_chains", 1}, {"insert_sort", 0}, {"insert_pipeline", 1},
 };

@@ -158,7 +158,7 @@ int hg_ctx_synchronize(hg_ctx* ctx);
  *                         cyclic-reduction factorisation of the LM step instead of the default (twisted block)
  *   window_capacity, window_tiles, batch_tiles   launch shapes of the window / batched residual passes (0: automatic)
  *   window_batch       0: windows of a batch solved one after the other
- *   partition_min      batch size from which the level partition is used (default 48; 0: never)
+ *   partition_min      batch size from which the level partition is used (default 32; 0: never)
  *   partition_at       LM iteration from which the batched residual launches read the partitioned returns (default 2)
  *   partition_fold     1 (default): the residual launch in front of that iteration classifies; 0: a lookup pass of its own
  *   host_times         1: host-side timing of hg_register_scan_sequence printed to stderr
