@@ -2538,15 +2538,40 @@ __global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restric
   const int level = blockIdx.y;
   uint32_t* const claim = G.claim[level];
   uint32_t* const counts = G.counts + 8 * level;
-  uint4* const work = jobs[0].P.lv[level].g.work;
+  // (the items likewise leave as global stores)
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) u4v gu4;
+  gu4* const work = (gu4*)jobs[0].P.lv[level].g.work;
   const unsigned slice_above = G.slice_records < 0 ? static_cast<unsigned>(-G.slice_records) : HG_SLICE_ABOVE;
   __shared__ unsigned s_nt[kStreamGroupMax + 1];  // prefix of the scans' touched counts
   __shared__ unsigned s_need[kUnitTiers + 2], s_base[kUnitTiers + 2];
   // (every scan's touched count by a thread of its own: one lane reading them in turn was 64 dependent loads, most of
   // this kernel's time once the chunks were spread over the chip)
   __shared__ unsigned s_cnt[kStreamGroupMax];
-  if (threadIdx.x < static_cast<unsigned>(kStreamGroupMax))
-    s_cnt[threadIdx.x] = static_cast<int>(threadIdx.x) < njobs ? jobs[threadIdx.x].P.lv[level].g.call[0] : 0u;
+  // Per scan: where its touched list, bin counts and bin offsets are, its offset in the group's record buffer and
+  // the bits of its seq numbers -- fetched once by a thread of its own and read from LDS below. (Read through the job
+  // table where they are used, 32 scans' pointers lived in scalar registers: 351 v_readlane / 291 v_writelane of
+  // spilled SGPRs and a scalar load in front of every vector load, 220 VGPRs; `r06 k_stream_units` in EXPERIMENTS.)
+  // (as device-memory addresses: through generic pointers the loads were FLAT operations, which count against the
+  // LDS / scalar counter as well -- every wait for a pointer from LDS then waited for the loads before it, and an
+  // owner's 64 loads went out one round trip after the other: 23 of this kernel's 36 us in workgroup 0, in-kernel stamps)
+  typedef __attribute__((address_space(1))) uint32_t gu32;
+  __shared__ const gu32* s_touched[kStreamGroupMax];
+  __shared__ gu32* s_bin_count[kStreamGroupMax];
+  __shared__ const gu32* s_bin_offset[kStreamGroupMax];
+  __shared__ unsigned s_rec_off[kStreamGroupMax], s_seq_bits[kStreamGroupMax];
+  if (threadIdx.x < static_cast<unsigned>(kStreamGroupMax)) {
+    const bool in = static_cast<int>(threadIdx.x) < njobs;
+    const InsertJob& Jq = jobs[in ? threadIdx.x : 0u];
+    const GridView& gq = Jq.P.lv[level].g;
+    s_cnt[threadIdx.x] = in ? gq.call[0] : 0u;
+    s_touched[threadIdx.x] = (const gu32*)gq.touched;
+    s_bin_count[threadIdx.x] = (gu32*)gq.bin_count;
+    s_bin_offset[threadIdx.x] = (const gu32*)gq.bin_offset;
+    s_rec_off[threadIdx.x] = static_cast<unsigned>(Jq.rec_keys - rec_base);
+    const unsigned rpl = Jq.records_per_level;
+    s_seq_bits[threadIdx.x] = 32u - static_cast<unsigned>(__builtin_clz((rpl > 2u ? rpl : 2u) - 1u));
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned acc = 0;
@@ -2568,7 +2593,7 @@ __global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restric
       int j = 0;
 #pragma unroll
       for (int q = 1; q < kStreamGroupMax; ++q) j = (e >= s_nt[q]) ? q : j;
-      slot = jobs[j].P.lv[level].g.touched[e - s_nt[j]];
+      slot = s_touched[j][e - s_nt[j]];
       // whichever scan's thread gets there first owns the block and reads EVERY scan's bin for it
       owner = atomicExch(&claim[slot], G.epoch) != G.epoch;
     }
@@ -2576,10 +2601,9 @@ __global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restric
     unsigned maxc = 0, touching = 0;
     if (owner) {
 #pragma unroll
-      for (int q = 0; q < kStreamGroupMax; ++q) cnt[q] = q < njobs ? jobs[q].P.lv[level].g.bin_count[slot] : 0u;
+      for (int q = 0; q < kStreamGroupMax; ++q) cnt[q] = q < njobs ? s_bin_count[q][slot] : 0u;
 #pragma unroll
-      for (int q = 0; q < kStreamGroupMax; ++q)
-        off[q] = cnt[q] ? jobs[q].P.lv[level].g.bin_offset[slot] + static_cast<unsigned>(jobs[q].rec_keys - rec_base) : 0u;
+      for (int q = 0; q < kStreamGroupMax; ++q) off[q] = cnt[q] ? s_bin_offset[q][slot] + s_rec_off[q] : 0u;
 #pragma unroll
       for (int q = 0; q < kStreamGroupMax; ++q) {
         maxc = max(maxc, cnt[q]);
@@ -2614,15 +2638,13 @@ __global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restric
 #pragma unroll
           for (int q = 0; q < kStreamGroupMax; ++q) {  // scan order
             if (!cnt[q]) continue;
-            const unsigned rpl = jobs[q].records_per_level;
-            const unsigned seq_bits = 32u - static_cast<unsigned>(__builtin_clz((rpl > 2u ? rpl : 2u) - 1u));
-            work[w++] = make_uint4(slot, (k * step) | (((k + 1u) * step) << 10) | (seq_bits << 20), cnt[q], off[q]);
+            work[w++] = u4v{slot, (k * step) | (((k + 1u) * step) << 10) | (s_seq_bits[q] << 20), cnt[q], off[q]};
           }
         }
       }
 #pragma unroll
       for (int q = 0; q < kStreamGroupMax; ++q)
-        if (cnt[q]) jobs[q].P.lv[level].g.bin_count[slot] = 0u;  // ready for the next call
+        if (cnt[q]) s_bin_count[q][slot] = 0u;  // ready for the next call
     }
     __syncthreads();  // s_need / s_base are reused by the next chunk
   }
