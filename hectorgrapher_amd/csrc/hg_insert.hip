@@ -2478,10 +2478,11 @@ __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply_jobs(const InsertJ
 // item, 32 times per call. The scans of a group cannot share a launch item by item -- a voxel's updates of scan
 // k + 1 must follow those of scan k -- but blocks (and voxel slices of a block) are independent of each other:
 //   k_stream_offsets_jobs   per (scan, level): bin offsets as k_bin_offsets_jobs, bin counts left in place
-//   k_stream_units          per level: the union of the group's touched blocks (a claim word per block, tagged with
-//                           the group's epoch); the owner of a block reads every scan's count and offset for it, cuts
-//                           the block into S voxel slices from the LARGEST of those bins, and emits per slice one
-//                           UNIT = the slice's work items of the scans that touch the block, in scan order
+//   k_stream_union          per level: the union of the group's touched blocks (a claim word per block, tagged with
+//                           the group's epoch; the entry that claims a block appends it to the level's list)
+//   k_stream_units          a wavefront per block of the union, lane = scan: every scan's count and offset for it, the
+//                           block cut into S voxel slices from the LARGEST of those bins, per slice one UNIT = the
+//                           slice's work items of the scans that touch the block, in scan order
 //   k_bin_apply_stream      one launch for the group: a workgroup (or, for blocks whose bins all hold <= 256 records, a
 //                           wavefront) takes a unit and applies its items one after the other (bin_apply_body)
 // Every voxel belongs to exactly one unit, so it receives the updates of the group's scans in scan order and, inside
@@ -2491,7 +2492,8 @@ struct StreamGroup {
   uint32_t* claim[kMaxInsLevels];      // per level: epoch of the group that last claimed the block slot
   uint2* wg_units[kMaxInsLevels];      // per level: unit tables and their counters {workgroup units, wavefront units,
   uint2* wave_units[kMaxInsLevels];    //   items} (counts[level][0..2]); the items go to lv[].g.work of job 0
-  uint32_t* counts;                    // kMaxInsLevels x 8 words (ApplyUnits::counts + the item cursor), zero between groups
+  uint32_t* counts;                    // kMaxInsLevels x 8 words (ApplyUnits::counts + the item cursor + the union's size), zero between groups
+  uint32_t* union_list[kMaxInsLevels]; // per level: the block slots the group touches, in claim order (k_stream_union)
   uint32_t unit_capacity, item_capacity;
   uint32_t epoch;
   int slice_records;                   // as PyramidIns::slice_records of the stream (< 0: -records per slice of large bins)
@@ -2525,52 +2527,32 @@ __global__ __launch_bounds__(1024) void k_stream_offsets_jobs(const InsertJob* _
   }
 }
 
-// grid (kStreamUnitWgs, levels), 256 threads; jobs = the group's scans in order (at most kStreamGroupMax).
-// (First form: one workgroup per level walking the scans' lists one after the other, every owner reserving its units
-// and items with returning atomics on the level's counters -- six dependent round trips per list pass and ~6000
-// atomics on five words per level: 160 us per group of eight, a third of the apply it feeds. Now the entries of all
-// scans are one flat list cut into chunks of 256 over 32 workgroups, an owner's eight counts / offsets are loaded
-// together, and a chunk reserves through LDS with ONE device atomic per counter.)
+// The union of the group's touched blocks, per level: grid (kStreamUnitWgs, levels), 256 threads; jobs = the group's
+// scans in order (at most kStreamGroupMax). The entries of all scans are one flat list in chunks of 256; whichever
+// entry claims a block first appends it to the level's union list (one device atomic per wavefront).
+// (Rounds of this step, docs/EXPERIMENTS.md: the claimer used to BE the block's owner and emit its units. Ownership
+// is first come, first served, and the workgroups dispatched first -- the ones holding scan 0's entries -- won almost
+// every claim: nine workgroups did a level's owner work while 247 waited, 72 - 93 us per group of 32 scans. Now the
+// claim only builds the list, and k_stream_units spreads the list over the chip.)
 constexpr int kStreamGroupMax = 32;
 constexpr unsigned kStreamUnitWgs = 256;  // (a chunk of 256 entries each for a group of 32 scans: one pass per workgroup)
-__global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restrict__ jobs, int njobs, int levels, StreamGroup G,
-                                                      const uint32_t* rec_base /* the group's record buffer: jobs[j].rec_keys - rec_base = job j's offset in it */) {
+constexpr unsigned kUnionCount = 6;        // word of a level's counters that holds the size of its union list
+typedef __attribute__((address_space(1))) uint32_t hg_gu32;  // (device-memory addresses: through generic pointers the
+                                                              // loads below are FLAT operations, which also count against the LDS / scalar counter)
+__global__ __launch_bounds__(256) void k_stream_union(const InsertJob* __restrict__ jobs, int njobs, int levels, StreamGroup G) {
   const int level = blockIdx.y;
   uint32_t* const claim = G.claim[level];
   uint32_t* const counts = G.counts + 8 * level;
-  // (the items likewise leave as global stores)
-  typedef unsigned u4v __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(1))) u4v gu4;
-  gu4* const work = (gu4*)jobs[0].P.lv[level].g.work;
-  const unsigned slice_above = G.slice_records < 0 ? static_cast<unsigned>(-G.slice_records) : HG_SLICE_ABOVE;
+  hg_gu32* const list = (hg_gu32*)G.union_list[level];
   __shared__ unsigned s_nt[kStreamGroupMax + 1];  // prefix of the scans' touched counts
-  __shared__ unsigned s_need[kUnitTiers + 2], s_base[kUnitTiers + 2];
-  // (every scan's touched count by a thread of its own: one lane reading them in turn was 64 dependent loads, most of
-  // this kernel's time once the chunks were spread over the chip)
   __shared__ unsigned s_cnt[kStreamGroupMax];
-  // Per scan: where its touched list, bin counts and bin offsets are, its offset in the group's record buffer and
-  // the bits of its seq numbers -- fetched once by a thread of its own and read from LDS below. (Read through the job
-  // table where they are used, 32 scans' pointers lived in scalar registers: 351 v_readlane / 291 v_writelane of
-  // spilled SGPRs and a scalar load in front of every vector load, 220 VGPRs; `r06 k_stream_units` in EXPERIMENTS.)
-  // (as device-memory addresses: through generic pointers the loads were FLAT operations, which count against the
-  // LDS / scalar counter as well -- every wait for a pointer from LDS then waited for the loads before it, and an
-  // owner's 64 loads went out one round trip after the other: 23 of this kernel's 36 us in workgroup 0, in-kernel stamps)
-  typedef __attribute__((address_space(1))) uint32_t gu32;
-  __shared__ const gu32* s_touched[kStreamGroupMax];
-  __shared__ gu32* s_bin_count[kStreamGroupMax];
-  __shared__ const gu32* s_bin_offset[kStreamGroupMax];
-  __shared__ unsigned s_rec_off[kStreamGroupMax], s_seq_bits[kStreamGroupMax];
+  __shared__ const hg_gu32* s_touched[kStreamGroupMax];
+  __shared__ unsigned s_won[5];
   if (threadIdx.x < static_cast<unsigned>(kStreamGroupMax)) {
     const bool in = static_cast<int>(threadIdx.x) < njobs;
-    const InsertJob& Jq = jobs[in ? threadIdx.x : 0u];
-    const GridView& gq = Jq.P.lv[level].g;
+    const GridView& gq = jobs[in ? threadIdx.x : 0u].P.lv[level].g;
     s_cnt[threadIdx.x] = in ? gq.call[0] : 0u;
-    s_touched[threadIdx.x] = (const gu32*)gq.touched;
-    s_bin_count[threadIdx.x] = (gu32*)gq.bin_count;
-    s_bin_offset[threadIdx.x] = (const gu32*)gq.bin_offset;
-    s_rec_off[threadIdx.x] = static_cast<unsigned>(Jq.rec_keys - rec_base);
-    const unsigned rpl = Jq.records_per_level;
-    s_seq_bits[threadIdx.x] = 32u - static_cast<unsigned>(__builtin_clz((rpl > 2u ? rpl : 2u) - 1u));
+    s_touched[threadIdx.x] = (const hg_gu32*)gq.touched;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2583,71 +2565,144 @@ __global__ __launch_bounds__(256) void k_stream_units(const InsertJob* __restric
   }
   __syncthreads();
   const unsigned total = s_nt[kStreamGroupMax];
+  const unsigned lane = threadIdx.x & 63u;
   for (unsigned c0 = blockIdx.x * 256u; c0 < total; c0 += gridDim.x * 256u) {
-    if (threadIdx.x < kUnitTiers + 2u) s_need[threadIdx.x] = 0u;
-    __syncthreads();
     const unsigned e = c0 + threadIdx.x;
-    bool owner = false;
+    bool won = false;
     uint32_t slot = 0;
     if (e < total) {
       int j = 0;
 #pragma unroll
       for (int q = 1; q < kStreamGroupMax; ++q) j = (e >= s_nt[q]) ? q : j;
       slot = s_touched[j][e - s_nt[j]];
-      // whichever scan's thread gets there first owns the block and reads EVERY scan's bin for it
-      owner = atomicExch(&claim[slot], G.epoch) != G.epoch;
+      won = atomicExch(&claim[slot], G.epoch) != G.epoch;
     }
-    unsigned cnt[kStreamGroupMax], off[kStreamGroupMax];
-    unsigned maxc = 0, touching = 0;
-    if (owner) {
+    // (one device atomic per workgroup and chunk: per wavefront, the 1 500 atomics of scans that share no block queued
+    // on the one word for 18 us)
+    const unsigned long long m = __ballot(won);
+    const unsigned wave = threadIdx.x >> 6;
+    if (lane == 0) s_won[wave] = static_cast<unsigned>(__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned n = s_won[0] + s_won[1] + s_won[2] + s_won[3];
+      s_won[4] = n ? atomicAdd(&counts[kUnionCount], n) : 0u;
+    }
+    __syncthreads();
+    if (won) {
+      unsigned at = s_won[4];
+      for (unsigned w = 0; w < wave; ++w) at += s_won[w];
+      list[at + static_cast<unsigned>(__popcll(m & ((1ull << lane) - 1ull)))] = slot;
+    }
+    __syncthreads();  // s_won is reused by the next chunk
+  }
+}
+
+// Units and items of the union's blocks: grid (G, levels), 512 threads; HALF A WAVEFRONT PER BLOCK, lane = scan. A
+// lane loads its scan's count and offset for the block (one round trip each), the half reduces the largest bin and the
+// scans that touch the block, cuts the block into S voxel slices from the LARGEST bin, and emits per slice one UNIT =
+// the slice's work items of the touching scans in scan order. The 16 R blocks of a batch (R per half) reserve their
+// units and items through LDS with one device atomic per counter.
+__global__ __launch_bounds__(512) void k_stream_units(const InsertJob* __restrict__ jobs, int njobs, int levels, StreamGroup G,
+                                                      const uint32_t* rec_base /* the group's record buffer: jobs[j].rec_keys - rec_base = job j's offset in it */) {
+  const int level = blockIdx.y;
+  uint32_t* const counts = G.counts + 8 * level;
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) u4v gu4;
+  typedef __attribute__((address_space(1))) u2v gu2;
+  gu4* const work = (gu4*)jobs[0].P.lv[level].g.work;
+  const hg_gu32* const list = (const hg_gu32*)G.union_list[level];
+  const unsigned slice_above = G.slice_records < 0 ? static_cast<unsigned>(-G.slice_records) : HG_SLICE_ABOVE;
+  __shared__ unsigned s_need[kUnitTiers + 2], s_base[kUnitTiers + 2];
+  __shared__ hg_gu32* s_bin_count[kStreamGroupMax];
+  __shared__ const hg_gu32* s_bin_offset[kStreamGroupMax];
+  __shared__ unsigned s_rec_off[kStreamGroupMax], s_seq_bits[kStreamGroupMax];
+  if (threadIdx.x < static_cast<unsigned>(kStreamGroupMax)) {
+    const bool in = static_cast<int>(threadIdx.x) < njobs;
+    const InsertJob& Jq = jobs[in ? threadIdx.x : 0u];
+    const GridView& gq = Jq.P.lv[level].g;
+    s_bin_count[threadIdx.x] = (hg_gu32*)gq.bin_count;
+    s_bin_offset[threadIdx.x] = (const hg_gu32*)gq.bin_offset;
+    s_rec_off[threadIdx.x] = static_cast<unsigned>(Jq.rec_keys - rec_base);
+    const unsigned rpl = Jq.records_per_level;
+    s_seq_bits[threadIdx.x] = 32u - static_cast<unsigned>(__builtin_clz((rpl > 2u ? rpl : 2u) - 1u));
+  }
+  __syncthreads();
+  const unsigned n_union = counts[kUnionCount];
+  const unsigned lane = threadIdx.x & 63u, q = lane & 31u, half = threadIdx.x >> 5;  // half: 0 .. 15
+  const int head = static_cast<int>(lane & 32u);                                        // first lane of this half
+  hg_gu32* const my_count = s_bin_count[q];
+  const hg_gu32* const my_offset = s_bin_offset[q];
+  const unsigned my_rec_off = s_rec_off[q], my_seq_bits = s_seq_bits[q];
+  const bool my_scan = static_cast<int>(q) < njobs;
+  // A batch = 16 halves x R blocks each (two barriers and one device atomic per counter per batch): R = 1 while the
+  // union is short (one room: 2 100 blocks on the finest level), R = 4 when it is long (scans that share no block:
+  // 100 000 blocks per group -- at one block per wavefront and batch the barriers made that 123 us)
+  auto batches = [&](auto r_tag) {
+    constexpr unsigned R = decltype(r_tag)::value;
+    for (unsigned b0 = blockIdx.x * 16u * R; b0 < n_union; b0 += gridDim.x * 16u * R) {  // (uniform)
+      if (threadIdx.x < kUnitTiers + 2u) s_need[threadIdx.x] = 0u;
+      __syncthreads();
+      uint32_t slot[R];
+      unsigned c[R], o[R], touch_mask[R], slices[R], cls[R], lu[R], lw[R];
 #pragma unroll
-      for (int q = 0; q < kStreamGroupMax; ++q) cnt[q] = q < njobs ? s_bin_count[q][slot] : 0u;
-#pragma unroll
-      for (int q = 0; q < kStreamGroupMax; ++q) off[q] = cnt[q] ? s_bin_offset[q][slot] + s_rec_off[q] : 0u;
-#pragma unroll
-      for (int q = 0; q < kStreamGroupMax; ++q) {
-        maxc = max(maxc, cnt[q]);
-        touching += cnt[q] ? 1u : 0u;
+      for (unsigned r = 0; r < R; ++r) {
+        const unsigned b = b0 + half * R + r;
+        slot[r] = b < n_union ? list[b] : 0xFFFFFFFFu;  // (uniform over the half)
       }
-    }
-    const bool small = maxc <= kSmallBinInKernel;
-    unsigned slices = owner ? 1u : 0u;
-    if (owner && !small) {
-      const unsigned per_slice = maxc < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above;
-      while (slices < 128u && maxc > slices * per_slice) slices <<= 1;
-    }
-    const unsigned cls = small ? kUnitTiers : (maxc >= 16384u ? 0u : maxc >= 4096u ? 1u : maxc >= 1024u ? 2u : 3u);
-    unsigned lu = 0, lw = 0;
-    if (owner) {
-      lu = atomicAdd(&s_need[cls], slices);
-      lw = atomicAdd(&s_need[kUnitTiers + 1u], slices * touching);
-    }
-    __syncthreads();
-    if (threadIdx.x < kUnitTiers + 2u && s_need[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_need[threadIdx.x]);
-    __syncthreads();
-    if (owner) {
-      const unsigned u0 = s_base[cls] + lu, w0 = s_base[kUnitTiers + 1u] + lw;
-      if (u0 + slices > G.unit_capacity || w0 + slices * touching > G.item_capacity) {
-        atomicOr(&jobs[0].P.lv[level].g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes both from the group's records
-      } else {
-        uint2* const table = small ? G.wave_units[level] : G.wg_units[level] + static_cast<size_t>(cls) * G.unit_capacity;
-        const unsigned step = 512u / slices;
-        for (unsigned k = 0; k < slices; ++k) {
-          table[u0 + k] = make_uint2(w0 + k * touching, touching);
-          unsigned w = w0 + k * touching;
 #pragma unroll
-          for (int q = 0; q < kStreamGroupMax; ++q) {  // scan order
-            if (!cnt[q]) continue;
-            work[w++] = u4v{slot, (k * step) | (((k + 1u) * step) << 10) | (s_seq_bits[q] << 20), cnt[q], off[q]};
-          }
+      for (unsigned r = 0; r < R; ++r) c[r] = (slot[r] != 0xFFFFFFFFu && my_scan) ? my_count[slot[r]] : 0u;
+#pragma unroll
+      for (unsigned r = 0; r < R; ++r) o[r] = c[r] ? my_offset[slot[r]] : 0u;
+#pragma unroll
+      for (unsigned r = 0; r < R; ++r) {
+        o[r] = c[r] ? o[r] + my_rec_off : 0u;
+        unsigned maxc = c[r];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) maxc = max(maxc, static_cast<unsigned>(__shfl_xor(static_cast<int>(maxc), off)));
+        touch_mask[r] = static_cast<unsigned>((__ballot(c[r] != 0u) >> head) & 0xFFFFFFFFull);
+        const unsigned touching = static_cast<unsigned>(__popc(touch_mask[r]));
+        const bool small = maxc <= kSmallBinInKernel;
+        slices[r] = touching ? 1u : 0u;
+        if (touching && !small) {
+          const unsigned per_slice = maxc < HG_SLICE_THRESH ? HG_SLICE_BELOW : slice_above;
+          while (slices[r] < 128u && maxc > slices[r] * per_slice) slices[r] <<= 1;
+        }
+        cls[r] = small ? kUnitTiers : (maxc >= 16384u ? 0u : maxc >= 4096u ? 1u : maxc >= 1024u ? 2u : 3u);
+        lu[r] = lw[r] = 0u;
+        if (q == 0u && touching) {
+          lu[r] = atomicAdd(&s_need[cls[r]], slices[r]);
+          lw[r] = atomicAdd(&s_need[kUnitTiers + 1u], slices[r] * touching);
+        }
+        lu[r] = static_cast<unsigned>(__shfl(static_cast<int>(lu[r]), head));
+        lw[r] = static_cast<unsigned>(__shfl(static_cast<int>(lw[r]), head));
+      }
+      __syncthreads();
+      if (threadIdx.x < kUnitTiers + 2u && s_need[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_need[threadIdx.x]);
+      __syncthreads();
+#pragma unroll
+      for (unsigned r = 0; r < R; ++r) {
+        const unsigned touching = static_cast<unsigned>(__popc(touch_mask[r]));
+        if (touching) {  // (uniform over the half)
+          const unsigned u0 = s_base[cls[r]] + lu[r], w0 = s_base[kUnitTiers + 1u] + lw[r];
+          if (u0 + slices[r] > G.unit_capacity || w0 + slices[r] * touching > G.item_capacity) {
+            if (q == 0u) atomicOr(&jobs[0].P.lv[level].g.counters[1], kFlagWorkOverflow);  // cannot happen: the host sizes both from the group's records
+          } else {
+            gu2* const table = (gu2*)(cls[r] == kUnitTiers ? G.wave_units[level] : G.wg_units[level] + static_cast<size_t>(cls[r]) * G.unit_capacity);
+            const unsigned rank = static_cast<unsigned>(__popc(touch_mask[r] & ((1u << q) - 1u)));  // scan order
+            const unsigned step = 512u / slices[r];
+            for (unsigned k = q; k < slices[r]; k += 32u) table[u0 + k] = u2v{w0 + k * touching, touching};
+            if (c[r])
+              for (unsigned k = 0; k < slices[r]; ++k)
+                work[w0 + k * touching + rank] = u4v{slot[r], (k * step) | (((k + 1u) * step) << 10) | (my_seq_bits << 20), c[r], o[r]};
+            }
+          if (c[r]) my_count[slot[r]] = 0u;  // ready for the next call
         }
       }
-#pragma unroll
-      for (int q = 0; q < kStreamGroupMax; ++q)
-        if (cnt[q]) s_bin_count[q][slot] = 0u;  // ready for the next call
     }
-    __syncthreads();  // s_need / s_base are reused by the next chunk
-  }
+  };
+  if (n_union >= 32u * gridDim.x) batches(std::integral_constant<unsigned, 4>{});
+  else batches(std::integral_constant<unsigned, 1>{});
 }
 
 // grid (G, levels): one launch for the group; the pyramid of the group's first scan stands for all (same grids).
@@ -3402,7 +3457,8 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   }
   const size_t touched_cap = std::min<size_t>(static_cast<size_t>(n_max) * kMaxRuns, max_blocks) + 64u;
   // shadow layout: [group][levels] call counters (4 words), then per (job slot, level)
-  // bin_count[pool], bin_offset[pool], touched[touched_cap]; merged apply: + per level claim[pool], + 16 counter words
+  // bin_count[pool], bin_offset[pool], touched[touched_cap]; merged apply: + per level claim[pool], + 8 counter words per
+  // level, + per level union[pool]
   // stream_merge (default 1): ONE apply launch per group of scans (k_stream_units / k_bin_apply_stream) instead of one per
   // scan. Measured on one box, interleaved (scripts/r06_stream_ab.sh, groups of 8): 32 scans of one room 18.3k -> 18.8k
   // scans/s, 32 scans over 32 rooms 16.4k -> 22.1k, 64 over 64 rooms 9.2k -> 17.7k, 500 over 400 rooms (2 GB of voxels)
@@ -3413,7 +3469,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   std::vector<char> group_merged((count + group - 1) / group, merged ? 1 : 0);
   const size_t call_words = static_cast<size_t>(group) * levels * 4u;
   const size_t per_slot_level = 2u * max_pool + touched_cap;
-  const size_t claim_words = merged ? max_pool * levels + 8u * kMaxInsLevels : 0u;
+  const size_t claim_words = merged ? 2u * max_pool * levels + 8u * kMaxInsLevels : 0u;  // claim words, counters, union lists
   const size_t shadow_words = call_words + per_slot_level * levels * group + claim_words;
   // merged apply: unit tables and items of a group, per level (k_stream_units)
   size_t unit_cap = 0, item_cap = 0;
@@ -3547,6 +3603,7 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
         SG.wave_units[l] = tables + kUnitTiers * unit_cap;
       }
       SG.counts = claim0 + max_pool * levels;
+      for (int l = 0; l < levels; ++l) SG.union_list[l] = SG.counts + 8u * kMaxInsLevels + max_pool * l;
       SG.unit_capacity = static_cast<uint32_t>(unit_cap);
       SG.item_capacity = static_cast<uint32_t>(item_cap);
       if (++c->stream_epoch == 0u) ++c->stream_epoch;  // (0 = never claimed; a tag of 2^32 groups ago cannot be met again: the layout is re-zeroed long before)
@@ -3572,7 +3629,8 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
 #ifndef HG_BIN_STAMPS
       if (merged_g) {
         // one apply launch for the group: units of (block, voxel slice) x scans (k_stream_units)
-        hipLaunchKernelGGL(k_stream_units, dim3(kStreamUnitWgs, static_cast<unsigned>(levels)), dim3(256), 0, s, d_jobs + g0, gn,
+        hipLaunchKernelGGL(k_stream_union, dim3(kStreamUnitWgs, static_cast<unsigned>(levels)), dim3(256), 0, s, d_jobs + g0, gn, levels, SG);
+        hipLaunchKernelGGL(k_stream_units, dim3(kStreamUnitWgs, static_cast<unsigned>(levels)), dim3(512), 0, s, d_jobs + g0, gn,
                            levels, SG, static_cast<const uint32_t*>(jobs[g0].rec_keys));
         hipLaunchKernelGGL(k_bin_apply_stream, dim3(1024u, static_cast<unsigned>(levels)), dim3(kBinThreads), 0, s, jobs[g0].P,
                            jobs[g0].rec_keys, jobs[g0].rec_vals, SG);

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; cd $R
 for w in "--stream-scans 32" "--stream-scans 64 --stream-tiles 64 --prof-every 1"; do
   rm -rf /tmp/up
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/up -o s -- python3 bench.py --workload insert_stream $w --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-  echo "== $w"; grep -h "k_stream_units\|k_bin_apply_stream" $(find /tmp/up -name "*kernel_stats.csv") | cut -c1-40,100-190
+  echo "== $w"; grep -h "k_stream_units\|k_stream_union\|k_bin_apply_stream" $(find /tmp/up -name "*kernel_stats.csv") | cut -c1-40,100-190
 done
 for rep in 1 2; do
 python3 bench.py --workload insert_stream --stream-scans 32 --cpu-scans 2 2>/dev/null | python3 -c "
