@@ -347,6 +347,25 @@ struct LevelIns {
   uint4* heavy_list;        // kHeavyPerWg entries {cell, offset, updates, -} per workgroup of the level's grid row
   uint32_t heavy_capacity;  // values heavy_vals holds (>= the level's records of the call: nothing can overflow)
 };
+// The kernels over a job table read their pointers from device memory, where nothing tells the compiler what they point
+// to: every access through them became a FLAT operation, which counts against the LDS / scalar counter as well as the
+// vector-memory one -- a wait for an LDS read then waits for the loads and stores in flight (k_stream_units, round 6:
+// an owner's 64 loads one round trip after the other). Such a kernel passes its pointers through the device-memory
+// address space once (a cast there and back: the compiler then follows the pointer as a global one).
+template <typename T>
+__device__ __forceinline__ T* as_device(T* p) {  // p: uniform (a word of the job table)
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)p;
+  asm volatile("" : "+s"(g));  // (keeps the pair of casts from being folded away)
+  return (T*)g;
+}
+__device__ __forceinline__ LevelIns level_as_device(LevelIns L) {
+  L.g.table = as_device(L.g.table); L.g.voxels = as_device(L.g.voxels); L.g.block_keys = as_device(L.g.block_keys);
+  L.g.block_list = as_device(L.g.block_list); L.g.counters = as_device(L.g.counters); L.g.call = as_device(L.g.call);
+  L.g.bin_count = as_device(L.g.bin_count); L.g.bin_offset = as_device(L.g.bin_offset); L.g.touched = as_device(L.g.touched);
+  L.g.work = as_device(L.g.work); L.gate = as_device(L.gate); L.heavy_vals = as_device(L.heavy_vals);
+  L.heavy_list = as_device(L.heavy_list);
+  return L;
+}
 struct PyramidIns {
   LevelIns lv[kMaxInsLevels];
   int levels;
@@ -1044,8 +1063,8 @@ __global__ __launch_bounds__(256) void k_bin_count(PyramidIns P, const ScanTable
 __global__ __launch_bounds__(256) void k_bin_count_jobs(const InsertJob* __restrict__ jobs, int levels) {
   const InsertJob& J = jobs[blockIdx.y / levels];
   if (blockIdx.x >= J.nwg) return;
-  const LevelIns L = J.P.lv[blockIdx.y % levels];  // a copy, see k_bin_apply_small_jobs
-  bin_count_body(J.P, L, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.wg_hits);
+  const LevelIns L = level_as_device(J.P.lv[blockIdx.y % levels]);  // a copy, see k_bin_apply_small_jobs
+  bin_count_body(J.P, L, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, as_device(J.xyz), J.n, as_device(J.runs), as_device(J.wg_hits));
 }
 
 // ==========================================================================================
@@ -1385,7 +1404,7 @@ __global__ __launch_bounds__(1024) void k_bin_offsets(PyramidIns P, unsigned rec
 // grid (jobs * levels)
 __global__ __launch_bounds__(1024) void k_bin_offsets_jobs(const InsertJob* __restrict__ jobs, int levels) {
   const InsertJob& J = jobs[blockIdx.x / levels];
-  const LevelIns L = J.P.lv[blockIdx.x % levels];
+  const LevelIns L = level_as_device(J.P.lv[blockIdx.x % levels]);
   bin_offsets_body(J.P, L, blockIdx.x % levels, J.records_per_level);
 }
 
@@ -1467,8 +1486,9 @@ __global__ __launch_bounds__(256) void k_bin_scatter(PyramidIns P, const ScanTab
 __global__ __launch_bounds__(256) void k_bin_scatter_jobs(const InsertJob* __restrict__ jobs, int levels) {
   const InsertJob& J = jobs[blockIdx.y / levels];
   if (blockIdx.x >= J.nwg) return;
-  const LevelIns L = J.P.lv[blockIdx.y % levels];
-  bin_scatter_body(J.P, L, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, J.xyz, J.n, J.runs, J.rec_keys, J.rec_vals);
+  const LevelIns L = level_as_device(J.P.lv[blockIdx.y % levels]);
+  bin_scatter_body(J.P, L, blockIdx.y % levels, blockIdx.x, J.nwg, nullptr, 1u, as_device(J.xyz), J.n, as_device(J.runs),
+                   as_device(J.rec_keys), as_device(J.rec_vals));
 }
 
 // ==========================================================================================
@@ -1820,8 +1840,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_bin_apply_small_jobs(const In
   // compiler reloads it inside the loops (possible aliasing with the voxel stores), which made the
   // apply pass 40 % slower than with the pyramid as a kernel argument
   const InsertJob& J = jobs[blockIdx.y / levels];
-  const LevelIns L = J.P.lv[blockIdx.y % levels];
-  bin_apply_small_body(L, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals);
+  const LevelIns L = level_as_device(J.P.lv[blockIdx.y % levels]);
+  bin_apply_small_body(L, blockIdx.x, gridDim.x, as_device(J.rec_keys), as_device(J.rec_vals));
 }
 
 // `order` = position of the level in dispatch order (0 = coarsest), `bx` of `gstride` = workgroup of
@@ -2466,8 +2486,8 @@ __global__ __launch_bounds__(kBinThreads, HG_APPLY_WAVES) void k_bin_apply(Pyram
 __global__ __launch_bounds__(kBinThreads, 6) void k_bin_apply_jobs(const InsertJob* __restrict__ jobs, int njobs) {
   const InsertJob& J = jobs[blockIdx.y % njobs];
   const unsigned order = blockIdx.y / njobs;
-  const LevelIns L = J.P.lv[J.P.levels - 1 - order];  // a copy, see k_bin_apply_small_jobs
-  bin_apply_body(L, order, blockIdx.x, gridDim.x, J.rec_keys, J.rec_vals, J.P.slice_records <= 0);
+  const LevelIns L = level_as_device(J.P.lv[J.P.levels - 1 - order]);  // a copy, see k_bin_apply_small_jobs
+  bin_apply_body(L, order, blockIdx.x, gridDim.x, as_device(J.rec_keys), as_device(J.rec_vals), J.P.slice_records <= 0);
 }
 #endif
 
@@ -2502,7 +2522,7 @@ struct StreamGroup {
 __global__ __launch_bounds__(1024) void k_stream_offsets_jobs(const InsertJob* __restrict__ jobs, int levels) {
   const InsertJob& J = jobs[blockIdx.x / levels];
   const int level = blockIdx.x % levels;
-  const LevelIns L = J.P.lv[level];
+  const LevelIns L = level_as_device(J.P.lv[level]);
   __shared__ unsigned s_scan[16];
   __shared__ unsigned s_base;
   const unsigned nt = L.g.call[0];

@@ -4618,6 +4618,17 @@ __global__ __launch_bounds__(256) void k_level_scatter(const PartJob* __restrict
     *reinterpret_cast<__attribute__((address_space(1))) f3*>(const_cast<__attribute__((address_space(1))) char*>(as_global(J.out)) + 12ull * pos) = pt;
   }
 }
+// (A kernel over a job table reads its pointers from device memory, where nothing tells the compiler what they point to:
+// every access through them became a FLAT operation -- 175 of them in this kernel against 1 in k_window_residuals --
+// which counts against the LDS / scalar counter as well as the vector-memory one, so that a wait for an LDS read waits
+// for the loads and stores in flight. The pointers pass through the device-memory address space once; the inline asm
+// keeps the pair of casts from being folded away. p: uniform.)
+template <typename T>
+__device__ __forceinline__ T* as_device(T* p) {
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)p;
+  asm volatile("" : "+s"(g));
+  return (T*)g;
+}
 // Uploads every problem's solver head from its mailbox and prepares its first transform (k_lm
 // MODE_PREPARE for all problems of a batch in one launch).
 __global__ __launch_bounds__(kLmBlock) void k_lm_prepare_batch(const SingleJob* __restrict__ jobs) {
@@ -4629,7 +4640,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm_single_batch(const SingleJo
   if (J.G->h.done) return;
   constexpr size_t kTail = ((kEvalThreads / kAcc) + 1) * kAcc * sizeof(double) + sizeof(LmHead) + 36 * sizeof(double);
   __shared__ __align__(16) unsigned char smem[kTail];
-  lm_step_single(reinterpret_cast<double*>(smem), J.G, const_cast<BlockXform*>(J.xf), J.partials, J.num_wg);
+  lm_step_single(reinterpret_cast<double*>(smem), as_device(J.G), as_device(const_cast<BlockXform*>(J.xf)), as_device(J.partials), J.num_wg);
 }
 
 // All residual blocks of a problem in ONE launch per LM iteration: workgroup -> (block, local
@@ -4724,8 +4735,9 @@ __global__ __launch_bounds__(kBatchThreads, UNWARP ? 2 : HG_WINDOW_JOBS_WAVES) v
   // the odometry / IMU blocks ride on the per-scan launch
   const unsigned tsdf_wg = UNWARP ? J.wg_unwarp : J.wg_plain, small = UNWARP ? 0u : J.num_small;
   if (blockIdx.x >= tsdf_wg + small) return;
-  window_eval<UNWARP>(J.blocks + (UNWARP ? J.num_plain : 0), UNWARP ? J.num_unwarp : J.num_plain, J.tiles, nullptr, J.G,
-                      J.xf, J.partials, J.small_out, tsdf_wg, small, J.tickets, J.loc, blockIdx.x);
+  window_eval<UNWARP>(as_device(J.blocks) + (UNWARP ? J.num_plain : 0), UNWARP ? J.num_unwarp : J.num_plain, J.tiles, nullptr,
+                      as_device(J.G), as_device(J.xf), as_device(J.partials), as_device(J.small_out), tsdf_wg, small,
+                      as_device(J.tickets), as_device(J.loc), blockIdx.x);
 }
 __global__ __launch_bounds__(kLmBlock) void k_lm_jobs(const WindowJob* __restrict__ jobs, int mode) {
   const WindowJob& J = jobs[blockIdx.x];
