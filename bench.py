@@ -1778,29 +1778,31 @@ OFFLINE_LEG = {"total_submaps": OFFLINE_SUBMAPS, "scans_per_submap": 30, "steps"
 
 def secondary_workloads(args):
     """Bounded runs of the other workloads inside the default command, so that the driver's record holds
-    them too: each {value, unit, ms_per_step, frac (algorithmic bytes / HBM peak of its dominant kernel),
+    them too (their wall time is map building and the oracle legs; the timed steps are milliseconds, so they run as many
+    steps as the stand-alone workloads' profiles and sample the kernels by HIP events on every fourth or fifth -- an
+    event pair serialises the stream, which with half of four steps sampled read 5 % low in round 6's first record): each {value, unit, ms_per_step, frac (algorithmic bytes / HBM peak of its dominant kernel),
     parity_ok (its in-run oracle gate)}. Every run builds its own context and maps and frees them."""
     import copy
     out = {}
     plan = [
-        ("match_batch_64", run_match_batch, {"workload": "match_batch", "batch": 64, "steps": 8, "warmup": 2, "prof_every": 2, "cpu_scans": 2}),
-        ("register_batch_8", run_register_batch, {"workload": "register_batch", "batch_submaps": 8, "batch_threads": 1, "steps": 6, "warmup": 2, "prof_every": 2, "cpu_scans": 2}),
-        ("insert_stream_32", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "steps": 4, "warmup": 1, "prof_every": 2, "cpu_scans": 2}),
+        ("match_batch_64", run_match_batch, {"workload": "match_batch", "batch": 64, "steps": 12, "warmup": 2, "prof_every": 4, "cpu_scans": 2}),
+        ("register_batch_8", run_register_batch, {"workload": "register_batch", "batch_submaps": 8, "batch_threads": 1, "steps": 12, "warmup": 2, "prof_every": 4, "cpu_scans": 2}),
+        ("insert_stream_32", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "steps": 10, "warmup": 2, "prof_every": 5, "cpu_scans": 2}),
         # the tolerance mode of the same stream (order-free sums on the bins, one closed-form update per voxel and chunk)
-        ("insert_stream_fast", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "insert_mode": "fast", "steps": 6,
-                                                   "warmup": 1, "prof_every": 2, "cpu_scans": 2}),
+        ("insert_stream_fast", run_insert_stream, {"workload": "insert_stream", "stream_scans": 32, "insert_mode": "fast", "steps": 12,
+                                                   "warmup": 2, "prof_every": 4, "cpu_scans": 2}),
         # BASELINE configs[0]: the 10k-point scan into one 0.10 m grid, all points matched and through the C++ builder
         ("c1_10k", run_c1_10k, {"workload": "c1_10k", "steps": 30, "warmup": 3, "cpu_scans": 3}),
-        ("window_10", run_window, {"workload": "window", "window": 10, "steps": 12, "warmup": 3, "prof_every": 3}),
+        ("window_10", run_window, {"workload": "window", "window": 10, "steps": 20, "warmup": 3, "prof_every": 5}),
         # BASELINE configs[2] with the voxels in HBM: 64 scans over 64 copies of the room (~0.4 GB of voxel
         # blocks touched per call, beyond the 256 MB Infinity Cache); insert_stream_32 above stays in cache
         ("insert_stream_64_hbm", run_insert_stream, {"workload": "insert_stream", "stream_scans": 64, "stream_tiles": 64,
-                                                     "steps": 3, "warmup": 1, "prof_every": 1, "cpu_scans": 2}),
+                                                     "steps": 4, "warmup": 1, "prof_every": 2, "cpu_scans": 2}),
         # configs[3] with the reference's real builder: 8 submaps, each a 10-control-point window per step, shared launches
         # (its all-cores CPU leg inside this bounded run: 64 threads -- a window of nine 100k-point blocks per thread on all 256
         # cores of the driver box took 215 s of wall time; `--workload window_batch` on its own uses every core)
-        ("window_batch_8", run_window_batch, {"workload": "window_batch", "window": 10, "batch_submaps": 8, "steps": 4, "warmup": 2,
-                                              "prof_every": 2, "cpu_threads": 64}),
+        ("window_batch_8", run_window_batch, {"workload": "window_batch", "window": 10, "batch_submaps": 8, "steps": 8, "warmup": 2,
+                                              "prof_every": 4, "cpu_threads": 64}),
         # BASELINE configs[3] bounded: 8 submaps x 30 scans on this GPU, then the gather of all finished blocks
         # through a one-rank process group and its import / export-digest check (the full 8 x 500 run is
         # `bench.py --total-submaps 8 --scans-per-submap 500`, profiles/r05_bench_offline8x500.json)
