@@ -3485,7 +3485,11 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
   // 10.2k -> 18.8k: where the scans of a group touch different blocks their launches now run side by side. Groups of
   // 16 / 32 (the default since): one room 19.2k / 20.7k, 64 rooms 19.3k / 19.9k. What is left in one room is the unit of
   // the busiest (block, slice): its voxels' updates of all scans of the group in one serial chain.
+#ifdef HG_BIN_STAMPS
+  const bool merged = false;  // (the stamp build times k_bin_apply's items: a launch per scan)
+#else
   const bool merged = group >= 2 && group <= kStreamGroupMax && !heavy_enabled(c) && c->opt(OPT_STREAM_MERGE) != 0;
+#endif
   std::vector<char> group_merged((count + group - 1) / group, merged ? 1 : 0);
   const size_t call_words = static_cast<size_t>(group) * levels * 4u;
   const size_t per_slot_level = 2u * max_pool + touched_cap;
@@ -3633,8 +3637,11 @@ int insert_stream_grouped(hg_ctx* c, const PyramidIns& P0, const float* origins,
 #endif
     {
       ProfScope ps(c, HG_K_SCAN, gn * levels);
+#ifndef HG_BIN_STAMPS
       if (merged_g) hipLaunchKernelGGL(k_stream_offsets_jobs, dim3(gn * levels), dim3(1024), 0, s, d_jobs + g0, levels);
-      else hipLaunchKernelGGL(k_bin_offsets_jobs, dim3(gn * levels), dim3(1024), 0, s, d_jobs + g0, levels);
+      else
+#endif
+        hipLaunchKernelGGL(k_bin_offsets_jobs, dim3(gn * levels), dim3(1024), 0, s, d_jobs + g0, levels);
     }
     {
       ProfScope ps(c, HG_K_RAY_EXPAND, units);
