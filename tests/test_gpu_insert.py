@@ -445,6 +445,35 @@ def test_grouped_stream_calls_of_different_layouts_on_one_context(po, hg):
         c.close()
 
 
+def test_stream_over_different_rooms_with_a_long_union(po, hg):
+    """Sixteen 40k-point scans inserted 60 m apart from each other in ONE stream call: no block is shared, the union of
+    the group's blocks holds ~30 000 entries on the finest level -- k_stream_units then gives half a wavefront FOUR
+    blocks per batch (the short unions of the other stream tests take one) -- and most blocks live in the overflow area
+    of the pool. Every voxel equals the oracle inserting the scans one after the other."""
+    c = hg.Context(0)
+    try:
+        res3 = [0.05, 0.10, 0.20]
+        pyr = [hg.HybridGridTSDF(c, r, max_blocks=1 << 16) for r in res3]
+        opyr = [po.Grid(r) for r in res3]
+        scans = []
+        for j in range(16):
+            pose = synth.pose_k(j % 5).copy()
+            pts = synth.generate_scan(pose, 16, 2500, stream=1300 + j)
+            pose[0] += 60.0 * (j % 4)
+            pose[1] += 60.0 * (j // 4)
+            scans.append((pose, pts))
+        _stream_call(hg, pyr, scans)
+        for pose, pts in scans:
+            loc = synth.transform_points(pose, pts)
+            for g in opyr:
+                g.insert(pose[:3].astype(np.float32), loc)
+        for o, g in zip(opyr, pyr):
+            assert_grids_equal(o, g)
+        assert pyr[0].num_blocks() >= 16 * 512  # (the union was long enough for the four-blocks path: 32 blocks per workgroup)
+    finally:
+        c.close()
+
+
 def test_async_insert_errors_are_per_grid(hg):
     """A full grid reports its sticky error through calls that work on IT (and hg_ctx_synchronize); other
     grids of the context keep working, and clearing one of them does not drop the full grid's error."""
@@ -502,7 +531,7 @@ def test_apply_schedules_are_all_bit_exact(env):
     child_env = dict(os.environ)
     child_env.update(env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                          "grouped_stream or thousands_of_rays or giant_voxel or small_block_pool or batch_equals or 2_pow_20"],
+                          "grouped_stream or long_union or thousands_of_rays or giant_voxel or small_block_pool or batch_equals or 2_pow_20"],
                          env=child_env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
