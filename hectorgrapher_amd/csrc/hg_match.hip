@@ -3583,17 +3583,23 @@ __device__ unsigned long long g_tail_stamps[8];
 #endif
 __device__ inline int b6(int i, int j) { return i * 6 + 5 - (i - j); }  // band_index(i, j, W = 6), j <= i
 
-template <bool FIRST = false, bool PERSIST = false /* called from the persistent solve */>
+template <bool FIRST_T = false, bool PERSIST = false /* called from the persistent solve */>
 __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, BlockXform* xf, const double* partials,
                                unsigned num_wg, const PinBox* host_up = nullptr, unsigned up_words = 0,
                                unsigned epoch = 0 /* != 0: `partials` holds tagged granules of this epoch */,
                                double* persist_out = nullptr /* LDS, 8 doubles: the next candidate and the done flag (persistent solve) */,
                                int* timeout_flag = nullptr /* LDS: set when a granule never arrived; the step then ends the solve as failed */,
-                               unsigned long long* persist_bcast = nullptr /* persistent solve: kBcastReplicas x 8 granule pairs, the hand-back to the other workgroups */) {
+                               unsigned long long* persist_bcast = nullptr /* persistent solve: kBcastReplicas x 8 granule pairs, the hand-back to the other workgroups */,
+                               bool first_rt = false /* PERSIST: this is the solve's first step (run time) */) {
   // (Round 5: multiply-adds of this function are fused -- the file is compiled -ffp-contract=off for the voxel lookups,
   // whose discrete decisions need the reference's roundings; nothing in the LM step takes one, and the tail is a chain
   // of dependent fp64 operations: 14.7 -> 14.0 us per launch together with the right-looking factorisation below.)
 #pragma clang fp contract(fast)
+  // The first step of a solve differs in its upload. A launch per evaluation has a kernel of its own for it (FIRST_T);
+  // the persistent solve decides at run time and runs ONE copy of the step for all its evaluations: two inlined copies
+  // meant that the second evaluation found none of its instructions in the cache the first one had just filled.
+  constexpr bool kMaybeFirst = FIRST_T || PERSIST;
+  const bool FIRST = PERSIST ? first_rt : FIRST_T;
   const int t = threadIdx.x;
   LmHead& gh = G->h;
   TAIL_STAMP(0);
@@ -3603,8 +3609,8 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   LmHead& sh = *reinterpret_cast<LmHead*>(scratch + (stripes0 + 1) * kAcc);
   double* sH = reinterpret_cast<double*>(&sh + 1);
   constexpr int kUp = static_cast<int>((sizeof(LmHead) / 8 + kEvalThreads - 1) / kEvalThreads);  // mailbox words per thread: 3
-  unsigned long long up_val[FIRST ? kUp : 1];
-  unsigned up_idx[FIRST ? kUp : 1];
+  unsigned long long up_val[kMaybeFirst ? kUp : 1];
+  unsigned up_idx[kMaybeFirst ? kUp : 1];
   if (FIRST) {
     // the head arrives as its non-zero words in the host's mailbox: reads in flight now, scattered
     // into the zeroed LDS head behind the first barrier below
@@ -4387,12 +4393,8 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
     PSTAMP(195u, 6);
     if (wg == 0u) {
       __syncthreads();  // (ends this workgroup's use of the tiles in smem)
-      if (e == 0u)
-        lm_step_single<true, true>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, up.box,
-                                   up.up_words, epoch, s_out, &s_timeout, bcast);
-      else
-        lm_step_single<false, true>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, nullptr, 0u,
-                                    epoch, s_out, &s_timeout, bcast);
+      lm_step_single<false, true>(reinterpret_cast<double*>(smem), G, const_cast<BlockXform*>(xf), granules, num_wg, up.box,
+                                  up.up_words, epoch, s_out, &s_timeout, bcast, e == 0u);
       // (the hand-back -- kBcastReplicas copies, a 128-byte line each: 195 workgroups polling ONE line queue at its
       // memory channel -- has left from inside the step, ahead of the head's write-back)
       PSTAMP(0u, 2);
