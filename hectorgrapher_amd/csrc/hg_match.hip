@@ -3600,7 +3600,10 @@ __device__ __forceinline__ void lm_step_single(double* scratch, LmState* G, Bloc
   // meant that the second evaluation found none of its instructions in the cache the first one had just filled.
   constexpr bool kMaybeFirst = FIRST_T || PERSIST;
   const bool FIRST = PERSIST ? first_rt : FIRST_T;
-  const int t = threadIdx.x;
+  int t_opaque = threadIdx.x;
+  if (PERSIST) asm volatile("" : "+v"(t_opaque));  // (the persistent solve calls the step inside its evaluation loop: addresses formed
+                                                   // from the thread index were hoisted in front of the loop and spilled there)
+  const int t = t_opaque;
   LmHead& gh = G->h;
   TAIL_STAMP(0);
   // the solver head and H are staged through LDS by all threads while the partial loads are in
@@ -4359,10 +4362,13 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
   __shared__ double s_out[8];
   __shared__ int s_timeout;
   const unsigned wg = blockIdx.x, num_wg = gridDim.x;
-  double pose[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) pose[k] = up.pose[k];
+  // The candidate of an evaluation is read from s_out at its start (the first one put there from the kernel argument):
+  // carried in registers from the end of one evaluation to the next it lived across workgroup 0's LM step, where it was
+  // spilled in the prologue and reloaded behind every exit of the step.
+  if (threadIdx.x < 7u) s_out[threadIdx.x] = up.pose[threadIdx.x];
+  if (threadIdx.x == 7u) s_out[7] = 0.0;
   if (threadIdx.x == 0) s_timeout = 0;  // (the body's barriers come before anything reads it)
+  __syncthreads();
 #ifdef HG_EVAL_STAMPS
   const int eval_it = 0;
 #endif
@@ -4379,6 +4385,10 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
 #endif
   for (unsigned e = 0; e < evals; ++e) {
     const unsigned epoch = epoch0 + e;
+    double pose[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pose[k] = uniform_f64(s_out[k]);  // (into scalar registers, as a kernel argument would be)
+    __syncthreads();  // everyone has the candidate before workgroup 0's step rewrites s_out
     PSTAMP(0u, 0);
     tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, granules, nullptr,
                                  reinterpret_cast<double (*)[kWave][8]>(smem),
@@ -4428,9 +4438,6 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
     }
     if (s_timeout != 0) break;     // (uniform per workgroup)
     if (s_out[7] != 0.0) break;    // the solve has terminated
-#pragma unroll
-    for (int k = 0; k < 7; ++k) pose[k] = uniform_f64(s_out[k]);  // (into scalar registers, as a kernel argument would be)
-    __syncthreads();  // everyone has the candidate before workgroup 0's next step rewrites s_out
   }
 }
 #endif  // !HG_BIG
