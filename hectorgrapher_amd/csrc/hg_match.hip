@@ -4388,8 +4388,7 @@ __global__ __launch_bounds__(THREADS) void k_tsdf_residuals_single_persist(
     double pose[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) pose[k] = uniform_f64(s_out[k]);  // (into scalar registers, as a kernel argument would be)
-    // (no barrier of its own: s_out is rewritten by workgroup 0's step or by the poll below, both behind the barriers
-    // inside the body, which no thread passes before it has read the candidate here)
+    __syncthreads();  // everyone has the candidate before workgroup 0's step rewrites s_out
     PSTAMP(0u, 0);
     tsdf_residuals_body<THREADS>(pv, xyz, n, scaling, xf, granules, nullptr,
                                  reinterpret_cast<double (*)[kWave][8]>(smem),
