@@ -680,7 +680,10 @@ constexpr unsigned kSmallBinInKernel = 256;  // the same inside k_bin_apply
 #define HG_SLICE_BELOW 2048u
 #endif
 #ifndef HG_SLICE_ABOVE
-#define HG_SLICE_ABOVE 512u
+// (512 until late in round 6; measured on the headline, one box, interleaved: 512 -> 4606 - 4628 scans/s, 640 -> 4681 - 4705,
+// 768 -> 4662 - 4680, 896 -> 4500 - 4511, 1024 -> 4323 - 4335: every slice of a bin reads the whole bin, so fewer slices of the
+// mid-size bins are fewer re-reads, until a slice no longer fits one LDS pass)
+#define HG_SLICE_ABOVE 640u
 #endif
   // bins from this size on head the work list (their slices carry the long chains)
 constexpr unsigned kSeqBits = 23;   // seq < 2^23: at most 2^20 returns per call on this path
